@@ -1,0 +1,240 @@
+"""ctypes binding of oracle/libs3d_oracle.so (built by oracle/Makefile).
+
+TEST INFRASTRUCTURE ONLY — never imported by the product package slam3d_amd.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libs3d_oracle.so")
+
+ALG_ICP, ALG_GICP, ALG_GICP_OMP, ALG_NDT, ALG_NDT_OMP = range(5)
+(STATUS_OK, STATUS_TOO_FEW_POINTS, STATUS_NOT_CONVERGED, STATUS_FITNESS_EXCEEDED, STATUS_TOO_FAR_FROM_GUESS,
+ STATUS_UNKNOWN_ALGORITHM, STATUS_UNSUPPORTED_ALGORITHM, STATUS_INVALID_ARGUMENT, STATUS_BACKEND_ERROR) = range(9)
+
+
+class RegParams(C.Structure):
+    """Mirror of s3d_reg_params (include/slam3d_registration_types.h)."""
+    _fields_ = [
+        ("registration_algorithm", C.c_int),
+        ("point_cloud_density", C.c_double),
+        ("max_fitness_score", C.c_double),
+        ("max_translation", C.c_double),
+        ("max_rotation", C.c_double),
+        ("euclidean_fitness_epsilon", C.c_double),
+        ("transformation_epsilon", C.c_double),
+        ("max_correspondence_distance", C.c_double),
+        ("maximum_iterations", C.c_int),
+        ("rotation_epsilon", C.c_double),
+        ("correspondence_randomness", C.c_int),
+        ("maximum_optimizer_iterations", C.c_int),
+        ("resolution", C.c_float),
+        ("step_size", C.c_double),
+        ("outlier_ratio", C.c_double),
+    ]
+
+
+class VoxelInfo(C.Structure):
+    _fields_ = [("min_b", C.c_int * 3), ("max_b", C.c_int * 3), ("div_b", C.c_int * 3),
+                ("passthrough", C.c_int), ("min_p", C.c_float * 3), ("max_p", C.c_float * 3)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("final_transformation", C.c_float * 16), ("converged", C.c_int), ("iterations", C.c_int),
+                ("correspondences", C.c_int), ("fitness", C.c_double), ("inner_iterations_total", C.c_int),
+                ("evaluations_total", C.c_int)]
+
+
+class AlignInfo(C.Structure):
+    _fields_ = [("n_source_filtered", C.c_int), ("n_target_filtered", C.c_int), ("iterations", C.c_int),
+                ("converged", C.c_int), ("correspondences", C.c_int), ("fitness", C.c_double)]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "s3d_oracle.c")):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B" if force else "all"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        dp = C.POINTER(C.c_double)
+        ip = C.POINTER(C.c_int)
+        L.s3o_voxel_downsample.restype = C.c_int
+        L.s3o_voxel_downsample.argtypes = [fp, C.c_int, C.c_int, C.c_double, fp, C.POINTER(VoxelInfo)]
+        L.s3o_nn_search.argtypes = [fp, C.c_int, fp, C.c_int, ip, fp]
+        L.s3o_nn_search_brute.argtypes = [fp, C.c_int, fp, C.c_int, ip, fp]
+        L.s3o_gicp_covariances.restype = C.c_int
+        L.s3o_gicp_covariances.argtypes = [fp, C.c_int, C.c_int, C.c_double, dp, dp]
+        for f in (L.s3o_gicp, L.s3o_icp_point_to_plane):
+            f.restype = C.c_int
+            f.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.POINTER(RegParams), C.c_int, C.POINTER(IcpResult)]
+        L.s3o_fitness_score.restype = C.c_double
+        L.s3o_fitness_score.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.c_double]
+        L.s3o_align.restype = C.c_int
+        L.s3o_align.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int, dp, C.POINTER(RegParams), C.c_int, dp,
+                                C.POINTER(AlignInfo)]
+        L.s3o_create_constraint.restype = C.c_int
+        L.s3o_create_constraint.argtypes = [fp, C.c_int, C.c_int, dp, fp, C.c_int, C.c_int, dp, dp, C.c_int,
+                                            C.POINTER(RegParams), C.POINTER(RegParams), C.c_double, dp, dp,
+                                            C.POINTER(AlignInfo)]
+        L.s3o_default_params.argtypes = [C.POINTER(RegParams)]
+        L.s3o_sym_eig3.argtypes = [dp, dp, dp]
+        L.s3o_rotation_angle.restype = C.c_double
+        L.s3o_rotation_angle.argtypes = [dp]
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def default_params(**overrides):
+    p = RegParams()
+    lib().s3o_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _cloud(a):
+    a = _f32(a)
+    assert a.ndim == 2 and a.shape[1] in (3, 4), a.shape
+    return a, a.shape[0], a.shape[1]
+
+
+def colmajor(T):
+    """4x4 numpy (row, col) -> 16 doubles column-major (Eigen layout)."""
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float64).T.reshape(16))
+
+
+def from_colmajor(v):
+    return np.asarray(v, dtype=np.float64).reshape(4, 4).T.copy()
+
+
+def voxel_downsample(xyz, leaf):
+    a, n, stride = _cloud(xyz)
+    out = np.empty((max(n, 1), 3), np.float32)
+    info = VoxelInfo()
+    m = lib().s3o_voxel_downsample(_fptr(a), n, stride, float(leaf), _fptr(out), C.byref(info))
+    return out[:m].copy(), info
+
+
+def nn_search(tgt, qry, brute=False):
+    t, n, st = _cloud(tgt)
+    q, m, sq = _cloud(qry)
+    assert st == 3 and sq == 3
+    idx = np.empty(m, np.int32)
+    d2 = np.empty(m, np.float32)
+    (lib().s3o_nn_search_brute if brute else lib().s3o_nn_search)(_fptr(t), n, _fptr(q), m, _iptr(idx), _fptr(d2))
+    return idx, d2
+
+
+def gicp_covariances(xyz, k=20, eps=1e-3):
+    a, n, st = _cloud(xyz)
+    assert st == 3
+    cov = np.empty((n, 3, 3), np.float64)
+    nrm = np.empty((n, 3), np.float64)
+    rc = lib().s3o_gicp_covariances(_fptr(a), n, k, eps, _dptr(cov), _dptr(nrm))
+    if rc:
+        raise ValueError("k > n")
+    return cov, nrm
+
+
+def _icp(fn, pcl_source, pcl_target, guess, params, force_iterations):
+    s, m, ss = _cloud(pcl_source)
+    t, n, st = _cloud(pcl_target)
+    assert ss == 3 and st == 3
+    g = np.ascontiguousarray(np.asarray(guess, np.float32).T.reshape(16))
+    r = IcpResult()
+    rc = fn(_fptr(s), m, _fptr(t), n, _fptr(g), C.byref(params), int(force_iterations), C.byref(r))
+    if rc:
+        raise ValueError("oracle icp failed rc=%d" % rc)
+    T = np.array(r.final_transformation[:], np.float32).reshape(4, 4).T.copy()
+    return dict(T=T, converged=bool(r.converged), iterations=r.iterations, correspondences=r.correspondences,
+                fitness=r.fitness, inner_iterations=r.inner_iterations_total, evaluations=r.evaluations_total)
+
+
+def gicp(pcl_source, pcl_target, guess=np.eye(4), params=None, force_iterations=False):
+    return _icp(lib().s3o_gicp, pcl_source, pcl_target, guess, params or default_params(), force_iterations)
+
+
+def icp_point_to_plane(pcl_source, pcl_target, guess=np.eye(4), params=None, force_iterations=False):
+    return _icp(lib().s3o_icp_point_to_plane, pcl_source, pcl_target, guess, params or default_params(),
+                force_iterations)
+
+
+def fitness_score(pcl_source, pcl_target, T, max_range):
+    s, m, _ = _cloud(pcl_source)
+    t, n, _ = _cloud(pcl_target)
+    g = np.ascontiguousarray(np.asarray(T, np.float32).T.reshape(16))
+    return lib().s3o_fitness_score(_fptr(s), m, _fptr(t), n, _fptr(g), float(max_range))
+
+
+def align(source, target, guess=np.eye(4), params=None, force_iterations=False):
+    """PointCloudSensor.cpp:119-174 align().  Returns (status, 4x4 double, info dict)."""
+    s, ns, ss = _cloud(source)
+    t, nt, st = _cloud(target)
+    params = params or default_params()
+    g = colmajor(guess)
+    res = np.empty(16, np.float64)
+    info = AlignInfo()
+    status = lib().s3o_align(_fptr(s), ns, ss, _fptr(t), nt, st, _dptr(g), C.byref(params), int(force_iterations),
+                             _dptr(res), C.byref(info))
+    return status, from_colmajor(res), {k: getattr(info, k) for k, _ in AlignInfo._fields_}
+
+
+def create_constraint(source, source_pose, target, target_pose, odometry, loop=False, fine=None, coarse=None,
+                      covariance_scale=1.0):
+    s, ns, ss = _cloud(source)
+    t, nt, st = _cloud(target)
+    fine = fine or default_params()
+    coarse = coarse or default_params()
+    rel = np.empty(16, np.float64)
+    inf = np.empty(36, np.float64)
+    info = AlignInfo()
+    sp, tp, od = colmajor(source_pose), colmajor(target_pose), colmajor(odometry)
+    status = lib().s3o_create_constraint(_fptr(s), ns, ss, _dptr(sp), _fptr(t), nt, st, _dptr(tp), _dptr(od),
+                                         int(loop), C.byref(fine), C.byref(coarse), float(covariance_scale),
+                                         _dptr(rel), _dptr(inf), C.byref(info))
+    return status, from_colmajor(rel), inf.reshape(6, 6), {k: getattr(info, k) for k, _ in AlignInfo._fields_}
+
+
+def set_eval_precision(mode):
+    """0: PCL-literal float functor (default); 1: double arithmetic; 2: double matrix (see s3d_oracle.h)."""
+    lib().s3o_set_eval_precision(int(mode))
+
+
+def set_debug_perturbation(rel):
+    lib().s3o_set_debug_perturbation(C.c_double(float(rel)))
+
+
+def set_trace(on):
+    lib().s3o_set_trace(int(bool(on)))

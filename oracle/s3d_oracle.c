@@ -1,0 +1,1222 @@
+/* s3d_oracle.c — CPU restatement (plain C99, no third-party deps) of the
+ * registration hot path of dfki-ric/slam3d.  See s3d_oracle.h for the status
+ * of this file (test infrastructure, parity unpinned).
+ *
+ * Compile with -ffp-contract=off: float expressions are written in the order
+ * the reference stack evaluates them and must not be fused.
+ *
+ * Citations "PCS.cpp:N" = /root/reference/slam3d/sensor/pcl/PointCloudSensor.cpp:N.
+ * "PCL <file>" = PCL 1.12.1 source file restated from its published algorithm
+ * (PCL is an un-vendored dependency: slam3d-dependencies.cmake:22).
+ */
+#include "s3d_oracle.h"
+
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+/* ------------------------------------------------------------------ utils */
+
+void s3o_default_params(s3d_reg_params* p) {
+  /* RegistrationParameters.hpp:36-97 in-class defaults */
+  p->registration_algorithm = S3D_ALG_GICP;
+  p->point_cloud_density = 0.2;
+  p->max_fitness_score = 2.0;
+  p->max_translation = 1.0;
+  p->max_rotation = 1.0;
+  p->euclidean_fitness_epsilon = 1.0;
+  p->transformation_epsilon = 1e-5;
+  p->max_correspondence_distance = 2.5;
+  p->maximum_iterations = 50;
+  p->rotation_epsilon = 2e-3;
+  p->correspondence_randomness = 20;
+  p->maximum_optimizer_iterations = 20;
+  p->resolution = 1.0f;
+  p->step_size = 0.05;
+  p->outlier_ratio = 0.35;
+}
+
+/* column-major 4x4 helpers: element (r,c) = m[c*4+r] */
+#define M4(m, r, c) ((m)[(c) * 4 + (r)])
+
+void s3o_mat4d_mul(const double a[16], const double b[16], double out[16]) {
+  double t[16];
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += M4(a, r, k) * M4(b, k, c);
+      t[c * 4 + r] = s;
+    }
+  memcpy(out, t, sizeof t);
+}
+
+/* Eigen::Transform<double,3,Isometry>::inverse(): R^T, -R^T t */
+void s3o_mat4d_inverse_isometry(const double a[16], double out[16]) {
+  double t[16] = {0};
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) M4(t, r, c) = M4(a, c, r);
+  for (int r = 0; r < 3; ++r) {
+    double s = 0;
+    for (int k = 0; k < 3; ++k) s += M4(t, r, k) * M4(a, k, 3);
+    M4(t, r, 3) = -s;
+  }
+  M4(t, 3, 3) = 1.0;
+  memcpy(out, t, sizeof t);
+}
+
+/* Eigen::AngleAxisd(R).angle(): via quaternion, angle = 2*atan2(|vec|, |w|) in [0,pi] */
+double s3o_rotation_angle(const double m[16]) {
+  /* rotation matrix -> quaternion (Eigen's Shepperd branch selection) */
+  double m00 = M4(m, 0, 0), m11 = M4(m, 1, 1), m22 = M4(m, 2, 2);
+  double t = m00 + m11 + m22, w, x, y, z;
+  if (t > 0) {
+    t = sqrt(t + 1.0);
+    w = 0.5 * t;
+    t = 0.5 / t;
+    x = (M4(m, 2, 1) - M4(m, 1, 2)) * t;
+    y = (M4(m, 0, 2) - M4(m, 2, 0)) * t;
+    z = (M4(m, 1, 0) - M4(m, 0, 1)) * t;
+  } else {
+    int i = 0;
+    if (m11 > m00) i = 1;
+    if (m22 > M4(m, i, i)) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    double q[3];
+    t = sqrt(M4(m, i, i) - M4(m, j, j) - M4(m, k, k) + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    w = (M4(m, k, j) - M4(m, j, k)) * t;
+    q[j] = (M4(m, j, i) + M4(m, i, j)) * t;
+    q[k] = (M4(m, k, i) + M4(m, i, k)) * t;
+    x = q[0]; y = q[1]; z = q[2];
+  }
+  double n = sqrt(x * x + y * y + z * z);
+  return 2.0 * atan2(n, fabs(w));
+}
+
+/* cyclic Jacobi for a symmetric 3x3 (row-major a); eigenvalues descending,
+ * eigenvectors in the COLUMNS of v (row-major 3x3).  Stands in for
+ * Eigen::JacobiSVD<Matrix3d>(cov, ComputeFullU) on a symmetric PSD matrix
+ * (PCL gicp.hpp computeCovariances): singular values == eigenvalues, U == V. */
+void s3o_sym_eig3(const double a_in[9], double ev[3], double v[9]) {
+  double a[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) a[i][j] = a_in[i * 3 + j];
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+    double diag = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+    if (off <= 1e-300 || off <= 1e-34 * diag) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (a[p][q] == 0.0) continue;
+        double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) { /* A <- A J */
+          double akp = a[k][p], akq = a[k][q];
+          a[k][p] = c * akp - s * akq;
+          a[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) { /* A <- J^T A */
+          double apk = a[p][k], aqk = a[q][k];
+          a[p][k] = c * apk - s * aqk;
+          a[q][k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; ++k) {
+          double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  int order[3] = {0, 1, 2};
+  double d[3] = {a[0][0], a[1][1], a[2][2]};
+  for (int i = 0; i < 2; ++i)
+    for (int j = i + 1; j < 3; ++j)
+      if (d[order[j]] > d[order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+  for (int k = 0; k < 3; ++k) {
+    ev[k] = d[order[k]];
+    for (int r = 0; r < 3; ++r) v[r * 3 + k] = V[r][order[k]];
+  }
+}
+
+/* Eigen 3x3 inverse (compute_inverse_size3_helper): cofactors / determinant */
+static void mat3_inverse(const double m[3][3], double inv[3][3]) {
+  double c00 = m[1][1] * m[2][2] - m[1][2] * m[2][1];
+  double c10 = m[1][2] * m[2][0] - m[1][0] * m[2][2]; /* cofactor(1,0) of transpose layout */
+  double c20 = m[1][0] * m[2][1] - m[1][1] * m[2][0];
+  double det = m[0][0] * c00 + m[0][1] * c10 + m[0][2] * c20;
+  double id = 1.0 / det;
+  inv[0][0] = c00 * id;
+  inv[1][0] = c10 * id;
+  inv[2][0] = c20 * id;
+  inv[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * id;
+  inv[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) * id;
+  inv[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) * id;
+  inv[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * id;
+  inv[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) * id;
+  inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) * id;
+}
+
+/* pcl::transformPointCloud(cloud, cloud, Matrix4f): pcl::detail::Transformer::se3
+ * (PCL common/impl/transforms.hpp): p0 + (p1 + (p2 + c3)) */
+static inline void xf_pcl(const float m[16], const float p[3], float o[3]) {
+  for (int r = 0; r < 3; ++r) {
+    float p0 = M4(m, r, 0) * p[0], p1 = M4(m, r, 1) * p[1], p2 = M4(m, r, 2) * p[2];
+    o[r] = p0 + (p1 + (p2 + M4(m, r, 3)));
+  }
+}
+/* Eigen Matrix4f * Vector4f (w = 1): ((c0*x + c1*y) + c2*z) + c3*w */
+static inline void xf_eigen(const float m[16], const float p[3], float o[3]) {
+  for (int r = 0; r < 3; ++r)
+    o[r] = ((M4(m, r, 0) * p[0] + M4(m, r, 1) * p[1]) + M4(m, r, 2) * p[2]) + M4(m, r, 3);
+}
+/* Eigen Matrix4f * Matrix4f, coefficient order k = 0..3 */
+static void mat4f_mul(const float a[16], const float b[16], float out[16]) {
+  float t[16];
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+      t[c * 4 + r] = ((M4(a, r, 0) * M4(b, 0, c) + M4(a, r, 1) * M4(b, 1, c)) + M4(a, r, 2) * M4(b, 2, c)) +
+                     M4(a, r, 3) * M4(b, 3, c);
+  memcpy(out, t, sizeof t);
+}
+
+/* ------------------------------------------------------------------ voxel grid (A3) */
+
+typedef struct { unsigned key; int idx; } key_idx;
+static int cmp_key_idx(const void* a, const void* b) {
+  const key_idx *x = (const key_idx*)a, *y = (const key_idx*)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+
+int s3o_voxel_downsample(const float* xyz, int n, int stride, double leaf_size, float* out,
+                         s3o_voxel_info* info) {
+  s3o_voxel_info li;
+  memset(&li, 0, sizeof li);
+  if (n <= 0) { /* PCS.cpp:193: empty in -> empty out */
+    if (info) *info = li;
+    return 0;
+  }
+  /* PCS.cpp:196 setLeafSize(double->float); PCL voxel_grid.h: inverse = 1/leaf (float) */
+  const float leaf = (float)leaf_size;
+  const float inv = 1.0f / leaf;
+  /* PCL common getMinMax3D */
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  int n_finite = 0;
+  for (int i = 0; i < n; ++i) {
+    const float* p = xyz + (size_t)i * stride;
+    if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+    ++n_finite;
+    for (int a = 0; a < 3; ++a) {
+      if (p[a] < mn[a]) mn[a] = p[a];
+      if (p[a] > mx[a]) mx[a] = p[a];
+    }
+  }
+  if (n_finite == 0) {
+    if (info) *info = li;
+    return 0;
+  }
+  for (int a = 0; a < 3; ++a) { li.min_p[a] = mn[a]; li.max_p[a] = mx[a]; }
+  /* PCL voxel_grid.hpp applyFilter: overflow check */
+  int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1;
+  int64_t dy = (int64_t)((mx[1] - mn[1]) * inv) + 1;
+  int64_t dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+  if (dx * dy * dz > (int64_t)INT_MAX) {
+    li.passthrough = 1; /* "Leaf size is too small": output = input */
+    for (int i = 0; i < n; ++i)
+      for (int a = 0; a < 3; ++a) out[(size_t)i * 3 + a] = xyz[(size_t)i * stride + a];
+    if (info) *info = li;
+    return n;
+  }
+  for (int a = 0; a < 3; ++a) {
+    li.min_b[a] = (int)floorf(mn[a] * inv);
+    li.max_b[a] = (int)floorf(mx[a] * inv);
+    li.div_b[a] = li.max_b[a] - li.min_b[a] + 1;
+  }
+  const int mul[3] = {1, li.div_b[0], li.div_b[0] * li.div_b[1]};
+  key_idx* kv = (key_idx*)malloc(sizeof(key_idx) * (size_t)n);
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) {
+    const float* p = xyz + (size_t)i * stride;
+    if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+    int ijk0 = (int)(floorf(p[0] * inv) - (float)li.min_b[0]);
+    int ijk1 = (int)(floorf(p[1] * inv) - (float)li.min_b[1]);
+    int ijk2 = (int)(floorf(p[2] * inv) - (float)li.min_b[2]);
+    kv[cnt].key = (unsigned)(ijk0 * mul[0] + ijk1 * mul[1] + ijk2 * mul[2]);
+    kv[cnt].idx = i;
+    ++cnt;
+  }
+  /* PCL sorts by voxel index only (order inside a voxel unspecified); the
+   * restatement fixes it to ascending point index. */
+  qsort(kv, (size_t)cnt, sizeof(key_idx), cmp_key_idx);
+  int total = 0;
+  for (int i = 0; i < cnt;) {
+    int j = i;
+    float sx = 0.f, sy = 0.f, sz = 0.f; /* AccumulatorXYZ: Eigen::Vector3f sum */
+    while (j < cnt && kv[j].key == kv[i].key) {
+      const float* p = xyz + (size_t)kv[j].idx * stride;
+      sx += p[0]; sy += p[1]; sz += p[2];
+      ++j;
+    }
+    const float c = (float)(j - i);
+    out[(size_t)total * 3 + 0] = sx / c;
+    out[(size_t)total * 3 + 1] = sy / c;
+    out[(size_t)total * 3 + 2] = sz / c;
+    ++total;
+    i = j;
+  }
+  free(kv);
+  if (info) *info = li;
+  return total;
+}
+
+/* ------------------------------------------------------------------ kd-tree (A7) */
+
+typedef struct {
+  int   left, right;   /* children, -1 for leaf */
+  int   lo, hi;        /* leaf: range in perm[] */
+  int   dim;
+  float divlow, divhigh;
+} kd_node;
+
+struct s3o_kdtree {
+  const float* pts; /* packed xyz, not owned */
+  int      n;
+  int*     perm;
+  kd_node* nodes;
+  int      n_nodes, cap_nodes;
+  float    bbmin[3], bbmax[3];
+};
+
+#define KD_LEAF 15 /* FLANN KDTreeSingleIndexParams default leaf_max_size (PCL kdtree_flann.hpp) */
+
+static int kd_new_node(s3o_kdtree* t) {
+  if (t->n_nodes == t->cap_nodes) {
+    t->cap_nodes = t->cap_nodes ? t->cap_nodes * 2 : 1024;
+    t->nodes = (kd_node*)realloc(t->nodes, sizeof(kd_node) * (size_t)t->cap_nodes);
+  }
+  return t->n_nodes++;
+}
+
+static void kd_select(s3o_kdtree* t, int lo, int hi, int k, int dim) {
+  /* quickselect on perm[lo..hi) by coordinate dim (ties by index for determinism) */
+  int* p = t->perm;
+  const float* x = t->pts;
+  while (hi - lo > 1) {
+    int mid = lo + (hi - lo) / 2;
+    float pv = x[(size_t)p[mid] * 3 + dim];
+    int pi = p[mid];
+    int i = lo, j = hi - 1;
+    while (i <= j) {
+      while (x[(size_t)p[i] * 3 + dim] < pv || (x[(size_t)p[i] * 3 + dim] == pv && p[i] < pi)) ++i;
+      while (x[(size_t)p[j] * 3 + dim] > pv || (x[(size_t)p[j] * 3 + dim] == pv && p[j] > pi)) --j;
+      if (i <= j) { int tmp = p[i]; p[i] = p[j]; p[j] = tmp; ++i; --j; }
+    }
+    if (k <= j) hi = j + 1;
+    else if (k >= i) lo = i;
+    else return;
+  }
+}
+
+static int kd_build_rec(s3o_kdtree* t, int lo, int hi) {
+  int id = kd_new_node(t);
+  kd_node nd;
+  nd.left = nd.right = -1; nd.lo = lo; nd.hi = hi; nd.dim = 0; nd.divlow = nd.divhigh = 0;
+  if (hi - lo <= KD_LEAF) { t->nodes[id] = nd; return id; }
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = lo; i < hi; ++i)
+    for (int a = 0; a < 3; ++a) {
+      float v = t->pts[(size_t)t->perm[i] * 3 + a];
+      if (v < mn[a]) mn[a] = v;
+      if (v > mx[a]) mx[a] = v;
+    }
+  int dim = 0;
+  if (mx[1] - mn[1] > mx[dim] - mn[dim]) dim = 1;
+  if (mx[2] - mn[2] > mx[dim] - mn[dim]) dim = 2;
+  int mid = lo + (hi - lo) / 2;
+  kd_select(t, lo, hi, mid, dim);
+  float dl = -FLT_MAX, dh = FLT_MAX;
+  for (int i = lo; i < mid; ++i) { float v = t->pts[(size_t)t->perm[i] * 3 + dim]; if (v > dl) dl = v; }
+  dh = FLT_MAX;
+  for (int i = mid; i < hi; ++i) { float v = t->pts[(size_t)t->perm[i] * 3 + dim]; if (v < dh) dh = v; }
+  nd.dim = dim; nd.divlow = dl; nd.divhigh = dh;
+  t->nodes[id] = nd;
+  int l = kd_build_rec(t, lo, mid);
+  int r = kd_build_rec(t, mid, hi);
+  t->nodes[id].left = l;
+  t->nodes[id].right = r;
+  return id;
+}
+
+s3o_kdtree* s3o_kdtree_build(const float* xyz, int n) {
+  s3o_kdtree* t = (s3o_kdtree*)calloc(1, sizeof *t);
+  t->pts = xyz; t->n = n;
+  t->perm = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  for (int i = 0; i < n; ++i) t->perm[i] = i;
+  for (int a = 0; a < 3; ++a) { t->bbmin[a] = FLT_MAX; t->bbmax[a] = -FLT_MAX; }
+  for (int i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a) {
+      float v = xyz[(size_t)i * 3 + a];
+      if (v < t->bbmin[a]) t->bbmin[a] = v;
+      if (v > t->bbmax[a]) t->bbmax[a] = v;
+    }
+  if (n > 0) kd_build_rec(t, 0, n);
+  return t;
+}
+void s3o_kdtree_free(s3o_kdtree* t) {
+  if (!t) return;
+  free(t->perm); free(t->nodes); free(t);
+}
+
+/* FLANN L2_Simple: result += diff*diff over dims, float */
+static inline float dist2f(const float* a, const float* b) {
+  float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+typedef struct {
+  const s3o_kdtree* t;
+  const float* q;
+  int k, cnt;
+  int* idx;   /* sorted ascending by (d2, idx) */
+  float* d2;
+} kd_query;
+
+static inline int lex_less(float d2a, int ia, float d2b, int ib) {
+  return d2a < d2b || (d2a == d2b && ia < ib);
+}
+static void kq_insert(kd_query* s, float d2, int i) {
+  if (s->cnt == s->k && !lex_less(d2, i, s->d2[s->k - 1], s->idx[s->k - 1])) return;
+  int pos = s->cnt < s->k ? s->cnt++ : s->k - 1;
+  while (pos > 0 && lex_less(d2, i, s->d2[pos - 1], s->idx[pos - 1])) {
+    s->d2[pos] = s->d2[pos - 1]; s->idx[pos] = s->idx[pos - 1]; --pos;
+  }
+  s->d2[pos] = d2; s->idx[pos] = i;
+}
+static void kd_search_rec(kd_query* s, int id, double mind2, double dists[3]) {
+  const kd_node* nd = &s->t->nodes[id];
+  if (nd->left < 0) {
+    for (int i = nd->lo; i < nd->hi; ++i) {
+      int pi = s->t->perm[i];
+      kq_insert(s, dist2f(s->q, s->t->pts + (size_t)pi * 3), pi);
+    }
+    return;
+  }
+  int dim = nd->dim;
+  double val = s->q[dim];
+  double diff1 = val - nd->divlow, diff2 = val - nd->divhigh;
+  int best, other; double cut;
+  if (diff1 + diff2 < 0) { best = nd->left; other = nd->right; cut = diff2 * diff2; }
+  else { best = nd->right; other = nd->left; cut = diff1 * diff1; }
+  kd_search_rec(s, best, mind2, dists);
+  double dst = dists[dim];
+  double m2 = mind2 + cut - dst;
+  dists[dim] = cut;
+  /* exact search (eps = 0); small relative margin so that float rounding of the
+   * point distances can never prune a lexicographically better candidate */
+  if (s->cnt < s->k || m2 * (1.0 - 1e-6) <= (double)s->d2[s->k - 1]) kd_search_rec(s, other, m2, dists);
+  dists[dim] = dst;
+}
+int s3o_kdtree_knn(const s3o_kdtree* t, const float q[3], int k, int* idx, float* d2) {
+  if (t->n == 0 || k <= 0) return 0;
+  kd_query s = {t, q, k < t->n ? k : t->n, 0, idx, d2};
+  double dists[3] = {0, 0, 0}, m = 0;
+  for (int a = 0; a < 3; ++a) {
+    if (q[a] < t->bbmin[a]) { double d = (double)q[a] - t->bbmin[a]; dists[a] = d * d; }
+    if (q[a] > t->bbmax[a]) { double d = (double)q[a] - t->bbmax[a]; dists[a] = d * d; }
+    m += dists[a];
+  }
+  kd_search_rec(&s, 0, m, dists);
+  return s.cnt;
+}
+void s3o_kdtree_nn1(const s3o_kdtree* t, const float q[3], int* idx, float* d2) {
+  *idx = -1; *d2 = FLT_MAX;
+  s3o_kdtree_knn(t, q, 1, idx, d2);
+}
+void s3o_nn_search(const float* tgt, int n, const float* qry, int m, int* idx, float* d2) {
+  s3o_kdtree* t = s3o_kdtree_build(tgt, n);
+  for (int i = 0; i < m; ++i) s3o_kdtree_nn1(t, qry + (size_t)i * 3, &idx[i], &d2[i]);
+  s3o_kdtree_free(t);
+}
+void s3o_nn_search_brute(const float* tgt, int n, const float* qry, int m, int* idx, float* d2) {
+  for (int i = 0; i < m; ++i) {
+    int bi = -1; float bd = FLT_MAX;
+    for (int j = 0; j < n; ++j) {
+      float d = dist2f(qry + (size_t)i * 3, tgt + (size_t)j * 3);
+      if (d < bd) { bd = d; bi = j; }
+    }
+    idx[i] = bi; d2[i] = bd;
+  }
+}
+
+/* ------------------------------------------------------------------ covariances (A6) */
+
+static int gicp_covariances_tree(const s3o_kdtree* tree, const float* xyz, int n, int k, double eps,
+                                 double* cov, double* normals) {
+  if (k > n) return -1; /* PCL gicp.hpp: "Number of points in cloud is less than k_correspondences_" */
+  int* nn_i = (int*)malloc(sizeof(int) * (size_t)k);
+  float* nn_d = (float*)malloc(sizeof(float) * (size_t)k);
+  for (int i = 0; i < n; ++i) {
+    double c[3][3] = {{0}}, mean[3] = {0, 0, 0};
+    s3o_kdtree_knn(tree, xyz + (size_t)i * 3, k, nn_i, nn_d);
+    for (int j = 0; j < k; ++j) {
+      const float* pt = xyz + (size_t)nn_i[j] * 3;
+      mean[0] += pt[0]; mean[1] += pt[1]; mean[2] += pt[2];
+      /* PCL: cov(0,0) += pt.x * pt.x;  — float product, double accumulation */
+      c[0][0] += pt[0] * pt[0];
+      c[1][0] += pt[1] * pt[0];
+      c[1][1] += pt[1] * pt[1];
+      c[2][0] += pt[2] * pt[0];
+      c[2][1] += pt[2] * pt[1];
+      c[2][2] += pt[2] * pt[2];
+    }
+    for (int a = 0; a < 3; ++a) mean[a] /= (double)k;
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b <= a; ++b) {
+        c[a][b] /= (double)k;
+        c[a][b] -= mean[a] * mean[b];
+        c[b][a] = c[a][b];
+      }
+    double ev[3], U[9];
+    s3o_sym_eig3((const double*)c, ev, U);
+    /* cov = sum_k v_k u_k u_k^T, v = (1, 1, gicp_epsilon) */
+    double* out = cov + (size_t)i * 9;
+    for (int a = 0; a < 9; ++a) out[a] = 0;
+    for (int kk = 0; kk < 3; ++kk) {
+      double v = kk == 2 ? eps : 1.0;
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) out[a * 3 + b] += v * U[a * 3 + kk] * U[b * 3 + kk];
+    }
+    if (normals) for (int a = 0; a < 3; ++a) normals[(size_t)i * 3 + a] = U[a * 3 + 2];
+  }
+  free(nn_i); free(nn_d);
+  return 0;
+}
+int s3o_gicp_covariances(const float* xyz, int n, int k, double eps, double* cov, double* normals) {
+  s3o_kdtree* t = s3o_kdtree_build(xyz, n);
+  int rc = gicp_covariances_tree(t, xyz, n, k, eps, cov, normals);
+  s3o_kdtree_free(t);
+  return rc;
+}
+
+/* ------------------------------------------------------------------ GICP (A4, A5, A8) */
+static int g_eval_double; static double g_perturb; static int g_trace;
+
+typedef struct {
+  const float* src;      /* `output` cloud: pcl source transformed by guess, packed xyz */
+  const float* tgt;      /* pcl target */
+  const int*   idx_src;
+  const int*   idx_tgt;
+  const double* mahal;   /* per pcl-source point 3x3 row-major */
+  int m;
+  int evals;
+} gicp_functor;
+
+/* PCL gicp.hpp applyState on base_transformation_ = Identity:
+ * R = Rz(x5) Ry(x4) Rx(x3) as float, t = float(x0..2).  (Eigen composes
+ * AngleAxisf quaternions in float; here R is formed in double and rounded.) */
+static void apply_state(const double x[6], float t[16]) {
+  double cphi = cos(x[3]), sphi = sin(x[3]);
+  double cth = cos(x[4]), sth = sin(x[4]);
+  double cpsi = cos(x[5]), spsi = sin(x[5]);
+  double R[3][3] = {{cpsi * cth, cpsi * sth * sphi - spsi * cphi, cpsi * sth * cphi + spsi * sphi},
+                    {spsi * cth, spsi * sth * sphi + cpsi * cphi, spsi * sth * cphi - cpsi * sphi},
+                    {-sth, cth * sphi, cth * cphi}};
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) M4(t, r, c) = (float)R[r][c];
+    M4(t, r, 3) = (float)x[r];
+    M4(t, 3, r) = 0.f;
+  }
+  M4(t, 3, 3) = 1.f;
+}
+
+/* PCL OptimizationFunctorWithIndices::fdf — f and gradient in one pass */
+static void gicp_fdf(gicp_functor* F, const double x[6], double* f_out, double g[6], int want_f, int want_g) {
+  float T[16];
+  apply_state(x, T);
+  double Td[3][4];
+  {
+    double cphi = cos(x[3]), sphi = sin(x[3]), cth = cos(x[4]), sth = sin(x[4]), cpsi = cos(x[5]), spsi = sin(x[5]);
+    Td[0][0] = cpsi * cth; Td[0][1] = cpsi * sth * sphi - spsi * cphi; Td[0][2] = cpsi * sth * cphi + spsi * sphi;
+    Td[1][0] = spsi * cth; Td[1][1] = spsi * sth * sphi + cpsi * cphi; Td[1][2] = spsi * sth * cphi - cpsi * sphi;
+    Td[2][0] = -sth; Td[2][1] = cth * sphi; Td[2][2] = cth * cphi;
+    Td[0][3] = x[0]; Td[1][3] = x[1]; Td[2][3] = x[2];
+  }
+  double f = 0, gt[3] = {0, 0, 0}, Rs[3][3] = {{0}};
+  F->evals++;
+  for (int i = 0; i < F->m; ++i) {
+    const float* ps = F->src + (size_t)F->idx_src[i] * 3;
+    const float* pt = F->tgt + (size_t)F->idx_tgt[i] * 3;
+    double res[3];
+    if (!g_eval_double) {
+      float pp[3];
+      xf_eigen(T, ps, pp); /* Eigen::Vector4f pp(transformation_matrix * p_src) */
+      res[0] = (double)(pp[0] - pt[0]); res[1] = (double)(pp[1] - pt[1]); res[2] = (double)(pp[2] - pt[2]);
+    } else if (g_eval_double == 1) { /* variant 1: same float matrix, products and sums carried in double */
+      for (int a = 0; a < 3; ++a)
+        res[a] = ((double)M4(T, a, 0) * ps[0] + (double)M4(T, a, 1) * ps[1] + (double)M4(T, a, 2) * ps[2] +
+                  (double)M4(T, a, 3)) - (double)pt[a];
+    } else { /* variant 2: the matrix itself is kept in double (smooth objective) */
+      for (int a = 0; a < 3; ++a)
+        res[a] = (Td[a][0] * ps[0] + Td[a][1] * ps[1] + Td[a][2] * ps[2] + Td[a][3]) - (double)pt[a];
+    }
+    const double* M = F->mahal + (size_t)F->idx_src[i] * 9;
+    double tmp[3];
+    for (int a = 0; a < 3; ++a) tmp[a] = M[a * 3 + 0] * res[0] + M[a * 3 + 1] * res[1] + M[a * 3 + 2] * res[2];
+    if (want_f) f += res[0] * tmp[0] + res[1] * tmp[1] + res[2] * tmp[2];
+    if (want_g) {
+      for (int a = 0; a < 3; ++a) gt[a] += tmp[a];
+      /* pp = base_transformation_ (Identity) * p_src */
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) Rs[a][b] += (double)ps[a] * tmp[b];
+    }
+  }
+  if (want_f) *f_out = f / (double)F->m;
+  if (want_g) {
+    double s = 2.0 / (double)F->m;
+    for (int a = 0; a < 3; ++a) g[a] = gt[a] * s;
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) Rs[a][b] *= s;
+    /* computeRDerivative: g[3+k] = sum_ij dR_k(j,i) * Rs(i,j) */
+    double cphi = cos(x[3]), sphi = sin(x[3]);
+    double cth = cos(x[4]), sth = sin(x[4]);
+    double cpsi = cos(x[5]), spsi = sin(x[5]);
+    double dPhi[3][3] = {{0, sphi * spsi + cphi * cpsi * sth, cphi * spsi - cpsi * sphi * sth},
+                         {0, -cpsi * sphi + cphi * spsi * sth, -cphi * cpsi - sphi * spsi * sth},
+                         {0, cphi * cth, -cth * sphi}};
+    double dTh[3][3] = {{-cpsi * sth, cpsi * cth * sphi, cphi * cpsi * cth},
+                        {-spsi * sth, cth * sphi * spsi, cphi * cth * spsi},
+                        {-cth, -sphi * sth, -cphi * sth}};
+    double dPsi[3][3] = {{-cth * spsi, -cphi * cpsi - sphi * spsi * sth, cpsi * sphi - cphi * spsi * sth},
+                         {cpsi * cth, -cphi * spsi + cpsi * sphi * sth, sphi * spsi + cphi * cpsi * sth},
+                         {0, 0, 0}};
+    g[3] = g[4] = g[5] = 0;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        g[3] += dPhi[j][i] * Rs[i][j];
+        g[4] += dTh[j][i] * Rs[i][j];
+        g[5] += dPsi[j][i] * Rs[i][j];
+      }
+  }
+}
+
+/* diagnostics / variants (all default to the PCL-literal behaviour) */
+static int    g_eval_double = 0; /* see s3d_oracle.h: 0 PCL-literal, 1 double arithmetic, 2 double matrix */
+static double g_perturb = 0.0;   /* relative noise injected into the Mahalanobis matrices */
+static int    g_trace = 0;
+void s3o_set_eval_precision(int mode) { g_eval_double = mode; }
+void s3o_set_debug_perturbation(double rel) { g_perturb = rel; }
+void s3o_set_trace(int on) { g_trace = on; }
+
+/* ---- PCL registration/bfgs.h (a port of GSL vector_bfgs2 + Fletcher line search) */
+enum { BFGS_RUNNING = -1, BFGS_SUCCESS = 0, BFGS_NOPROGRESS = 1 };
+
+typedef struct {
+  gicp_functor* F;
+  double f, gradient[6];
+  double x0[6], g0[6], p[6], dx0[6], dg0[6];
+  double g0norm, pnorm, fp0, delta_f;
+  /* line-search cache ("wrapper" of GSL) */
+  double x_alpha[6], g_alpha[6], f_alpha, df_alpha;
+  double f_cache_key, df_cache_key, x_cache_key, g_cache_key;
+} bfgs_t;
+
+static double vnorm6(const double* v) { double s = 0; for (int i = 0; i < 6; ++i) s += v[i] * v[i]; return sqrt(s); }
+static double vdot6(const double* a, const double* b) { double s = 0; for (int i = 0; i < 6; ++i) s += a[i] * b[i]; return s; }
+
+static void bfgs_move_to(bfgs_t* b, double alpha) {
+  if (alpha == b->x_cache_key) return;
+  for (int i = 0; i < 6; ++i) b->x_alpha[i] = b->x0[i] + alpha * b->p[i];
+  b->x_cache_key = alpha;
+}
+static double bfgs_slope(bfgs_t* b) { return vdot6(b->g_alpha, b->p); }
+static double bfgs_apply_f(bfgs_t* b, double alpha) {
+  if (alpha == b->f_cache_key) return b->f_alpha;
+  bfgs_move_to(b, alpha);
+  gicp_fdf(b->F, b->x_alpha, &b->f_alpha, NULL, 1, 0);
+  b->f_cache_key = alpha;
+  return b->f_alpha;
+}
+static double bfgs_apply_df(bfgs_t* b, double alpha) {
+  if (alpha == b->df_cache_key) return b->df_alpha;
+  bfgs_move_to(b, alpha);
+  if (alpha != b->g_cache_key) {
+    gicp_fdf(b->F, b->x_alpha, NULL, b->g_alpha, 0, 1);
+    b->g_cache_key = alpha;
+  }
+  b->df_alpha = bfgs_slope(b);
+  b->df_cache_key = alpha;
+  return b->df_alpha;
+}
+static void bfgs_apply_fdf(bfgs_t* b, double alpha, double* f, double* df) {
+  if (alpha == b->f_cache_key && alpha == b->df_cache_key) { *f = b->f_alpha; *df = b->df_alpha; return; }
+  if (alpha == b->f_cache_key || alpha == b->df_cache_key) {
+    *f = bfgs_apply_f(b, alpha);
+    *df = bfgs_apply_df(b, alpha);
+    return;
+  }
+  bfgs_move_to(b, alpha);
+  gicp_fdf(b->F, b->x_alpha, &b->f_alpha, b->g_alpha, 1, 1);
+  b->f_cache_key = alpha;
+  b->g_cache_key = alpha;
+  b->df_alpha = bfgs_slope(b);
+  b->df_cache_key = alpha;
+  *f = b->f_alpha; *df = b->df_alpha;
+}
+static void bfgs_update_position(bfgs_t* b, double alpha, double x[6], double* f, double g[6]) {
+  double fa, dfa;
+  bfgs_apply_fdf(b, alpha, &fa, &dfa);
+  *f = fa;
+  memcpy(x, b->x_alpha, sizeof b->x_alpha);
+  memcpy(g, b->g_alpha, sizeof b->g_alpha);
+}
+static void bfgs_change_direction(bfgs_t* b) {
+  memcpy(b->x_alpha, b->x0, sizeof b->x0);
+  b->x_cache_key = 0.0;
+  b->f_cache_key = 0.0;
+  memcpy(b->g_alpha, b->g0, sizeof b->g0);
+  b->g_cache_key = 0.0;
+  b->df_alpha = bfgs_slope(b);
+  b->df_cache_key = 0.0;
+}
+
+static double poly3(const double c[4], double z) { return c[0] + z * (c[1] + z * (c[2] + z * c[3])); }
+static void check_extremum(const double c[4], double z, double* zmin, double* fmin) {
+  double y = poly3(c, z);
+  if (y < *fmin) { *zmin = z; *fmin = y; }
+}
+/* PCL BFGS::interpolate (GSL interpolate / interp_cubic / interp_quad) */
+static double bfgs_interpolate(double a, double fa, double fpa, double b, double fb, double fpb, double xmin,
+                               double xmax, int order) {
+  double y, ymin = (xmin - a) / (b - a), ymax = (xmax - a) / (b - a);
+  if (ymin > ymax) { double t = ymin; ymin = ymax; ymax = t; }
+  if (order > 2 && !(fpb != fpb) && fpb != INFINITY) {
+    fpa = fpa * (b - a);
+    fpb = fpb * (b - a);
+    double eta = 3 * (fb - fa) - 2 * fpa - fpb;
+    double xi = fpa + fpb - 2 * (fb - fa);
+    double c[4] = {fa, fpa, eta, xi};
+    y = ymin;
+    double fmin = poly3(c, ymin);
+    check_extremum(c, ymax, &y, &fmin);
+    /* roots of c1 + 2 c2 z + 3 c3 z^2 */
+    double A = 3 * c[3], B = 2 * c[2], C = c[1];
+    if (A == 0) {
+      if (B != 0) {
+        double y0 = -C / B;
+        if (y0 > ymin && y0 < ymax) check_extremum(c, y0, &y, &fmin);
+      }
+    } else {
+      double disc = B * B - 4 * A * C;
+      if (disc > 0) {
+        double sq = sqrt(disc);
+        double tq = -0.5 * (B + (B > 0 ? sq : -sq));
+        double y0 = tq / A, y1 = (tq != 0) ? C / tq : y0;
+        if (y0 > y1) { double t = y0; y0 = y1; y1 = t; }
+        if (y0 > ymin && y0 < ymax) check_extremum(c, y0, &y, &fmin);
+        if (y1 > ymin && y1 < ymax) check_extremum(c, y1, &y, &fmin);
+      } else if (disc == 0) {
+        double y0 = -0.5 * B / A;
+        if (y0 > ymin && y0 < ymax) check_extremum(c, y0, &y, &fmin);
+      }
+    }
+  } else {
+    fpa = fpa * (b - a);
+    double fl = fa + ymin * (fpa + ymin * (fb - fa - fpa));
+    double fh = fa + ymax * (fpa + ymax * (fb - fa - fpa));
+    double c = 2 * (fb - fa - fpa); /* curvature */
+    y = ymin;
+    double fmin = fl;
+    if (fh < fmin) { y = ymax; fmin = fh; }
+    /* PCL bfgs.h writes `if (c > a)` where GSL has `c > 0`; a == 0 in the
+     * common first-bracket case.  Restated as PCL has it. */
+    if (c > a) {
+      double z = -fpa / c;
+      if (z > ymin && z < ymax) {
+        double f = fa + z * (fpa + z * (fb - fa - fpa));
+        if (f < fmin) { y = z; fmin = f; }
+      }
+    }
+  }
+  return a + y * (b - a);
+}
+
+static int bfgs_line_search(bfgs_t* B, double rho, double sigma, double tau1, double tau2, double tau3, int order,
+                            double alpha1, double* alpha_new) {
+  const int bracket_iters = 100, section_iters = 100;
+  double f0, fp0, falpha, falpha_prev, fpalpha, fpalpha_prev, delta, alpha_next;
+  double alpha = alpha1, alpha_prev = 0.0;
+  double a, b, fa, fb, fpa, fpb;
+  int i = 0;
+  bfgs_apply_fdf(B, 0.0, &f0, &fp0);
+  falpha_prev = f0; fpalpha_prev = fp0;
+  a = 0.0; b = alpha; fa = f0; fb = 0.0; fpa = fp0; fpb = 0.0;
+  while (i++ < bracket_iters) {
+    falpha = bfgs_apply_f(B, alpha);
+    if (falpha > f0 + alpha * rho * fp0 || falpha >= falpha_prev) {
+      a = alpha_prev; fa = falpha_prev; fpa = fpalpha_prev;
+      b = alpha; fb = falpha; fpb = NAN;
+      break;
+    }
+    fpalpha = bfgs_apply_df(B, alpha);
+    if (fabs(fpalpha) <= -sigma * fp0) { *alpha_new = alpha; return BFGS_SUCCESS; }
+    if (fpalpha >= 0) {
+      a = alpha; fa = falpha; fpa = fpalpha;
+      b = alpha_prev; fb = falpha_prev; fpb = fpalpha_prev;
+      break;
+    }
+    delta = alpha - alpha_prev;
+    {
+      double lower = alpha + delta, upper = alpha + tau1 * delta;
+      alpha_next = bfgs_interpolate(alpha_prev, falpha_prev, fpalpha_prev, alpha, falpha, fpalpha, lower, upper, order);
+    }
+    alpha_prev = alpha; falpha_prev = falpha; fpalpha_prev = fpalpha; alpha = alpha_next;
+  }
+  while (i++ < section_iters) {
+    delta = b - a;
+    {
+      double lower = a + tau2 * delta, upper = b - tau3 * delta;
+      alpha = bfgs_interpolate(a, fa, fpa, b, fb, fpb, lower, upper, order);
+    }
+    falpha = bfgs_apply_f(B, alpha);
+    if ((a - alpha) * fpa <= DBL_EPSILON) return BFGS_NOPROGRESS; /* roundoff prevents progress */
+    if (falpha > f0 + rho * alpha * fp0 || falpha >= fa) {
+      b = alpha; fb = falpha; fpb = NAN;
+    } else {
+      fpalpha = bfgs_apply_df(B, alpha);
+      if (fabs(fpalpha) <= -sigma * fp0) { *alpha_new = alpha; return BFGS_SUCCESS; }
+      if (((b - a) >= 0 && fpalpha >= 0) || ((b - a) <= 0 && fpalpha <= 0)) {
+        b = a; fb = fa; fpb = fpa;
+        a = alpha; fa = falpha; fpa = fpalpha;
+      } else {
+        a = alpha; fa = falpha; fpa = fpalpha;
+      }
+    }
+  }
+  return BFGS_SUCCESS;
+}
+
+static void bfgs_init(bfgs_t* b, gicp_functor* F, const double x[6]) {
+  memset(b, 0, sizeof *b);
+  b->F = F;
+  b->delta_f = 0;
+  gicp_fdf(F, x, &b->f, b->gradient, 1, 1);
+  memcpy(b->x0, x, sizeof b->x0);
+  memcpy(b->g0, b->gradient, sizeof b->g0);
+  b->g0norm = vnorm6(b->g0);
+  for (int i = 0; i < 6; ++i) b->p[i] = b->gradient[i] * -1 / b->g0norm;
+  b->pnorm = vnorm6(b->p);
+  b->fp0 = -b->g0norm;
+  memcpy(b->x_alpha, b->x0, sizeof b->x0);
+  b->x_cache_key = 0;
+  b->f_alpha = b->f; b->f_cache_key = 0;
+  memcpy(b->g_alpha, b->g0, sizeof b->g0);
+  b->g_cache_key = 0;
+  b->df_alpha = bfgs_slope(b);
+  b->df_cache_key = 0;
+}
+
+static int bfgs_one_step(bfgs_t* b, double x[6]) {
+  /* parameters set at PCL gicp.hpp estimateRigidTransformationBFGS */
+  const double sigma = 0.01, rho = 0.01, tau1 = 9, tau2 = 0.05, tau3 = 0.5, step_size = 1.0;
+  const int order = 3;
+  double alpha = 0.0, alpha1;
+  double f0 = b->f;
+  if (b->pnorm == 0.0 || b->g0norm == 0.0 || b->fp0 == 0) return BFGS_NOPROGRESS;
+  if (b->delta_f < 0) {
+    double del = fmax(-b->delta_f, 10 * DBL_EPSILON * fabs(f0));
+    alpha1 = fmin(1.0, 2.0 * del / (-b->fp0));
+  } else {
+    alpha1 = fabs(step_size);
+  }
+  int status = bfgs_line_search(b, rho, sigma, tau1, tau2, tau3, order, alpha1, &alpha);
+  if (status != BFGS_SUCCESS) return status;
+  bfgs_update_position(b, alpha, x, &b->f, b->gradient);
+  b->delta_f = b->f - f0;
+  {
+    double dxg, dgg, dxdg, dgnorm, A, Bc;
+    for (int i = 0; i < 6; ++i) { b->dx0[i] = x[i] - b->x0[i]; b->dg0[i] = b->gradient[i] - b->g0[i]; }
+    dxg = vdot6(b->dx0, b->gradient);
+    dgg = vdot6(b->dg0, b->gradient);
+    dxdg = vdot6(b->dx0, b->dg0);
+    dgnorm = vnorm6(b->dg0);
+    if (dxdg != 0) {
+      Bc = dxg / dxdg;
+      A = -(1.0 + dgnorm * dgnorm / dxdg) * Bc + dgg / dxdg;
+    } else {
+      Bc = 0; A = 0;
+    }
+    for (int i = 0; i < 6; ++i) b->p[i] = -A * b->dx0[i] + b->gradient[i] - Bc * b->dg0[i];
+  }
+  memcpy(b->g0, b->gradient, sizeof b->g0);
+  memcpy(b->x0, x, sizeof b->x0);
+  b->g0norm = vnorm6(b->g0);
+  b->pnorm = vnorm6(b->p);
+  double dir = (vdot6(b->p, b->gradient) > 0) ? -1.0 : 1.0;
+  for (int i = 0; i < 6; ++i) b->p[i] *= dir / b->pnorm;
+  b->pnorm = vnorm6(b->p);
+  b->fp0 = vdot6(b->p, b->g0);
+  bfgs_change_direction(b);
+  return BFGS_SUCCESS;
+}
+
+/* PCL gicp.hpp estimateRigidTransformationBFGS.  returns 0 ok, -1 = exception */
+static int gicp_estimate_bfgs(gicp_functor* F, int max_inner, float T[16], int* inner_out) {
+  if (F->m < 4) return -1; /* NotEnoughPointsException */
+  double x[6];
+  x[0] = M4(T, 0, 3); x[1] = M4(T, 1, 3); x[2] = M4(T, 2, 3);
+  x[3] = atan2((double)M4(T, 2, 1), (double)M4(T, 2, 2));
+  x[4] = asin(-(double)M4(T, 2, 0));
+  x[5] = atan2((double)M4(T, 1, 0), (double)M4(T, 0, 0));
+  const double gradient_tol = 1e-2;
+  bfgs_t b;
+  bfgs_init(&b, F, x);
+  int inner = 0, result = BFGS_RUNNING;
+  do {
+    inner++;
+    result = bfgs_one_step(&b, x);
+    if (result) break;
+    result = vnorm6(b.gradient) < gradient_tol ? BFGS_SUCCESS : BFGS_RUNNING; /* testGradient */
+  } while (result == BFGS_RUNNING && inner < max_inner);
+  *inner_out = inner;
+  if (result == BFGS_NOPROGRESS || result == BFGS_SUCCESS || inner == max_inner) {
+    apply_state(x, T); /* setIdentity(); applyState() */
+    return 0;
+  }
+  return -1; /* SolverDidntConvergeException */
+}
+
+static const float IDENT4F[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+
+/* Registration::getFitnessScore (PCL registration.hpp), called at PCS.cpp:73 with
+ * max_range = max_correspondence_distance (compared against SQUARED distances). */
+static double fitness_tree(const s3o_kdtree* tree, const float* pcl_source, int m, const float final_tf[16],
+                           double max_range) {
+  double score = 0;
+  int nr = 0;
+  for (int i = 0; i < m; ++i) {
+    float q[3];
+    xf_pcl(final_tf, pcl_source + (size_t)i * 3, q);
+    int j; float d2;
+    s3o_kdtree_nn1(tree, q, &j, &d2);
+    if ((double)d2 <= max_range) { score += d2; nr++; }
+  }
+  return nr > 0 ? score / nr : DBL_MAX;
+}
+double s3o_fitness_score(const float* pcl_source, int m, const float* pcl_target, int n, const float final_tf[16],
+                         double max_range) {
+  s3o_kdtree* t = s3o_kdtree_build(pcl_target, n);
+  double f = fitness_tree(t, pcl_source, m, final_tf, max_range);
+  s3o_kdtree_free(t);
+  return f;
+}
+
+/* PCL gicp.hpp computeTransformation + Registration::align + PCS.cpp:52-82 */
+int s3o_gicp(const float* input, int m, const float* target, int n, const float guess[16],
+             const s3d_reg_params* cfg, int force_iterations, s3o_icp_result* out) {
+  memset(out, 0, sizeof *out);
+  const int k = cfg->correspondence_randomness;
+  const double gicp_epsilon = 0.001; /* PCL default gicp_epsilon_ */
+  s3o_kdtree* tree = s3o_kdtree_build(target, n);       /* tree_            */
+  s3o_kdtree* tree_r = s3o_kdtree_build(input, m);      /* tree_reciprocal_ */
+  double* cov_t = (double*)malloc(sizeof(double) * 9 * (size_t)n);
+  double* cov_i = (double*)malloc(sizeof(double) * 9 * (size_t)m);
+  double* mahal = (double*)malloc(sizeof(double) * 9 * (size_t)m);
+  float* output = (float*)malloc(sizeof(float) * 3 * (size_t)m);
+  int* si = (int*)malloc(sizeof(int) * (size_t)m);
+  int* ti = (int*)malloc(sizeof(int) * (size_t)m);
+  int rc = 0;
+  if (gicp_covariances_tree(tree, target, n, k, gicp_epsilon, cov_t, NULL) ||
+      gicp_covariances_tree(tree_r, input, m, k, gicp_epsilon, cov_i, NULL)) {
+    rc = -1;
+    goto done;
+  }
+  for (int i = 0; i < m; ++i)
+    for (int a = 0; a < 9; ++a) mahal[(size_t)i * 9 + a] = (a % 4 == 0) ? 1.0 : 0.0;
+  float transformation[16], previous[16];
+  memcpy(transformation, IDENT4F, sizeof IDENT4F);
+  memcpy(previous, IDENT4F, sizeof IDENT4F);
+  int nr_iterations = 0, converged = 0;
+  const double dist_threshold = cfg->max_correspondence_distance * cfg->max_correspondence_distance;
+  /* pcl::transformPointCloud(output, output, guess) */
+  for (int i = 0; i < m; ++i) xf_pcl(guess, input + (size_t)i * 3, output + (size_t)i * 3);
+  int cnt = 0;
+  while (!converged) {
+    cnt = 0;
+    double tR[4][4];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        double s = 0;
+        for (int kk = 0; kk < 4; ++kk) s += (double)M4(transformation, i, kk) * (double)M4(guess, kk, j);
+        tR[i][j] = s;
+      }
+    for (int i = 0; i < m; ++i) {
+      float q[3];
+      xf_eigen(transformation, output + (size_t)i * 3, q);
+      int j; float d2;
+      s3o_kdtree_nn1(tree, q, &j, &d2);
+      if ((double)d2 < dist_threshold) {
+        const double* C1 = cov_i + (size_t)i * 9;
+        const double* C2 = cov_t + (size_t)j * 9;
+        double Mt[3][3], tmp[3][3], inv[3][3];
+        for (int a = 0; a < 3; ++a) /* M = R*C1 */
+          for (int b = 0; b < 3; ++b) Mt[a][b] = tR[a][0] * C1[0 * 3 + b] + tR[a][1] * C1[1 * 3 + b] + tR[a][2] * C1[2 * 3 + b];
+        for (int a = 0; a < 3; ++a) /* temp = M*R' + C2 */
+          for (int b = 0; b < 3; ++b)
+            tmp[a][b] = (Mt[a][0] * tR[b][0] + Mt[a][1] * tR[b][1] + Mt[a][2] * tR[b][2]) + C2[a * 3 + b];
+        mat3_inverse(tmp, inv);
+        if (g_perturb != 0.0) /* conditioning probe, see s3o_set_debug_perturbation */
+          for (int a = 0; a < 3; ++a)
+            for (int b = a; b < 3; ++b) {
+              double r = 1.0 + g_perturb * ((double)rand() / RAND_MAX - 0.5);
+              inv[a][b] *= r; inv[b][a] = inv[a][b];
+            }
+        memcpy(mahal + (size_t)i * 9, inv, sizeof inv);
+        si[cnt] = i; ti[cnt] = j; cnt++;
+      }
+    }
+    memcpy(previous, transformation, sizeof previous);
+    gicp_functor F = {output, target, si, ti, mahal, cnt, 0};
+    int inner = 0;
+    if (gicp_estimate_bfgs(&F, cfg->maximum_optimizer_iterations, transformation, &inner)) {
+      out->evaluations_total += F.evals;
+      break; /* PCLException: converged_ stays false */
+    }
+    out->inner_iterations_total += inner;
+    out->evaluations_total += F.evals;
+    if (g_trace) fprintf(stderr, "[oracle] it %d cnt %d inner %d evals %d t=(%.9g %.9g %.9g) r21 %.9g r10 %.9g\n", nr_iterations, cnt, inner, F.evals, M4(transformation,0,3), M4(transformation,1,3), M4(transformation,2,3), M4(transformation,2,1), M4(transformation,1,0));
+    double delta = 0;
+    for (int kk = 0; kk < 4; ++kk)
+      for (int l = 0; l < 4; ++l) {
+        double ratio = (kk < 3 && l < 3) ? 1.0 / cfg->rotation_epsilon : 1.0 / cfg->transformation_epsilon;
+        double c_delta = ratio * fabs((double)M4(previous, kk, l) - (double)M4(transformation, kk, l));
+        if (c_delta > delta) delta = c_delta;
+      }
+    nr_iterations++;
+    if (nr_iterations >= cfg->maximum_iterations || (!force_iterations && delta < 1)) {
+      converged = 1;
+      memcpy(previous, transformation, sizeof previous);
+    }
+  }
+  mat4f_mul(previous, guess, out->final_transformation);
+  out->converged = converged;
+  out->iterations = nr_iterations;
+  out->correspondences = cnt;
+  out->fitness = fitness_tree(tree, input, m, out->final_transformation, cfg->max_correspondence_distance);
+done:
+  free(cov_t); free(cov_i); free(mahal); free(output); free(si); free(ti);
+  s3o_kdtree_free(tree); s3o_kdtree_free(tree_r);
+  return rc;
+}
+
+/* ------------------------------------------------------------------ point-to-plane ICP
+ * Not in the reference (enumerator ICP has no `case`, PCS.cpp:139-165).  Defined here
+ * (and in DESIGN.md) so that the HIP path for that enumerator has a CPU statement:
+ *   normals  = smallest-eigenvector of the k-NN covariance of the pcl TARGET cloud
+ *              (the same pre-pass GICP runs, k = correspondence_randomness);
+ *   outer loop, distance gate, delta stopping rule, fitness: as GICP above;
+ *   step: Gauss-Newton on sum (n_j . (p' + w x p' + dt - q_j))^2, 6x6 normal equations
+ *         solved by Cholesky in double, update T <- Exp(w, dt) * T kept in float. */
+static int chol6_solve(double A[6][6], double b[6], double x[6]) {
+  double L[6][6] = {{0}};
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = A[i][j];
+      for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+      if (i == j) { if (s <= 0) return -1; L[i][i] = sqrt(s); }
+      else L[i][j] = s / L[j][j];
+    }
+  double y[6];
+  for (int i = 0; i < 6; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= L[i][k] * y[k]; y[i] = s / L[i][i]; }
+  for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k]; x[i] = s / L[i][i]; }
+  return 0;
+}
+static void rodrigues(const double w[3], double R[3][3]) {
+  double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2), a, b;
+  if (th < 1e-8) { a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; }
+  else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; }
+  double K[3][3] = {{0, -w[2], w[1]}, {w[2], 0, -w[0]}, {-w[1], w[0], 0}};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double kk = K[i][0] * K[0][j] + K[i][1] * K[1][j] + K[i][2] * K[2][j];
+      R[i][j] = (i == j) + a * K[i][j] + b * kk;
+    }
+}
+
+int s3o_icp_point_to_plane(const float* input, int m, const float* target, int n, const float guess[16],
+                           const s3d_reg_params* cfg, int force_iterations, s3o_icp_result* out) {
+  memset(out, 0, sizeof *out);
+  const int k = cfg->correspondence_randomness;
+  s3o_kdtree* tree = s3o_kdtree_build(target, n);
+  double* cov_t = (double*)malloc(sizeof(double) * 9 * (size_t)n);
+  double* nrm = (double*)malloc(sizeof(double) * 3 * (size_t)n);
+  float* output = (float*)malloc(sizeof(float) * 3 * (size_t)m);
+  int rc = 0;
+  if (gicp_covariances_tree(tree, target, n, k, 0.001, cov_t, nrm)) { rc = -1; goto done; }
+  float transformation[16], previous[16];
+  memcpy(transformation, IDENT4F, sizeof IDENT4F);
+  memcpy(previous, IDENT4F, sizeof IDENT4F);
+  const double dist_threshold = cfg->max_correspondence_distance * cfg->max_correspondence_distance;
+  for (int i = 0; i < m; ++i) xf_pcl(guess, input + (size_t)i * 3, output + (size_t)i * 3);
+  int nr_iterations = 0, converged = 0, cnt = 0;
+  while (!converged) {
+    double A[6][6] = {{0}}, b[6] = {0};
+    cnt = 0;
+    for (int i = 0; i < m; ++i) {
+      float q[3];
+      xf_eigen(transformation, output + (size_t)i * 3, q);
+      int j; float d2;
+      s3o_kdtree_nn1(tree, q, &j, &d2);
+      if (!((double)d2 < dist_threshold)) continue;
+      /* normals are stored as float on the device path (xyz+normal SoA) */
+      const double nx = (double)(float)nrm[(size_t)j * 3 + 0], ny = (double)(float)nrm[(size_t)j * 3 + 1],
+                   nz = (double)(float)nrm[(size_t)j * 3 + 2];
+      const double px = q[0], py = q[1], pz = q[2];
+      const float* t = target + (size_t)j * 3;
+      double r = nx * (px - t[0]) + ny * (py - t[1]) + nz * (pz - t[2]);
+      double J[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
+      for (int a = 0; a < 6; ++a) {
+        b[a] -= J[a] * r;
+        for (int c = 0; c <= a; ++c) A[a][c] += J[a] * J[c];
+      }
+      cnt++;
+    }
+    for (int a = 0; a < 6; ++a)
+      for (int c = a + 1; c < 6; ++c) A[a][c] = A[c][a];
+    memcpy(previous, transformation, sizeof previous);
+    double xi[6];
+    if (cnt < 6 || chol6_solve(A, b, xi)) break; /* degenerate: converged_ stays false */
+    double R[3][3];
+    rodrigues(xi, R);
+    float nt[16];
+    memcpy(nt, IDENT4F, sizeof nt);
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 4; ++c) {
+        double s = 0;
+        for (int kk = 0; kk < 3; ++kk) s += R[r][kk] * (double)M4(transformation, kk, c);
+        if (c == 3) s += xi[3 + r];
+        M4(nt, r, c) = (float)s;
+      }
+    }
+    memcpy(transformation, nt, sizeof nt);
+    double delta = 0;
+    for (int kk = 0; kk < 4; ++kk)
+      for (int l = 0; l < 4; ++l) {
+        double ratio = (kk < 3 && l < 3) ? 1.0 / cfg->rotation_epsilon : 1.0 / cfg->transformation_epsilon;
+        double c_delta = ratio * fabs((double)M4(previous, kk, l) - (double)M4(transformation, kk, l));
+        if (c_delta > delta) delta = c_delta;
+      }
+    nr_iterations++;
+    if (nr_iterations >= cfg->maximum_iterations || (!force_iterations && delta < 1)) {
+      converged = 1;
+      memcpy(previous, transformation, sizeof previous);
+    }
+  }
+  mat4f_mul(previous, guess, out->final_transformation);
+  out->converged = converged;
+  out->iterations = nr_iterations;
+  out->correspondences = cnt;
+  out->fitness = fitness_tree(tree, input, m, out->final_transformation, cfg->max_correspondence_distance);
+done:
+  free(cov_t); free(nrm); free(output);
+  s3o_kdtree_free(tree);
+  return rc;
+}
+
+/* ------------------------------------------------------------------ align (A2) */
+
+int s3o_align(const float* source, int n_source, int stride_source, const float* target, int n_target,
+              int stride_target, const double guess[16], const s3d_reg_params* cfg, int force_iterations,
+              double result[16], s3o_align_info* info) {
+  s3o_align_info li;
+  memset(&li, 0, sizeof li);
+  int status = S3D_STATUS_OK;
+  float* fs = (float*)malloc(sizeof(float) * 3 * (size_t)(n_source > 0 ? n_source : 1));
+  float* ft = (float*)malloc(sizeof(float) * 3 * (size_t)(n_target > 0 ? n_target : 1));
+  int ns, nt;
+  if (cfg->point_cloud_density > 0) { /* PCS.cpp:127-131 */
+    ns = s3o_voxel_downsample(source, n_source, stride_source, cfg->point_cloud_density, fs, NULL);
+    nt = s3o_voxel_downsample(target, n_target, stride_target, cfg->point_cloud_density, ft, NULL);
+  } else {
+    ns = n_source; nt = n_target;
+    for (int i = 0; i < ns; ++i) for (int a = 0; a < 3; ++a) fs[(size_t)i * 3 + a] = source[(size_t)i * stride_source + a];
+    for (int i = 0; i < nt; ++i) for (int a = 0; a < 3; ++a) ft[(size_t)i * 3 + a] = target[(size_t)i * stride_target + a];
+  }
+  li.n_source_filtered = ns; li.n_target_filtered = nt;
+  for (int i = 0; i < 16; ++i) result[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  if (nt < 100 || ns < 100) { status = S3D_STATUS_TOO_FEW_POINTS; goto done; } /* PCS.cpp:134-135 */
+  float guess_f[16];
+  for (int i = 0; i < 16; ++i) guess_f[i] = (float)guess[i]; /* PCS.cpp:70 guess.matrix().cast<float>() */
+  s3o_icp_result r;
+  int rc;
+  switch (cfg->registration_algorithm) { /* PCS.cpp:139-165 */
+    case S3D_ALG_GICP:
+    case S3D_ALG_GICP_OMP:
+      /* setInputSource(target); setInputTarget(source)  PCS.cpp:68-69 */
+      rc = s3o_gicp(ft, nt, fs, ns, guess_f, cfg, force_iterations, &r);
+      break;
+    case S3D_ALG_ICP:
+      rc = s3o_icp_point_to_plane(ft, nt, fs, ns, guess_f, cfg, force_iterations, &r);
+      break;
+    case S3D_ALG_NDT:
+    case S3D_ALG_NDT_OMP:
+      status = S3D_STATUS_UNSUPPORTED_ALGORITHM; goto done;
+    default:
+      status = S3D_STATUS_UNKNOWN_ALGORITHM; goto done;
+  }
+  if (rc) { status = S3D_STATUS_INVALID_ARGUMENT; goto done; }
+  li.iterations = r.iterations; li.converged = r.converged; li.correspondences = r.correspondences;
+  li.fitness = r.fitness;
+  /* PCS.cpp:80: Transform(Eigen::Isometry3f(getFinalTransformation())) — widen, no re-orthonormalisation */
+  for (int i = 0; i < 16; ++i) result[i] = (double)r.final_transformation[i];
+  result[3] = result[7] = result[11] = 0.0; result[15] = 1.0;
+  if (!r.converged) { status = S3D_STATUS_NOT_CONVERGED; goto done; }          /* PCS.cpp:74 */
+  if (r.fitness > cfg->max_fitness_score) { status = S3D_STATUS_FITNESS_EXCEEDED; goto done; }
+  {
+    /* PCS.cpp:167-172 */
+    double ginv[16], delta[16];
+    s3o_mat4d_inverse_isometry(guess, ginv);
+    s3o_mat4d_mul(ginv, result, delta);
+    double tn = sqrt(M4(delta, 0, 3) * M4(delta, 0, 3) + M4(delta, 1, 3) * M4(delta, 1, 3) + M4(delta, 2, 3) * M4(delta, 2, 3));
+    double ang = s3o_rotation_angle(delta);
+    if (tn > cfg->max_translation || ang > cfg->max_rotation) status = S3D_STATUS_TOO_FAR_FROM_GUESS;
+  }
+done:
+  free(fs); free(ft);
+  if (info) *info = li;
+  return status;
+}
+
+/* ------------------------------------------------------------------ createConstraint (A1) */
+
+int s3o_create_constraint(const float* source, int n_source, int stride_source, const double source_sensor_pose[16],
+                          const float* target, int n_target, int stride_target, const double target_sensor_pose[16],
+                          const double odometry[16], int loop, const s3d_reg_params* fine,
+                          const s3d_reg_params* coarse, double covariance_scale, double relative_pose[16],
+                          double information[36], s3o_align_info* info) {
+  double sinv[16], tinv[16], guess[16], tmp[16];
+  s3o_mat4d_inverse_isometry(source_sensor_pose, sinv);
+  s3o_mat4d_inverse_isometry(target_sensor_pose, tinv);
+  /* PCS.cpp:274 */
+  s3o_mat4d_mul(sinv, odometry, tmp);
+  s3o_mat4d_mul(tmp, target_sensor_pose, guess);
+  int st;
+  if (loop) { /* PCS.cpp:286-289 */
+    double coarse_result[16];
+    st = s3o_align(source, n_source, stride_source, target, n_target, stride_target, guess, coarse, 0, coarse_result, info);
+    if (st != S3D_STATUS_OK) return st;
+    memcpy(guess, coarse_result, sizeof guess);
+  }
+  double icp_result[16];
+  st = s3o_align(source, n_source, stride_source, target, n_target, stride_target, guess, fine, 0, icp_result, info); /* :292 */
+  if (st != S3D_STATUS_OK) return st;
+  s3o_mat4d_mul(source_sensor_pose, icp_result, tmp); /* :295 */
+  s3o_mat4d_mul(tmp, tinv, relative_pose);
+  for (int i = 0; i < 36; ++i) information[i] = 0;
+  for (int i = 0; i < 6; ++i) information[i * 6 + i] = 1.0 / covariance_scale; /* :296-298 (I*scale)^-1 */
+  return S3D_STATUS_OK;
+}

@@ -1,0 +1,830 @@
+// s3d_core.h — per-thread math of the registration path, shared by the HIP
+// kernels (s3d_kernels.hip) and by the CPU emulation harness under tests/emu/
+// (g++; debugging aid only — the product library has no CPU back-end).
+//
+// Everything here is written MI355X-first: per-point covariances are stored as
+// a unit normal (C = I - (1-eps) n n^T), the GICP objective is accumulated ONCE
+// per outer iteration as a quadratic form in the 12 entries of [R|t] (73
+// doubles), and the BFGS inner loop then runs on that form without touching
+// the point data again.  The reference's (PCL's) per-evaluation loops over all
+// correspondences are restated in oracle/s3d_oracle.c; parity between the two
+// formulations is what tests/ check.
+//
+// Compile with -ffp-contract=off: float expressions marked "order matters"
+// must evaluate exactly as the oracle's; fma() is used explicitly elsewhere.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define S3D_HD __host__ __device__ __forceinline__
+#else
+#define S3D_HD inline
+#endif
+
+namespace s3d {
+
+// ------------------------------------------------------------------ small types
+
+struct F3 { float x, y, z; };
+struct F4 { float x, y, z, w; };
+
+// 4x4 float, column-major: (r,c) = m[c*4+r]  (Eigen::Matrix4f layout)
+struct Mat4f { float m[16]; };
+#define S3D_M(mat, r, c) ((mat).m[(c) * 4 + (r)])
+
+S3D_HD Mat4f mat4f_identity() {
+  Mat4f I;
+  for (int i = 0; i < 16; ++i) I.m[i] = (i % 5 == 0) ? 1.f : 0.f;
+  return I;
+}
+
+// pcl::transformPointCloud(Matrix4f): p0 + (p1 + (p2 + c3))   [order matters]
+S3D_HD F3 xf_pcl(const Mat4f& T, float x, float y, float z) {
+  F3 o;
+  o.x = S3D_M(T, 0, 0) * x + (S3D_M(T, 0, 1) * y + (S3D_M(T, 0, 2) * z + S3D_M(T, 0, 3)));
+  o.y = S3D_M(T, 1, 0) * x + (S3D_M(T, 1, 1) * y + (S3D_M(T, 1, 2) * z + S3D_M(T, 1, 3)));
+  o.z = S3D_M(T, 2, 0) * x + (S3D_M(T, 2, 1) * y + (S3D_M(T, 2, 2) * z + S3D_M(T, 2, 3)));
+  return o;
+}
+// Eigen Matrix4f * Vector4f (w = 1): ((c0 x + c1 y) + c2 z) + c3   [order matters]
+S3D_HD F3 xf_eigen(const Mat4f& T, float x, float y, float z) {
+  F3 o;
+  o.x = ((S3D_M(T, 0, 0) * x + S3D_M(T, 0, 1) * y) + S3D_M(T, 0, 2) * z) + S3D_M(T, 0, 3);
+  o.y = ((S3D_M(T, 1, 0) * x + S3D_M(T, 1, 1) * y) + S3D_M(T, 1, 2) * z) + S3D_M(T, 1, 3);
+  o.z = ((S3D_M(T, 2, 0) * x + S3D_M(T, 2, 1) * y) + S3D_M(T, 2, 2) * z) + S3D_M(T, 2, 3);
+  return o;
+}
+// Eigen Matrix4f * Matrix4f, k = 0..3 in order   [order matters]
+S3D_HD Mat4f mat4f_mul(const Mat4f& a, const Mat4f& b) {
+  Mat4f t;
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+      S3D_M(t, r, c) = ((S3D_M(a, r, 0) * S3D_M(b, 0, c) + S3D_M(a, r, 1) * S3D_M(b, 1, c)) +
+                        S3D_M(a, r, 2) * S3D_M(b, 2, c)) + S3D_M(a, r, 3) * S3D_M(b, 3, c);
+  return t;
+}
+
+// FLANN L2_Simple: (dx^2 + dy^2) + dz^2 in float   [order matters]
+S3D_HD float dist2(float ax, float ay, float az, float bx, float by, float bz) {
+  float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+S3D_HD bool lex_less(float d2a, int ia, float d2b, int ib) { return d2a < d2b || (d2a == d2b && ia < ib); }
+
+S3D_HD int imin(int a, int b) { return a < b ? a : b; }
+S3D_HD int imax(int a, int b) { return a > b ? a : b; }
+
+// ------------------------------------------------------------------ voxel grid (K1)
+// pcl::VoxelGrid key of one point (voxel_grid.hpp applyFilter first pass)
+
+struct VoxelParams {
+  float inv_leaf;
+  int   min_b[3];
+  int   div_b[3];
+  int   passthrough;  // dx*dy*dz > INT_MAX: every point is its own voxel (output = input)
+};
+
+S3D_HD VoxelParams voxel_params_from_bbox(const float mn[3], const float mx[3], float leaf) {
+  VoxelParams vp;
+  vp.inv_leaf = 1.0f / leaf;
+  int64_t d[3];
+  for (int a = 0; a < 3; ++a) {
+    d[a] = (int64_t)((mx[a] - mn[a]) * vp.inv_leaf) + 1;
+    vp.min_b[a] = (int)floorf(mn[a] * vp.inv_leaf);
+    int max_b = (int)floorf(mx[a] * vp.inv_leaf);
+    vp.div_b[a] = max_b - vp.min_b[a] + 1;
+  }
+  vp.passthrough = (d[0] * d[1] * d[2] > (int64_t)2147483647) ? 1 : 0;
+  return vp;
+}
+
+S3D_HD uint32_t voxel_key(const VoxelParams& vp, float x, float y, float z) {
+  int i0 = (int)(floorf(x * vp.inv_leaf) - (float)vp.min_b[0]);
+  int i1 = (int)(floorf(y * vp.inv_leaf) - (float)vp.min_b[1]);
+  int i2 = (int)(floorf(z * vp.inv_leaf) - (float)vp.min_b[2]);
+  return (uint32_t)(i0 + i1 * vp.div_b[0] + i2 * vp.div_b[0] * vp.div_b[1]);
+}
+
+// ------------------------------------------------------------------ search grid (K3)
+// Dense uniform grid over one cloud; points are stored cell-sorted (x fastest)
+// so that the cells (ix-r .. ix+r, iy, iz) of one row are ONE contiguous run.
+
+struct GridParams {
+  float origin[3];
+  float h, inv_h;
+  int   dim[3];
+  int   ncells;
+};
+
+// h0: wanted cell edge; the edge is grown (x 2^(1/3)) until the cell count fits `cap`
+S3D_HD GridParams grid_params_from_bbox(const float mn[3], const float mx[3], float h0, int cap) {
+  GridParams g;
+  float h = h0;
+  for (int it = 0; it < 200; ++it) {
+    int64_t nc = 1;
+    for (int a = 0; a < 3; ++a) {
+      g.dim[a] = (int)floorf((mx[a] - mn[a]) / h) + 1;
+      nc *= g.dim[a];
+    }
+    if (nc <= (int64_t)cap) break;
+    h *= 1.2599210f;
+  }
+  g.h = h;
+  g.inv_h = 1.0f / h;
+  for (int a = 0; a < 3; ++a) g.origin[a] = mn[a];
+  g.ncells = g.dim[0] * g.dim[1] * g.dim[2];
+  return g;
+}
+
+S3D_HD int grid_coord(const GridParams& g, int axis, float v) {
+  // clamp in float first: a far-away query must not overflow the int conversion
+  float f = floorf((v - g.origin[axis]) * g.inv_h);
+  f = fminf(fmaxf(f, -1.0e6f), 1.0e6f);
+  return (int)f;
+}
+S3D_HD int grid_cell_of_point(const GridParams& g, float x, float y, float z) {
+  int ix = imin(imax(grid_coord(g, 0, x), 0), g.dim[0] - 1);
+  int iy = imin(imax(grid_coord(g, 1, y), 0), g.dim[1] - 1);
+  int iz = imin(imax(grid_coord(g, 2, z), 0), g.dim[2] - 1);
+  return ix + g.dim[0] * (iy + g.dim[1] * iz);
+}
+
+// Exact 1-NN by ring expansion.  pts: cell-sorted float4 (xyz, w = bit-cast index
+// in the un-sorted cloud); cell_start: ncells+1 entries.  Ties: lowest index.
+// max_d: only neighbours closer than this matter (search stops beyond it).
+struct NNResult { int idx; float d2; int pos; };
+
+template <typename F4T>
+S3D_HD NNResult grid_nn1(const GridParams& g, const uint32_t* __restrict__ cell_start,
+                         const F4T* __restrict__ pts, float qx, float qy, float qz, float max_d) {
+  NNResult best;
+  best.idx = -1; best.d2 = 3.0e38f; best.pos = -1;
+  const float fx = (qx - g.origin[0]) * g.inv_h, fy = (qy - g.origin[1]) * g.inv_h,
+              fz = (qz - g.origin[2]) * g.inv_h;
+  const int ix = grid_coord(g, 0, qx), iy = grid_coord(g, 1, qy), iz = grid_coord(g, 2, qz);
+  // distance (in cells) from the query to the nearest face of its own cell, shrunk by a
+  // safety margin that covers float rounding of cell assignment and of the bound itself
+  float ox = fx - (float)ix, oy = fy - (float)iy, oz = fz - (float)iz;
+  float face = fminf(fminf(fminf(ox, 1.f - ox), fminf(oy, 1.f - oy)), fminf(oz, 1.f - oz));
+  face = fmaxf(face - 2.0e-3f, 0.f);
+  const int rmax = (int)ceilf(max_d * g.inv_h) + 1;
+  // rings that cannot touch the grid are skipped at once
+  int r0 = 0;
+  r0 = imax(r0, imax(-ix, ix - (g.dim[0] - 1)));
+  r0 = imax(r0, imax(-iy, iy - (g.dim[1] - 1)));
+  r0 = imax(r0, imax(-iz, iz - (g.dim[2] - 1)));
+  for (int r = r0; r <= rmax; ++r) {
+    const int z0 = imax(iz - r, 0), z1 = imin(iz + r, g.dim[2] - 1);
+    const int y0 = imax(iy - r, 0), y1 = imin(iy + r, g.dim[1] - 1);
+    const int xl = ix - r, xh = ix + r;
+    for (int cz = z0; cz <= z1; ++cz) {
+      const bool zface = (cz == iz - r) || (cz == iz + r);
+      for (int cy = y0; cy <= y1; ++cy) {
+        const bool full = zface || (cy == iy - r) || (cy == iy + r);
+        const int rowbase = g.dim[0] * (cy + g.dim[1] * cz);
+        // shell cells of this row: the whole run [xl, xh] on a face, else the two end cells
+        for (int part = 0; part < 2; ++part) {
+          int xa, xb;
+          if (full) {
+            if (part) break;
+            xa = imax(xl, 0); xb = imin(xh, g.dim[0] - 1);
+          } else {
+            if (r == 0) { if (part) break; xa = xb = ix; }
+            else { xa = xb = part ? xh : xl; }
+            if (xa < 0 || xa >= g.dim[0]) continue;
+          }
+          if (xa > xb) continue;
+          const uint32_t s = cell_start[rowbase + xa], e = cell_start[rowbase + xb + 1];
+          for (uint32_t k = s; k < e; ++k) {
+            const F4T p = pts[k];
+            const float d2 = dist2(qx, qy, qz, p.x, p.y, p.z);
+            const int pi = __builtin_bit_cast(int, p.w);
+            if (lex_less(d2, pi, best.d2, best.idx < 0 ? 2147483647 : best.idx)) {
+              best.d2 = d2; best.idx = pi; best.pos = (int)k;
+            }
+          }
+        }
+      }
+    }
+    // every point outside the cube of rings <= r is farther than (r + face) * h
+    const float bound = ((float)r + face) * g.h;
+    if (best.idx >= 0 && best.d2 <= bound * bound) break;
+    if (bound > max_d) break;
+  }
+  return best;
+}
+
+// Exact k-NN of a point among its own cloud by ring expansion.  The k best are
+// kept in caller-provided storage addressed as d2s[j*stride], idxs[j*stride]
+// (LDS columns on the GPU).  Order of the result is unspecified.
+template <typename F4T>
+S3D_HD int grid_knn(const GridParams& g, const uint32_t* __restrict__ cell_start, const F4T* __restrict__ pts,
+                    float qx, float qy, float qz, int k, float* d2s, int* idxs, int stride) {
+  int cnt = 0, maxslot = 0;
+  float maxd = -1.f; int maxi = -1;
+  const float fx = (qx - g.origin[0]) * g.inv_h, fy = (qy - g.origin[1]) * g.inv_h,
+              fz = (qz - g.origin[2]) * g.inv_h;
+  const int ix = grid_coord(g, 0, qx), iy = grid_coord(g, 1, qy), iz = grid_coord(g, 2, qz);
+  float ox = fx - (float)ix, oy = fy - (float)iy, oz = fz - (float)iz;
+  float face = fminf(fminf(fminf(ox, 1.f - ox), fminf(oy, 1.f - oy)), fminf(oz, 1.f - oz));
+  face = fmaxf(face - 2.0e-3f, 0.f);
+  const int rmax = imax(imax(g.dim[0], g.dim[1]), g.dim[2]);
+  for (int r = 0; r <= rmax; ++r) {
+    const int z0 = imax(iz - r, 0), z1 = imin(iz + r, g.dim[2] - 1);
+    const int y0 = imax(iy - r, 0), y1 = imin(iy + r, g.dim[1] - 1);
+    const int xl = ix - r, xh = ix + r;
+    for (int cz = z0; cz <= z1; ++cz) {
+      const bool zface = (cz == iz - r) || (cz == iz + r);
+      for (int cy = y0; cy <= y1; ++cy) {
+        const bool full = zface || (cy == iy - r) || (cy == iy + r);
+        const int rowbase = g.dim[0] * (cy + g.dim[1] * cz);
+        for (int part = 0; part < 2; ++part) {
+          int xa, xb;
+          if (full) {
+            if (part) break;
+            xa = imax(xl, 0); xb = imin(xh, g.dim[0] - 1);
+          } else {
+            if (r == 0) { if (part) break; xa = xb = ix; }
+            else { xa = xb = part ? xh : xl; }
+            if (xa < 0 || xa >= g.dim[0]) continue;
+          }
+          if (xa > xb) continue;
+          const uint32_t s = cell_start[rowbase + xa], e = cell_start[rowbase + xb + 1];
+          for (uint32_t kk = s; kk < e; ++kk) {
+            const F4T p = pts[kk];
+            const float d2 = dist2(qx, qy, qz, p.x, p.y, p.z);
+            const int pi = __builtin_bit_cast(int, p.w);
+            if (cnt < k) {
+              d2s[cnt * stride] = d2; idxs[cnt * stride] = pi;
+              if (cnt == 0 || lex_less(maxd, maxi, d2, pi)) { maxd = d2; maxi = pi; maxslot = cnt; }
+              ++cnt;
+            } else if (lex_less(d2, pi, maxd, maxi)) {
+              d2s[maxslot * stride] = d2; idxs[maxslot * stride] = pi;
+              maxd = d2; maxi = pi;  // provisional; rescan for the true maximum
+              for (int j = 0; j < k; ++j) {
+                const float dj = d2s[j * stride]; const int ij = idxs[j * stride];
+                if (lex_less(maxd, maxi, dj, ij)) { maxd = dj; maxi = ij; maxslot = j; }
+              }
+            }
+          }
+        }
+      }
+    }
+    const float bound = ((float)r + face) * g.h;
+    if (cnt >= k && maxd <= bound * bound) break;
+  }
+  return cnt;
+}
+
+// ------------------------------------------------------------------ covariance -> normal (K4)
+
+// cyclic Jacobi on a symmetric 3x3; returns the unit eigenvector of the SMALLEST
+// eigenvalue (= third column of U in PCL's JacobiSVD of the covariance)
+S3D_HD void sym3_smallest_eigvec(double a00, double a01, double a02, double a11, double a12, double a22,
+                                 double n[3]) {
+  double a[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
+  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+    double diag = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+    if (off <= 1e-300 || off <= 1e-34 * diag) break;
+#define S3D_JROT(p, q)                                                                       \
+  if (a[p][q] != 0.0) {                                                                      \
+    double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);                                    \
+    double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));        \
+    double c = 1.0 / sqrt(t * t + 1.0), s = t * c;                                           \
+    for (int k = 0; k < 3; ++k) {                                                            \
+      double akp = a[k][p], akq = a[k][q];                                                   \
+      a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq;                              \
+    }                                                                                        \
+    for (int k = 0; k < 3; ++k) {                                                            \
+      double apk = a[p][k], aqk = a[q][k];                                                   \
+      a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk;                              \
+    }                                                                                        \
+    for (int k = 0; k < 3; ++k) {                                                            \
+      double vkp = V[k][p], vkq = V[k][q];                                                   \
+      V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;                              \
+    }                                                                                        \
+  }
+    S3D_JROT(0, 1)
+    S3D_JROT(0, 2)
+    S3D_JROT(1, 2)
+#undef S3D_JROT
+  }
+  const double d0 = a[0][0], d1 = a[1][1], d2 = a[2][2];
+  // same selection as a descending sort that keeps the earlier column on ties
+  int m = 0;
+  double dm = d0;
+  if (d1 <= dm) { m = 1; dm = d1; }
+  if (d2 <= dm) { m = 2; dm = d2; }
+  // (ties: the LAST minimal column, matching the oracle's stable descending order)
+  n[0] = m == 0 ? V[0][0] : (m == 1 ? V[0][1] : V[0][2]);
+  n[1] = m == 0 ? V[1][0] : (m == 1 ? V[1][1] : V[1][2]);
+  n[2] = m == 0 ? V[2][0] : (m == 1 ? V[2][1] : V[2][2]);
+}
+
+// PCL computeCovariances moments of the k neighbours: float products, double sums
+struct Moments { double mean[3]; double c00, c10, c11, c20, c21, c22; };
+S3D_HD void moments_init(Moments& m) {
+  m.mean[0] = m.mean[1] = m.mean[2] = 0; m.c00 = m.c10 = m.c11 = m.c20 = m.c21 = m.c22 = 0;
+}
+S3D_HD void moments_add(Moments& m, float x, float y, float z) {
+  m.mean[0] += x; m.mean[1] += y; m.mean[2] += z;
+  m.c00 += x * x; m.c10 += y * x; m.c11 += y * y; m.c20 += z * x; m.c21 += z * y; m.c22 += z * z;
+}
+S3D_HD void moments_normal(const Moments& m, int k, double n[3]) {
+  const double kd = (double)k;
+  const double mx = m.mean[0] / kd, my = m.mean[1] / kd, mz = m.mean[2] / kd;
+  const double c00 = m.c00 / kd - mx * mx, c10 = m.c10 / kd - my * mx, c11 = m.c11 / kd - my * my;
+  const double c20 = m.c20 / kd - mz * mx, c21 = m.c21 / kd - mz * my, c22 = m.c22 / kd - mz * mz;
+  sym3_smallest_eigvec(c00, c10, c20, c11, c21, c22, n);
+}
+
+// ------------------------------------------------------------------ GICP quadratic form (K6/K7)
+//
+//   f(x) * m = sum_i (Theta P_i - q_i)^T M_i (Theta P_i - q_i),  Theta = [R(x) | t(x)],  P = (p,1)
+//            = sum_{a,b,c,d} Theta_ca Theta_db A[ab][cd] - 2 sum_{c,a} Theta_ca B[c][a] + C0
+//   A[ab][cd] = sum_i P_a P_b M_cd   (10 x 6),  B[c][a] = sum_i (M q)_c P_a  (3 x 4),  C0 = sum q^T M q
+//
+// Layout of the 76-double accumulator record:
+//   [0..59]  A[pair(a,b)][sym(c,d)]   pair order (0,0)(0,1)(0,2)(0,3)(1,1)(1,2)(1,3)(2,2)(2,3)(3,3)
+//                                     sym  order 00 01 02 11 12 22
+//   [60..71] B[c*4+a]   [72] C0   [73] number of correspondences   [74..75] spare
+enum { GQ_NACC = 76, GQ_B = 60, GQ_C0 = 72, GQ_CNT = 73 };
+
+S3D_HD int gq_pair(int a, int b) {  // a <= b, a,b in 0..3
+  return a * 4 - (a * (a - 1)) / 2 + (b - a);
+}
+S3D_HD int gq_sym(int c, int d) {  // c <= d in 0..2
+  return c * 3 - (c * (c - 1)) / 2 + (d - c);
+}
+
+// Mahalanobis matrix of one correspondence (PCL gicp.hpp computeTransformation):
+//   M = (R C1 R^T + C2)^-1,  C = I - (1-eps) n n^T  (== U diag(1,1,eps) U^T)
+// S = R R^T (sym, 6 values: 00 01 02 11 12 22), n1r = R n1 (already rotated), n2 unit.
+S3D_HD void gicp_mahalanobis(const double S[6], const double n1r[3], const double n2[3], double eps, double M[6]) {
+  const double w = 1.0 - eps;
+  double t00 = S[0] + 1.0 - w * (n1r[0] * n1r[0] + n2[0] * n2[0]);
+  double t01 = S[1] - w * (n1r[0] * n1r[1] + n2[0] * n2[1]);
+  double t02 = S[2] - w * (n1r[0] * n1r[2] + n2[0] * n2[2]);
+  double t11 = S[3] + 1.0 - w * (n1r[1] * n1r[1] + n2[1] * n2[1]);
+  double t12 = S[4] - w * (n1r[1] * n1r[2] + n2[1] * n2[2]);
+  double t22 = S[5] + 1.0 - w * (n1r[2] * n1r[2] + n2[2] * n2[2]);
+  // symmetric cofactor inverse
+  double c00 = t11 * t22 - t12 * t12;
+  double c01 = t02 * t12 - t01 * t22;
+  double c02 = t01 * t12 - t02 * t11;
+  double det = t00 * c00 + t01 * c01 + t02 * c02;
+  double id = 1.0 / det;
+  M[0] = c00 * id; M[1] = c01 * id; M[2] = c02 * id;
+  M[3] = (t00 * t22 - t02 * t02) * id;
+  M[4] = (t01 * t02 - t00 * t12) * id;
+  M[5] = (t00 * t11 - t01 * t01) * id;
+}
+
+// add one correspondence (p = guess-transformed query, q = matched target, M sym) to acc[76]
+S3D_HD void gq_accumulate(double* acc, const double p[3], const double q[3], const double M[6]) {
+  const double P[4] = {p[0], p[1], p[2], 1.0};
+  int o = 0;
+  for (int a = 0; a < 4; ++a)
+    for (int b = a; b < 4; ++b) {
+      const double pp = P[a] * P[b];
+      for (int s = 0; s < 6; ++s) acc[o + s] = fma(pp, M[s], acc[o + s]);
+      o += 6;
+    }
+  const double Mq0 = M[0] * q[0] + M[1] * q[1] + M[2] * q[2];
+  const double Mq1 = M[1] * q[0] + M[3] * q[1] + M[4] * q[2];
+  const double Mq2 = M[2] * q[0] + M[4] * q[1] + M[5] * q[2];
+  for (int a = 0; a < 4; ++a) {
+    acc[GQ_B + 0 * 4 + a] = fma(Mq0, P[a], acc[GQ_B + 0 * 4 + a]);
+    acc[GQ_B + 1 * 4 + a] = fma(Mq1, P[a], acc[GQ_B + 1 * 4 + a]);
+    acc[GQ_B + 2 * 4 + a] = fma(Mq2, P[a], acc[GQ_B + 2 * 4 + a]);
+  }
+  acc[GQ_C0] += q[0] * Mq0 + q[1] * Mq1 + q[2] * Mq2;
+  acc[GQ_CNT] += 1.0;
+}
+
+// PCL applyState on an identity base: Theta = [float(Rz Ry Rx) | float(x0..2)]
+S3D_HD void gicp_apply_state(const double x[6], Mat4f& T) {
+  const double cphi = cos(x[3]), sphi = sin(x[3]);
+  const double cth = cos(x[4]), sth = sin(x[4]);
+  const double cpsi = cos(x[5]), spsi = sin(x[5]);
+  T = mat4f_identity();
+  S3D_M(T, 0, 0) = (float)(cpsi * cth);
+  S3D_M(T, 0, 1) = (float)(cpsi * sth * sphi - spsi * cphi);
+  S3D_M(T, 0, 2) = (float)(cpsi * sth * cphi + spsi * sphi);
+  S3D_M(T, 1, 0) = (float)(spsi * cth);
+  S3D_M(T, 1, 1) = (float)(spsi * sth * sphi + cpsi * cphi);
+  S3D_M(T, 1, 2) = (float)(spsi * sth * cphi - cpsi * sphi);
+  S3D_M(T, 2, 0) = (float)(-sth);
+  S3D_M(T, 2, 1) = (float)(cth * sphi);
+  S3D_M(T, 2, 2) = (float)(cth * cphi);
+  S3D_M(T, 0, 3) = (float)x[0];
+  S3D_M(T, 1, 3) = (float)x[1];
+  S3D_M(T, 2, 3) = (float)x[2];
+}
+
+// f(x) and gradient from the quadratic form (PCL OptimizationFunctorWithIndices::fdf)
+S3D_HD void gq_eval(const double* acc, const double x[6], double* f, double g[6]) {
+  // Theta = [Rz(x5) Ry(x4) Rx(x3) | x0..2] carried in DOUBLE.  PCL's applyState rounds
+  // Theta to float before every evaluation, which turns f(x) into a 1e-7-level staircase
+  // and makes the line search terminate on rounding noise ("conditioning");
+  // the float rounding is applied once per outer iteration instead (gicp_apply_state),
+  // where PCL stores transformation_ as Matrix4f.
+  double Th[3][4];
+  {
+    const double cphi = cos(x[3]), sphi = sin(x[3]), cth = cos(x[4]), sth = sin(x[4]);
+    const double cpsi = cos(x[5]), spsi = sin(x[5]);
+    Th[0][0] = cpsi * cth; Th[0][1] = cpsi * sth * sphi - spsi * cphi; Th[0][2] = cpsi * sth * cphi + spsi * sphi;
+    Th[1][0] = spsi * cth; Th[1][1] = spsi * sth * sphi + cpsi * cphi; Th[1][2] = spsi * sth * cphi - cpsi * sphi;
+    Th[2][0] = -sth; Th[2][1] = cth * sphi; Th[2][2] = cth * cphi;
+    Th[0][3] = x[0]; Th[1][3] = x[1]; Th[2][3] = x[2];
+  }
+  // G[a][c] = sum_{d,b} Th[d][b] A[ab][cd] - B[c][a]   ( = sum_i P_a (M res_i)_c )
+  double G[4][3];
+  double fsum = 0.0;
+  for (int a = 0; a < 4; ++a)
+    for (int c = 0; c < 3; ++c) {
+      double s = 0.0;
+      for (int b = 0; b < 4; ++b) {
+        const int pr = a <= b ? gq_pair(a, b) : gq_pair(b, a);
+        for (int d = 0; d < 3; ++d) {
+          const int sm = c <= d ? gq_sym(c, d) : gq_sym(d, c);
+          s = fma(Th[d][b], acc[pr * 6 + sm], s);
+        }
+      }
+      const double Bca = acc[GQ_B + c * 4 + a];
+      G[a][c] = s - Bca;
+      fsum += Th[c][a] * (G[a][c] - Bca);
+    }
+  const double m = acc[GQ_CNT];
+  *f = (fsum + acc[GQ_C0]) / m;
+  const double sc = 2.0 / m;
+  g[0] = G[3][0] * sc; g[1] = G[3][1] * sc; g[2] = G[3][2] * sc;
+  double Rs[3][3];
+  for (int a = 0; a < 3; ++a)
+    for (int c = 0; c < 3; ++c) Rs[a][c] = G[a][c] * sc;
+  // PCL computeRDerivative: g[3+k] = sum_ij dR_k(j,i) Rs(i,j)
+  const double cphi = cos(x[3]), sphi = sin(x[3]);
+  const double cth = cos(x[4]), sth = sin(x[4]);
+  const double cpsi = cos(x[5]), spsi = sin(x[5]);
+  const double dPhi[3][3] = {{0, sphi * spsi + cphi * cpsi * sth, cphi * spsi - cpsi * sphi * sth},
+                             {0, -cpsi * sphi + cphi * spsi * sth, -cphi * cpsi - sphi * spsi * sth},
+                             {0, cphi * cth, -cth * sphi}};
+  const double dTh[3][3] = {{-cpsi * sth, cpsi * cth * sphi, cphi * cpsi * cth},
+                            {-spsi * sth, cth * sphi * spsi, cphi * cth * spsi},
+                            {-cth, -sphi * sth, -cphi * sth}};
+  const double dPsi[3][3] = {{-cth * spsi, -cphi * cpsi - sphi * spsi * sth, cpsi * sphi - cphi * spsi * sth},
+                             {cpsi * cth, -cphi * spsi + cpsi * sphi * sth, sphi * spsi + cphi * cpsi * sth},
+                             {0, 0, 0}};
+  double g3 = 0, g4 = 0, g5 = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      g3 += dPhi[j][i] * Rs[i][j];
+      g4 += dTh[j][i] * Rs[i][j];
+      g5 += dPsi[j][i] * Rs[i][j];
+    }
+  g[3] = g3; g[4] = g4; g[5] = g5;
+}
+
+// ---- BFGS (PCL registration/bfgs.h == GSL vector_bfgs2 + Fletcher line search)
+// on the quadratic form.  Every evaluation yields f and the gradient together
+// (they are O(1) here), which returns the same values PCL's cached
+// applyF/applyDF/applyFDF would.
+struct Bfgs {
+  const double* acc;
+  double f, gradient[6];
+  double x0[6], g0[6], p[6];
+  double g0norm, pnorm, fp0, delta_f;
+  // cache of the last evaluated line-search point
+  double c_alpha, c_f, c_df, c_x[6], c_g[6];
+  int evals;
+};
+enum { BFGS_RUNNING = -1, BFGS_SUCCESS = 0, BFGS_NOPROGRESS = 1 };
+
+S3D_HD double v6norm(const double* v) {
+  double s = 0;
+  for (int i = 0; i < 6; ++i) s += v[i] * v[i];
+  return sqrt(s);
+}
+S3D_HD double v6dot(const double* a, const double* b) {
+  double s = 0;
+  for (int i = 0; i < 6; ++i) s += a[i] * b[i];
+  return s;
+}
+S3D_HD void bfgs_eval(Bfgs& b, double alpha) {
+  if (alpha == b.c_alpha) return;
+  for (int i = 0; i < 6; ++i) b.c_x[i] = b.x0[i] + alpha * b.p[i];
+  gq_eval(b.acc, b.c_x, &b.c_f, b.c_g);
+  b.c_df = v6dot(b.c_g, b.p);
+  b.c_alpha = alpha;
+  b.evals++;
+}
+S3D_HD double bfgs_f(Bfgs& b, double alpha) { bfgs_eval(b, alpha); return b.c_f; }
+S3D_HD double bfgs_df(Bfgs& b, double alpha) { bfgs_eval(b, alpha); return b.c_df; }
+
+S3D_HD double poly3(const double c[4], double z) { return c[0] + z * (c[1] + z * (c[2] + z * c[3])); }
+S3D_HD void check_extremum(const double c[4], double z, double* zmin, double* fmin) {
+  double y = poly3(c, z);
+  if (y < *fmin) { *zmin = z; *fmin = y; }
+}
+S3D_HD double bfgs_interpolate(double a, double fa, double fpa, double b, double fb, double fpb, double xmin,
+                               double xmax, int order) {
+  double y, ymin = (xmin - a) / (b - a), ymax = (xmax - a) / (b - a);
+  if (ymin > ymax) { double t = ymin; ymin = ymax; ymax = t; }
+  if (order > 2 && !(fpb != fpb) && fpb != INFINITY) {
+    fpa = fpa * (b - a);
+    fpb = fpb * (b - a);
+    const double eta = 3 * (fb - fa) - 2 * fpa - fpb;
+    const double xi = fpa + fpb - 2 * (fb - fa);
+    const double c[4] = {fa, fpa, eta, xi};
+    y = ymin;
+    double fmin = poly3(c, ymin);
+    check_extremum(c, ymax, &y, &fmin);
+    const double A = 3 * c[3], B = 2 * c[2], C = c[1];
+    if (A == 0) {
+      if (B != 0) {
+        double y0 = -C / B;
+        if (y0 > ymin && y0 < ymax) check_extremum(c, y0, &y, &fmin);
+      }
+    } else {
+      double disc = B * B - 4 * A * C;
+      if (disc > 0) {
+        double sq = sqrt(disc);
+        double tq = -0.5 * (B + (B > 0 ? sq : -sq));
+        double y0 = tq / A, y1 = (tq != 0) ? C / tq : y0;
+        if (y0 > y1) { double t = y0; y0 = y1; y1 = t; }
+        if (y0 > ymin && y0 < ymax) check_extremum(c, y0, &y, &fmin);
+        if (y1 > ymin && y1 < ymax) check_extremum(c, y1, &y, &fmin);
+      } else if (disc == 0) {
+        double y0 = -0.5 * B / A;
+        if (y0 > ymin && y0 < ymax) check_extremum(c, y0, &y, &fmin);
+      }
+    }
+  } else {
+    fpa = fpa * (b - a);
+    double fl = fa + ymin * (fpa + ymin * (fb - fa - fpa));
+    double fh = fa + ymax * (fpa + ymax * (fb - fa - fpa));
+    double c = 2 * (fb - fa - fpa);
+    y = ymin;
+    double fmin = fl;
+    if (fh < fmin) { y = ymax; fmin = fh; }
+    if (c > a) {  // sic: PCL bfgs.h (GSL: c > 0)
+      double z = -fpa / c;
+      if (z > ymin && z < ymax) {
+        double f = fa + z * (fpa + z * (fb - fa - fpa));
+        if (f < fmin) { y = z; fmin = f; }
+      }
+    }
+  }
+  return a + y * (b - a);
+}
+
+S3D_HD int bfgs_line_search(Bfgs& B, double rho, double sigma, double tau1, double tau2, double tau3, int order,
+                            double alpha1, double* alpha_new) {
+  const int bracket_iters = 100, section_iters = 100;
+  double f0, fp0, falpha, falpha_prev, fpalpha, fpalpha_prev, delta, alpha_next;
+  double alpha = alpha1, alpha_prev = 0.0;
+  double a, b, fa, fb, fpa, fpb;
+  int i = 0;
+  f0 = B.f; fp0 = B.fp0;  // == applyFDF(0): position 0 is x0 with cached f, slope
+  falpha_prev = f0; fpalpha_prev = fp0;
+  a = 0.0; b = alpha; fa = f0; fb = 0.0; fpa = fp0; fpb = 0.0;
+  while (i++ < bracket_iters) {
+    falpha = bfgs_f(B, alpha);
+    if (falpha > f0 + alpha * rho * fp0 || falpha >= falpha_prev) {
+      a = alpha_prev; fa = falpha_prev; fpa = fpalpha_prev;
+      b = alpha; fb = falpha; fpb = NAN;
+      break;
+    }
+    fpalpha = bfgs_df(B, alpha);
+    if (fabs(fpalpha) <= -sigma * fp0) { *alpha_new = alpha; return BFGS_SUCCESS; }
+    if (fpalpha >= 0) {
+      a = alpha; fa = falpha; fpa = fpalpha;
+      b = alpha_prev; fb = falpha_prev; fpb = fpalpha_prev;
+      break;
+    }
+    delta = alpha - alpha_prev;
+    {
+      double lower = alpha + delta, upper = alpha + tau1 * delta;
+      alpha_next = bfgs_interpolate(alpha_prev, falpha_prev, fpalpha_prev, alpha, falpha, fpalpha, lower, upper, order);
+    }
+    alpha_prev = alpha; falpha_prev = falpha; fpalpha_prev = fpalpha; alpha = alpha_next;
+  }
+  while (i++ < section_iters) {
+    delta = b - a;
+    {
+      double lower = a + tau2 * delta, upper = b - tau3 * delta;
+      alpha = bfgs_interpolate(a, fa, fpa, b, fb, fpb, lower, upper, order);
+    }
+    falpha = bfgs_f(B, alpha);
+    if ((a - alpha) * fpa <= 2.220446049250313e-16) return BFGS_NOPROGRESS;
+    if (falpha > f0 + rho * alpha * fp0 || falpha >= fa) {
+      b = alpha; fb = falpha; fpb = NAN;
+    } else {
+      fpalpha = bfgs_df(B, alpha);
+      if (fabs(fpalpha) <= -sigma * fp0) { *alpha_new = alpha; return BFGS_SUCCESS; }
+      if (((b - a) >= 0 && fpalpha >= 0) || ((b - a) <= 0 && fpalpha <= 0)) {
+        b = a; fb = fa; fpb = fpa;
+        a = alpha; fa = falpha; fpa = fpalpha;
+      } else {
+        a = alpha; fa = falpha; fpa = fpalpha;
+      }
+    }
+  }
+  return BFGS_SUCCESS;
+}
+
+S3D_HD void bfgs_init(Bfgs& b, const double* acc, const double x[6]) {
+  b.acc = acc;
+  b.delta_f = 0;
+  b.evals = 1;
+  gq_eval(acc, x, &b.f, b.gradient);
+  for (int i = 0; i < 6; ++i) { b.x0[i] = x[i]; b.g0[i] = b.gradient[i]; }
+  b.g0norm = v6norm(b.g0);
+  for (int i = 0; i < 6; ++i) b.p[i] = b.gradient[i] * -1 / b.g0norm;
+  b.pnorm = v6norm(b.p);
+  b.fp0 = -b.g0norm;
+  b.c_alpha = 0.0; b.c_f = b.f; b.c_df = v6dot(b.g0, b.p);
+  for (int i = 0; i < 6; ++i) { b.c_x[i] = b.x0[i]; b.c_g[i] = b.g0[i]; }
+}
+
+S3D_HD int bfgs_one_step(Bfgs& b, double x[6]) {
+  const double sigma = 0.01, rho = 0.01, tau1 = 9, tau2 = 0.05, tau3 = 0.5, step_size = 1.0;
+  const int order = 3;
+  double alpha = 0.0, alpha1;
+  const double f0 = b.f;
+  if (b.pnorm == 0.0 || b.g0norm == 0.0 || b.fp0 == 0) return BFGS_NOPROGRESS;
+  if (b.delta_f < 0) {
+    double del = fmax(-b.delta_f, 10 * 2.220446049250313e-16 * fabs(f0));
+    alpha1 = fmin(1.0, 2.0 * del / (-b.fp0));
+  } else {
+    alpha1 = fabs(step_size);
+  }
+  int status = bfgs_line_search(b, rho, sigma, tau1, tau2, tau3, order, alpha1, &alpha);
+  if (status != BFGS_SUCCESS) return status;
+  // updatePosition(alpha)
+  if (alpha == 0.0) {  // (section loop ran out without setting alpha: position unchanged)
+    for (int i = 0; i < 6; ++i) { x[i] = b.x0[i]; b.gradient[i] = b.g0[i]; }
+  } else {
+    bfgs_eval(b, alpha);
+    b.f = b.c_f;
+    for (int i = 0; i < 6; ++i) { x[i] = b.c_x[i]; b.gradient[i] = b.c_g[i]; }
+  }
+  b.delta_f = b.f - f0;
+  double dx0[6], dg0[6];
+  for (int i = 0; i < 6; ++i) { dx0[i] = x[i] - b.x0[i]; dg0[i] = b.gradient[i] - b.g0[i]; }
+  const double dxg = v6dot(dx0, b.gradient), dgg = v6dot(dg0, b.gradient), dxdg = v6dot(dx0, dg0);
+  const double dgnorm = v6norm(dg0);
+  double A, Bc;
+  if (dxdg != 0) {
+    Bc = dxg / dxdg;
+    A = -(1.0 + dgnorm * dgnorm / dxdg) * Bc + dgg / dxdg;
+  } else {
+    Bc = 0; A = 0;
+  }
+  for (int i = 0; i < 6; ++i) b.p[i] = -A * dx0[i] + b.gradient[i] - Bc * dg0[i];
+  for (int i = 0; i < 6; ++i) { b.g0[i] = b.gradient[i]; b.x0[i] = x[i]; }
+  b.g0norm = v6norm(b.g0);
+  b.pnorm = v6norm(b.p);
+  const double dir = (v6dot(b.p, b.gradient) > 0) ? -1.0 : 1.0;
+  for (int i = 0; i < 6; ++i) b.p[i] *= dir / b.pnorm;
+  b.pnorm = v6norm(b.p);
+  b.fp0 = v6dot(b.p, b.g0);
+  // changeDirection(): cache is position 0 of the new line
+  b.c_alpha = 0.0; b.c_f = b.f; b.c_df = b.fp0;
+  for (int i = 0; i < 6; ++i) { b.c_x[i] = b.x0[i]; b.c_g[i] = b.g0[i]; }
+  return BFGS_SUCCESS;
+}
+
+// PCL estimateRigidTransformationBFGS on the quadratic form.
+// returns 0 and updates T, or -1 (the PCLException path: < 4 pairs / solver failure)
+S3D_HD int gicp_estimate_bfgs(const double* acc, int max_inner, Mat4f& T, int* inner_out, int* evals_out) {
+  *inner_out = 0; *evals_out = 0;
+  if (acc[GQ_CNT] < 4.0) return -1;
+  double x[6];
+  x[0] = S3D_M(T, 0, 3); x[1] = S3D_M(T, 1, 3); x[2] = S3D_M(T, 2, 3);
+  x[3] = atan2((double)S3D_M(T, 2, 1), (double)S3D_M(T, 2, 2));
+  x[4] = asin(-(double)S3D_M(T, 2, 0));
+  x[5] = atan2((double)S3D_M(T, 1, 0), (double)S3D_M(T, 0, 0));
+  const double gradient_tol = 1e-2;
+  Bfgs b;
+  bfgs_init(b, acc, x);
+  int inner = 0, result = BFGS_RUNNING;
+  do {
+    inner++;
+    result = bfgs_one_step(b, x);
+    if (result) break;
+    result = v6norm(b.gradient) < gradient_tol ? BFGS_SUCCESS : BFGS_RUNNING;
+  } while (result == BFGS_RUNNING && inner < max_inner);
+  *inner_out = inner; *evals_out = b.evals;
+  if (result == BFGS_NOPROGRESS || result == BFGS_SUCCESS || inner == max_inner) {
+    gicp_apply_state(x, T);
+    return 0;
+  }
+  return -1;
+}
+
+// PCL GICP outer-loop stopping quantity
+S3D_HD double icp_delta(const Mat4f& prev, const Mat4f& cur, double rotation_epsilon, double transformation_epsilon) {
+  double delta = 0;
+  for (int k = 0; k < 4; ++k)
+    for (int l = 0; l < 4; ++l) {
+      const double ratio = (k < 3 && l < 3) ? 1.0 / rotation_epsilon : 1.0 / transformation_epsilon;
+      const double c = ratio * fabs((double)S3D_M(prev, k, l) - (double)S3D_M(cur, k, l));
+      if (c > delta) delta = c;
+    }
+  return delta;
+}
+
+// transform_R = double(transformation_) * double(guess); returns R (3x3 row-major) and S = R R^T (sym 6)
+S3D_HD void gicp_rotation(const Mat4f& T, const Mat4f& guess, double R[9], double S[6]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += (double)S3D_M(T, i, k) * (double)S3D_M(guess, k, j);
+      R[i * 3 + j] = s;
+    }
+  int o = 0;
+  for (int a = 0; a < 3; ++a)
+    for (int b = a; b < 3; ++b) S[o++] = R[a * 3 + 0] * R[b * 3 + 0] + R[a * 3 + 1] * R[b * 3 + 1] + R[a * 3 + 2] * R[b * 3 + 2];
+}
+
+// ------------------------------------------------------------------ point-to-plane (ICP enumerator)
+// accumulator record: [0..20] lower triangle of J^T J (row-major a>=c), [21..26] -J^T r,
+// [27] sum r^2, [28] count   (PP_NACC = 32 with padding)
+enum { PP_NACC = 32, PP_B = 21, PP_R2 = 27, PP_CNT = 28 };
+
+S3D_HD void pp_accumulate(double* acc, const double p[3], const double q[3], const double n[3]) {
+  const double r = n[0] * (p[0] - q[0]) + n[1] * (p[1] - q[1]) + n[2] * (p[2] - q[2]);
+  const double J[6] = {p[1] * n[2] - p[2] * n[1], p[2] * n[0] - p[0] * n[2], p[0] * n[1] - p[1] * n[0],
+                       n[0], n[1], n[2]};
+  int o = 0;
+  for (int a = 0; a < 6; ++a) {
+    for (int c = 0; c <= a; ++c) { acc[o] = fma(J[a], J[c], acc[o]); ++o; }
+    acc[PP_B + a] = fma(-J[a], r, acc[PP_B + a]);
+  }
+  acc[PP_R2] = fma(r, r, acc[PP_R2]);
+  acc[PP_CNT] += 1.0;
+}
+
+S3D_HD int chol6_solve(const double* accA /*lower tri, 21*/, const double* b, double x[6]) {
+  double L[6][6];
+  int o = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = accA[o++];
+      for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+      if (i == j) {
+        if (!(s > 0)) return -1;
+        L[i][i] = sqrt(s);
+      } else {
+        L[i][j] = s / L[j][j];
+      }
+    }
+  double y[6];
+  for (int i = 0; i < 6; ++i) {
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+    y[i] = s / L[i][i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double s = y[i];
+    for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k];
+    x[i] = s / L[i][i];
+  }
+  return 0;
+}
+
+// T <- Exp(w, dt) * T, kept in float.  returns -1 when the system is degenerate
+S3D_HD int pp_update(const double* acc, Mat4f& T) {
+  if (acc[PP_CNT] < 6.0) return -1;
+  double xi[6];
+  if (chol6_solve(acc, acc + PP_B, xi)) return -1;
+  const double th2 = xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2], th = sqrt(th2);
+  double a, b;
+  if (th < 1e-8) { a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; }
+  else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; }
+  const double K[3][3] = {{0, -xi[2], xi[1]}, {xi[2], 0, -xi[0]}, {-xi[1], xi[0], 0}};
+  double R[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const double kk = K[i][0] * K[0][j] + K[i][1] * K[1][j] + K[i][2] * K[2][j];
+      R[i][j] = (i == j ? 1.0 : 0.0) + a * K[i][j] + b * kk;
+    }
+  Mat4f nt = mat4f_identity();
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) {
+      double s = 0;
+      for (int k = 0; k < 3; ++k) s += R[r][k] * (double)S3D_M(T, k, c);
+      if (c == 3) s += xi[3 + r];
+      S3D_M(nt, r, c) = (float)s;
+    }
+  T = nt;
+  return 0;
+}
+
+}  // namespace s3d

@@ -1,0 +1,266 @@
+// emu_pipeline.cpp — TEST-ONLY sequential emulation of the device pipeline.
+//
+// Runs the exact per-thread functions of slam3d_amd/csrc/s3d_core.h (the ones the
+// HIP kernels call) on the CPU, with std::stable_sort standing in for the radix
+// sort and sequential sums for the wave/block reductions.  It exists so that the
+// GPU-side reformulations (normal-only covariances, quadratic-form GICP, BFGS on
+// the form, grid NN/k-NN) can be checked against oracle/ in this GPU-less
+// container.  It is NOT a back-end of the product library and is never linked
+// into it.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../include/slam3d_registration_types.h"
+#include "../../slam3d_amd/csrc/s3d_core.h"
+
+using namespace s3d;
+
+static double g_emu_perturb = 0.0;
+extern "C" void emu_set_perturb(double e) { g_emu_perturb = e; }
+namespace {
+
+struct Cloud {
+  std::vector<F4> pts;  // filtered order, w = 1
+};
+struct Grid {
+  GridParams g;
+  std::vector<uint32_t> cell_start;
+  std::vector<F4> sorted;  // w = index bits
+};
+
+void bbox(const std::vector<F4>& p, float mn[3], float mx[3]) {
+  for (int a = 0; a < 3; ++a) { mn[a] = FLT_MAX; mx[a] = -FLT_MAX; }
+  for (const F4& q : p) {
+    const float v[3] = {q.x, q.y, q.z};
+    for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], v[a]); mx[a] = std::max(mx[a], v[a]); }
+  }
+}
+
+Cloud voxel(const float* xyz, int n, int stride, double leaf) {
+  Cloud out;
+  std::vector<F4> raw;
+  raw.reserve(n);
+  for (int i = 0; i < n; ++i) {
+    const float* p = xyz + (size_t)i * stride;
+    if (std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2])) raw.push_back({p[0], p[1], p[2], 1.f});
+  }
+  if (leaf <= 0 || raw.empty()) { out.pts = raw; return out; }
+  float mn[3], mx[3];
+  bbox(raw, mn, mx);
+  VoxelParams vp = voxel_params_from_bbox(mn, mx, (float)leaf);
+  std::vector<std::pair<uint32_t, int>> kv(raw.size());
+  for (size_t i = 0; i < raw.size(); ++i)
+    kv[i] = {vp.passthrough ? (uint32_t)i : voxel_key(vp, raw[i].x, raw[i].y, raw[i].z), (int)i};
+  std::stable_sort(kv.begin(), kv.end(), [](auto& a, auto& b) { return a.first < b.first; });
+  for (size_t i = 0; i < kv.size();) {
+    size_t j = i;
+    float sx = 0, sy = 0, sz = 0;
+    while (j < kv.size() && kv[j].first == kv[i].first) {
+      const F4& p = raw[kv[j].second];
+      sx += p.x; sy += p.y; sz += p.z;
+      ++j;
+    }
+    const float c = (float)(j - i);
+    out.pts.push_back({sx / c, sy / c, sz / c, 1.f});
+    i = j;
+  }
+  return out;
+}
+
+Grid build_grid(const Cloud& c, float h0, int cells_per_point) {
+  Grid G;
+  float mn[3], mx[3];
+  bbox(c.pts, mn, mx);
+  int cap = (int)std::min<int64_t>((int64_t)cells_per_point * (int64_t)c.pts.size(), 1 << 24);
+  G.g = grid_params_from_bbox(mn, mx, h0, std::max(cap, 64));
+  std::vector<std::pair<uint32_t, int>> kv(c.pts.size());
+  for (size_t i = 0; i < c.pts.size(); ++i)
+    kv[i] = {(uint32_t)grid_cell_of_point(G.g, c.pts[i].x, c.pts[i].y, c.pts[i].z), (int)i};
+  std::stable_sort(kv.begin(), kv.end(), [](auto& a, auto& b) { return a.first < b.first; });
+  G.cell_start.assign(G.g.ncells + 1, 0);
+  G.sorted.resize(c.pts.size());
+  size_t k = 0;
+  for (int cell = 0; cell <= G.g.ncells; ++cell) {
+    while (k < kv.size() && kv[k].first < (uint32_t)cell) ++k;
+    G.cell_start[cell] = (uint32_t)k;
+  }
+  for (size_t i = 0; i < kv.size(); ++i) {
+    const F4& p = c.pts[kv[i].second];
+    G.sorted[i] = {p.x, p.y, p.z, __builtin_bit_cast(float, kv[i].second)};
+  }
+  return G;
+}
+
+std::vector<F4> normals(const Cloud& c, const Grid& G, int k) {
+  std::vector<F4> out(c.pts.size());
+  std::vector<float> d2(k);
+  std::vector<int> idx(k);
+  for (size_t i = 0; i < c.pts.size(); ++i) {
+    const F4& q = c.pts[i];
+    int cnt = grid_knn(G.g, G.cell_start.data(), G.sorted.data(), q.x, q.y, q.z, k, d2.data(), idx.data(), 1);
+    Moments m;
+    moments_init(m);
+    for (int j = 0; j < cnt; ++j) { const F4& p = c.pts[idx[j]]; moments_add(m, p.x, p.y, p.z); }
+    double n[3];
+    moments_normal(m, k, n);
+    out[i] = {(float)n[0], (float)n[1], (float)n[2], 0.f};
+  }
+  return out;
+}
+
+inline void unit3(const F4& nf, double n[3]) {
+  double x = nf.x, y = nf.y, z = nf.z, l = std::sqrt(x * x + y * y + z * z);
+  if (l > 0) { n[0] = x / l; n[1] = y / l; n[2] = z / l; } else { n[0] = n[1] = 0; n[2] = 1; }
+}
+
+float h0_for(double density) { return density > 0 ? (float)(2.0 * density) : 0.25f; }
+
+}  // namespace
+
+extern "C" {
+
+struct emu_info {
+  int n_source_filtered, n_target_filtered, iterations, converged, correspondences;
+  double fitness;
+  int inner_total, evals_total;
+};
+
+// stage exports for unit tests -------------------------------------------------
+int emu_voxel(const float* xyz, int n, int stride, double leaf, float* out) {
+  Cloud c = voxel(xyz, n, stride, leaf);
+  for (size_t i = 0; i < c.pts.size(); ++i) { out[i * 3] = c.pts[i].x; out[i * 3 + 1] = c.pts[i].y; out[i * 3 + 2] = c.pts[i].z; }
+  return (int)c.pts.size();
+}
+void emu_nn(const float* tgt, int n, const float* qry, int m, float h0, int cpp, float max_d, int* idx, float* d2) {
+  Cloud c = voxel(tgt, n, 3, 0.0);
+  Grid G = build_grid(c, h0, cpp);
+  for (int i = 0; i < m; ++i) {
+    NNResult r = grid_nn1(G.g, G.cell_start.data(), G.sorted.data(), qry[i * 3], qry[i * 3 + 1], qry[i * 3 + 2], max_d);
+    idx[i] = r.idx; d2[i] = r.d2;
+  }
+}
+void emu_normals(const float* xyz, int n, int k, float h0, int cpp, float* out) {
+  Cloud c = voxel(xyz, n, 3, 0.0);
+  Grid G = build_grid(c, h0, cpp);
+  std::vector<F4> nr = normals(c, G, k);
+  for (int i = 0; i < n; ++i) { out[i * 3] = nr[i].x; out[i * 3 + 1] = nr[i].y; out[i * 3 + 2] = nr[i].z; }
+}
+
+// align() as the device pipeline runs it -------------------------------------------
+int emu_align(const float* source, int n_source, int stride_source, const float* target, int n_target,
+              int stride_target, const double guess_d[16], const s3d_reg_params* cfg, int force_iterations,
+              int cells_per_point, double result[16], emu_info* info) {
+  emu_info li;
+  std::memset(&li, 0, sizeof li);
+  for (int i = 0; i < 16; ++i) result[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  const int alg = cfg->registration_algorithm;
+  if (alg == S3D_ALG_NDT || alg == S3D_ALG_NDT_OMP) return S3D_STATUS_UNSUPPORTED_ALGORITHM;
+  if (alg < 0 || alg > 4) return S3D_STATUS_UNKNOWN_ALGORITHM;
+  Cloud S = voxel(source, n_source, stride_source, cfg->point_cloud_density);  // pcl TARGET (kd-tree side)
+  Cloud T = voxel(target, n_target, stride_target, cfg->point_cloud_density);  // pcl SOURCE (queries)
+  li.n_source_filtered = (int)S.pts.size();
+  li.n_target_filtered = (int)T.pts.size();
+  if (S.pts.size() < 100 || T.pts.size() < 100) { if (info) *info = li; return S3D_STATUS_TOO_FEW_POINTS; }
+  const int k = cfg->correspondence_randomness;
+  if (k > (int)S.pts.size() || k > (int)T.pts.size()) return S3D_STATUS_INVALID_ARGUMENT;
+  const float h0 = h0_for(cfg->point_cloud_density);
+  Grid GS = build_grid(S, h0, cells_per_point);
+  std::vector<F4> NS = normals(S, GS, k), NT;
+  const bool gicp = (alg == S3D_ALG_GICP || alg == S3D_ALG_GICP_OMP);
+  if (gicp) { Grid GT = build_grid(T, h0, cells_per_point); NT = normals(T, GT, k); }
+
+  Mat4f guess;
+  for (int i = 0; i < 16; ++i) guess.m[i] = (float)guess_d[i];
+  Mat4f Tr = mat4f_identity(), prev = mat4f_identity();
+  const double thr = cfg->max_correspondence_distance * cfg->max_correspondence_distance;
+  const float max_d = (float)cfg->max_correspondence_distance;
+  int nr = 0, converged = 0, cnt = 0;
+  while (!converged) {
+    double R[9], SS[6];
+    gicp_rotation(Tr, guess, R, SS);
+    double acc[GQ_NACC] = {0};
+    for (size_t i = 0; i < T.pts.size(); ++i) {
+      const F4& p0 = T.pts[i];
+      const F3 p = xf_pcl(guess, p0.x, p0.y, p0.z);
+      const F3 q = xf_eigen(Tr, p.x, p.y, p.z);
+      NNResult r = grid_nn1(GS.g, GS.cell_start.data(), GS.sorted.data(), q.x, q.y, q.z, max_d);
+      if (r.idx < 0 || !((double)r.d2 < thr)) continue;
+      const F4& t = S.pts[r.idx];
+      const double td[3] = {t.x, t.y, t.z};
+      double n2[3];
+      unit3(NS[r.idx], n2);
+      if (gicp) {
+        double n1[3], n1r[3], M[6];
+        unit3(NT[i], n1);
+        for (int a = 0; a < 3; ++a) n1r[a] = R[a * 3] * n1[0] + R[a * 3 + 1] * n1[1] + R[a * 3 + 2] * n1[2];
+        gicp_mahalanobis(SS, n1r, n2, 0.001, M);
+        if (g_emu_perturb != 0.0) for (int a = 0; a < 6; ++a) M[a] *= 1.0 + g_emu_perturb * ((double)rand() / RAND_MAX - 0.5);
+        const double pd[3] = {p.x, p.y, p.z};
+        gq_accumulate(acc, pd, td, M);
+      } else {
+        const double qd[3] = {q.x, q.y, q.z};
+        // device stores float normals; use them as stored (no renormalisation) like the oracle
+        const double nf[3] = {NS[r.idx].x, NS[r.idx].y, NS[r.idx].z};
+        pp_accumulate(acc, qd, td, nf);
+      }
+    }
+    prev = Tr;
+    int rc;
+    if (gicp) {
+      cnt = (int)acc[GQ_CNT];
+      int inner = 0, evals = 0;
+      rc = gicp_estimate_bfgs(acc, cfg->maximum_optimizer_iterations, Tr, &inner, &evals);
+      li.inner_total += inner; li.evals_total += evals;
+      if (getenv("S3O_DEBUG")) fprintf(stderr, "[emu]    it %d cnt %d inner %d evals %d t=(%.9g %.9g %.9g) r21 %.9g r10 %.9g\n", nr, cnt, inner, evals, S3D_M(Tr,0,3), S3D_M(Tr,1,3), S3D_M(Tr,2,3), S3D_M(Tr,2,1), S3D_M(Tr,1,0));
+    } else {
+      cnt = (int)acc[PP_CNT];
+      rc = pp_update(acc, Tr);
+    }
+    if (rc) break;
+    const double delta = icp_delta(prev, Tr, cfg->rotation_epsilon, cfg->transformation_epsilon);
+    nr++;
+    if (nr >= cfg->maximum_iterations || (!force_iterations && delta < 1)) { converged = 1; prev = Tr; }
+  }
+  const Mat4f fin = mat4f_mul(prev, guess);
+  // fitness (PointCloudSensor.cpp:73): squared distance compared against the un-squared range
+  const double max_range = cfg->max_correspondence_distance;
+  const float fit_d = (float)(std::sqrt(max_range) * 1.0001);
+  double fsum = 0; int fnr = 0;
+  for (size_t i = 0; i < T.pts.size(); ++i) {
+    const F3 q = xf_pcl(fin, T.pts[i].x, T.pts[i].y, T.pts[i].z);
+    NNResult r = grid_nn1(GS.g, GS.cell_start.data(), GS.sorted.data(), q.x, q.y, q.z, fit_d);
+    if (r.idx >= 0 && (double)r.d2 <= max_range) { fsum += r.d2; fnr++; }
+  }
+  li.fitness = fnr > 0 ? fsum / fnr : DBL_MAX;
+  li.iterations = nr; li.converged = converged; li.correspondences = cnt;
+  for (int i = 0; i < 16; ++i) result[i] = (double)fin.m[i];
+  result[3] = result[7] = result[11] = 0.0; result[15] = 1.0;
+  if (info) *info = li;
+  if (!converged) return S3D_STATUS_NOT_CONVERGED;
+  if (li.fitness > cfg->max_fitness_score) return S3D_STATUS_FITNESS_EXCEEDED;
+  return S3D_STATUS_OK;  // (delta-from-guess gate is host code shared with the product; tested there)
+}
+}
+
+// ---- unit hooks for the quadratic-form algebra (tests/test_core_math.py)
+extern "C" {
+void emu_gq_build(const double* p, const double* q, const double* M6, int m, double* acc /*GQ_NACC*/) {
+  for (int i = 0; i < GQ_NACC; ++i) acc[i] = 0;
+  for (int i = 0; i < m; ++i) gq_accumulate(acc, p + 3 * i, q + 3 * i, M6 + 6 * i);
+}
+void emu_gq_eval(const double* acc, const double* x, double* f, double* g) { gq_eval(acc, x, f, g); }
+void emu_apply_state(const double* x, float* T16) { Mat4f T; gicp_apply_state(x, T); for (int i = 0; i < 16; ++i) T16[i] = T.m[i]; }
+int emu_bfgs(const double* acc, int max_inner, float* T16, int* inner, int* evals) {
+  Mat4f T; for (int i = 0; i < 16; ++i) T.m[i] = T16[i];
+  int rc = gicp_estimate_bfgs(acc, max_inner, T, inner, evals);
+  for (int i = 0; i < 16; ++i) T16[i] = T.m[i];
+  return rc;
+}
+void emu_mahalanobis(const double* S6, const double* n1r, const double* n2, double eps, double* M6) { gicp_mahalanobis(S6, n1r, n2, eps, M6); }
+}
