@@ -1,0 +1,126 @@
+/* slam3d_hip.h — C ABI of the MI355X registration back-end (libslam3d_hip.so).
+ *
+ * The reference (dfki-ric/slam3d) has no FFI: its plugin contract is the C++
+ * virtual interface slam3d::Sensor / ScanSensor / PointCloudSensor
+ * (slam3d/core/ScanSensor.hpp:122-125, slam3d/sensor/pcl/PointCloudSensor.hpp:106-243).
+ * This header is the boundary a maintainer binds instead of PCL: every entry
+ * point names the reference code it replaces.  Plain pointers and sizes only;
+ * host pointers are borrowed for the duration of the call, results are returned
+ * by value into caller buffers, no device pointer crosses the ABI except through
+ * the explicit s3d_cloud handle.  The C++ mirror of the reference classes that
+ * sits on top of this ABI is cpp/slam3d/sensor/hip/PointCloudSensor.hpp; the
+ * binding stub is shown in INTEGRATION.md.
+ *
+ * There is no CPU fallback: every call fails with S3D_STATUS_BACKEND_ERROR when
+ * no HIP device is usable.
+ *
+ * Matrices: 4x4 double, COLUMN-major (the memory layout of slam3d::Transform =
+ * Eigen::Transform<double,3,Isometry>, slam3d/core/Types.hpp:53).
+ * Point clouds: float32, `stride` floats per point (3 = packed xyz,
+ * 4 = pcl::PointXYZ / KITTI layout), xyz first.
+ */
+#ifndef SLAM3D_HIP_H
+#define SLAM3D_HIP_H
+
+#include "slam3d_registration_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct s3d_context s3d_context; /* one HIP device + stream + workspace; calls on one context are serialised */
+typedef struct s3d_cloud   s3d_cloud;   /* a device-resident point cloud (immutable, like a slam3d Measurement)   */
+
+/* knobs that are not part of slam3d::RegistrationParameters */
+typedef struct s3d_exec_options {
+  int force_iterations;     /* != 0: run exactly maximum_iterations outer iterations (bench mode, no early exit) */
+  int check_interval;       /* host polls "all pairs converged" every N outer iterations (0 = default 4)          */
+  int grid_cells_per_point; /* search-grid budget, cells per input point (0 = default 16)                        */
+  int profile;              /* != 0: record per-stage HIP-event timings, read with s3d_last_profile()            */
+} s3d_exec_options;
+
+typedef struct s3d_align_info {   /* diagnostics of one align() */
+  int    n_source_filtered, n_target_filtered;   /* points after the voxel filter            */
+  int    iterations, converged, correspondences; /* outer iterations, pcl hasConverged()      */
+  double fitness;                                /* pcl getFitnessScore(max_corr_distance)    */
+  int    inner_iterations, evaluations;          /* BFGS steps / objective evaluations (GICP) */
+} s3d_align_info;
+
+typedef struct s3d_profile {      /* milliseconds, HIP events on the context's stream */
+  double voxel_ms, grid_ms, normals_ms, icp_ms, fitness_ms, total_ms;
+  double nn_ms;       /* sum over the NN-search kernel launches of the ICP loop */
+  int    nn_launches;
+  long long nn_queries, nn_targets; /* summed over launches: queries searched, target points indexed */
+} s3d_profile;
+
+/* ---- context ------------------------------------------------------------------ */
+/* hip_stream: a hipStream_t to run on (e.g. torch's current stream) or NULL for a private stream. */
+int  s3d_context_create(int device, void* hip_stream, s3d_context** out);
+void s3d_context_destroy(s3d_context* ctx);
+const char* s3d_last_error(const s3d_context* ctx);
+/* fills "name|gcnArch|CUs|HBM bytes"; returns S3D_STATUS_BACKEND_ERROR without a device */
+int  s3d_backend_info(int device, char* buf, int len);
+int  s3d_last_profile(const s3d_context* ctx, s3d_profile* out);
+void s3d_default_params(s3d_reg_params* p);          /* RegistrationParameters.hpp:36-97 defaults */
+
+/* ---- device-resident clouds ----------------------------------------------------- */
+int  s3d_cloud_upload(s3d_context* ctx, const float* xyz, int n, int stride, s3d_cloud** out);
+/* wrap n float4 (x,y,z,*) already in HBM (e.g. a torch tensor); not copied, not freed */
+int  s3d_cloud_wrap_device(s3d_context* ctx, const void* device_float4, int n, s3d_cloud** out);
+int  s3d_cloud_size(const s3d_cloud* c);
+void s3d_cloud_release(s3d_context* ctx, s3d_cloud* c);
+
+/* ---- A3  PointCloudSensor::downsample (PointCloudSensor.cpp:190-201, pcl::VoxelGrid) ----
+ * out_xyz: capacity 3*n floats (packed).  Empty input -> *n_out = 0. */
+int  s3d_voxel_downsample(s3d_context* ctx, const float* xyz, int n, int stride, double leaf_size,
+                          float* out_xyz, int* n_out);
+
+/* ---- A7  exact 1-NN (pcl::search::KdTree::nearestKSearch(q, 1), FLANN, inside align and
+ *          getFitnessScore, call sites PointCloudSensor.cpp:70, :73).  Neighbours farther than
+ *          max_distance need not be found (idx = -1 / a farther point).  Ties: lowest index. */
+int  s3d_nn_search(s3d_context* ctx, const float* target_xyz, int n, int stride_t, const float* query_xyz, int m,
+                   int stride_q, double max_distance, int* idx, float* d2);
+
+/* ---- A6  GICP computeCovariances pre-pass (PointCloudSensor.cpp:63 setCorrespondenceRandomness):
+ *          unit eigenvector of the smallest eigenvalue of the k-NN covariance, packed xyz.
+ *          The regularised covariance PCL builds is C = I - (1 - 0.001) n n^T. */
+int  s3d_knn_normals(s3d_context* ctx, const float* xyz, int n, int stride, int k, float* normals_xyz);
+
+/* ---- A2  align() (PointCloudSensor.cpp:119-174): downsample both, 100-point gate, doICP
+ *          (A4: :52-82), fitness gate, distance-from-guess gate.  Returns enum s3d_status;
+ *          result is written for every status that got as far as the ICP. */
+int  s3d_align(s3d_context* ctx, const float* source_xyz, int n_source, int stride_source,
+               const float* target_xyz, int n_target, int stride_target, const double guess[16],
+               const s3d_reg_params* params, const s3d_exec_options* opts, double result[16],
+               s3d_align_info* info);
+
+/* ---- A2 batched: many independent pairs (ScanSensor::linkToNeighbors candidates,
+ *          ScanSensor.cpp:179-201) in lock-step launches.  The same cloud handle may appear in
+ *          many pairs; its voxel filter / grid / normals are then computed once.
+ *          guesses: 16*n_pairs doubles.  records: n_pairs (status inside).  infos: optional.
+ *          Returns S3D_STATUS_OK unless the batch itself could not run. */
+int  s3d_align_batch(s3d_context* ctx, int n_pairs, s3d_cloud* const* sources, s3d_cloud* const* targets,
+                     const double* guesses, const s3d_reg_params* params, const s3d_exec_options* opts,
+                     s3d_edge_record* records, s3d_align_info* infos);
+
+/* ---- A1  PointCloudSensor::createConstraint (PointCloudSensor.cpp:269-299): frame algebra,
+ *          optional coarse align (loop closures), fine align, (I * covariance_scale)^-1.
+ *          information: 6x6 row-major. */
+int  s3d_create_constraint(s3d_context* ctx, const float* source_xyz, int n_source, int stride_source,
+                           const double source_sensor_pose[16], const float* target_xyz, int n_target,
+                           int stride_target, const double target_sensor_pose[16], const double odometry[16],
+                           int loop, const s3d_reg_params* fine, const s3d_reg_params* coarse,
+                           double covariance_scale, const s3d_exec_options* opts, double relative_pose[16],
+                           double information[36], s3d_align_info* info);
+
+/* ---- measurement hook (bench.py roofline): time `reps` launches of the NN-search kernel
+ *          (K5, one ICP iteration's correspondence pass at transformation_ = I) with HIP events
+ *          on the context's stream.  n_queries / n_targets: points after the voxel filter. */
+int  s3d_profile_nn_kernel(s3d_context* ctx, int n_pairs, s3d_cloud* const* sources, s3d_cloud* const* targets,
+                           const double* guesses, const s3d_reg_params* params, int reps, double* avg_ms,
+                           long long* n_queries, long long* n_targets);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,333 @@
+"""ctypes binding of include/slam3d_hip.h (libslam3d_hip.so).  No compute happens in Python."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "lib", "libslam3d_hip.so")
+_CSRC = os.path.join(_HERE, "csrc")
+
+ALG_ICP, ALG_GICP, ALG_GICP_OMP, ALG_NDT, ALG_NDT_OMP = range(5)
+STATUS_NAMES = ["OK", "TOO_FEW_POINTS", "NOT_CONVERGED", "FITNESS_EXCEEDED", "TOO_FAR_FROM_GUESS",
+                "UNKNOWN_ALGORITHM", "UNSUPPORTED_ALGORITHM", "INVALID_ARGUMENT", "BACKEND_ERROR"]
+EDGE_RECORD_DOUBLES = 16
+
+
+class BackendError(RuntimeError):
+    """The HIP back-end is missing or failed.  There is deliberately no CPU fallback."""
+
+
+class RegParams(C.Structure):
+    """s3d_reg_params == slam3d::RegistrationParameters (RegistrationParameters.hpp:36-97)."""
+    _fields_ = [
+        ("registration_algorithm", C.c_int), ("point_cloud_density", C.c_double), ("max_fitness_score", C.c_double),
+        ("max_translation", C.c_double), ("max_rotation", C.c_double), ("euclidean_fitness_epsilon", C.c_double),
+        ("transformation_epsilon", C.c_double), ("max_correspondence_distance", C.c_double),
+        ("maximum_iterations", C.c_int), ("rotation_epsilon", C.c_double), ("correspondence_randomness", C.c_int),
+        ("maximum_optimizer_iterations", C.c_int), ("resolution", C.c_float), ("step_size", C.c_double),
+        ("outlier_ratio", C.c_double)]
+
+
+class ExecOptions(C.Structure):
+    _fields_ = [("force_iterations", C.c_int), ("check_interval", C.c_int), ("grid_cells_per_point", C.c_int),
+                ("profile", C.c_int)]
+
+
+class AlignInfo(C.Structure):
+    _fields_ = [("n_source_filtered", C.c_int), ("n_target_filtered", C.c_int), ("iterations", C.c_int),
+                ("converged", C.c_int), ("correspondences", C.c_int), ("fitness", C.c_double),
+                ("inner_iterations", C.c_int), ("evaluations", C.c_int)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class EdgeRecord(C.Structure):
+    _fields_ = [("transform", C.c_double * 12), ("fitness", C.c_double), ("iterations", C.c_double),
+                ("correspondences", C.c_double), ("status", C.c_double)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("voxel_ms", C.c_double), ("grid_ms", C.c_double), ("normals_ms", C.c_double), ("icp_ms", C.c_double),
+                ("fitness_ms", C.c_double), ("total_ms", C.c_double), ("nn_ms", C.c_double), ("nn_launches", C.c_int),
+                ("nn_queries", C.c_longlong), ("nn_targets", C.c_longlong)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def lib_path():
+    return _LIB
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in ("s3d_api.hip", "s3d_kernels.h", "s3d_core.h")]
+    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("slam3d_hip.h", "slam3d_registration_types.h")]
+    stale = force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
+    if stale:
+        cmd = ["make", "-C", _CSRC] + (["-B"] if force else [])
+        subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libslam3d_hip.so and declare every symbol of include/slam3d_hip.h.  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise BackendError("HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                           "slam3d_amd has no CPU fallback" % _LIB)
+    L = C.CDLL(_LIB)
+    vp, fp, dp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int)
+    pp, op = C.POINTER(RegParams), C.POINTER(ExecOptions)
+    sig = {
+        "s3d_context_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
+        "s3d_context_destroy": (None, [vp]),
+        "s3d_last_error": (C.c_char_p, [vp]),
+        "s3d_backend_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+        "s3d_last_profile": (C.c_int, [vp, C.POINTER(Profile)]),
+        "s3d_default_params": (None, [pp]),
+        "s3d_cloud_upload": (C.c_int, [vp, fp, C.c_int, C.c_int, C.POINTER(vp)]),
+        "s3d_cloud_wrap_device": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp)]),
+        "s3d_cloud_size": (C.c_int, [vp]),
+        "s3d_cloud_release": (None, [vp, vp]),
+        "s3d_voxel_downsample": (C.c_int, [vp, fp, C.c_int, C.c_int, C.c_double, fp, ip]),
+        "s3d_nn_search": (C.c_int, [vp, fp, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_double, ip, fp]),
+        "s3d_knn_normals": (C.c_int, [vp, fp, C.c_int, C.c_int, C.c_int, fp]),
+        "s3d_align": (C.c_int, [vp, fp, C.c_int, C.c_int, fp, C.c_int, C.c_int, dp, pp, op, dp, C.POINTER(AlignInfo)]),
+        "s3d_align_batch": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, pp, op, C.POINTER(EdgeRecord),
+                                      C.POINTER(AlignInfo)]),
+        "s3d_create_constraint": (C.c_int, [vp, fp, C.c_int, C.c_int, dp, fp, C.c_int, C.c_int, dp, dp, C.c_int, pp, pp,
+                                            C.c_double, op, dp, dp, C.POINTER(AlignInfo)]),
+        "s3d_profile_nn_kernel": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, pp, C.c_int, dp,
+                                            C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)  # AttributeError if the symbol is not exported
+        f.restype = res
+        f.argtypes = args
+    L._s3d_symbols = sorted(sig)
+    _lib = L
+    return L
+
+
+def default_params(**overrides):
+    p = RegParams()
+    load_library().s3d_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def backend_info(device=0):
+    buf = C.create_string_buffer(256)
+    st = load_library().s3d_backend_info(device, buf, 256)
+    if st != 0:
+        raise BackendError("no usable HIP device (%s)" % buf.value.decode())
+    name, arch, cus, mem = buf.value.decode().split("|")
+    return dict(name=name, arch=arch, compute_units=int(cus), hbm_bytes=int(mem))
+
+
+def _cloud(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] not in (3, 4):
+        raise ValueError("cloud must be (n,3) or (n,4) float32, got %r" % (a.shape,))
+    return a, a.shape[0], a.shape[1]
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _colmajor(T):
+    return np.ascontiguousarray(np.asarray(T, np.float64).T.reshape(-1))
+
+
+def _from_colmajor(v):
+    return np.asarray(v, np.float64).reshape(4, 4).T.copy()
+
+
+class Cloud:
+    """Device-resident point cloud handle (s3d_cloud)."""
+
+    def __init__(self, ctx, handle, n):
+        self.ctx, self.handle, self.n = ctx, handle, n
+
+    def release(self):
+        if self.handle:
+            self.ctx._L.s3d_cloud_release(self.ctx._h, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class Context:
+    """One HIP device + stream + workspace (s3d_context)."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = load_library()
+        h = C.c_void_p()
+        st = self._L.s3d_context_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if st != 0 or not h:
+            raise BackendError("s3d_context_create failed: no usable HIP device %d (no CPU fallback)" % device)
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.s3d_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st == 8:
+            raise BackendError(self._L.s3d_last_error(self._h).decode())
+        return st
+
+    # ---- stage entry points -------------------------------------------------------
+    def voxel_downsample(self, xyz, leaf):
+        a, n, stride = _cloud(xyz)
+        out = np.empty((max(n, 1), 3), np.float32)
+        m = C.c_int(0)
+        st = self._check(self._L.s3d_voxel_downsample(self._h, _fp(a), n, stride, float(leaf), _fp(out), C.byref(m)))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
+        return out[:m.value].copy()
+
+    def nn_search(self, target, query, max_distance):
+        t, n, st_ = _cloud(target)
+        q, m, sq = _cloud(query)
+        idx = np.empty(max(m, 1), np.int32)
+        d2 = np.empty(max(m, 1), np.float32)
+        st = self._check(self._L.s3d_nn_search(self._h, _fp(t), n, st_, _fp(q), m, sq, float(max_distance),
+                                               idx.ctypes.data_as(C.POINTER(C.c_int)), _fp(d2)))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
+        return idx[:m], d2[:m]
+
+    def knn_normals(self, xyz, k=20):
+        a, n, stride = _cloud(xyz)
+        out = np.empty((max(n, 1), 3), np.float32)
+        st = self._check(self._L.s3d_knn_normals(self._h, _fp(a), n, stride, int(k), _fp(out)))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
+        return out[:n]
+
+    # ---- align / createConstraint ---------------------------------------------------
+    def align(self, source, target, guess=np.eye(4), params=None, opts=None):
+        s, ns, ss = _cloud(source)
+        t, nt, st_ = _cloud(target)
+        params = params or default_params()
+        g = _colmajor(guess)
+        res = np.empty(16, np.float64)
+        info = AlignInfo()
+        st = self._check(self._L.s3d_align(self._h, _fp(s), ns, ss, _fp(t), nt, st_, _dp(g), C.byref(params),
+                                           C.byref(opts) if opts else None, _dp(res), C.byref(info)))
+        return st, _from_colmajor(res), info.asdict()
+
+    def create_constraint(self, source, source_pose, target, target_pose, odometry, loop=False, fine=None,
+                          coarse=None, covariance_scale=1.0, opts=None):
+        s, ns, ss = _cloud(source)
+        t, nt, st_ = _cloud(target)
+        fine = fine or default_params()
+        coarse = coarse or default_params()
+        rel = np.empty(16, np.float64)
+        inf = np.empty(36, np.float64)
+        info = AlignInfo()
+        sp, tp, od = _colmajor(source_pose), _colmajor(target_pose), _colmajor(odometry)
+        st = self._check(self._L.s3d_create_constraint(
+            self._h, _fp(s), ns, ss, _dp(sp), _fp(t), nt, st_, _dp(tp), _dp(od), int(loop), C.byref(fine),
+            C.byref(coarse), float(covariance_scale), C.byref(opts) if opts else None, _dp(rel), _dp(inf),
+            C.byref(info)))
+        return st, _from_colmajor(rel), inf.reshape(6, 6), info.asdict()
+
+    # ---- device-resident batch --------------------------------------------------------
+    def upload(self, xyz):
+        a, n, stride = _cloud(xyz)
+        h = C.c_void_p()
+        st = self._check(self._L.s3d_cloud_upload(self._h, _fp(a), n, stride, C.byref(h)))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
+        return Cloud(self, h, n)
+
+    def wrap_device(self, device_ptr, n):
+        h = C.c_void_p()
+        st = self._check(self._L.s3d_cloud_wrap_device(self._h, C.c_void_p(device_ptr), int(n), C.byref(h)))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
+        return Cloud(self, h, n)
+
+    def _handles(self, clouds):
+        arr = (C.c_void_p * len(clouds))()
+        for i, c in enumerate(clouds):
+            arr[i] = c.handle
+        return arr
+
+    def align_batch(self, sources, targets, guesses=None, params=None, opts=None, want_infos=False):
+        """Returns an (n_pairs, 16) float64 array of edge records (12 transform col-major 3x4, fitness,
+        iterations, correspondences, status) and optionally the per-pair AlignInfo list."""
+        n = len(sources)
+        assert len(targets) == n
+        params = params or default_params()
+        if guesses is None:
+            guesses = np.tile(np.eye(4), (n, 1, 1))
+        g = np.ascontiguousarray(np.asarray(guesses, np.float64).transpose(0, 2, 1).reshape(n, 16))
+        rec = np.zeros((max(n, 1), EDGE_RECORD_DOUBLES), np.float64)
+        infos = (AlignInfo * max(n, 1))() if want_infos else None
+        st = self._check(self._L.s3d_align_batch(self._h, n, self._handles(sources), self._handles(targets), _dp(g),
+                                                 C.byref(params), C.byref(opts) if opts else None,
+                                                 rec.ctypes.data_as(C.POINTER(EdgeRecord)), infos))
+        if st not in (0, 5, 6):
+            raise ValueError(STATUS_NAMES[st])
+        rec = rec[:n]
+        if want_infos:
+            return rec, [infos[i].asdict() for i in range(n)]
+        return rec
+
+    def profile_nn_kernel(self, sources, targets, guesses=None, params=None, reps=20):
+        n = len(sources)
+        params = params or default_params()
+        if guesses is None:
+            guesses = np.tile(np.eye(4), (n, 1, 1))
+        g = np.ascontiguousarray(np.asarray(guesses, np.float64).transpose(0, 2, 1).reshape(n, 16))
+        ms, nq, nt = C.c_double(), C.c_longlong(), C.c_longlong()
+        st = self._check(self._L.s3d_profile_nn_kernel(self._h, n, self._handles(sources), self._handles(targets),
+                                                       _dp(g), C.byref(params), int(reps), C.byref(ms), C.byref(nq),
+                                                       C.byref(nt)))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
+        return dict(avg_ms=ms.value, n_queries=nq.value, n_targets=nt.value)
+
+    def last_profile(self):
+        p = Profile()
+        self._L.s3d_last_profile(self._h, C.byref(p))
+        return p.asdict()
+
+
+def record_transform(rec):
+    """(16,) edge record -> 4x4 transform."""
+    T = np.eye(4)
+    T[:3, :4] = np.asarray(rec[:12]).reshape(4, 3).T
+    return T

@@ -1,0 +1,873 @@
+// s3d_api.hip — host orchestration + C ABI (include/slam3d_hip.h) of the MI355X
+// registration back-end.  One translation unit: kernels in s3d_kernels.h.
+//
+// A call never routes to a CPU implementation: without a usable HIP device every
+// entry point returns S3D_STATUS_BACKEND_ERROR.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/slam3d_hip.h"
+#include "s3d_kernels.h"
+
+using namespace s3d;
+
+// ------------------------------------------------------------------ host structs
+
+struct s3d_cloud {
+  float4* d = nullptr;
+  int n = 0;
+  bool owned = false;
+};
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct HipError {
+  hipError_t e;
+  const char* what;
+  int line;
+};
+#define HIPCHK(expr)                                            \
+  do {                                                          \
+    hipError_t _e = (expr);                                     \
+    if (_e != hipSuccess) throw HipError{_e, #expr, __LINE__};  \
+  } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- host-side 4x4 double algebra for the acceptance gate (PointCloudSensor.cpp:167-172)
+#define HM(m, r, c) ((m)[(c) * 4 + (r)])
+void mat4d_mul(const double a[16], const double b[16], double out[16]) {
+  double t[16];
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += HM(a, r, k) * HM(b, k, c);
+      t[c * 4 + r] = s;
+    }
+  std::memcpy(out, t, sizeof t);
+}
+void mat4d_inverse_isometry(const double a[16], double out[16]) {  // Eigen Isometry inverse: R^T, -R^T t
+  double t[16] = {0};
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) HM(t, r, c) = HM(a, c, r);
+  for (int r = 0; r < 3; ++r) {
+    double s = 0;
+    for (int k = 0; k < 3; ++k) s += HM(t, r, k) * HM(a, k, 3);
+    HM(t, r, 3) = -s;
+  }
+  HM(t, 3, 3) = 1.0;
+  std::memcpy(out, t, sizeof t);
+}
+double rotation_angle(const double m[16]) {  // Eigen::AngleAxisd(R).angle() via the quaternion
+  const double m00 = HM(m, 0, 0), m11 = HM(m, 1, 1), m22 = HM(m, 2, 2);
+  double t = m00 + m11 + m22, w, x, y, z;
+  if (t > 0) {
+    t = std::sqrt(t + 1.0);
+    w = 0.5 * t;
+    t = 0.5 / t;
+    x = (HM(m, 2, 1) - HM(m, 1, 2)) * t;
+    y = (HM(m, 0, 2) - HM(m, 2, 0)) * t;
+    z = (HM(m, 1, 0) - HM(m, 0, 1)) * t;
+  } else {
+    int i = 0;
+    if (m11 > m00) i = 1;
+    if (m22 > HM(m, i, i)) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double q[3];
+    t = std::sqrt(HM(m, i, i) - HM(m, j, j) - HM(m, k, k) + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    w = (HM(m, k, j) - HM(m, j, k)) * t;
+    q[j] = (HM(m, j, i) + HM(m, i, j)) * t;
+    q[k] = (HM(m, k, i) + HM(m, i, k)) * t;
+    x = q[0]; y = q[1]; z = q[2];
+  }
+  return 2.0 * std::atan2(std::sqrt(x * x + y * y + z * z), std::fabs(w));
+}
+
+}  // namespace
+
+struct s3d_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  std::mutex mtx;
+  s3d_profile prof{};
+  // workspace (grown on demand, reused across calls)
+  DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, normals, cell_start, counts, blockcnt, corr_idx,
+      corr_d2, partials, n_active;
+  int* h_active = nullptr;  // pinned
+  hipEvent_t ev[8] = {};
+  std::vector<hipEvent_t> nn_ev;
+
+  void ensure(DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return;
+    if (b.p) HIPCHK(hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(hipMalloc(&b.p, want));
+    b.cap = want;
+  }
+  void release_all() {
+    DevBuf* all[] = {&slots, &pairs, &keysA, &keysB, &valsA, &valsB, &filt, &sorted, &normals, &cell_start,
+                     &counts, &blockcnt, &corr_idx, &corr_d2, &partials, &n_active};
+    for (DevBuf* b : all)
+      if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+  }
+};
+
+namespace {
+
+int fail(s3d_context* ctx, const HipError& e) {
+  char buf[512];
+  std::snprintf(buf, sizeof buf, "HIP error %d (%s) at s3d_api.hip:%d: %s", (int)e.e, hipGetErrorString(e.e), e.line,
+                e.what);
+  if (ctx) ctx->err = buf;
+  return S3D_STATUS_BACKEND_ERROR;
+}
+
+// ------------------------------------------------------------------ one batch of align() jobs
+
+struct Batch {
+  s3d_context* ctx;
+  RunParams rp{};
+  s3d_exec_options opts{};
+  std::vector<const s3d_cloud*> slot_clouds;
+  std::vector<SlotDev> h_slots;
+  std::vector<PairDev> h_pairs;
+  int max_n = 0, max_n_t = 0, nb_sort = 0, nb_head = 0, accum_blocks = 1;
+  size_t total_pts = 0, total_cells = 0, total_corr = 0;
+
+  SlotDev* d_slots() { return (SlotDev*)ctx->slots.p; }
+  PairDev* d_pairs() { return (PairDev*)ctx->pairs.p; }
+  uint32_t* kA() { return (uint32_t*)ctx->keysA.p; }
+  uint32_t* kB() { return (uint32_t*)ctx->keysB.p; }
+  uint32_t* vA() { return (uint32_t*)ctx->valsA.p; }
+  uint32_t* vB() { return (uint32_t*)ctx->valsB.p; }
+  float4* filt() { return (float4*)ctx->filt.p; }
+  float4* sorted() { return (float4*)ctx->sorted.p; }
+  float4* normals() { return (float4*)ctx->normals.p; }
+  uint32_t* cells() { return (uint32_t*)ctx->cell_start.p; }
+  int C() const { return (int)h_slots.size(); }
+  int P() const { return (int)h_pairs.size(); }
+
+  void set_params(const s3d_reg_params* p, const s3d_exec_options* o) {
+    if (o) opts = *o;
+    if (opts.check_interval <= 0) opts.check_interval = 4;
+    if (opts.grid_cells_per_point <= 0) opts.grid_cells_per_point = 16;
+    rp.algorithm = p->registration_algorithm == S3D_ALG_ICP ? 0 : 1;
+    rp.k = p->correspondence_randomness;
+    rp.max_iterations = p->maximum_iterations;
+    rp.max_inner = p->maximum_optimizer_iterations;
+    rp.force_iterations = opts.force_iterations;
+    rp.max_corr = p->max_correspondence_distance;
+    rp.dist_threshold = p->max_correspondence_distance * p->max_correspondence_distance;
+    rp.rotation_epsilon = p->rotation_epsilon;
+    rp.transformation_epsilon = p->transformation_epsilon;
+    rp.fit_range = p->max_correspondence_distance;  // PointCloudSensor.cpp:73 (un-squared)
+    rp.gicp_epsilon = 0.001;                        // PCL default gicp_epsilon_
+    rp.leaf = (float)p->point_cloud_density;        // PointCloudSensor.cpp:196 setLeafSize(double -> float)
+    rp.h0 = p->point_cloud_density > 0 ? (float)(2.0 * p->point_cloud_density) : 0.25f;
+  }
+
+  int add_slot(const s3d_cloud* c, std::map<const s3d_cloud*, int>& index) {
+    auto it = index.find(c);
+    if (it != index.end()) return it->second;
+    SlotDev s;
+    std::memset(&s, 0, sizeof s);
+    s.raw = c->d;
+    s.n_raw = c->n;
+    s.off = (int)total_pts;
+    total_pts += (size_t)((c->n + 3) & ~3);
+    const long long cap =
+        std::min<long long>(std::max<long long>((long long)opts.grid_cells_per_point * c->n, 64), 1ll << 24);
+    s.cell_cap = (int)cap;
+    s.cell_off = (int)total_cells;
+    total_cells += (size_t)cap + 1;
+    max_n = std::max(max_n, c->n);
+    const int id = (int)h_slots.size();
+    h_slots.push_back(s);
+    slot_clouds.push_back(c);
+    index[c] = id;
+    return id;
+  }
+
+  void add_pairs(int n_pairs, s3d_cloud* const* sources, s3d_cloud* const* targets, const double* guesses) {
+    std::map<const s3d_cloud*, int> index;
+    for (int p = 0; p < n_pairs; ++p) {
+      PairDev P;
+      std::memset(&P, 0, sizeof P);
+      P.slot_s = add_slot(sources[p], index);
+      P.slot_t = add_slot(targets[p], index);
+      P.corr_off = (int)total_corr;
+      total_corr += (size_t)((targets[p]->n + 3) & ~3);
+      max_n_t = std::max(max_n_t, targets[p]->n);
+      for (int i = 0; i < 16; ++i) P.guess.m[i] = (float)guesses[(size_t)p * 16 + i];  // :70 cast<float>()
+      h_pairs.push_back(P);
+    }
+  }
+
+  void allocate() {
+    if (total_pts > (size_t)0x7FFFFFF0 || total_cells > (size_t)0x7FFFFFF0 || total_corr > (size_t)0x7FFFFFF0)
+      throw HipError{hipErrorInvalidValue, "batch too large for 32-bit offsets", __LINE__};
+    nb_sort = std::max(1, cdiv(max_n, kSortTile));
+    nb_head = std::max(1, cdiv(max_n, kBlock));
+    accum_blocks = std::min(kAccumBlocks, std::max(1, cdiv(max_n_t, kBlock * 8)));
+    const size_t np = std::max<size_t>(total_pts, 4);
+    ctx->ensure(ctx->slots, sizeof(SlotDev) * std::max(1, C()));
+    ctx->ensure(ctx->pairs, sizeof(PairDev) * std::max(1, P()));
+    ctx->ensure(ctx->keysA, 4 * np); ctx->ensure(ctx->keysB, 4 * np);
+    ctx->ensure(ctx->valsA, 4 * np); ctx->ensure(ctx->valsB, 4 * np);
+    ctx->ensure(ctx->filt, 16 * np); ctx->ensure(ctx->sorted, 16 * np); ctx->ensure(ctx->normals, 16 * np);
+    ctx->ensure(ctx->cell_start, 4 * std::max<size_t>(total_cells, 4));
+    ctx->ensure(ctx->counts, 4 * (size_t)std::max(1, C()) * 256 * nb_sort);
+    ctx->ensure(ctx->blockcnt, 4 * (size_t)std::max(1, C()) * nb_head);
+    ctx->ensure(ctx->corr_idx, 4 * std::max<size_t>(total_corr, 4));
+    ctx->ensure(ctx->corr_d2, 4 * std::max<size_t>(total_corr, 4));
+    ctx->ensure(ctx->partials, 8 * (size_t)std::max(1, P()) * kAccumBlocks * GQ_NACC);
+    ctx->ensure(ctx->n_active, 64);
+    if (!ctx->h_active) HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
+    hipStream_t st = ctx->stream;
+    if (C()) HIPCHK(hipMemcpyAsync(ctx->slots.p, h_slots.data(), sizeof(SlotDev) * C(), hipMemcpyHostToDevice, st));
+    if (P()) HIPCHK(hipMemcpyAsync(ctx->pairs.p, h_pairs.data(), sizeof(PairDev) * P(), hipMemcpyHostToDevice, st));
+  }
+
+  // segmented LSD radix sort of (keys, vals) of every slot; `passes` 8-bit digits.
+  // input in A; result in A for even `passes`, in B for odd.
+  void sort(int passes) {
+    hipStream_t st = ctx->stream;
+    uint32_t *ki = kA(), *vi = vA(), *ko = kB(), *vo = vB();
+    uint32_t* cnt = (uint32_t*)ctx->counts.p;
+    for (int p = 0; p < passes; ++p) {
+      const int shift = 8 * p;
+      k_sort_hist<<<dim3(nb_sort, C()), kBlock, 0, st>>>(d_slots(), ki, cnt, shift, nb_sort);
+      k_sort_scan<<<C(), kBlock, 0, st>>>(d_slots(), cnt, nb_sort);
+      k_sort_scatter<<<dim3(nb_sort, C()), kBlock, 0, st>>>(d_slots(), ki, vi, ko, vo, cnt, shift, nb_sort);
+      std::swap(ki, ko);
+      std::swap(vi, vo);
+    }
+  }
+
+  // K1 + K2: pcl::VoxelGrid of every slot (or a plain copy when leaf <= 0)
+  void stage_voxel() {
+    hipStream_t st = ctx->stream;
+    if (C() == 0) return;
+    if (rp.leaf > 0.f) {
+      k_slot_reset_bbox<<<C(), 64, 0, st>>>(d_slots());
+      k_bbox<0><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), C()), kBlock, 0, st>>>(d_slots(), filt());
+      k_voxel_params<<<cdiv(C(), 64), 64, 0, st>>>(d_slots(), rp, C());
+      k_voxel_keys<<<dim3(nb_head, C()), kBlock, 0, st>>>(d_slots(), kA(), vA());
+      sort(4);
+      uint32_t* bc = (uint32_t*)ctx->blockcnt.p;
+      k_heads_count<<<dim3(nb_head, C()), kBlock, 0, st>>>(d_slots(), kA(), bc, nb_head);
+      k_heads_scan<<<C(), kBlock, 0, st>>>(d_slots(), bc, nb_head);
+      k_centroids<<<dim3(nb_head, C()), kBlock, 0, st>>>(d_slots(), kA(), vA(), bc, filt(), nb_head);
+    } else {
+      k_copy_raw<<<dim3(nb_head, C()), kBlock, 0, st>>>(d_slots(), filt());
+    }
+  }
+
+  // K3: dense search grid + cell-sorted copy of every slot
+  void stage_grid() {
+    hipStream_t st = ctx->stream;
+    if (C() == 0) return;
+    k_slot_reset_bbox<<<C(), 64, 0, st>>>(d_slots());
+    k_bbox<1><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), C()), kBlock, 0, st>>>(d_slots(), filt());
+    k_grid_params<<<cdiv(C(), 64), 64, 0, st>>>(d_slots(), rp, C());
+    k_cell_keys<<<dim3(nb_head, C()), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA());
+    sort(3);  // cell ids < 2^24
+    k_grid_finalize<<<dim3(cdiv(max_n + 1, kBlock), C()), kBlock, 0, st>>>(d_slots(), filt(), kB(), vB(), sorted(),
+                                                                           cells());
+  }
+
+  // K4
+  void stage_normals() {
+    hipStream_t st = ctx->stream;
+    if (C() == 0) return;
+    const int k = std::max(1, std::min(rp.k, 64));
+    const size_t smem = (size_t)k * kBlock * 8;
+    k_normals<<<dim3(nb_head, C()), kBlock, smem, st>>>(d_slots(), filt(), sorted(), cells(), normals(), k);
+  }
+
+  void launch_nn(int mode, float max_d) {
+    hipStream_t st = ctx->stream;
+    dim3 grid(cdiv(std::max(max_n_t, 1), kBlock), P());
+    if (mode == 0)
+      s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), filt(), sorted(), cells(),
+                                                        (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, max_d);
+    else
+      s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), filt(), sorted(), cells(),
+                                                        (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, max_d);
+  }
+
+  // K5-K7 loop.  The host only polls the active-pair counter every check_interval iterations.
+  void stage_icp() {
+    hipStream_t st = ctx->stream;
+    if (P() == 0) return;
+    int* d_active = (int*)ctx->n_active.p;
+    k_pair_init<<<cdiv(P(), 64), 64, 0, st>>>(d_pairs(), P(), d_active);
+    const float max_d = (float)(rp.max_corr * 1.0001);
+    double* part = (double*)ctx->partials.p;
+    const bool prof = opts.profile != 0;
+    for (int it = 0; it < rp.max_iterations; ++it) {
+      if (prof) {
+        if ((int)ctx->nn_ev.size() < 2 * (it + 1)) {
+          hipEvent_t a, b;
+          HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+          ctx->nn_ev.push_back(a); ctx->nn_ev.push_back(b);
+        }
+        HIPCHK(hipEventRecord(ctx->nn_ev[2 * it], st));
+      }
+      launch_nn(0, max_d);
+      if (prof) HIPCHK(hipEventRecord(ctx->nn_ev[2 * it + 1], st));
+      if (rp.algorithm)
+        s3d_gicp_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
+            d_pairs(), d_slots(), filt(), normals(), (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, part, rp);
+      else
+        s3d_p2plane_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
+            d_pairs(), d_slots(), filt(), normals(), (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, part, rp);
+      s3d_icp_control_kernel<<<P(), 128, 0, st>>>(d_pairs(), part, accum_blocks, rp, d_active);
+      ctx->prof.nn_launches = it + 1;
+      if (!rp.force_iterations && (it + 1) % opts.check_interval == 0 && it + 1 < rp.max_iterations) {
+        HIPCHK(hipMemcpyAsync(ctx->h_active, d_active, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (*ctx->h_active <= 0) break;
+      }
+    }
+  }
+
+  // A9: final_transformation_, one more NN pass, masked mean
+  void stage_fitness() {
+    hipStream_t st = ctx->stream;
+    if (P() == 0) return;
+    k_pair_finalize<<<cdiv(P(), 64), 64, 0, st>>>(d_pairs(), P());
+    launch_nn(1, (float)(std::sqrt(std::max(rp.fit_range, 0.0)) * 1.0001));
+    double* part = (double*)ctx->partials.p;
+    s3d_fitness_partial_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(d_pairs(), d_slots(), (int*)ctx->corr_idx.p,
+                                                                           (float*)ctx->corr_d2.p, part, rp);
+    k_fitness_final<<<cdiv(P(), 64), 64, 0, st>>>(d_pairs(), part, accum_blocks, P());
+  }
+
+  void download() {
+    hipStream_t st = ctx->stream;
+    if (C()) HIPCHK(hipMemcpyAsync(h_slots.data(), ctx->slots.p, sizeof(SlotDev) * C(), hipMemcpyDeviceToHost, st));
+    if (P()) HIPCHK(hipMemcpyAsync(h_pairs.data(), ctx->pairs.p, sizeof(PairDev) * P(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+  }
+
+  void run_all() {
+    hipStream_t st = ctx->stream;
+    const bool prof = opts.profile != 0;
+    auto mark = [&](int i) {
+      if (!prof) return;
+      if (!ctx->ev[i]) HIPCHK(hipEventCreate(&ctx->ev[i]));
+      HIPCHK(hipEventRecord(ctx->ev[i], st));
+    };
+    ctx->prof = s3d_profile{};
+    mark(0);
+    stage_voxel();
+    mark(1);
+    stage_grid();
+    mark(2);
+    stage_normals();
+    mark(3);
+    stage_icp();
+    mark(4);
+    stage_fitness();
+    mark(5);
+    download();
+    if (prof) {
+      float ms = 0;
+      auto el = [&](int a, int b) { HIPCHK(hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b])); return (double)ms; };
+      ctx->prof.voxel_ms = el(0, 1); ctx->prof.grid_ms = el(1, 2); ctx->prof.normals_ms = el(2, 3);
+      ctx->prof.icp_ms = el(3, 4); ctx->prof.fitness_ms = el(4, 5); ctx->prof.total_ms = el(0, 5);
+      long long nq = 0, nt = 0;
+      for (const PairDev& P : h_pairs) { nq += h_slots[P.slot_t].n; nt += h_slots[P.slot_s].n; }
+      for (int i = 0; i < ctx->prof.nn_launches; ++i) {
+        HIPCHK(hipEventElapsedTime(&ms, ctx->nn_ev[2 * i], ctx->nn_ev[2 * i + 1]));
+        ctx->prof.nn_ms += ms;
+      }
+      ctx->prof.nn_queries = nq * ctx->prof.nn_launches;
+      ctx->prof.nn_targets = nt * ctx->prof.nn_launches;
+    }
+  }
+
+  // gates of doICP / align() applied on the host to the downloaded pair state
+  int finish_pair(int p, const s3d_reg_params* params, const double guess[16], double result[16],
+                  s3d_align_info* info) const {
+    const PairDev& P = h_pairs[p];
+    const SlotDev& Ss = h_slots[P.slot_s];
+    const SlotDev& St = h_slots[P.slot_t];
+    if (info) {
+      info->n_source_filtered = Ss.n; info->n_target_filtered = St.n;
+      info->iterations = P.iterations; info->converged = P.converged; info->correspondences = P.correspondences;
+      info->fitness = P.fitness; info->inner_iterations = P.inner_total; info->evaluations = P.evals_total;
+    }
+    for (int i = 0; i < 16; ++i) result[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    if (St.n < 100 || Ss.n < 100) return S3D_STATUS_TOO_FEW_POINTS;  // PointCloudSensor.cpp:134-135
+    if (params->correspondence_randomness > Ss.n || params->correspondence_randomness > St.n ||
+        params->correspondence_randomness > 64 || params->correspondence_randomness < 1)
+      return S3D_STATUS_INVALID_ARGUMENT;
+    // :80-81 Transform(Eigen::Isometry3f(getFinalTransformation())): widen, no re-orthonormalisation
+    for (int i = 0; i < 16; ++i) result[i] = (double)P.final_T.m[i];
+    result[3] = result[7] = result[11] = 0.0;
+    result[15] = 1.0;
+    if (!P.converged) return S3D_STATUS_NOT_CONVERGED;                                   // :74
+    if (P.fitness > params->max_fitness_score) return S3D_STATUS_FITNESS_EXCEEDED;       // :74
+    double ginv[16], delta[16];
+    mat4d_inverse_isometry(guess, ginv);
+    mat4d_mul(ginv, result, delta);                                                      // :167
+    const double tn = std::sqrt(HM(delta, 0, 3) * HM(delta, 0, 3) + HM(delta, 1, 3) * HM(delta, 1, 3) +
+                                HM(delta, 2, 3) * HM(delta, 2, 3));
+    if (tn > params->max_translation || rotation_angle(delta) > params->max_rotation)    // :169
+      return S3D_STATUS_TOO_FAR_FROM_GUESS;
+    return S3D_STATUS_OK;
+  }
+};
+
+int check_algorithm(const s3d_reg_params* p) {
+  switch (p->registration_algorithm) {  // PointCloudSensor.cpp:139-165
+    case S3D_ALG_ICP: case S3D_ALG_GICP: case S3D_ALG_GICP_OMP: return S3D_STATUS_OK;
+    case S3D_ALG_NDT: case S3D_ALG_NDT_OMP: return S3D_STATUS_UNSUPPORTED_ALGORITHM;
+    default: return S3D_STATUS_UNKNOWN_ALGORITHM;
+  }
+}
+
+int upload_cloud(s3d_context* ctx, const float* xyz, int n, int stride, s3d_cloud* c) {
+  c->n = n; c->owned = true; c->d = nullptr;
+  HIPCHK(hipMalloc((void**)&c->d, sizeof(float4) * (size_t)std::max(n, 1)));
+  if (n > 0) {
+    if (stride == 4) {
+      HIPCHK(hipMemcpyAsync(c->d, xyz, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    } else {
+      std::vector<float4> tmp((size_t)n);
+      for (int i = 0; i < n; ++i) {
+        const float* p = xyz + (size_t)i * stride;
+        tmp[i] = make_float4(p[0], p[1], p[2], 1.f);
+      }
+      HIPCHK(hipMemcpyAsync(c->d, tmp.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+  }
+  return S3D_STATUS_OK;
+}
+void free_cloud(s3d_cloud* c) {
+  if (c->owned && c->d) (void)hipFree(c->d);
+  c->d = nullptr;
+}
+
+struct ScopedDevice {
+  explicit ScopedDevice(s3d_context* ctx) : lock(ctx->mtx) { HIPCHK(hipSetDevice(ctx->device)); }
+  std::lock_guard<std::mutex> lock;
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI
+
+extern "C" {
+
+void s3d_default_params(s3d_reg_params* p) {
+  p->registration_algorithm = S3D_ALG_GICP;
+  p->point_cloud_density = 0.2;
+  p->max_fitness_score = 2.0;
+  p->max_translation = 1.0;
+  p->max_rotation = 1.0;
+  p->euclidean_fitness_epsilon = 1.0;
+  p->transformation_epsilon = 1e-5;
+  p->max_correspondence_distance = 2.5;
+  p->maximum_iterations = 50;
+  p->rotation_epsilon = 2e-3;
+  p->correspondence_randomness = 20;
+  p->maximum_optimizer_iterations = 20;
+  p->resolution = 1.0f;
+  p->step_size = 0.05;
+  p->outlier_ratio = 0.35;
+}
+
+int s3d_backend_info(int device, char* buf, int len) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
+    if (buf && len > 0) std::snprintf(buf, len, "no HIP device");
+    return S3D_STATUS_BACKEND_ERROR;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return S3D_STATUS_BACKEND_ERROR;
+  if (buf && len > 0)
+    std::snprintf(buf, len, "%s|%s|%d|%zu", prop.name, prop.gcnArchName, prop.multiProcessorCount,
+                  (size_t)prop.totalGlobalMem);
+  return S3D_STATUS_OK;
+}
+
+int s3d_context_create(int device, void* hip_stream, s3d_context** out) {
+  if (!out) return S3D_STATUS_INVALID_ARGUMENT;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+    return S3D_STATUS_BACKEND_ERROR;  // no CPU fallback, by design
+  s3d_context* ctx = new s3d_context();
+  ctx->device = device;
+  try {
+    HIPCHK(hipSetDevice(device));
+    if (hip_stream) {
+      ctx->stream = (hipStream_t)hip_stream;
+    } else {
+      HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+      ctx->own_stream = true;
+    }
+  } catch (const HipError& e) {
+    fail(ctx, e);
+    delete ctx;
+    return S3D_STATUS_BACKEND_ERROR;
+  }
+  *out = ctx;
+  return S3D_STATUS_OK;
+}
+
+void s3d_context_destroy(s3d_context* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  ctx->release_all();
+  if (ctx->h_active) (void)hipHostFree(ctx->h_active);
+  for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->nn_ev) (void)hipEventDestroy(e);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* s3d_last_error(const s3d_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int s3d_last_profile(const s3d_context* ctx, s3d_profile* out) {
+  if (!ctx || !out) return S3D_STATUS_INVALID_ARGUMENT;
+  *out = ctx->prof;
+  return S3D_STATUS_OK;
+}
+
+int s3d_cloud_upload(s3d_context* ctx, const float* xyz, int n, int stride, s3d_cloud** out) {
+  if (!ctx || !out || n < 0 || stride < 3 || (n > 0 && !xyz)) return S3D_STATUS_INVALID_ARGUMENT;
+  s3d_cloud* c = new s3d_cloud();
+  try {
+    ScopedDevice sd(ctx);
+    upload_cloud(ctx, xyz, n, stride, c);
+  } catch (const HipError& e) {
+    free_cloud(c);
+    delete c;
+    return fail(ctx, e);
+  }
+  *out = c;
+  return S3D_STATUS_OK;
+}
+
+int s3d_cloud_wrap_device(s3d_context* ctx, const void* device_float4, int n, s3d_cloud** out) {
+  if (!ctx || !out || n < 0 || (n > 0 && !device_float4)) return S3D_STATUS_INVALID_ARGUMENT;
+  s3d_cloud* c = new s3d_cloud();
+  c->d = (float4*)device_float4;
+  c->n = n;
+  c->owned = false;
+  *out = c;
+  return S3D_STATUS_OK;
+}
+
+int s3d_cloud_size(const s3d_cloud* c) { return c ? c->n : 0; }
+
+void s3d_cloud_release(s3d_context* ctx, s3d_cloud* c) {
+  if (!c) return;
+  if (ctx) {
+    std::lock_guard<std::mutex> lock(ctx->mtx);
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_cloud(c);
+  } else {
+    free_cloud(c);
+  }
+  delete c;
+}
+
+int s3d_align_batch(s3d_context* ctx, int n_pairs, s3d_cloud* const* sources, s3d_cloud* const* targets,
+                    const double* guesses, const s3d_reg_params* params, const s3d_exec_options* opts,
+                    s3d_edge_record* records, s3d_align_info* infos) {
+  if (!ctx || n_pairs < 0 || !params || (n_pairs > 0 && (!sources || !targets || !guesses || !records)))
+    return S3D_STATUS_INVALID_ARGUMENT;
+  const int alg = check_algorithm(params);
+  if (alg != S3D_STATUS_OK) {
+    for (int p = 0; p < n_pairs; ++p) {
+      std::memset(&records[p], 0, sizeof records[p]);
+      records[p].transform[0] = records[p].transform[4] = records[p].transform[8] = 1.0;
+      records[p].status = alg;
+    }
+    return alg;
+  }
+  try {
+    ScopedDevice sd(ctx);
+    Batch b;
+    b.ctx = ctx;
+    b.set_params(params, opts);
+    b.add_pairs(n_pairs, sources, targets, guesses);
+    b.allocate();
+    b.run_all();
+    for (int p = 0; p < n_pairs; ++p) {
+      double result[16];
+      s3d_align_info info{};
+      const int st = b.finish_pair(p, params, guesses + (size_t)p * 16, result, &info);
+      s3d_edge_record& r = records[p];
+      for (int c = 0; c < 4; ++c)
+        for (int rr = 0; rr < 3; ++rr) r.transform[c * 3 + rr] = result[c * 4 + rr];
+      r.fitness = info.fitness;
+      r.iterations = info.iterations;
+      r.correspondences = info.correspondences;
+      r.status = st;
+      if (infos) infos[p] = info;
+    }
+  } catch (const HipError& e) {
+    return fail(ctx, e);
+  }
+  return S3D_STATUS_OK;
+}
+
+int s3d_align(s3d_context* ctx, const float* source_xyz, int n_source, int stride_source, const float* target_xyz,
+              int n_target, int stride_target, const double guess[16], const s3d_reg_params* params,
+              const s3d_exec_options* opts, double result[16], s3d_align_info* info) {
+  if (!ctx || !guess || !params || !result || n_source < 0 || n_target < 0 || stride_source < 3 || stride_target < 3)
+    return S3D_STATUS_INVALID_ARGUMENT;
+  for (int i = 0; i < 16; ++i) result[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  if (info) std::memset(info, 0, sizeof *info);
+  const int alg = check_algorithm(params);
+  s3d_cloud cs, ct;
+  int status = S3D_STATUS_OK;
+  try {
+    ScopedDevice sd(ctx);
+    upload_cloud(ctx, source_xyz, n_source, stride_source, &cs);
+    upload_cloud(ctx, target_xyz, n_target, stride_target, &ct);
+    Batch b;
+    b.ctx = ctx;
+    s3d_cloud* ps = &cs; s3d_cloud* pt = &ct;
+    if (alg != S3D_STATUS_OK) {
+      // the reference downsamples and applies the 100-point gate before it dispatches (:127-135)
+      s3d_reg_params tmp = *params;
+      tmp.registration_algorithm = S3D_ALG_GICP;
+      tmp.maximum_iterations = 0;
+      b.set_params(&tmp, opts);
+      b.add_pairs(1, &ps, &pt, guess);
+      b.allocate();
+      b.stage_voxel();
+      b.download();
+      status = (b.h_slots[0].n < 100 || b.h_slots[1].n < 100) ? S3D_STATUS_TOO_FEW_POINTS : alg;
+      if (info) { info->n_source_filtered = b.h_slots[0].n; info->n_target_filtered = b.h_slots[1].n; }
+    } else {
+      b.set_params(params, opts);
+      b.add_pairs(1, &ps, &pt, guess);
+      b.allocate();
+      b.run_all();
+      status = b.finish_pair(0, params, guess, result, info);
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    free_cloud(&cs);
+    free_cloud(&ct);
+  } catch (const HipError& e) {
+    free_cloud(&cs);
+    free_cloud(&ct);
+    return fail(ctx, e);
+  }
+  return status;
+}
+
+int s3d_create_constraint(s3d_context* ctx, const float* source_xyz, int n_source, int stride_source,
+                          const double source_sensor_pose[16], const float* target_xyz, int n_target,
+                          int stride_target, const double target_sensor_pose[16], const double odometry[16], int loop,
+                          const s3d_reg_params* fine, const s3d_reg_params* coarse, double covariance_scale,
+                          const s3d_exec_options* opts, double relative_pose[16], double information[36],
+                          s3d_align_info* info) {
+  if (!ctx || !source_sensor_pose || !target_sensor_pose || !odometry || !fine || (loop && !coarse) ||
+      !relative_pose || !information)
+    return S3D_STATUS_INVALID_ARGUMENT;
+  double sinv[16], tinv[16], guess[16], tmp[16];
+  mat4d_inverse_isometry(source_sensor_pose, sinv);
+  mat4d_inverse_isometry(target_sensor_pose, tinv);
+  mat4d_mul(sinv, odometry, tmp);              // PointCloudSensor.cpp:274
+  mat4d_mul(tmp, target_sensor_pose, guess);
+  int st;
+  if (loop) {                                  // :286-289
+    double coarse_result[16];
+    st = s3d_align(ctx, source_xyz, n_source, stride_source, target_xyz, n_target, stride_target, guess, coarse, opts,
+                   coarse_result, info);
+    if (st != S3D_STATUS_OK) return st;
+    std::memcpy(guess, coarse_result, sizeof guess);
+  }
+  double icp_result[16];
+  st = s3d_align(ctx, source_xyz, n_source, stride_source, target_xyz, n_target, stride_target, guess, fine, opts,
+                 icp_result, info);           // :292
+  if (st != S3D_STATUS_OK) return st;
+  mat4d_mul(source_sensor_pose, icp_result, tmp);  // :295
+  mat4d_mul(tmp, tinv, relative_pose);
+  for (int i = 0; i < 36; ++i) information[i] = 0.0;
+  for (int i = 0; i < 6; ++i) information[i * 6 + i] = 1.0 / covariance_scale;  // :296-298
+  return S3D_STATUS_OK;
+}
+
+int s3d_voxel_downsample(s3d_context* ctx, const float* xyz, int n, int stride, double leaf_size, float* out_xyz,
+                         int* n_out) {
+  if (!ctx || !n_out || n < 0 || stride < 3 || (n > 0 && (!xyz || !out_xyz))) return S3D_STATUS_INVALID_ARGUMENT;
+  *n_out = 0;
+  if (n == 0) return S3D_STATUS_OK;  // PointCloudSensor.cpp:193
+  s3d_cloud c;
+  try {
+    ScopedDevice sd(ctx);
+    upload_cloud(ctx, xyz, n, stride, &c);
+    s3d_reg_params p;
+    s3d_default_params(&p);
+    p.point_cloud_density = leaf_size;
+    Batch b;
+    b.ctx = ctx;
+    b.set_params(&p, nullptr);
+    std::map<const s3d_cloud*, int> index;
+    b.add_slot(&c, index);
+    b.allocate();
+    b.stage_voxel();
+    b.download();
+    const int m = b.h_slots[0].n;
+    std::vector<float4> tmp((size_t)std::max(m, 1));
+    if (m > 0) HIPCHK(hipMemcpy(tmp.data(), b.filt() + b.h_slots[0].off, sizeof(float4) * (size_t)m, hipMemcpyDeviceToHost));
+    for (int i = 0; i < m; ++i) {
+      out_xyz[(size_t)i * 3 + 0] = tmp[i].x; out_xyz[(size_t)i * 3 + 1] = tmp[i].y; out_xyz[(size_t)i * 3 + 2] = tmp[i].z;
+    }
+    *n_out = m;
+    free_cloud(&c);
+  } catch (const HipError& e) {
+    free_cloud(&c);
+    return fail(ctx, e);
+  }
+  return S3D_STATUS_OK;
+}
+
+int s3d_nn_search(s3d_context* ctx, const float* target_xyz, int n, int stride_t, const float* query_xyz, int m,
+                  int stride_q, double max_distance, int* idx, float* d2) {
+  if (!ctx || n < 0 || m < 0 || stride_t < 3 || stride_q < 3 || (m > 0 && (!idx || !d2 || !query_xyz)) ||
+      (n > 0 && !target_xyz))
+    return S3D_STATUS_INVALID_ARGUMENT;
+  s3d_cloud ct, cq;
+  try {
+    ScopedDevice sd(ctx);
+    upload_cloud(ctx, target_xyz, n, stride_t, &ct);
+    upload_cloud(ctx, query_xyz, m, stride_q, &cq);
+    s3d_reg_params p;
+    s3d_default_params(&p);
+    p.point_cloud_density = 0.0;  // search the clouds as given
+    p.max_correspondence_distance = max_distance;
+    Batch b;
+    b.ctx = ctx;
+    b.set_params(&p, nullptr);
+    s3d_cloud* ps = &ct; s3d_cloud* pq = &cq;
+    const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    b.add_pairs(1, &ps, &pq, ident);
+    b.allocate();
+    b.stage_voxel();
+    b.stage_grid();
+    k_pair_init<<<1, 64, 0, ctx->stream>>>(b.d_pairs(), 1, (int*)ctx->n_active.p);  // final_T = guess = I
+    b.launch_nn(1, (float)(max_distance * 1.0001));
+    b.download();
+    if (m > 0) {
+      HIPCHK(hipMemcpy(idx, (int*)ctx->corr_idx.p + b.h_pairs[0].corr_off, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(d2, (float*)ctx->corr_d2.p + b.h_pairs[0].corr_off, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost));
+    }
+    free_cloud(&ct);
+    free_cloud(&cq);
+  } catch (const HipError& e) {
+    free_cloud(&ct);
+    free_cloud(&cq);
+    return fail(ctx, e);
+  }
+  return S3D_STATUS_OK;
+}
+
+int s3d_knn_normals(s3d_context* ctx, const float* xyz, int n, int stride, int k, float* normals_xyz) {
+  if (!ctx || n < 0 || stride < 3 || k < 1 || k > 64 || (n > 0 && (!xyz || !normals_xyz)))
+    return S3D_STATUS_INVALID_ARGUMENT;
+  if (k > n) return S3D_STATUS_INVALID_ARGUMENT;  // PCL: "Number of points in cloud is less than k"
+  s3d_cloud c;
+  try {
+    ScopedDevice sd(ctx);
+    upload_cloud(ctx, xyz, n, stride, &c);
+    s3d_reg_params p;
+    s3d_default_params(&p);
+    p.point_cloud_density = 0.0;
+    p.correspondence_randomness = k;
+    Batch b;
+    b.ctx = ctx;
+    b.set_params(&p, nullptr);
+    std::map<const s3d_cloud*, int> index;
+    b.add_slot(&c, index);
+    b.allocate();
+    b.stage_voxel();
+    b.stage_grid();
+    b.stage_normals();
+    b.download();
+    std::vector<float4> tmp((size_t)std::max(n, 1));
+    HIPCHK(hipMemcpy(tmp.data(), b.normals() + b.h_slots[0].off, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+      normals_xyz[(size_t)i * 3 + 0] = tmp[i].x; normals_xyz[(size_t)i * 3 + 1] = tmp[i].y;
+      normals_xyz[(size_t)i * 3 + 2] = tmp[i].z;
+    }
+    free_cloud(&c);
+  } catch (const HipError& e) {
+    free_cloud(&c);
+    return fail(ctx, e);
+  }
+  return S3D_STATUS_OK;
+}
+
+int s3d_profile_nn_kernel(s3d_context* ctx, int n_pairs, s3d_cloud* const* sources, s3d_cloud* const* targets,
+                          const double* guesses, const s3d_reg_params* params, int reps, double* avg_ms,
+                          long long* n_queries, long long* n_targets) {
+  if (!ctx || n_pairs <= 0 || !sources || !targets || !guesses || !params || reps <= 0 || !avg_ms)
+    return S3D_STATUS_INVALID_ARGUMENT;
+  try {
+    ScopedDevice sd(ctx);
+    Batch b;
+    b.ctx = ctx;
+    b.set_params(params, nullptr);
+    b.add_pairs(n_pairs, sources, targets, guesses);
+    b.allocate();
+    b.stage_voxel();
+    b.stage_grid();
+    k_pair_init<<<cdiv(n_pairs, 64), 64, 0, ctx->stream>>>(b.d_pairs(), n_pairs, (int*)ctx->n_active.p);
+    const float max_d = (float)(b.rp.max_corr * 1.0001);
+    b.launch_nn(0, max_d);  // warm-up
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < reps; ++r) b.launch_nn(0, max_d);
+    HIPCHK(hipEventRecord(e1, ctx->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    b.download();
+    long long nq = 0, nt = 0;
+    for (const PairDev& P : b.h_pairs) { nq += b.h_slots[P.slot_t].n; nt += b.h_slots[P.slot_s].n; }
+    *avg_ms = (double)ms / reps;
+    if (n_queries) *n_queries = nq;
+    if (n_targets) *n_targets = nt;
+  } catch (const HipError& e) {
+    return fail(ctx, e);
+  }
+  return S3D_STATUS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,679 @@
+// s3d_kernels.h — HIP kernels (gfx950 / CDNA4, wave64) of the registration path.
+// Included once by s3d_api.hip.  Kernel ids K1..K8 follow SURVEY.md §8a.
+//
+// Launch geometry: every per-cloud kernel runs on a 2-D grid (chunk, slot) and every
+// per-pair kernel on (chunk, pair); the real element counts live in device memory
+// (the host never learns N' after the voxel filter), so blocks whose chunk lies beyond
+// the device-side count exit at once.  Nothing in the per-iteration loop syncs with
+// the host.
+//
+// Reductions are deterministic: wave shuffle tree -> LDS -> fixed-order sum over
+// blocks in the controller kernel.  No float atomics anywhere; the only atomics are
+// integer min/max (bbox, order-independent) and the active-pair counter.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "s3d_core.h"
+
+namespace s3d {
+
+constexpr int kBlock = 256;        // 4 waves
+constexpr int kWave = 64;
+constexpr int kSortTile = 1024;    // elements per block and pass in the radix sort
+constexpr int kAccumBlocks = 32;   // max blocks per pair in the accumulate kernels
+constexpr uint32_t kInvalidKey = 0xFFFFFFFFu;
+
+// ------------------------------------------------------------------ device-side records
+
+struct SlotDev {          // one cloud of the batch
+  const float4* raw;      // uploaded points (x, y, z, *)
+  int   n_raw;
+  int   off;              // offset of this slot in the per-point work arrays (capacity n_raw)
+  int   cell_off;         // offset of this slot's cell_start[] (capacity cell_cap + 1)
+  int   cell_cap;
+  // device-computed
+  int   n;                // points after the voxel filter
+  int   n_sort;           // element count of the sort in flight
+  unsigned int bb[6];     // bbox as order-preserving uint (min xyz, max xyz), atomics
+  VoxelParams vp;
+  GridParams  g;
+};
+
+struct PairDev {          // one align() job
+  int   slot_s, slot_t;   // slam3d source (kd-tree side) / target (query side) slots
+  int   corr_off;         // offset into corr arrays (capacity n_raw of slot_t)
+  int   active, converged, iterations, correspondences;
+  int   inner_total, evals_total;
+  Mat4f guess, T, prev, final_T;
+  double fitness;
+  int   fit_count;
+  int   pad;
+};
+
+struct RunParams {        // per batch, passed by value
+  int    algorithm;       // S3D_ALG_*
+  int    k;               // correspondence_randomness
+  int    max_iterations, max_inner, force_iterations;
+  double max_corr, dist_threshold;   // distance and its square
+  double rotation_epsilon, transformation_epsilon;
+  double fit_range;       // getFitnessScore max_range (compared with SQUARED distances)
+  double gicp_epsilon;
+  float  leaf;            // voxel leaf (<= 0: no filter)
+  float  h0;              // wanted grid cell edge
+};
+
+// ------------------------------------------------------------------ helpers
+
+__device__ __forceinline__ unsigned int f2ord(float f) {
+  unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned int u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+__device__ __forceinline__ bool finite3(float x, float y, float z) {
+  return isfinite(x) && isfinite(y) && isfinite(z);
+}
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+  return v;
+}
+
+// exclusive prefix over the 256 threads of a block of a 0/1 flag; returns also the block total
+__device__ __forceinline__ int block_excl_flag(bool flag, int* total, int* lds4 /*4 ints*/) {
+  const unsigned long long m = __ballot(flag);
+  const int lane = lane_id(), w = wave_id();
+  const int inwave = __popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) lds4[w] = __popcll(m);
+  __syncthreads();
+  int before = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < kBlock / kWave; ++i) {
+    const int c = lds4[i];
+    if (i < w) before += c;
+    tot += c;
+  }
+  __syncthreads();
+  *total = tot;
+  return before + inwave;
+}
+
+// ------------------------------------------------------------------ K1: bbox + voxel keys
+
+__global__ void __launch_bounds__(kBlock) k_slot_reset_bbox(SlotDev* slots) {
+  SlotDev& s = slots[blockIdx.x];
+  if (threadIdx.x < 3) s.bb[threadIdx.x] = 0xFFFFFFFFu;
+  else if (threadIdx.x < 6) s.bb[threadIdx.x] = 0u;
+}
+
+// which = 0: raw points (n_raw); 1: filtered points (n)
+template <int WHICH>
+__global__ void __launch_bounds__(kBlock) k_bbox(SlotDev* slots, const float4* __restrict__ filt) {
+  SlotDev& s = slots[blockIdx.y];
+  const int n = WHICH == 0 ? s.n_raw : s.n;
+  const float4* __restrict__ p = WHICH == 0 ? s.raw : filt + s.off;
+  const int base = blockIdx.x * (kBlock * 4);
+  if (base >= n) return;
+  unsigned int mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = base + r * kBlock + threadIdx.x;
+    if (i < n) {
+      const float4 v = p[i];
+      if (finite3(v.x, v.y, v.z)) {
+        const unsigned int a = f2ord(v.x), b = f2ord(v.y), c = f2ord(v.z);
+        mn[0] = min(mn[0], a); mn[1] = min(mn[1], b); mn[2] = min(mn[2], c);
+        mx[0] = max(mx[0], a); mx[1] = max(mx[1], b); mx[2] = max(mx[2], c);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      mn[a] = min(mn[a], (unsigned int)__shfl_down((int)mn[a], o, kWave));
+      mx[a] = max(mx[a], (unsigned int)__shfl_down((int)mx[a], o, kWave));
+    }
+  }
+  if (lane_id() == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      atomicMin(&s.bb[a], mn[a]);
+      atomicMax(&s.bb[3 + a], mx[a]);
+    }
+  }
+}
+
+__global__ void k_voxel_params(SlotDev* slots, RunParams rp, int nslots) {
+  const int si = blockIdx.x * blockDim.x + threadIdx.x;
+  if (si >= nslots) return;
+  SlotDev& s = slots[si];
+  if (s.n_raw <= 0 || s.bb[0] == 0xFFFFFFFFu) {  // empty or all non-finite
+    s.vp.inv_leaf = 1.f; s.vp.passthrough = 1;
+    for (int a = 0; a < 3; ++a) { s.vp.min_b[a] = 0; s.vp.div_b[a] = 1; }
+  } else {
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; ++a) { mn[a] = ord2f(s.bb[a]); mx[a] = ord2f(s.bb[3 + a]); }
+    s.vp = voxel_params_from_bbox(mn, mx, rp.leaf);
+  }
+  s.n_sort = s.n_raw;
+}
+
+__global__ void __launch_bounds__(kBlock) k_voxel_keys(const SlotDev* __restrict__ slots, uint32_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ vals) {
+  const SlotDev& s = slots[blockIdx.y];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= s.n_raw) return;
+  const float4 v = s.raw[i];
+  uint32_t key = kInvalidKey;
+  if (finite3(v.x, v.y, v.z)) key = s.vp.passthrough ? (uint32_t)i : voxel_key(s.vp, v.x, v.y, v.z);
+  keys[s.off + i] = key;
+  vals[s.off + i] = (uint32_t)i;
+}
+
+// leaf <= 0: the filtered cloud is the raw cloud (PointCloudSensor.cpp:125-131)
+__global__ void __launch_bounds__(kBlock) k_copy_raw(SlotDev* slots, float4* __restrict__ filt) {
+  SlotDev& s = slots[blockIdx.y];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i == 0) s.n = s.n_raw;
+  if (i >= s.n_raw) return;
+  float4 v = s.raw[i];
+  v.w = 1.f;
+  filt[s.off + i] = v;
+}
+
+// ------------------------------------------------------------------ K2a: segmented stable LSD radix sort
+// 8-bit digits, (key, value) pairs, one segment per slot.  counts layout:
+// counts[(slot * 256 + digit) * nb_max + block]
+
+__global__ void __launch_bounds__(kBlock) k_sort_hist(const SlotDev* __restrict__ slots, const uint32_t* __restrict__ keys,
+                                                       uint32_t* __restrict__ counts, int shift, int nb_max) {
+  __shared__ unsigned int hist[256];
+  const SlotDev& s = slots[blockIdx.y];
+  const int n = s.n_sort;
+  const int nb = (n + kSortTile - 1) / kSortTile;
+  if ((int)blockIdx.x >= nb) return;
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * kSortTile;
+#pragma unroll
+  for (int r = 0; r < kSortTile / kBlock; ++r) {
+    const int i = base + r * kBlock + threadIdx.x;
+    if (i < n) atomicAdd(&hist[(keys[s.off + i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  counts[((size_t)blockIdx.y * 256 + threadIdx.x) * nb_max + blockIdx.x] = hist[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(kBlock) k_sort_scan(const SlotDev* __restrict__ slots, uint32_t* __restrict__ counts,
+                                                       int nb_max) {
+  __shared__ unsigned int tot[256];
+  const SlotDev& s = slots[blockIdx.x];
+  const int nb = (s.n_sort + kSortTile - 1) / kSortTile;
+  uint32_t* c = counts + ((size_t)blockIdx.x * 256 + threadIdx.x) * nb_max;
+  unsigned int sum = 0;
+  for (int b = 0; b < nb; ++b) sum += c[b];
+  tot[threadIdx.x] = sum;
+  __syncthreads();
+  // exclusive scan over the 256 digit totals (Hillis-Steele, 8 steps)
+  unsigned int v = sum;
+  for (int o = 1; o < 256; o <<= 1) {
+    unsigned int t = (threadIdx.x >= (unsigned)o) ? tot[threadIdx.x - o] : 0u;
+    __syncthreads();
+    v += t;
+    tot[threadIdx.x] = v;
+    __syncthreads();
+  }
+  unsigned int run = v - sum;
+  for (int b = 0; b < nb; ++b) {
+    const unsigned int t = c[b];
+    c[b] = run;
+    run += t;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restrict__ slots,
+                                                          const uint32_t* __restrict__ keys_in,
+                                                          const uint32_t* __restrict__ vals_in,
+                                                          uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                          const uint32_t* __restrict__ counts, int shift, int nb_max) {
+  __shared__ unsigned int digit_base[256];
+  __shared__ unsigned int wave_cnt[kBlock / kWave][256];
+  const SlotDev& s = slots[blockIdx.y];
+  const int n = s.n_sort;
+  const int nb = (n + kSortTile - 1) / kSortTile;
+  if ((int)blockIdx.x >= nb) return;
+  digit_base[threadIdx.x] = counts[((size_t)blockIdx.y * 256 + threadIdx.x) * nb_max + blockIdx.x];
+#pragma unroll
+  for (int w = 0; w < kBlock / kWave; ++w) wave_cnt[w][threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = lane_id(), w = wave_id();
+  const int base = blockIdx.x * kSortTile;
+  for (int r = 0; r < kSortTile / kBlock; ++r) {
+    const int i = base + r * kBlock + threadIdx.x;
+    const bool act = i < n;
+    uint32_t key = 0, val = 0;
+    if (act) { key = keys_in[s.off + i]; val = vals_in[s.off + i]; }
+    const unsigned int d = (key >> shift) & 255u;
+    // lanes of this wave holding the same digit
+    unsigned long long peers = __ballot(act);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long m = __ballot(act && ((d >> b) & 1u));
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+    if (act && rank == 0) wave_cnt[w][d] = (unsigned int)__popcll(peers);
+    __syncthreads();
+    if (act) {
+      unsigned int pos = digit_base[d] + (unsigned int)rank;
+      for (int ww = 0; ww < w; ++ww) pos += wave_cnt[ww][d];
+      keys_out[s.off + pos] = key;
+      vals_out[s.off + pos] = val;
+    }
+    __syncthreads();
+    {
+      unsigned int add = 0;
+#pragma unroll
+      for (int ww = 0; ww < kBlock / kWave; ++ww) { add += wave_cnt[ww][threadIdx.x]; wave_cnt[ww][threadIdx.x] = 0; }
+      digit_base[threadIdx.x] += add;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ K2b: segmented centroid
+
+__device__ __forceinline__ bool voxel_head(const uint32_t* __restrict__ keys, int i) {
+  const uint32_t k = keys[i];
+  return k != kInvalidKey && (i == 0 || keys[i - 1] != k);
+}
+
+__global__ void __launch_bounds__(kBlock) k_heads_count(const SlotDev* __restrict__ slots, const uint32_t* __restrict__ keys,
+                                                         uint32_t* __restrict__ blockcnt, int nb_max) {
+  __shared__ int lds4[4];
+  const SlotDev& s = slots[blockIdx.y];
+  const int base = blockIdx.x * kBlock;
+  if (base >= s.n_raw) return;
+  const int i = base + threadIdx.x;
+  const bool head = i < s.n_raw && voxel_head(keys + s.off, i);
+  int total;
+  block_excl_flag(head, &total, lds4);
+  if (threadIdx.x == 0) blockcnt[(size_t)blockIdx.y * nb_max + blockIdx.x] = (uint32_t)total;
+}
+
+__global__ void __launch_bounds__(kBlock) k_heads_scan(SlotDev* slots, uint32_t* __restrict__ blockcnt, int nb_max) {
+  __shared__ unsigned int part[kBlock];
+  SlotDev& s = slots[blockIdx.x];
+  const int nb = (s.n_raw + kBlock - 1) / kBlock;
+  uint32_t* c = blockcnt + (size_t)blockIdx.x * nb_max;
+  // each thread owns a contiguous run of blocks
+  const int per = (nb + kBlock - 1) / kBlock;
+  const int b0 = min((int)threadIdx.x * per, nb), b1 = min(b0 + per, nb);
+  unsigned int sum = 0;
+  for (int b = b0; b < b1; ++b) sum += c[b];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  unsigned int v = sum;
+  for (int o = 1; o < kBlock; o <<= 1) {
+    unsigned int t = (threadIdx.x >= (unsigned)o) ? part[threadIdx.x - o] : 0u;
+    __syncthreads();
+    v += t;
+    part[threadIdx.x] = v;
+    __syncthreads();
+  }
+  unsigned int run = v - sum;
+  for (int b = b0; b < b1; ++b) {
+    const unsigned int t = c[b];
+    c[b] = run;
+    run += t;
+  }
+  if (threadIdx.x == kBlock - 1) s.n = (int)v;
+}
+
+// one thread per sorted element; heads walk their run and emit the centroid
+// (pcl::VoxelGrid fourth pass: float sum in order, divided by float count)
+__global__ void __launch_bounds__(kBlock) k_centroids(const SlotDev* __restrict__ slots, const uint32_t* __restrict__ keys,
+                                                       const uint32_t* __restrict__ vals, const uint32_t* __restrict__ blockcnt,
+                                                       float4* __restrict__ filt, int nb_max) {
+  __shared__ int lds4[4];
+  const SlotDev& s = slots[blockIdx.y];
+  const int base = blockIdx.x * kBlock;
+  if (base >= s.n_raw) return;
+  const int i = base + threadIdx.x;
+  const uint32_t* __restrict__ k = keys + s.off;
+  const uint32_t* __restrict__ v = vals + s.off;
+  const bool head = i < s.n_raw && voxel_head(k, i);
+  int total;
+  const int pos = block_excl_flag(head, &total, lds4) + (int)blockcnt[(size_t)blockIdx.y * nb_max + blockIdx.x];
+  if (!head) return;
+  const uint32_t key = k[i];
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  int j = i;
+  for (; j < s.n_raw && k[j] == key; ++j) {
+    const float4 p = s.raw[v[j]];
+    sx += p.x; sy += p.y; sz += p.z;
+  }
+  const float c = (float)(j - i);
+  filt[s.off + pos] = make_float4(sx / c, sy / c, sz / c, 1.f);
+}
+
+// ------------------------------------------------------------------ K3: search grid
+
+__global__ void k_grid_params(SlotDev* slots, RunParams rp, int nslots) {
+  const int si = blockIdx.x * blockDim.x + threadIdx.x;
+  if (si >= nslots) return;
+  SlotDev& s = slots[si];
+  float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+  if (s.n > 0 && s.bb[0] != 0xFFFFFFFFu)
+    for (int a = 0; a < 3; ++a) { mn[a] = ord2f(s.bb[a]); mx[a] = ord2f(s.bb[3 + a]); }
+  s.g = grid_params_from_bbox(mn, mx, rp.h0, s.cell_cap);
+  s.n_sort = s.n;
+}
+
+__global__ void __launch_bounds__(kBlock) k_cell_keys(const SlotDev* __restrict__ slots, const float4* __restrict__ filt,
+                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const SlotDev& s = slots[blockIdx.y];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= s.n) return;
+  const float4 p = filt[s.off + i];
+  keys[s.off + i] = (uint32_t)grid_cell_of_point(s.g, p.x, p.y, p.z);
+  vals[s.off + i] = (uint32_t)i;
+}
+
+// cell-sorted copy of the points (w = index in filtered order) and cell_start[] by gap fill:
+// sorted position i owns the cells (key[i-1], key[i]]; position n owns the tail up to ncells.
+__global__ void __launch_bounds__(kBlock) k_grid_finalize(const SlotDev* __restrict__ slots, const float4* __restrict__ filt,
+                                                           const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                           float4* __restrict__ sorted, uint32_t* __restrict__ cell_start) {
+  const SlotDev& s = slots[blockIdx.y];
+  const int n = s.n;
+  const int base = blockIdx.x * kBlock;
+  if (base > n) return;
+  const int i = base + threadIdx.x;
+  const uint32_t* __restrict__ k = keys + s.off;
+  uint32_t* __restrict__ cs = cell_start + s.cell_off;
+  int lo = 0, hi = -1;  // cells lo..hi (inclusive) get value i
+  if (i <= n) {
+    lo = (i == 0) ? 0 : (int)k[i - 1] + 1;
+    hi = (i == n) ? s.g.ncells : (int)k[i];
+    if (i < n) {
+      const uint32_t src = vals[s.off + i];
+      const float4 p = filt[s.off + src];
+      sorted[s.off + i] = make_float4(p.x, p.y, p.z, __uint_as_float(src));
+    }
+  }
+  const int gap = hi - lo + 1;
+  // short gaps: own lane; long gaps: the whole wave fills them one after the other
+  if (gap > 0 && gap <= 8)
+    for (int c = lo; c <= hi; ++c) cs[c] = (uint32_t)i;
+  unsigned long long big = __ballot(gap > 8);
+  const int lane = lane_id();
+  while (big) {
+    const int src = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const int l = __shfl(lo, src, kWave), h = __shfl(hi, src, kWave), v = __shfl(i, src, kWave);
+    for (int c = l + lane; c <= h; c += kWave) cs[c] = (uint32_t)v;
+  }
+}
+
+// ------------------------------------------------------------------ K4: k-NN -> covariance -> normal
+
+__global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ slots, const float4* __restrict__ filt,
+                                                     const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start,
+                                                     float4* __restrict__ normals, int k) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* d2s = reinterpret_cast<float*>(smem);               // [k][kBlock]
+  int* idxs = reinterpret_cast<int*>(smem) + k * kBlock;      // [k][kBlock]
+  const SlotDev& s = slots[blockIdx.y];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= s.n) return;
+  const float4* __restrict__ P = filt + s.off;
+  const float4 q = P[i];
+  const int cnt = grid_knn(s.g, cell_start + s.cell_off, sorted + s.off, q.x, q.y, q.z, k, d2s + threadIdx.x,
+                           idxs + threadIdx.x, kBlock);
+  Moments m;
+  moments_init(m);
+  for (int j = 0; j < cnt; ++j) {
+    const float4 p = P[idxs[j * kBlock + threadIdx.x]];
+    moments_add(m, p.x, p.y, p.z);
+  }
+  double n[3];
+  moments_normal(m, k, n);
+  normals[s.off + i] = make_float4((float)n[0], (float)n[1], (float)n[2], 0.f);
+}
+
+// ------------------------------------------------------------------ pair state
+
+__global__ void k_pair_init(PairDev* pairs, int npairs, int* n_active) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p == 0) *n_active = npairs;
+  if (p >= npairs) return;
+  PairDev& P = pairs[p];
+  P.active = 1; P.converged = 0; P.iterations = 0; P.correspondences = 0;
+  P.inner_total = 0; P.evals_total = 0;
+  P.T = mat4f_identity(); P.prev = mat4f_identity(); P.final_T = P.guess;
+  P.fitness = 0.0; P.fit_count = 0;
+}
+
+// ------------------------------------------------------------------ K5: transform + exact 1-NN
+// MODE 0: ICP iteration  q = transformation_ * (guess * p)   (Eigen product of the PCL-transformed point)
+// MODE 1: fitness pass   q = final_transformation * p        (pcl::transformPointCloud)
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __restrict__ pairs,
+                                                                const SlotDev* __restrict__ slots,
+                                                                const float4* __restrict__ filt,
+                                                                const float4* __restrict__ sorted,
+                                                                const uint32_t* __restrict__ cell_start,
+                                                                int* __restrict__ corr_idx, float* __restrict__ corr_d2,
+                                                                float max_d) {
+  const PairDev& P = pairs[blockIdx.y];
+  if (MODE == 0 && !P.active) return;
+  const SlotDev& St = slots[P.slot_t];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= St.n) return;
+  const SlotDev& Ss = slots[P.slot_s];
+  const float4 p0 = filt[St.off + i];
+  F3 q;
+  if (MODE == 0) {
+    const F3 p = xf_pcl(P.guess, p0.x, p0.y, p0.z);
+    q = xf_eigen(P.T, p.x, p.y, p.z);
+  } else {
+    q = xf_pcl(P.final_T, p0.x, p0.y, p0.z);
+  }
+  const NNResult r = grid_nn1(Ss.g, cell_start + Ss.cell_off, sorted + Ss.off, q.x, q.y, q.z, max_d);
+  corr_idx[P.corr_off + i] = r.idx;
+  corr_d2[P.corr_off + i] = r.d2;
+}
+
+// ------------------------------------------------------------------ K6: per-correspondence terms + reduction
+
+template <int NACC>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* __restrict__ out) {
+  __shared__ double red[kBlock / kWave][NACC];
+  const int lane = lane_id(), w = wave_id();
+#pragma unroll
+  for (int c = 0; c < NACC; ++c) {
+    const double v = wave_sum(acc[c]);
+    if (lane == 0) red[w][c] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double v = red[0][threadIdx.x];
+#pragma unroll
+    for (int ww = 1; ww < kBlock / kWave; ++ww) v += red[ww][threadIdx.x];
+    out[threadIdx.x] = v;
+  }
+}
+
+__device__ __forceinline__ void unit3(const float4 nf, double n[3]) {
+  const double x = nf.x, y = nf.y, z = nf.z;
+  const double l = sqrt(x * x + y * y + z * z);
+  if (l > 0) { n[0] = x / l; n[1] = y / l; n[2] = z / l; }
+  else { n[0] = 0; n[1] = 0; n[2] = 1; }
+}
+
+// GICP: Mahalanobis matrix + 73-term quadratic form (s3d_core.h "GICP quadratic form")
+__global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairDev* __restrict__ pairs,
+                                                                      const SlotDev* __restrict__ slots,
+                                                                      const float4* __restrict__ filt,
+                                                                      const float4* __restrict__ normals,
+                                                                      const int* __restrict__ corr_idx,
+                                                                      const float* __restrict__ corr_d2,
+                                                                      double* __restrict__ partials, RunParams rp) {
+  const PairDev& P = pairs[blockIdx.y];
+  if (!P.active) return;
+  const SlotDev& St = slots[P.slot_t];
+  const SlotDev& Ss = slots[P.slot_s];
+  double R[9], S[6];
+  gicp_rotation(P.T, P.guess, R, S);
+  double acc[GQ_NACC];
+#pragma unroll
+  for (int c = 0; c < GQ_NACC; ++c) acc[c] = 0.0;
+  const int M = St.n;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < M; i += gridDim.x * kBlock) {
+    const int j = corr_idx[P.corr_off + i];
+    const float d2 = corr_d2[P.corr_off + i];
+    if (j < 0 || !((double)d2 < rp.dist_threshold)) continue;
+    const float4 p0 = filt[St.off + i];
+    const F3 pf = xf_pcl(P.guess, p0.x, p0.y, p0.z);
+    const float4 qf = filt[Ss.off + j];
+    double n1[3], n2[3], n1r[3], Mm[6];
+    unit3(normals[St.off + i], n1);
+    unit3(normals[Ss.off + j], n2);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) n1r[a] = R[a * 3] * n1[0] + R[a * 3 + 1] * n1[1] + R[a * 3 + 2] * n1[2];
+    gicp_mahalanobis(S, n1r, n2, rp.gicp_epsilon, Mm);
+    const double pd[3] = {pf.x, pf.y, pf.z};
+    const double qd[3] = {qf.x, qf.y, qf.z};
+    gq_accumulate(acc, pd, qd, Mm);
+  }
+  block_reduce_store<GQ_NACC>(acc, partials + ((size_t)blockIdx.y * kAccumBlocks + blockIdx.x) * GQ_NACC);
+}
+
+// point-to-plane: J^T J (21) + J^T r (6) + r^2 + count
+__global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const PairDev* __restrict__ pairs,
+                                                                         const SlotDev* __restrict__ slots,
+                                                                         const float4* __restrict__ filt,
+                                                                         const float4* __restrict__ normals,
+                                                                         const int* __restrict__ corr_idx,
+                                                                         const float* __restrict__ corr_d2,
+                                                                         double* __restrict__ partials, RunParams rp) {
+  const PairDev& P = pairs[blockIdx.y];
+  if (!P.active) return;
+  const SlotDev& St = slots[P.slot_t];
+  const SlotDev& Ss = slots[P.slot_s];
+  double acc[PP_NACC];
+#pragma unroll
+  for (int c = 0; c < PP_NACC; ++c) acc[c] = 0.0;
+  const int M = St.n;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < M; i += gridDim.x * kBlock) {
+    const int j = corr_idx[P.corr_off + i];
+    const float d2 = corr_d2[P.corr_off + i];
+    if (j < 0 || !((double)d2 < rp.dist_threshold)) continue;
+    const float4 p0 = filt[St.off + i];
+    const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
+    const F3 pq = xf_eigen(P.T, pg.x, pg.y, pg.z);
+    const float4 qf = filt[Ss.off + j];
+    const float4 nf = normals[Ss.off + j];
+    const double pd[3] = {pq.x, pq.y, pq.z};
+    const double qd[3] = {qf.x, qf.y, qf.z};
+    const double nd[3] = {nf.x, nf.y, nf.z};
+    pp_accumulate(acc, pd, qd, nd);
+  }
+  block_reduce_store<PP_NACC>(acc, partials + ((size_t)blockIdx.y * kAccumBlocks + blockIdx.x) * GQ_NACC);
+}
+
+// ------------------------------------------------------------------ K7: per-pair controller
+// fixed-order sum of the block partials, then the solver step and the PCL stopping rule.
+// One block per pair; the scalar solver runs on lane 0 with the record in LDS.
+__global__ void __launch_bounds__(128) s3d_icp_control_kernel(PairDev* pairs, const double* __restrict__ partials,
+                                                               int nblocks, RunParams rp, int* n_active) {
+  __shared__ double acc[GQ_NACC];
+  PairDev& P = pairs[blockIdx.x];
+  if (!P.active) return;
+  const bool gicp = rp.algorithm != 0;
+  const int nacc = gicp ? GQ_NACC : PP_NACC;
+  if ((int)threadIdx.x < nacc) {
+    const double* src = partials + (size_t)blockIdx.x * kAccumBlocks * GQ_NACC + threadIdx.x;
+    double v = 0.0;
+    for (int b = 0; b < nblocks; ++b) v += src[(size_t)b * GQ_NACC];
+    acc[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  Mat4f T = P.T;
+  const Mat4f prev = T;
+  int rc, inner = 0, evals = 0;
+  if (gicp) {
+    P.correspondences = (int)acc[GQ_CNT];
+    rc = gicp_estimate_bfgs(acc, rp.max_inner, T, &inner, &evals);
+  } else {
+    P.correspondences = (int)acc[PP_CNT];
+    rc = pp_update(acc, T);
+  }
+  P.prev = prev;
+  if (rc) {  // PCLException path: loop breaks, converged_ stays false
+    P.active = 0; P.converged = 0;
+    atomicSub(n_active, 1);
+    return;
+  }
+  P.inner_total += inner; P.evals_total += evals;
+  P.T = T;
+  const double delta = icp_delta(prev, T, rp.rotation_epsilon, rp.transformation_epsilon);
+  const int it = ++P.iterations;
+  if (it >= rp.max_iterations || (!rp.force_iterations && delta < 1.0)) {
+    P.converged = 1; P.active = 0; P.prev = T;
+    atomicSub(n_active, 1);
+  }
+}
+
+// final_transformation_ = previous_transformation_ * guess
+__global__ void k_pair_finalize(PairDev* pairs, int npairs) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npairs) return;
+  pairs[p].final_T = mat4f_mul(pairs[p].prev, pairs[p].guess);
+}
+
+// ------------------------------------------------------------------ K8: fitness (masked mean of d2)
+__global__ void __launch_bounds__(kBlock) s3d_fitness_partial_kernel(const PairDev* __restrict__ pairs,
+                                                                      const SlotDev* __restrict__ slots,
+                                                                      const int* __restrict__ corr_idx,
+                                                                      const float* __restrict__ corr_d2,
+                                                                      double* __restrict__ partials, RunParams rp) {
+  __shared__ double red[kBlock / kWave][2];
+  const PairDev& P = pairs[blockIdx.y];
+  const int M = slots[P.slot_t].n;
+  double s = 0.0, c = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < M; i += gridDim.x * kBlock) {
+    const float d2 = corr_d2[P.corr_off + i];
+    if (corr_idx[P.corr_off + i] >= 0 && (double)d2 <= rp.fit_range) { s += (double)d2; c += 1.0; }
+  }
+  s = wave_sum(s); c = wave_sum(c);
+  if (lane_id() == 0) { red[wave_id()][0] = s; red[wave_id()][1] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / kWave; ++w) { red[0][0] += red[w][0]; red[0][1] += red[w][1]; }
+    double* out = partials + ((size_t)blockIdx.y * kAccumBlocks + blockIdx.x) * GQ_NACC;
+    out[0] = red[0][0]; out[1] = red[0][1];
+  }
+}
+
+__global__ void k_fitness_final(PairDev* pairs, const double* __restrict__ partials, int nblocks, int npairs) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npairs) return;
+  double s = 0.0, c = 0.0;
+  for (int b = 0; b < nblocks; ++b) {
+    const double* in = partials + ((size_t)p * kAccumBlocks + b) * GQ_NACC;
+    s += in[0]; c += in[1];
+  }
+  pairs[p].fitness = c > 0.0 ? s / c : 1.7976931348623157e308;
+  pairs[p].fit_count = (int)c;
+}
+
+}  // namespace s3d
