@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — scan-pair registrations/sec on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the registration hot path (align(): voxel filter of both clouds ->
+search grid -> k-NN normals -> exactly `--iters` outer ICP iterations -> fitness pass -> gates)
+over the rank's batch of `--pairs` independent synthetic scan pairs that are already resident in
+HBM.  value = pairs processed by all ranks / max-over-ranks wall time.
+
+Workload at N=1: BASELINE.json configs[2] ("batch of 256 independent 100k-pt scan pairs,
+1xMI355X"), the largest single-GPU configuration and the per-GPU share of the 8-GPU sweep
+(configs[3], 512 pairs per GPU) — the metric is a throughput.  configs[1] (one pair) is reported
+beside it as `single_pair` latency.  Multi-GPU: pairs are sharded over ranks (no data-path
+collective); each step ends with one RCCL all-gather of the 128-byte edge records.
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 under torch.distributed.run.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def _gen_pair(args):
+    n, idx = args
+    import slam3d_amd.synthetic as syn
+    return syn.make_pair(n, idx)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=256, help="scan pairs per GPU and step")
+    ap.add_argument("--points", type=int, default=100000)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--algorithm", default="gicp", choices=["gicp", "icp"])
+    ap.add_argument("--density", type=float, default=0.02)
+    ap.add_argument("--cpu-pairs", type=int, default=3, help="pairs timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--nn-reps", type=int, default=20)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import torch
+    import slam3d_amd as s3d
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- synthetic input (SURVEY.md §8d generator), distinct pairs per rank
+    t0 = time.time()
+    from multiprocessing import Pool
+    jobs = [(args.points, rank * args.pairs + i) for i in range(args.pairs)]
+    with Pool(min(8, os.cpu_count() or 1)) as pool:
+        pairs = pool.map(_gen_pair, jobs, chunksize=4)
+    gen_s = time.time() - t0
+
+    ctx = s3d.Context(local_rank)
+    alg = s3d.ALG_GICP if args.algorithm == "gicp" else s3d.ALG_ICP
+    params = s3d.default_params(registration_algorithm=alg, point_cloud_density=args.density,
+                                maximum_iterations=args.iters, max_correspondence_distance=2.5,
+                                correspondence_randomness=20)
+    opts = s3d.ExecOptions(force_iterations=1, check_interval=0, grid_cells_per_point=0, profile=0)
+    src = [ctx.upload(p[0]) for p in pairs]
+    tgt = [ctx.upload(p[1]) for p in pairs]
+    guesses = np.tile(np.eye(4), (args.pairs, 1, 1))
+
+    def step():
+        rec = ctx.align_batch(src, tgt, guesses, params, opts)
+        if dist is not None:
+            local = torch.from_numpy(rec).to(dev)
+            out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=local.dtype, device=dev)
+            dist.all_gather_into_tensor(out, local)  # RCCL over xGMI: 128 B per edge
+            return out
+        return rec
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    total_pairs = args.pairs * world * args.steps
+    value = total_pairs / elapsed
+    rec_local = last.cpu().numpy() if hasattr(last, "cpu") else last
+    n_ok = int((rec_local[:, 15] == 0).sum())
+
+    line = None
+    if rank == 0:
+        # ---- accuracy of this rank's batch vs the generator's ground truth (information only)
+        errs = []
+        for i in range(min(args.pairs, rec_local.shape[0])):
+            T = s3d.api.record_transform(rec_local[i])
+            d = np.linalg.inv(pairs[i][2]) @ T
+            errs.append(np.linalg.norm(d[:3, 3]))
+        # ---- per-stage profile of one step + NN kernel timing (HIP events on the context stream)
+        popts = s3d.ExecOptions(force_iterations=1, check_interval=0, grid_cells_per_point=0, profile=1)
+        ctx.align_batch(src, tgt, guesses, params, popts)
+        prof = ctx.last_profile()
+        nn = ctx.profile_nn_kernel(src, tgt, guesses, params, reps=args.nn_reps)
+        alg_bytes = 20.0 * nn["n_queries"] + 12.0 * nn["n_targets"]  # 20*M + 12*N per NN pass
+        achieved = alg_bytes / (nn["avg_ms"] * 1e-3) / 1e9
+        roofline = {"kernel": "s3d_nn_search_kernel", "bound": "hbm", "achieved": round(achieved, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": None, "avg_launch_ms": round(nn["avg_ms"], 4),
+                    "algorithmic_bytes_per_launch": int(alg_bytes),
+                    "queries_per_launch": nn["n_queries"], "targets_per_launch": nn["n_targets"],
+                    "in_loop_avg_launch_ms": round(prof["nn_ms"] / max(prof["nn_launches"], 1), 4)}
+        # ---- single pair latency (BASELINE.json configs[1])
+        one_s, one_t = [src[0]], [tgt[0]]
+        ctx.align_batch(one_s, one_t, guesses[:1], params, opts)
+        t1 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            ctx.align_batch(one_s, one_t, guesses[:1], params, opts)
+        single_ms = (time.perf_counter() - t1) / reps * 1e3
+        # ---- CPU baseline: the oracle (a port of the reference path), one thread, same inputs/iterations
+        cpu = None
+        if not args.no_cpu and world == 1:
+            import oracle
+            op = oracle.default_params(registration_algorithm=alg, point_cloud_density=args.density,
+                                       maximum_iterations=args.iters, max_correspondence_distance=2.5,
+                                       correspondence_randomness=20)
+            times = []
+            for i in range(min(args.cpu_pairs, args.pairs)):
+                tc = time.perf_counter()
+                oracle.align(pairs[i][0], pairs[i][1], np.eye(4), op, force_iterations=True)
+                times.append(time.perf_counter() - tc)
+            cpu = {"value": round(1.0 / float(np.median(times)), 4), "unit": "registrations/s", "cores": 1,
+                   "kind": "port",
+                   "sample": "%d of the %d pairs of this workload, oracle/s3d_oracle.c align() (kd-tree + "
+                             "PCL-structured %s), median of %d runs, %.1f s total" %
+                             (len(times), args.pairs, args.algorithm.upper(), len(times), sum(times)),
+                   "host_cpus": os.cpu_count()}
+        line = {
+            "metric": "scan-pair registrations/sec (100k-pt clouds, 20 ICP iters)",
+            "value": round(value, 2), "unit": "registrations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 points / f64 accumulators", "data": "synthetic",
+            "config": {"workload": "batch of %d independent %dk-pt synthetic scan pairs per GPU, %d outer "
+                                   "iterations (early exit disabled), %s, voxel leaf %.2f m, "
+                                   "max_correspondence_distance 2.5 m, k=20" %
+                                   (args.pairs, args.points // 1000, args.iters,
+                                    "GICP (reference default)" if alg == s3d.ALG_GICP else "point-to-plane ICP",
+                                    args.density),
+                       "pairs_per_gpu": args.pairs, "points": args.points, "iterations": args.iters,
+                       "algorithm": args.algorithm, "parallelism": "pair-sharded x%d" % world,
+                       "collective": "all_gather of 128-B edge records (RCCL)" if world > 1 else "none"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "single_pair": {"latency_ms": round(single_ms, 3), "registrations_per_s": round(1e3 / single_ms, 2)},
+            "stage_ms": {k: round(v, 3) for k, v in prof.items() if k.endswith("_ms")},
+            "accuracy": {"status_ok": n_ok, "median_err_m": float(np.median(errs)), "max_err_m": float(np.max(errs))},
+            "input_generation_s": round(gen_s, 1),
+        }
+        print(json.dumps(line), flush=True)
+    for c in src + tgt:
+        c.release()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -83,6 +83,8 @@ def lib():
             f.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.POINTER(RegParams), C.c_int, C.POINTER(IcpResult)]
         L.s3o_fitness_score.restype = C.c_double
         L.s3o_fitness_score.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.c_double]
+        L.s3o_gicp_cost.restype = C.c_double
+        L.s3o_gicp_cost.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.POINTER(RegParams), ip]
         L.s3o_align.restype = C.c_int
         L.s3o_align.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int, dp, C.POINTER(RegParams), C.c_int, dp,
                                 C.POINTER(AlignInfo)]
@@ -196,6 +198,22 @@ def fitness_score(pcl_source, pcl_target, T, max_range):
     t, n, _ = _cloud(pcl_target)
     g = np.ascontiguousarray(np.asarray(T, np.float32).T.reshape(16))
     return lib().s3o_fitness_score(_fptr(s), m, _fptr(t), n, _fptr(g), float(max_range))
+
+
+def gicp_cost(source, target, T, params=None):
+    """GICP objective of a candidate align() result T (pose of `target` in `source` frame):
+    both clouds are voxel-filtered as align() does, then s3o_gicp_cost is evaluated."""
+    params = params or default_params()
+    if params.point_cloud_density > 0:
+        source, _ = voxel_downsample(source, params.point_cloud_density)
+        target, _ = voxel_downsample(target, params.point_cloud_density)
+    s, ns, _ = _cloud(np.ascontiguousarray(source)[:, :3])
+    t, nt, _ = _cloud(np.ascontiguousarray(target)[:, :3])
+    F = np.ascontiguousarray(np.asarray(T, np.float32).T.reshape(16))
+    cnt = C.c_int()
+    # pcl source = slam3d target (queries), pcl target = slam3d source
+    cost = lib().s3o_gicp_cost(_fptr(t), nt, _fptr(s), ns, _fptr(F), C.byref(params), C.byref(cnt))
+    return cost, cnt.value
 
 
 def align(source, target, guess=np.eye(4), params=None, force_iterations=False):

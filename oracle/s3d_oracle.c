@@ -1013,6 +1013,52 @@ done:
   return rc;
 }
 
+/* GICP objective of a candidate result F (= final_transformation_): correspondences and
+ * Mahalanobis matrices are rebuilt at F exactly as one outer iteration of
+ * computeTransformation would (guess = F, transformation_ = I), and the functor's f is
+ * returned.  Lets tests rank two candidate results by the reference's own objective. */
+double s3o_gicp_cost(const float* input, int m, const float* target, int n, const float F[16],
+                     const s3d_reg_params* cfg, int* n_corr) {
+  const int k = cfg->correspondence_randomness;
+  s3o_kdtree* tree = s3o_kdtree_build(target, n);
+  s3o_kdtree* tree_r = s3o_kdtree_build(input, m);
+  double* cov_t = (double*)malloc(sizeof(double) * 9 * (size_t)n);
+  double* cov_i = (double*)malloc(sizeof(double) * 9 * (size_t)m);
+  double cost = DBL_MAX;
+  int cnt = 0;
+  if (!gicp_covariances_tree(tree, target, n, k, 0.001, cov_t, NULL) &&
+      !gicp_covariances_tree(tree_r, input, m, k, 0.001, cov_i, NULL)) {
+    const double thr = cfg->max_correspondence_distance * cfg->max_correspondence_distance;
+    double f = 0;
+    for (int i = 0; i < m; ++i) {
+      float q[3];
+      xf_pcl(F, input + (size_t)i * 3, q);
+      int j; float d2;
+      s3o_kdtree_nn1(tree, q, &j, &d2);
+      if (!((double)d2 < thr)) continue;
+      const double* C1 = cov_i + (size_t)i * 9;
+      const double* C2 = cov_t + (size_t)j * 9;
+      double Mt[3][3], tmp[3][3], inv[3][3];
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+          Mt[a][b] = (double)M4(F, a, 0) * C1[0 * 3 + b] + (double)M4(F, a, 1) * C1[1 * 3 + b] + (double)M4(F, a, 2) * C1[2 * 3 + b];
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+          tmp[a][b] = (Mt[a][0] * (double)M4(F, b, 0) + Mt[a][1] * (double)M4(F, b, 1) + Mt[a][2] * (double)M4(F, b, 2)) + C2[a * 3 + b];
+      mat3_inverse(tmp, inv);
+      double res[3] = {(double)q[0] - target[(size_t)j * 3], (double)q[1] - target[(size_t)j * 3 + 1], (double)q[2] - target[(size_t)j * 3 + 2]};
+      for (int a = 0; a < 3; ++a)
+        f += res[a] * (inv[a][0] * res[0] + inv[a][1] * res[1] + inv[a][2] * res[2]);
+      cnt++;
+    }
+    if (cnt > 0) cost = f / cnt;
+  }
+  if (n_corr) *n_corr = cnt;
+  free(cov_t); free(cov_i);
+  s3o_kdtree_free(tree); s3o_kdtree_free(tree_r);
+  return cost;
+}
+
 /* ------------------------------------------------------------------ point-to-plane ICP
  * Not in the reference (enumerator ICP has no `case`, PCS.cpp:139-165).  Defined here
  * (and in DESIGN.md) so that the HIP path for that enumerator has a CPU statement:

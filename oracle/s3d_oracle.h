@@ -75,6 +75,10 @@ int s3o_icp_point_to_plane(const float* pcl_source, int m, const float* pcl_targ
                            const float guess[16], const s3d_reg_params* cfg, int force_iterations,
                            s3o_icp_result* out);
 
+/* GICP objective (mean Mahalanobis residual) of a candidate final transformation F */
+double s3o_gicp_cost(const float* pcl_source, int m, const float* pcl_target, int n, const float F[16],
+                     const s3d_reg_params* cfg, int* n_corr);
+
 double s3o_fitness_score(const float* pcl_source, int m, const float* pcl_target, int n,
                          const float final_transformation[16], double max_range);
 

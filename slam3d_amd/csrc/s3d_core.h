@@ -7,7 +7,7 @@
 // per outer iteration as a quadratic form in the 12 entries of [R|t] (73
 // doubles), and the BFGS inner loop then runs on that form without touching
 // the point data again.  The reference's (PCL's) per-evaluation loops over all
-// correspondences are restated in oracle/s3d_oracle.c; parity between the two
+// correspondences are restated by the CPU test oracle; parity between the two
 // formulations is what tests/ check.
 //
 // Compile with -ffp-contract=off: float expressions marked "order matters"

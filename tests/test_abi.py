@@ -1,0 +1,79 @@
+"""The C-ABI library loads and exports every symbol include/slam3d_hip.h declares (no compute)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "slam3d_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(s3d_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import slam3d_amd
+    slam3d_amd.build()
+    lib = ctypes.CDLL(slam3d_amd.lib_path())
+    names = declared_symbols()
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(lib, n), "missing export: " + n
+    L = slam3d_amd.load_library()
+    assert sorted(L._s3d_symbols) == names     # the binding declares exactly the header's functions
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    import slam3d_amd
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "slam3d_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(s3d_reg_params),sizeof(s3d_edge_record),sizeof(s3d_exec_options),sizeof(s3d_align_info),'
+                   'sizeof(s3d_profile),offsetof(s3d_reg_params,rotation_epsilon));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert sizes[0] == ctypes.sizeof(slam3d_amd.RegParams)
+    assert sizes[1] == ctypes.sizeof(slam3d_amd.EdgeRecord) == 128       # the all-gathered unit
+    assert sizes[2] == ctypes.sizeof(slam3d_amd.ExecOptions)
+    assert sizes[3] == ctypes.sizeof(slam3d_amd.AlignInfo)
+    assert sizes[4] == ctypes.sizeof(slam3d_amd.Profile)
+    assert sizes[5] == slam3d_amd.RegParams.rotation_epsilon.offset
+
+
+def test_default_params_match_reference_defaults():
+    import slam3d_amd
+    p = slam3d_amd.default_params()      # RegistrationParameters.hpp:36-97
+    assert (p.registration_algorithm, p.point_cloud_density, p.max_fitness_score) == (1, 0.2, 2.0)
+    assert (p.max_translation, p.max_rotation, p.euclidean_fitness_epsilon) == (1.0, 1.0, 1.0)
+    assert (p.transformation_epsilon, p.max_correspondence_distance, p.maximum_iterations) == (1e-5, 2.5, 50)
+    assert (p.rotation_epsilon, p.correspondence_randomness, p.maximum_optimizer_iterations) == (2e-3, 20, 20)
+    assert (p.resolution, p.step_size, p.outlier_ratio) == (1.0, 0.05, 0.35)
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the product refuses to run (it must never route to a CPU path)."""
+    import torch
+    import slam3d_amd
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(slam3d_amd.BackendError):
+        slam3d_amd.Context(0)
+    with pytest.raises(slam3d_amd.BackendError):
+        slam3d_amd.backend_info(0)
+
+
+def test_product_does_not_reference_the_oracle():
+    """oracle/ is test infrastructure: nothing under slam3d_amd/, cpp/ or include/ may mention it."""
+    bad = []
+    for base in ("slam3d_amd", "cpp", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".py", ".h", ".hpp", ".hip", ".cpp", ".c")) or fn == "Makefile":
+                    text = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"(import\s+oracle|from\s+oracle|s3d_oracle|libs3d_oracle|s3o_)", text):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad

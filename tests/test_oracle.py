@@ -1,0 +1,197 @@
+"""CPU suite: the oracle (oracle/s3d_oracle.c) against (a) independent numpy/scipy restatements of
+each stage and (b) the committed golden vectors.  The reference holds no expected values for this
+path and cannot be built here — parity vs PCL itself is UNPINNED."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+from scipy.spatial import cKDTree
+
+from conftest import GOLDEN, transform_delta
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(GOLDEN, "oracle_golden.json")) as f:
+        return json.load(f)
+
+
+def numpy_voxel(xyzi, leaf):
+    """Independent restatement of pcl::VoxelGrid for XYZ."""
+    p = xyzi[:, :3].astype(np.float32)
+    leaf = np.float32(leaf)
+    inv = np.float32(1.0) / leaf
+    mn, mx = p.min(0), p.max(0)
+    min_b = np.floor(mn * inv).astype(np.int64)
+    max_b = np.floor(mx * inv).astype(np.int64)
+    div = max_b - min_b + 1
+    ijk = (np.floor(p * inv) - min_b.astype(np.float32)).astype(np.int64)
+    key = ijk[:, 0] + ijk[:, 1] * div[0] + ijk[:, 2] * div[0] * div[1]
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    starts = np.flatnonzero(np.r_[True, ks[1:] != ks[:-1]])
+    cnt = np.diff(np.r_[starts, len(ks)])
+    sums = np.add.reduceat(p[order].astype(np.float64), starts, axis=0)
+    return (sums / cnt[:, None]), div
+
+
+def test_voxel_counts_match_survey(oracle_mod, fixture_clouds):
+    # SURVEY.md §8d "fixture characterisation": 60152 / 31834 / 10970 / 4273 voxels
+    for leaf, n in ((0.1, 60152), (0.2, 31834), (0.5, 10970), (1.0, 4273)):
+        v, info = oracle_mod.voxel_downsample(fixture_clouds[0], leaf)
+        assert len(v) == n
+    v, info = oracle_mod.voxel_downsample(fixture_clouds[0], 0.2)
+    assert list(info.div_b) == [781, 504, 73]
+    assert len(oracle_mod.voxel_downsample(fixture_clouds[1], 0.2)[0]) == 31481
+
+
+@pytest.mark.parametrize("leaf", [0.1, 0.2, 0.5])
+def test_voxel_vs_numpy(oracle_mod, fixture_clouds, leaf):
+    v, info = oracle_mod.voxel_downsample(fixture_clouds[0], leaf)
+    ref, div = numpy_voxel(fixture_clouds[0], leaf)
+    assert list(info.div_b) == list(div)
+    assert v.shape == ref.shape
+    # float32 running sums vs float64 sums: a few ulp of the coordinates
+    assert np.abs(v - ref).max() < 2e-4
+
+
+def test_voxel_golden(oracle_mod, fixture_clouds, golden):
+    for leaf, g in golden["voxel"].items():
+        v, info = oracle_mod.voxel_downsample(fixture_clouds[0], float(leaf))
+        assert len(v) == g["n"] and list(info.div_b) == g["div_b"] and list(info.min_b) == g["min_b"]
+        assert hashlib.sha256(v.tobytes()).hexdigest() == g["sha256"]
+        assert np.array_equal(v[:8], np.array(g["first8"], np.float32))
+
+
+def test_voxel_edge_cases(oracle_mod):
+    v, _ = oracle_mod.voxel_downsample(np.zeros((0, 3), np.float32), 0.2)
+    assert len(v) == 0                                   # PointCloudSensor.cpp:193
+    one = np.array([[1.0, 2.0, 3.0]], np.float32)
+    v, _ = oracle_mod.voxel_downsample(one, 0.2)
+    assert np.array_equal(v, one)
+    # leaf too small: dx*dy*dz > INT_MAX -> PCL returns the input cloud
+    far = np.array([[0, 0, 0], [1000, 1000, 1000], [5, 5, 5]], np.float32)
+    v, info = oracle_mod.voxel_downsample(far, 0.0005)
+    assert info.passthrough == 1 and np.array_equal(v, far)
+    # non-finite points are dropped
+    bad = np.array([[0, 0, 0], [np.nan, 0, 0], [0.01, 0, 0]], np.float32)
+    v, _ = oracle_mod.voxel_downsample(bad, 1.0)
+    assert len(v) == 1 and np.allclose(v[0], [0.005, 0, 0])
+
+
+def test_nn_vs_scipy_and_brute(oracle_mod, fixture_clouds, golden):
+    v1, _ = oracle_mod.voxel_downsample(fixture_clouds[0], 0.2)
+    v2, _ = oracle_mod.voxel_downsample(fixture_clouds[1], 0.2)
+    idx, d2 = oracle_mod.nn_search(v1, v2)
+    dd, ii = cKDTree(v1.astype(np.float64)).query(v2.astype(np.float64))
+    assert (ii != idx).mean() < 1e-4            # only exact-tie / rounding cases may differ
+    assert np.abs(dd ** 2 - d2).max() < 1e-4
+    bi, bd = oracle_mod.nn_search(v1[:3000], v2[:500], brute=True)
+    ki, kd = oracle_mod.nn_search(v1[:3000], v2[:500])
+    assert np.array_equal(bi, ki) and np.array_equal(bd, kd)
+    g = golden["nn"]
+    assert idx[g["queries"]].tolist() == g["idx"]
+    assert hashlib.sha256(idx.tobytes()).hexdigest() == g["sha256_idx"]
+
+
+def test_covariances_vs_numpy(oracle_mod, fixture_clouds):
+    v1, _ = oracle_mod.voxel_downsample(fixture_clouds[0], 0.5)
+    cov, nrm = oracle_mod.gicp_covariances(v1, 20)
+    tree = cKDTree(v1.astype(np.float64))
+    _, nb = tree.query(v1.astype(np.float64), k=20)
+    rng = np.random.default_rng(0)
+    for i in rng.choice(len(v1), 200, replace=False):
+        # PCL computeCovariances: float32 products, float64 sums, E[xx^T] - mean mean^T
+        Pf = v1[nb[i]]
+        prod = (Pf[:, :, None] * Pf[:, None, :]).astype(np.float64).sum(0) / 20.0
+        mean = Pf.astype(np.float64).sum(0) / 20.0
+        c = prod - np.outer(mean, mean)
+        w, U = np.linalg.eigh(c)                       # ascending
+        if w[1] - w[0] < 1e-6 * max(w[2], 1e-12):
+            continue                                   # (near-)degenerate smallest direction
+        ref = U @ np.diag([1e-3, 1.0, 1.0]) @ U.T      # PCL: (1, 1, gicp_epsilon) on descending order
+        assert np.abs(cov[i] - ref).max() < 1e-5
+        assert abs(abs(nrm[i] @ U[:, 0]) - 1) < 1e-6
+
+
+def test_gicp_oracle_golden(oracle_mod, fixture_clouds, golden):
+    """Replays every golden align() case bit-for-bit (same binary arithmetic on any x86-64 host)."""
+    for case in golden["align"]:
+        alg = oracle_mod.ALG_GICP if case["algorithm"] == "gicp" else oracle_mod.ALG_ICP
+        oracle_mod.set_eval_precision(case["eval_precision"])
+        try:
+            st, T, info = oracle_mod.align(fixture_clouds[case["source"] - 1], fixture_clouds[case["target"] - 1],
+                                           np.array(case["guess"]), oracle_mod.default_params(registration_algorithm=alg))
+        finally:
+            oracle_mod.set_eval_precision(0)
+        assert st == case["status"], case
+        assert info["iterations"] == case["info"]["iterations"]
+        dt, dr = transform_delta(np.array(case["T"]), T)
+        assert dt < 1e-9 and dr < 1e-7
+
+
+def test_fixture_motion_matches_survey(golden):
+    # consecutive sweeps move ~0.67 / 0.68 / 0.72 m; cloud4->cloud1 ~2.1 m and is
+    # rejected by the default max_translation = 1.0 gate when the guess is identity
+    by = {(c["algorithm"], c["eval_precision"], c["source"], c["target"], c["guess"][0][3]): c for c in golden["align"]}
+    assert abs(by[("gicp", 0, 1, 2, 0.0)]["T"][0][3] - 0.68) < 0.02
+    assert abs(by[("gicp", 0, 2, 3, 0.0)]["T"][0][3] - 0.69) < 0.02
+    assert abs(by[("gicp", 0, 3, 4, 0.0)]["T"][0][3] - 0.72) < 0.02
+    assert by[("gicp", 0, 1, 4, 0.0)]["status"] == oracle_status("TOO_FAR_FROM_GUESS")
+    assert by[("gicp", 0, 1, 4, 2.0)]["status"] == 0 and abs(by[("gicp", 0, 1, 4, 2.0)]["T"][0][3] - 2.1) < 0.03
+
+
+def oracle_status(name):
+    import oracle
+    return getattr(oracle, "STATUS_" + name)
+
+
+def test_align_gates(oracle_mod, fixture_clouds):
+    o = oracle_mod
+    few = fixture_clouds[0][:20]                                    # test.ply has 20 vertices
+    st, _, _ = o.align(few, fixture_clouds[1])
+    assert st == o.STATUS_TOO_FEW_POINTS                            # PointCloudSensor.cpp:134-135
+    st, _, _ = o.align(fixture_clouds[0], fixture_clouds[1], params=o.default_params(registration_algorithm=o.ALG_NDT))
+    assert st == o.STATUS_UNSUPPORTED_ALGORITHM
+    st, _, _ = o.align(fixture_clouds[0], fixture_clouds[1], params=o.default_params(registration_algorithm=9))
+    assert st == o.STATUS_UNKNOWN_ALGORITHM                         # :163-164
+    st, _, info = o.align(fixture_clouds[0], fixture_clouds[1], params=o.default_params(max_fitness_score=0.01))
+    assert st == o.STATUS_FITNESS_EXCEEDED and info["fitness"] > 0.01   # :74
+    st, _, _ = o.align(fixture_clouds[0], fixture_clouds[1], params=o.default_params(max_translation=0.1))
+    assert st == o.STATUS_TOO_FAR_FROM_GUESS                        # :169-172
+
+
+def test_create_constraint_frame_algebra(oracle_mod, fixture_clouds):
+    o = oracle_mod
+    ident = np.eye(4)
+    # point-to-plane mode: well-conditioned, so the 1e-16 rounding of the composed guess cannot
+    # change the result visibly (GICP can: tests/test_conditioning.py)
+    fine = o.default_params(registration_algorithm=o.ALG_ICP)
+    st, icp, _ = o.align(fixture_clouds[0], fixture_clouds[1], params=fine)
+    Ps = np.eye(4); Ps[:3, 3] = [0.5, 0.1, 1.2]
+    c, s = np.cos(0.3), np.sin(0.3)
+    Pt = np.eye(4); Pt[:3, :3] = [[c, -s, 0], [s, c, 0], [0, 0, 1]]; Pt[:3, 3] = [-0.2, 0.3, 1.0]
+    odo = Ps @ np.linalg.inv(Pt)          # makes guess = Ps^-1 * odo * Pt = I  (PointCloudSensor.cpp:274)
+    st2, rel, inf, _ = o.create_constraint(fixture_clouds[0], Ps, fixture_clouds[1], Pt, odo, fine=fine,
+                                           covariance_scale=4.0)
+    assert st == 0 and st2 == 0
+    dt, dr = transform_delta(Ps @ icp @ np.linalg.inv(Pt), rel)      # :295
+    assert dt < 1e-5 and dr < 1e-5
+    assert np.allclose(inf, np.eye(6) / 4.0)                         # :296-298
+    # loop closure: coarse + fine (:286-292)
+    coarse = o.default_params(point_cloud_density=0.5, max_correspondence_distance=5.0)
+    st3, rel3, _, _ = o.create_constraint(fixture_clouds[0], ident, fixture_clouds[1], ident, ident, loop=True,
+                                          coarse=coarse)
+    assert st3 == 0 and abs(rel3[0, 3] - 0.68) < 0.02
+
+
+def test_synthetic_known_answer(oracle_mod):
+    import slam3d_amd.synthetic as syn
+    src, tgt, T_true = syn.make_pair(20000, 5)
+    for alg in (oracle_mod.ALG_GICP, oracle_mod.ALG_ICP):
+        p = oracle_mod.default_params(registration_algorithm=alg, point_cloud_density=0.02)
+        st, T, info = oracle_mod.align(src, tgt, np.eye(4), p)
+        dt, dr = transform_delta(T_true, T)
+        assert st == 0 and dt < 5e-3 and dr < 1e-3      # independent resample + 1 cm noise: mm-level truth
