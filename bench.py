@@ -47,6 +47,11 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=3, help="pairs timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--nn-reps", type=int, default=20)
+    ap.add_argument("--cells-per-point", type=int, default=0, help="search-grid budget (0 = library default)")
+    ap.add_argument("--extras", action="store_true",
+                    help="also time a single pair (configs[1]) and the first-iteration NN launch; off by default so "
+                         "that every s3d_nn_search_kernel<0> launch of the run is the timed workload (rocprof average "
+                         "== roofline.avg_launch_ms)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -71,10 +76,11 @@ def main():
 
     # ---- synthetic input (SURVEY.md §8d generator), distinct pairs per rank
     t0 = time.time()
-    from multiprocessing import Pool
+    # threads, not processes: forking after a profiler / the HIP runtime is loaded hangs on this pool
+    from multiprocessing.pool import ThreadPool
     jobs = [(args.points, rank * args.pairs + i) for i in range(args.pairs)]
-    with Pool(min(8, os.cpu_count() or 1)) as pool:
-        pairs = pool.map(_gen_pair, jobs, chunksize=4)
+    with ThreadPool(min(16, os.cpu_count() or 1)) as pool:
+        pairs = pool.map(_gen_pair, jobs, chunksize=2)
     gen_s = time.time() - t0
 
     ctx = s3d.Context(local_rank)
@@ -82,7 +88,7 @@ def main():
     params = s3d.default_params(registration_algorithm=alg, point_cloud_density=args.density,
                                 maximum_iterations=args.iters, max_correspondence_distance=2.5,
                                 correspondence_randomness=20)
-    opts = s3d.ExecOptions(force_iterations=1, check_interval=0, grid_cells_per_point=0, profile=0)
+    opts = s3d.ExecOptions(force_iterations=1, check_interval=0, grid_cells_per_point=args.cells_per_point, profile=0)
     src = [ctx.upload(p[0]) for p in pairs]
     tgt = [ctx.upload(p[1]) for p in pairs]
     guesses = np.tile(np.eye(4), (args.pairs, 1, 1))
@@ -128,26 +134,36 @@ def main():
             d = np.linalg.inv(pairs[i][2]) @ T
             errs.append(np.linalg.norm(d[:3, 3]))
         # ---- per-stage profile of one step + NN kernel timing (HIP events on the context stream)
-        popts = s3d.ExecOptions(force_iterations=1, check_interval=0, grid_cells_per_point=0, profile=1)
+        popts = s3d.ExecOptions(force_iterations=1, check_interval=0, grid_cells_per_point=args.cells_per_point, profile=1)
         ctx.align_batch(src, tgt, guesses, params, popts)
         prof = ctx.last_profile()
-        nn = ctx.profile_nn_kernel(src, tgt, guesses, params, reps=args.nn_reps)
-        alg_bytes = 20.0 * nn["n_queries"] + 12.0 * nn["n_targets"]  # 20*M + 12*N per NN pass
-        achieved = alg_bytes / (nn["avg_ms"] * 1e-3) / 1e9
-        roofline = {"kernel": "s3d_nn_search_kernel", "bound": "hbm", "achieved": round(achieved, 2),
+        # roofline of the dominant kernel (K5, s3d_nn_search_kernel<0>): algorithmic bytes per launch
+        # (20*M + 12*N per NN pass, summed over the batch) / average launch duration over
+        # the ICP loop of one step, HIP events on the stream the kernel runs on.
+        n_launch = max(prof["nn_launches"], 1)
+        nq, nt = prof["nn_queries"] / n_launch, prof["nn_targets"] / n_launch
+        alg_bytes = 20.0 * nq + 12.0 * nt
+        avg_ms = prof["nn_ms"] / n_launch
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        roofline = {"kernel": "s3d_nn_search_kernel<0>", "bound": "hbm", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": None, "avg_launch_ms": round(nn["avg_ms"], 4),
+                    "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n_launch,
                     "algorithmic_bytes_per_launch": int(alg_bytes),
-                    "queries_per_launch": nn["n_queries"], "targets_per_launch": nn["n_targets"],
-                    "in_loop_avg_launch_ms": round(prof["nn_ms"] / max(prof["nn_launches"], 1), 4)}
-        # ---- single pair latency (BASELINE.json configs[1])
-        one_s, one_t = [src[0]], [tgt[0]]
-        ctx.align_batch(one_s, one_t, guesses[:1], params, opts)
-        t1 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
+                    "queries_per_launch": int(nq), "targets_per_launch": int(nt),
+                    "gqueries_per_s": round(nq / (avg_ms * 1e-3) / 1e9, 3)}
+        # ---- optional extras: single pair latency (BASELINE.json configs[1]), first-iteration NN launch
+        single = None
+        if args.extras:
+            one_s, one_t = [src[0]], [tgt[0]]
             ctx.align_batch(one_s, one_t, guesses[:1], params, opts)
-        single_ms = (time.perf_counter() - t1) / reps * 1e3
+            t1 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                ctx.align_batch(one_s, one_t, guesses[:1], params, opts)
+            single_ms = (time.perf_counter() - t1) / reps * 1e3
+            nn0 = ctx.profile_nn_kernel(src, tgt, guesses, params, reps=args.nn_reps)
+            single = {"latency_ms": round(single_ms, 3), "registrations_per_s": round(1e3 / single_ms, 2),
+                      "first_iteration_nn_launch_ms_full_batch": round(nn0["avg_ms"], 4)}
         # ---- CPU baseline: the oracle (a port of the reference path), one thread, same inputs/iterations
         cpu = None
         if not args.no_cpu and world == 1:
@@ -182,7 +198,7 @@ def main():
                        "collective": "all_gather of 128-B edge records (RCCL)" if world > 1 else "none"},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "single_pair": {"latency_ms": round(single_ms, 3), "registrations_per_s": round(1e3 / single_ms, 2)},
+            "single_pair": single,
             "stage_ms": {k: round(v, 3) for k, v in prof.items() if k.endswith("_ms")},
             "accuracy": {"status_ok": n_ok, "median_err_m": float(np.median(errs)), "max_err_m": float(np.max(errs))},
             "input_generation_s": round(gen_s, 1),

@@ -1,0 +1,140 @@
+// slam3d/core/Types.hpp (MI355X build) — the boundary value types of the registration path.
+//
+// Mirrors the names and members the hot path and its callers use from the reference's
+// slam3d/core/Types.hpp:46-187 and slam3d/core/Sensor.hpp:44-72.  The reference builds these on
+// Eigen + Boost, which are not available in this build environment; this header is a
+// dependency-free stand-in with the same spelling so that code written against the reference
+// (createConstraint callers, tests) reads the same.  On a machine that has the real slam3d core,
+// use the real headers and the binding shown in INTEGRATION.md instead.
+#pragma once
+
+#include <cmath>
+#include <cstring>
+#include <exception>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace slam3d {
+
+typedef unsigned IdType;
+typedef double ScalarType;
+
+struct Position {  // Eigen::Matrix<double,3,1>
+  double v[3] = {0, 0, 0};
+  double& operator[](int i) { return v[i]; }
+  double operator[](int i) const { return v[i]; }
+  double norm() const { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+};
+
+// Types.hpp:53  typedef Eigen::Transform<ScalarType,3,Eigen::Isometry> Transform;
+// 4x4 double, column-major storage like Eigen.
+class Transform {
+ public:
+  Transform() { setIdentity(); }
+  static Transform Identity() { return Transform(); }
+  void setIdentity() { for (int i = 0; i < 16; ++i) m_[i] = (i % 5 == 0) ? 1.0 : 0.0; }
+  double& operator()(int r, int c) { return m_[c * 4 + r]; }
+  double operator()(int r, int c) const { return m_[c * 4 + r]; }
+  double* data() { return m_; }             // == matrix().data()
+  const double* data() const { return m_; }
+  Position translation() const { Position p; p[0] = (*this)(0, 3); p[1] = (*this)(1, 3); p[2] = (*this)(2, 3); return p; }
+  Transform inverse() const {               // Isometry: R^T, -R^T t
+    Transform o;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) o(r, c) = (*this)(c, r);
+    for (int r = 0; r < 3; ++r) o(r, 3) = -(o(r, 0) * (*this)(0, 3) + o(r, 1) * (*this)(1, 3) + o(r, 2) * (*this)(2, 3));
+    return o;
+  }
+  Transform operator*(const Transform& b) const {
+    Transform o;
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 4; ++r) {
+        double s = 0;
+        for (int k = 0; k < 4; ++k) s += (*this)(r, k) * b(k, c);
+        o(r, c) = s;
+      }
+    return o;
+  }
+ private:
+  double m_[16];
+};
+
+template <unsigned N>
+struct Covariance {  // Eigen::Matrix<double,N,N>, row/col symmetric use only
+  double v[N * N];
+  static Covariance Identity() { Covariance c; for (unsigned i = 0; i < N * N; ++i) c.v[i] = (i % (N + 1) == 0) ? 1.0 : 0.0; return c; }
+  double& operator()(unsigned r, unsigned c) { return v[r * N + c]; }
+  double operator()(unsigned r, unsigned c) const { return v[r * N + c]; }
+};
+
+// Types.hpp:108-135
+class Measurement {
+ public:
+  typedef std::shared_ptr<Measurement> Ptr;  // reference: boost::shared_ptr
+  Measurement(const std::string& r, const std::string& s, const Transform& p)
+      : mRobotName(r), mSensorName(s), mSensorPose(p), mInverseSensorPose(p.inverse()) {}
+  virtual ~Measurement() {}
+  std::string getRobotName() const { return mRobotName; }
+  std::string getSensorName() const { return mSensorName; }
+  Transform getSensorPose() const { return mSensorPose; }
+  Transform getInverseSensorPose() const { return mInverseSensorPose; }
+  virtual const char* getTypeName() const = 0;
+ protected:
+  std::string mRobotName, mSensorName;
+  Transform mSensorPose, mInverseSensorPose;
+};
+
+enum ConstraintType { TENTATIVE, SE3, GRAVITY, POSITION, ORIENTATION, POSE };
+
+// Types.hpp:137-187
+class Constraint {
+ public:
+  typedef std::shared_ptr<Constraint> Ptr;
+  explicit Constraint(const std::string& s) : mSensorName(s) {}
+  virtual ~Constraint() {}
+  virtual ConstraintType getType() = 0;
+  virtual const char* getTypeName() = 0;
+  const std::string& getSensorName() const { return mSensorName; }
+ protected:
+  std::string mSensorName;
+};
+
+class SE3Constraint : public Constraint {
+ public:
+  typedef std::shared_ptr<SE3Constraint> Ptr;
+  SE3Constraint(const std::string& s, const Transform& t, const Covariance<6>& i) : Constraint(s), mRelativePose(t), mInformation(i) {}
+  ConstraintType getType() override { return SE3; }
+  const char* getTypeName() override { return "SE(3)"; }
+  const Transform& getRelativePose() const { return mRelativePose; }
+  const Covariance<6>& getInformation() const { return mInformation; }
+ protected:
+  Transform mRelativePose;
+  Covariance<6> mInformation;
+};
+
+// Sensor.hpp:44-72
+class BadMeasurementType : public std::exception {
+ public:
+  const char* what() const throw() override { return "Measurement type does not match sensor type!"; }
+};
+class NoMatch : public std::exception {
+ public:
+  explicit NoMatch(const std::string& msg) : message(msg) {}
+  const char* what() const throw() override { return message.c_str(); }
+  std::string message;
+};
+
+// Logger.hpp:47-107 (levels and message()); the default implementation writes to stderr
+enum LogLevel { DEBUG = 0, INFO = 1, WARNING = 2, ERROR = 3, FATAL = 4 };
+class Logger {
+ public:
+  virtual ~Logger() {}
+  void setLogLevel(LogLevel lvl) { mLogLevel = lvl; }
+  virtual void message(LogLevel lvl, const std::string& msg);
+ protected:
+  LogLevel mLogLevel = INFO;
+};
+
+}  // namespace slam3d

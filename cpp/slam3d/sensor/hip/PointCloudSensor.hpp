@@ -1,0 +1,110 @@
+// slam3d::PointCloudSensor on the MI355X back-end.
+//
+// Same class names, method names, argument meaning and exceptions as the reference's
+// slam3d/sensor/pcl/PointCloudSensor.hpp:43-243 for the registration path:
+//   createConstraint (PointCloudSensor.cpp:269-299), setRegistrationParameters (:320-340),
+//   downsample (:190-201), downsampleScan (:203-209), transform (:228-233), the scalar setters.
+// The arithmetic runs in libslam3d_hip.so through the C ABI (include/slam3d_hip.h); this header
+// only does what the reference's own 120 lines around PCL do: casts, exceptions, logging.
+// Out of scope here (SURVEY.md §8f "next"): getAccumulatedCloud / createCombinedMeasurement /
+// buildMap / removeOutliers / fillGroundPlane / loadPLY and the ScanSensor front-end policy, which
+// need the Mapper/Graph of slam3d core.
+#pragma once
+
+#include <cstdint>
+#include <mutex>
+#include <sstream>
+
+#include "../../../../include/slam3d_hip.h"
+#include "../../core/Types.hpp"
+#include "RegistrationParameters.hpp"
+
+namespace slam3d {
+
+static_assert(sizeof(RegistrationParameters) == sizeof(s3d_reg_params), "RegistrationParameters must match s3d_reg_params");
+static_assert(sizeof(RegistrationAlgorithm) == sizeof(int), "enum must be int-sized");
+
+// pcl::PointXYZ: 16 bytes (x, y, z, padding)
+struct PointType { float x, y, z, data_w; };
+struct PointCloudHeader { uint64_t stamp = 0; uint32_t seq = 0; std::string frame_id; };
+
+// the members of pcl::PointCloud<pcl::PointXYZ> the path touches
+class PointCloud {
+ public:
+  typedef std::shared_ptr<PointCloud> Ptr;
+  typedef std::shared_ptr<const PointCloud> ConstPtr;
+  std::vector<PointType> points;
+  PointCloudHeader header;
+  uint32_t width = 0, height = 1;
+  bool is_dense = true;
+  size_t size() const { return points.size(); }
+  void push_back(const PointType& p) { points.push_back(p); width = (uint32_t)points.size(); }
+  PointCloud& operator+=(const PointCloud& o) { points.insert(points.end(), o.points.begin(), o.points.end()); width = (uint32_t)points.size(); return *this; }
+};
+
+// PointCloudSensor.hpp:50-100
+class PointCloudMeasurement : public Measurement {
+ public:
+  typedef std::shared_ptr<PointCloudMeasurement> Ptr;
+  PointCloudMeasurement(const PointCloud::Ptr& cloud, const std::string& r, const std::string& s, const Transform& p)
+      : Measurement(r, s, p), mPointCloud(cloud) {}
+  const PointCloud::Ptr getPointCloud() const { return mPointCloud; }
+  const char* getTypeName() const override { return "slam3d::PointCloudMeasurement"; }
+ protected:
+  PointCloud::Ptr mPointCloud;
+};
+
+// the part of Sensor / ScanSensor (Sensor.hpp:84-168, ScanSensor.hpp:35-158) the path needs
+class Sensor {
+ public:
+  Sensor(const std::string& n, Logger* l) : mLogger(l), mName(n), mCovarianceScale(1.0) {}
+  virtual ~Sensor() {}
+  std::string getName() const { return mName; }
+  void setCovarianceScale(ScalarType s) { mCovarianceScale = s; }
+ protected:
+  Logger* mLogger;
+  std::string mName;
+  ScalarType mCovarianceScale;
+};
+
+class ScanSensor : public Sensor {
+ public:
+  ScanSensor(const std::string& n, Logger* l) : Sensor(n, l) {}
+  // ScanSensor.hpp:122-125 — THE plugin hook of the hot path
+  virtual Constraint::Ptr createConstraint(const Measurement::Ptr& source, const Measurement::Ptr& target,
+                                           const Transform& odometry, bool loop) = 0;
+};
+
+class PointCloudSensor : public ScanSensor {
+ public:
+  PointCloudSensor(const std::string& n, Logger* l, int device = 0);
+  ~PointCloudSensor();
+
+  Constraint::Ptr createConstraint(const Measurement::Ptr& source, const Measurement::Ptr& target,
+                                   const Transform& odometry, bool loop) override;
+  void setRegistrationParameters(const RegistrationParameters& param, bool coarse);
+  void setScanResolution(double r);
+  void setMapResolution(double r);
+  void setMapOutlierRemoval(double r, unsigned n);
+  static PointCloud::Ptr downsample(PointCloud::Ptr source, double resolution);
+  PointCloud::Ptr downsampleScan(PointCloud::Ptr source);
+  PointCloud::Ptr transform(PointCloud::ConstPtr source, const Transform tf) const;
+
+  // the same align() the reference keeps file-local (PointCloudSensor.cpp:119-174), exposed for tests
+  Transform align(const PointCloudMeasurement::Ptr& source, const PointCloudMeasurement::Ptr& target,
+                  const Transform& guess, const RegistrationParameters& config);
+
+ protected:
+  RegistrationParameters mFineConfiguration;
+  RegistrationParameters mCoarseConfiguration;
+  double mScanResolution;
+  double mMapResolution;
+  double mMapOutlierRadius;
+  unsigned mMapOutlierNeighbors;
+
+ private:
+  s3d_context* mContext;   // one HIP device + stream; calls are serialised inside the library,
+                           // so createConstraint may be entered from the link thread (ScanSensor.cpp:210)
+};
+
+}  // namespace slam3d

@@ -303,15 +303,16 @@ struct Batch {
     k_normals<<<dim3(nb_head, C()), kBlock, smem, st>>>(d_slots(), filt(), sorted(), cells(), normals(), k);
   }
 
+  int dbg_nn = getenv("S3D_DBG_NN") ? atoi(getenv("S3D_DBG_NN")) : 0;
   void launch_nn(int mode, float max_d) {
     hipStream_t st = ctx->stream;
     dim3 grid(cdiv(std::max(max_n_t, 1), kBlock), P());
     if (mode == 0)
       s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), filt(), sorted(), cells(),
-                                                        (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, max_d);
+                                                        (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, max_d, dbg_nn);
     else
       s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), filt(), sorted(), cells(),
-                                                        (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, max_d);
+                                                        (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, max_d, dbg_nn);
   }
 
   // K5-K7 loop.  The host only polls the active-pair counter every check_interval iterations.

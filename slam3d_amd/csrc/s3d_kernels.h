@@ -433,8 +433,11 @@ __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ 
   const SlotDev& s = slots[blockIdx.y];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= s.n) return;
+  // threads walk the cloud in CELL-SORTED order: the 64 lanes of a wave then sit in adjacent grid
+  // cells, so their cell_start / candidate loads fall into a handful of cache lines instead of 64
   const float4* __restrict__ P = filt + s.off;
-  const float4 q = P[i];
+  const float4 q = sorted[s.off + i];
+  const int orig = __float_as_int(q.w);
   const int cnt = grid_knn(s.g, cell_start + s.cell_off, sorted + s.off, q.x, q.y, q.z, k, d2s + threadIdx.x,
                            idxs + threadIdx.x, kBlock);
   Moments m;
@@ -445,7 +448,7 @@ __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ 
   }
   double n[3];
   moments_normal(m, k, n);
-  normals[s.off + i] = make_float4((float)n[0], (float)n[1], (float)n[2], 0.f);
+  normals[s.off + orig] = make_float4((float)n[0], (float)n[1], (float)n[2], 0.f);
 }
 
 // ------------------------------------------------------------------ pair state
@@ -471,14 +474,17 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
                                                                 const float4* __restrict__ sorted,
                                                                 const uint32_t* __restrict__ cell_start,
                                                                 int* __restrict__ corr_idx, float* __restrict__ corr_d2,
-                                                                float max_d) {
+                                                                float max_d, int dbg) {
   const PairDev& P = pairs[blockIdx.y];
   if (MODE == 0 && !P.active) return;
   const SlotDev& St = slots[P.slot_t];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= St.n) return;
   const SlotDev& Ss = slots[P.slot_s];
-  const float4 p0 = filt[St.off + i];
+  // queries are taken in the CELL-SORTED order of their own cloud (spatially coherent waves);
+  // the result is stored at the point's index in filtered order
+  const float4 p0 = (dbg & 1) ? filt[St.off + i] : sorted[St.off + i];
+  const int orig = (dbg & 3) ? i : __float_as_int(p0.w);
   F3 q;
   if (MODE == 0) {
     const F3 p = xf_pcl(P.guess, p0.x, p0.y, p0.z);
@@ -487,8 +493,8 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
     q = xf_pcl(P.final_T, p0.x, p0.y, p0.z);
   }
   const NNResult r = grid_nn1(Ss.g, cell_start + Ss.cell_off, sorted + Ss.off, q.x, q.y, q.z, max_d);
-  corr_idx[P.corr_off + i] = r.idx;
-  corr_d2[P.corr_off + i] = r.d2;
+  corr_idx[P.corr_off + orig] = r.idx;
+  corr_d2[P.corr_off + orig] = r.d2;
 }
 
 // ------------------------------------------------------------------ K6: per-correspondence terms + reduction

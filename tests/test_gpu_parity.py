@@ -339,3 +339,37 @@ def test_create_constraint(gpu_ctx, oracle_mod, fixture_clouds):
     st, _, _, _ = gpu_ctx.create_constraint(fixture_clouds[0], ident, fixture_clouds[3], ident, ident, loop=True,
                                             fine=fine, coarse=s3d.default_params(registration_algorithm=s3d.ALG_ICP))
     assert st == 4
+
+
+# ------------------------------------------------------------------ C++ mirror of the plugin API
+
+def _run_cpp_example(tmp_path, fixture_clouds, a, b, *flags):
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "cpp", "example_create_constraint")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "cpp")])
+    fa, fb = tmp_path / "a.bin", tmp_path / "b.bin"
+    fixture_clouds[a].astype(np.float32).tofile(fa)
+    fixture_clouds[b].astype(np.float32).tofile(fb)
+    out = subprocess.check_output([exe, str(fa), str(fb), *flags], stderr=subprocess.DEVNULL).decode().splitlines()
+    return out
+
+
+def test_cpp_point_cloud_sensor_create_constraint(gpu_ctx, fixture_clouds, tmp_path):
+    """slam3d::PointCloudSensor::createConstraint through the C++ mirror == the C ABI called from Python."""
+    import slam3d_amd as s3d
+    out = _run_cpp_example(tmp_path, fixture_clouds, 0, 1)
+    assert out[0] == "OK SE(3)"
+    T_cpp = np.array([[float(x) for x in line.split()] for line in out[1:5]])
+    st, rel, inf, _ = gpu_ctx.create_constraint(fixture_clouds[0], np.eye(4), fixture_clouds[1], np.eye(4), np.eye(4),
+                                                covariance_scale=4.0)
+    assert st == 0 and np.allclose(T_cpp, rel, atol=1e-11)
+    assert out[5] == "information00 0.25"
+    # exceptions of the reference: NoMatch (distance-from-guess gate), runtime_error (NDT)
+    out = _run_cpp_example(tmp_path, fixture_clouds, 0, 3)
+    assert out[0] == "NoMatch ICP result is to far away from guess"
+    out = _run_cpp_example(tmp_path, fixture_clouds, 0, 3, "loop", "ICP")
+    assert out[0] == "OK SE(3)" and abs(float(out[1].split()[3]) - 2.1) < 0.05
+    out = _run_cpp_example(tmp_path, fixture_clouds, 0, 1, "NDT")
+    assert out[0].startswith("runtime_error NDT")
