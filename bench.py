@@ -109,8 +109,11 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     last = None
+    step_ms = []
     for _ in range(args.steps):
-        last = step()
+        ts = time.perf_counter()
+        last = step()          # align_batch returns after its D2H of the records: the step is complete
+        step_ms.append(round((time.perf_counter() - ts) * 1e3, 3))
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -199,7 +202,9 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "single_pair": single,
-            "stage_ms": {k: round(v, 3) for k, v in prof.items() if k.endswith("_ms")},
+            "step_ms": step_ms,
+            "stage_ms": {k: round(v, 3) for k, v in prof.items() if k.endswith("_ms") and k != "nn_launch_ms"},
+            "nn_launch_ms": prof["nn_launch_ms"],
             "accuracy": {"status_ok": n_ok, "median_err_m": float(np.median(errs)), "max_err_m": float(np.max(errs))},
             "input_generation_s": round(gen_s, 1),
         }

@@ -51,6 +51,7 @@ typedef struct s3d_profile {      /* milliseconds, HIP events on the context's s
   double nn_ms;       /* sum over the NN-search kernel launches of the ICP loop */
   int    nn_launches;
   long long nn_queries, nn_targets; /* summed over launches: queries searched, target points indexed */
+  float  nn_launch_ms[64];          /* duration of the first 64 NN launches of the ICP loop, in order */
 } s3d_profile;
 
 /* ---- context ------------------------------------------------------------------ */

@@ -52,10 +52,12 @@ class EdgeRecord(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("voxel_ms", C.c_double), ("grid_ms", C.c_double), ("normals_ms", C.c_double), ("icp_ms", C.c_double),
                 ("fitness_ms", C.c_double), ("total_ms", C.c_double), ("nn_ms", C.c_double), ("nn_launches", C.c_int),
-                ("nn_queries", C.c_longlong), ("nn_targets", C.c_longlong)]
+                ("nn_queries", C.c_longlong), ("nn_targets", C.c_longlong), ("nn_launch_ms", C.c_float * 64)]
 
     def asdict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "nn_launch_ms"}
+        d["nn_launch_ms"] = [round(float(x), 4) for x in self.nn_launch_ms[:max(self.nn_launch_ms and self.nn_launches, 0)]][:64]
+        return d
 
 
 def lib_path():

@@ -160,7 +160,7 @@ struct Batch {
   uint32_t* vB() { return (uint32_t*)ctx->valsB.p; }
   float4* filt() { return (float4*)ctx->filt.p; }
   float4* sorted() { return (float4*)ctx->sorted.p; }
-  float4* normals() { return (float4*)ctx->normals.p; }
+  double4* normals() { return (double4*)ctx->normals.p; }
   uint32_t* cells() { return (uint32_t*)ctx->cell_start.p; }
   int C() const { return (int)h_slots.size(); }
   int P() const { return (int)h_pairs.size(); }
@@ -232,7 +232,7 @@ struct Batch {
     ctx->ensure(ctx->pairs, sizeof(PairDev) * std::max(1, P()));
     ctx->ensure(ctx->keysA, 4 * np); ctx->ensure(ctx->keysB, 4 * np);
     ctx->ensure(ctx->valsA, 4 * np); ctx->ensure(ctx->valsB, 4 * np);
-    ctx->ensure(ctx->filt, 16 * np); ctx->ensure(ctx->sorted, 16 * np); ctx->ensure(ctx->normals, 16 * np);
+    ctx->ensure(ctx->filt, 16 * np); ctx->ensure(ctx->sorted, 16 * np); ctx->ensure(ctx->normals, 32 * np);
     ctx->ensure(ctx->cell_start, 4 * std::max<size_t>(total_cells, 4));
     ctx->ensure(ctx->counts, 4 * (size_t)std::max(1, C()) * 256 * nb_sort);
     ctx->ensure(ctx->blockcnt, 4 * (size_t)std::max(1, C()) * nb_head);
@@ -299,13 +299,36 @@ struct Batch {
     hipStream_t st = ctx->stream;
     if (C() == 0) return;
     const int k = std::max(1, std::min(rp.k, 64));
-    const size_t smem = (size_t)k * kBlock * 8;
-    k_normals<<<dim3(nb_head, C()), kBlock, smem, st>>>(d_slots(), filt(), sorted(), cells(), normals(), k);
+    dim3 grid(nb_head, C());
+    if (k <= 8)
+      s3d_knn_normals_kernel<8><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), normals(), k);
+    else if (k <= 16)
+      s3d_knn_normals_kernel<16><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), normals(), k);
+    else if (k <= 20)
+      s3d_knn_normals_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), normals(), k);
+    else if (k <= 32)
+      s3d_knn_normals_kernel<32><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), normals(), k);
+    else
+      k_normals<<<grid, kBlock, (size_t)k * kBlock * 8, st>>>(d_slots(), filt(), sorted(), cells(), normals(), k);
   }
 
   int dbg_nn = getenv("S3D_DBG_NN") ? atoi(getenv("S3D_DBG_NN")) : 0;
   void launch_nn(int mode, float max_d) {
     hipStream_t st = ctx->stream;
+    if (dbg_nn & 8) {      // opt-in (S3D_DBG_NN=8): LDS-tiled kernel; measured slower than the default, see DESIGN.md
+      const int chunks = cdiv(std::max(max_n_t, 1), kBlock);
+      const int pairs8 = P() >= 8 ? cdiv(P(), 8) * 8 : P();
+      dim3 grid((unsigned)(pairs8 * chunks));
+      if (mode == 0)
+        s3d_nn_search_tiled_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(),
+                                                               (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, max_d,
+                                                               chunks, P());
+      else
+        s3d_nn_search_tiled_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(),
+                                                               (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, max_d,
+                                                               chunks, P());
+      return;
+    }
     dim3 grid(cdiv(std::max(max_n_t, 1), kBlock), P());
     if (mode == 0)
       s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), filt(), sorted(), cells(),
@@ -321,6 +344,8 @@ struct Batch {
     if (P() == 0) return;
     int* d_active = (int*)ctx->n_active.p;
     k_pair_init<<<cdiv(P(), 64), 64, 0, st>>>(d_pairs(), P(), d_active);
+    // no radius hint for the first NN pass: fill the distances with NaN (0xFF bytes)
+    HIPCHK(hipMemsetAsync(ctx->corr_d2.p, 0xFF, 4 * std::max<size_t>(total_corr, 4), st));
     const float max_d = (float)(rp.max_corr * 1.0001);
     double* part = (double*)ctx->partials.p;
     const bool prof = opts.profile != 0;
@@ -337,10 +362,10 @@ struct Batch {
       if (prof) HIPCHK(hipEventRecord(ctx->nn_ev[2 * it + 1], st));
       if (rp.algorithm)
         s3d_gicp_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
-            d_pairs(), d_slots(), filt(), normals(), (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, part, rp);
+            d_pairs(), d_slots(), sorted(), normals(), (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, part, rp);
       else
         s3d_p2plane_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
-            d_pairs(), d_slots(), filt(), normals(), (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, part, rp);
+            d_pairs(), d_slots(), sorted(), normals(), (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, part, rp);
       s3d_icp_control_kernel<<<P(), 128, 0, st>>>(d_pairs(), part, accum_blocks, rp, d_active);
       ctx->prof.nn_launches = it + 1;
       if (!rp.force_iterations && (it + 1) % opts.check_interval == 0 && it + 1 < rp.max_iterations) {
@@ -402,6 +427,7 @@ struct Batch {
       for (int i = 0; i < ctx->prof.nn_launches; ++i) {
         HIPCHK(hipEventElapsedTime(&ms, ctx->nn_ev[2 * i], ctx->nn_ev[2 * i + 1]));
         ctx->prof.nn_ms += ms;
+        if (i < 64) ctx->prof.nn_launch_ms[i] = ms;
       }
       ctx->prof.nn_queries = nq * ctx->prof.nn_launches;
       ctx->prof.nn_targets = nt * ctx->prof.nn_launches;
@@ -781,11 +807,15 @@ int s3d_nn_search(s3d_context* ctx, const float* target_xyz, int n, int stride_t
     b.stage_voxel();
     b.stage_grid();
     k_pair_init<<<1, 64, 0, ctx->stream>>>(b.d_pairs(), 1, (int*)ctx->n_active.p);  // final_T = guess = I
+    HIPCHK(hipMemsetAsync(ctx->corr_d2.p, 0xFF, 4 * std::max<size_t>(b.total_corr, 4), ctx->stream));
     b.launch_nn(1, (float)(max_distance * 1.0001));
+    // back to the caller's query order / target indices (keysA, keysB are free at this point)
+    k_export_corr<<<dim3(cdiv(std::max(m, 1), kBlock), 1), kBlock, 0, ctx->stream>>>(
+        b.d_pairs(), b.d_slots(), b.sorted(), (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, (int*)b.kA(), (float*)b.kB());
     b.download();
     if (m > 0) {
-      HIPCHK(hipMemcpy(idx, (int*)ctx->corr_idx.p + b.h_pairs[0].corr_off, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(d2, (float*)ctx->corr_d2.p + b.h_pairs[0].corr_off, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(idx, (int*)b.kA() + b.h_pairs[0].corr_off, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(d2, (float*)b.kB() + b.h_pairs[0].corr_off, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost));
     }
     free_cloud(&ct);
     free_cloud(&cq);
@@ -818,9 +848,11 @@ int s3d_knn_normals(s3d_context* ctx, const float* xyz, int n, int stride, int k
     b.stage_voxel();
     b.stage_grid();
     b.stage_normals();
+    k_export_normals<<<dim3(cdiv(std::max(n, 1), kBlock), 1), kBlock, 0, ctx->stream>>>(b.d_slots(), b.sorted(), b.normals(),
+                                                                                         b.filt());  // filt is free now
     b.download();
     std::vector<float4> tmp((size_t)std::max(n, 1));
-    HIPCHK(hipMemcpy(tmp.data(), b.normals() + b.h_slots[0].off, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tmp.data(), b.filt() + b.h_slots[0].off, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) {
       normals_xyz[(size_t)i * 3 + 0] = tmp[i].x; normals_xyz[(size_t)i * 3 + 1] = tmp[i].y;
       normals_xyz[(size_t)i * 3 + 2] = tmp[i].z;
@@ -849,7 +881,8 @@ int s3d_profile_nn_kernel(s3d_context* ctx, int n_pairs, s3d_cloud* const* sourc
     b.stage_grid();
     k_pair_init<<<cdiv(n_pairs, 64), 64, 0, ctx->stream>>>(b.d_pairs(), n_pairs, (int*)ctx->n_active.p);
     const float max_d = (float)(b.rp.max_corr * 1.0001);
-    b.launch_nn(0, max_d);  // warm-up
+    HIPCHK(hipMemsetAsync(ctx->corr_d2.p, 0xFF, 4 * std::max<size_t>(b.total_corr, 4), ctx->stream));
+    b.launch_nn(0, max_d);  // warm-up (also leaves first-pass distances as radius hints)
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, ctx->stream));

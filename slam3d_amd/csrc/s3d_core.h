@@ -217,6 +217,80 @@ S3D_HD NNResult grid_nn1(const GridParams& g, const uint32_t* __restrict__ cell_
   return best;
 }
 
+// Exact 1-NN by BOX search with a radius hint (the kernel's hot variant).
+// All points within distance d of the query lie in the cells that intersect the axis-aligned
+// box [q-d, q+d]; per (y,z) row those cells are one contiguous run.  Scan the box for the hint
+// radius; if the best candidate found is provably the nearest (best <= d) stop, otherwise the
+// nearest neighbour is at most as far as that candidate: rescan with exactly that radius (or
+// double the radius when nothing was found).  With the previous ICP iteration's distance as the
+// hint almost every query resolves in one tight scan.  Same result as grid_nn1 (ties: lowest index).
+template <typename F4T>
+S3D_HD void nn1_consider(NNResult& best, const F4T& p, uint32_t k, float qx, float qy, float qz) {
+  const float d2 = dist2(qx, qy, qz, p.x, p.y, p.z);
+  const int pi = __builtin_bit_cast(int, p.w);
+  if (lex_less(d2, pi, best.d2, best.idx < 0 ? 2147483647 : best.idx)) {
+    best.d2 = d2; best.idx = pi; best.pos = (int)k;
+  }
+}
+
+template <typename F4T>
+S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ cell_start,
+                             const F4T* __restrict__ pts, float qx, float qy, float qz, float max_d, float d_hint) {
+  NNResult best;
+  best.idx = -1; best.d2 = 3.0e38f; best.pos = -1;
+  float d = fminf(fmaxf(d_hint, 0.25f * g.h), max_d);
+  for (int attempt = 0; attempt < 64; ++attempt) {
+    // margin: float rounding of the cell assignment of the points and of the box corners
+    const float m = d * 1.0001f + 2.0e-3f * g.h;
+    const int x0 = imax(grid_coord(g, 0, qx - m), 0), x1 = imin(grid_coord(g, 0, qx + m), g.dim[0] - 1);
+    const int y0 = imax(grid_coord(g, 1, qy - m), 0), y1 = imin(grid_coord(g, 1, qy + m), g.dim[1] - 1);
+    const int z0 = imax(grid_coord(g, 2, qz - m), 0), z1 = imin(grid_coord(g, 2, qz + m), g.dim[2] - 1);
+    const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+    if (x0 <= x1 && ny > 0 && nz > 0) {
+      if (ny <= 3 && nz <= 3) {
+        // hot path (tight box): the memory accesses are issued as three independent BATCHES
+        // (all row ranges, then the first point of every row, then the rest) instead of one
+        // dependent load per step: the kernel is bound by DRAM latency x chain length.
+        uint32_t rs[9], re[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+          const int jy = r % 3, jz = r / 3;
+          const bool ok = jy < ny && jz < nz;
+          const int rowbase = g.dim[0] * ((y0 + (ok ? jy : 0)) + g.dim[1] * (z0 + (ok ? jz : 0)));
+          const uint32_t a = cell_start[rowbase + x0], b = cell_start[rowbase + x1 + 1];
+          rs[r] = a; re[r] = ok ? b : a;
+        }
+        F4T first[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) first[r] = pts[rs[r] < re[r] ? rs[r] : 0];
+#pragma unroll
+        for (int r = 0; r < 9; ++r)
+          if (rs[r] < re[r]) nn1_consider(best, first[r], rs[r], qx, qy, qz);
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+          for (uint32_t k = rs[r] + 1; k < re[r]; k += 2) {
+            const F4T pa = pts[k];
+            const F4T pb = pts[k + 1 < re[r] ? k + 1 : k];
+            nn1_consider(best, pa, k, qx, qy, qz);
+            if (k + 1 < re[r]) nn1_consider(best, pb, k + 1, qx, qy, qz);
+          }
+        }
+      } else {
+        for (int cz = z0; cz <= z1; ++cz)
+          for (int cy = y0; cy <= y1; ++cy) {
+            const int rowbase = g.dim[0] * (cy + g.dim[1] * cz);
+            const uint32_t s = cell_start[rowbase + x0], e = cell_start[rowbase + x1 + 1];
+            for (uint32_t k = s; k < e; ++k) nn1_consider(best, pts[k], k, qx, qy, qz);
+          }
+      }
+    }
+    if (best.idx >= 0 && best.d2 <= d * d) break;  // nothing outside the box can be closer
+    if (d >= max_d) break;                         // neighbours beyond max_d do not matter
+    d = best.idx >= 0 ? fminf(sqrtf(best.d2) * 1.0001f + 1.0e-6f, max_d) : fminf(2.0f * d, max_d);
+  }
+  return best;
+}
+
 // Exact k-NN of a point among its own cloud by ring expansion.  The k best are
 // kept in caller-provided storage addressed as d2s[j*stride], idxs[j*stride]
 // (LDS columns on the GPU).  Order of the result is unspecified.
@@ -277,6 +351,78 @@ S3D_HD int grid_knn(const GridParams& g, const uint32_t* __restrict__ cell_start
     if (cnt >= k && maxd <= bound * bound) break;
   }
   return cnt;
+}
+
+// Register-resident variant (the one the GPU runs for k <= 32): the k best are kept as a SORTED
+// list of packed 64-bit keys (float bits of d2 << 32 | index; d2 >= 0 so the integer order is the
+// lexicographic (d2, index) order).  An insertion is one unrolled min/max chain — no LDS, no
+// re-scan — and the list comes out in ascending distance, the order in which PCL sums the
+// neighbours.  keys[] must hold KMAX entries; returns the number of valid entries (<= k).
+template <int KMAX, typename F4T>
+S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cell_start,
+                           const F4T* __restrict__ pts, float qx, float qy, float qz, int k,
+                           unsigned long long (&keys)[KMAX]) {
+  const unsigned long long kInf = ~0ull;
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) keys[j] = kInf;
+  unsigned long long worst = kInf;  // == keys[k-1]
+  int cnt = 0;
+  const float fx = (qx - g.origin[0]) * g.inv_h, fy = (qy - g.origin[1]) * g.inv_h,
+              fz = (qz - g.origin[2]) * g.inv_h;
+  const int ix = grid_coord(g, 0, qx), iy = grid_coord(g, 1, qy), iz = grid_coord(g, 2, qz);
+  float ox = fx - (float)ix, oy = fy - (float)iy, oz = fz - (float)iz;
+  float face = fminf(fminf(fminf(ox, 1.f - ox), fminf(oy, 1.f - oy)), fminf(oz, 1.f - oz));
+  face = fmaxf(face - 2.0e-3f, 0.f);
+  const int rmax = imax(imax(g.dim[0], g.dim[1]), g.dim[2]);
+  for (int r = 0; r <= rmax; ++r) {
+    const int z0 = imax(iz - r, 0), z1 = imin(iz + r, g.dim[2] - 1);
+    const int y0 = imax(iy - r, 0), y1 = imin(iy + r, g.dim[1] - 1);
+    const int xl = ix - r, xh = ix + r;
+    for (int cz = z0; cz <= z1; ++cz) {
+      const bool zface = (cz == iz - r) || (cz == iz + r);
+      for (int cy = y0; cy <= y1; ++cy) {
+        const bool full = zface || (cy == iy - r) || (cy == iy + r);
+        const int rowbase = g.dim[0] * (cy + g.dim[1] * cz);
+        for (int part = 0; part < 2; ++part) {
+          int xa, xb;
+          if (full) {
+            if (part) break;
+            xa = imax(xl, 0); xb = imin(xh, g.dim[0] - 1);
+          } else {
+            xa = xb = part ? xh : xl;
+            if (xa < 0 || xa >= g.dim[0]) continue;
+          }
+          if (xa > xb) continue;
+          const uint32_t s = cell_start[rowbase + xa], e = cell_start[rowbase + xb + 1];
+          for (uint32_t kk = s; kk < e; ++kk) {
+            const F4T p = pts[kk];
+            const float d2 = dist2(qx, qy, qz, p.x, p.y, p.z);
+            unsigned long long c = ((unsigned long long)__builtin_bit_cast(uint32_t, d2) << 32) |
+                                   (unsigned long long)__builtin_bit_cast(uint32_t, p.w);
+            if (c < worst) {
+#pragma unroll
+              for (int j = 0; j < KMAX; ++j) {
+                const unsigned long long lo = keys[j] < c ? keys[j] : c;
+                c = keys[j] < c ? c : keys[j];
+                keys[j] = lo;
+              }
+              // worst = keys[k-1] without dynamic register indexing
+              worst = kInf;
+#pragma unroll
+              for (int j = 0; j < KMAX; ++j) worst = (j == k - 1) ? keys[j] : worst;
+              ++cnt;
+            }
+          }
+        }
+      }
+    }
+    const float bound = ((float)r + face) * g.h;
+    if (worst != kInf) {
+      const float dk = __builtin_bit_cast(float, (uint32_t)(worst >> 32));
+      if (dk <= bound * bound) break;
+    }
+  }
+  return cnt < k ? cnt : k;
 }
 
 // ------------------------------------------------------------------ covariance -> normal (K4)
@@ -385,9 +531,18 @@ S3D_HD void gicp_mahalanobis(const double S[6], const double n1r[3], const doubl
   M[5] = (t00 * t11 - t01 * t01) * id;
 }
 
-// add one correspondence (p = guess-transformed query, q = matched target, M sym) to acc[76]
-S3D_HD void gq_accumulate(double* acc, const double p[3], const double q[3], const double M[6]) {
+// add one correspondence (p = guess-transformed query, q = matched target, M sym) to acc[76].
+// The form is expanded ABOUT THE CURRENT TRANSFORM Th0 (= double(transformation_) at the start of the
+// outer iteration): with r = Th0 P - q and Theta = Th0 + dTheta,
+//   m f = sum_{abcd} dTheta_ca dTheta_db A[ab][cd] + 2 sum_{ca} dTheta_ca B[c][a] + C0,
+//   B[c][a] = sum (M r)_c P_a,  C0 = sum r^T M r.
+// Expanding about the origin instead (r = -q) is the same algebra but loses ~7 digits to
+// cancellation (|A Theta^2| ~ 1e11 against m f ~ 1e3), enough to disturb PCL's line search.
+S3D_HD void gq_accumulate(double* acc, const double p[3], const double qt[3], const double M[6], const double* Th0) {
   const double P[4] = {p[0], p[1], p[2], 1.0};
+  double q[3];  // q := -(r) so that the code below accumulates with the residual: B <- -(M r) P, see gq_eval
+  for (int c = 0; c < 3; ++c)
+    q[c] = qt[c] - (Th0[c * 4 + 0] * P[0] + Th0[c * 4 + 1] * P[1] + Th0[c * 4 + 2] * P[2] + Th0[c * 4 + 3]);
   int o = 0;
   for (int a = 0; a < 4; ++a)
     for (int b = a; b < 4; ++b) {
@@ -428,7 +583,8 @@ S3D_HD void gicp_apply_state(const double x[6], Mat4f& T) {
 }
 
 // f(x) and gradient from the quadratic form (PCL OptimizationFunctorWithIndices::fdf)
-S3D_HD void gq_eval(const double* acc, const double x[6], double* f, double g[6]) {
+// Th0: the expansion point used by gq_accumulate (3x4 row-major)
+S3D_HD void gq_eval(const double* acc, const double* Th0, const double x[6], double* f, double g[6]) {
   // Theta = [Rz(x5) Ry(x4) Rx(x3) | x0..2] carried in DOUBLE.  PCL's applyState rounds
   // Theta to float before every evaluation, which turns f(x) into a 1e-7-level staircase
   // and makes the line search terminate on rounding noise ("conditioning");
@@ -442,6 +598,8 @@ S3D_HD void gq_eval(const double* acc, const double x[6], double* f, double g[6]
     Th[1][0] = spsi * cth; Th[1][1] = spsi * sth * sphi + cpsi * cphi; Th[1][2] = spsi * sth * cphi - cpsi * sphi;
     Th[2][0] = -sth; Th[2][1] = cth * sphi; Th[2][2] = cth * cphi;
     Th[0][3] = x[0]; Th[1][3] = x[1]; Th[2][3] = x[2];
+    for (int c = 0; c < 3; ++c)
+      for (int a = 0; a < 4; ++a) Th[c][a] -= Th0[c * 4 + a];  // dTheta about the expansion point
   }
   // G[a][c] = sum_{d,b} Th[d][b] A[ab][cd] - B[c][a]   ( = sum_i P_a (M res_i)_c )
   double G[4][3];
@@ -496,6 +654,7 @@ S3D_HD void gq_eval(const double* acc, const double x[6], double* f, double g[6]
 // applyF/applyDF/applyFDF would.
 struct Bfgs {
   const double* acc;
+  const double* th0;
   double f, gradient[6];
   double x0[6], g0[6], p[6];
   double g0norm, pnorm, fp0, delta_f;
@@ -518,7 +677,7 @@ S3D_HD double v6dot(const double* a, const double* b) {
 S3D_HD void bfgs_eval(Bfgs& b, double alpha) {
   if (alpha == b.c_alpha) return;
   for (int i = 0; i < 6; ++i) b.c_x[i] = b.x0[i] + alpha * b.p[i];
-  gq_eval(b.acc, b.c_x, &b.c_f, b.c_g);
+  gq_eval(b.acc, b.th0, b.c_x, &b.c_f, b.c_g);
   b.c_df = v6dot(b.c_g, b.p);
   b.c_alpha = alpha;
   b.evals++;
@@ -638,11 +797,12 @@ S3D_HD int bfgs_line_search(Bfgs& B, double rho, double sigma, double tau1, doub
   return BFGS_SUCCESS;
 }
 
-S3D_HD void bfgs_init(Bfgs& b, const double* acc, const double x[6]) {
+S3D_HD void bfgs_init(Bfgs& b, const double* acc, const double* th0, const double x[6]) {
   b.acc = acc;
+  b.th0 = th0;
   b.delta_f = 0;
   b.evals = 1;
-  gq_eval(acc, x, &b.f, b.gradient);
+  gq_eval(acc, th0, x, &b.f, b.gradient);
   for (int i = 0; i < 6; ++i) { b.x0[i] = x[i]; b.g0[i] = b.gradient[i]; }
   b.g0norm = v6norm(b.g0);
   for (int i = 0; i < 6; ++i) b.p[i] = b.gradient[i] * -1 / b.g0norm;
@@ -711,8 +871,11 @@ S3D_HD int gicp_estimate_bfgs(const double* acc, int max_inner, Mat4f& T, int* i
   x[4] = asin(-(double)S3D_M(T, 2, 0));
   x[5] = atan2((double)S3D_M(T, 1, 0), (double)S3D_M(T, 0, 0));
   const double gradient_tol = 1e-2;
+  double th0[12];  // expansion point of the form = the transform the accumulate pass used
+  for (int c = 0; c < 3; ++c)
+    for (int a = 0; a < 4; ++a) th0[c * 4 + a] = (double)S3D_M(T, c, a);
   Bfgs b;
-  bfgs_init(b, acc, x);
+  bfgs_init(b, acc, th0, x);
   int inner = 0, result = BFGS_RUNNING;
   do {
     inner++;

@@ -424,20 +424,18 @@ __global__ void __launch_bounds__(kBlock) k_grid_finalize(const SlotDev* __restr
 
 // ------------------------------------------------------------------ K4: k-NN -> covariance -> normal
 
+// generic fallback (k > 32): top-k in LDS columns
 __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ slots, const float4* __restrict__ filt,
                                                      const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start,
-                                                     float4* __restrict__ normals, int k) {
+                                                     double4* __restrict__ normals, int k) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* d2s = reinterpret_cast<float*>(smem);               // [k][kBlock]
   int* idxs = reinterpret_cast<int*>(smem) + k * kBlock;      // [k][kBlock]
   const SlotDev& s = slots[blockIdx.y];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= s.n) return;
-  // threads walk the cloud in CELL-SORTED order: the 64 lanes of a wave then sit in adjacent grid
-  // cells, so their cell_start / candidate loads fall into a handful of cache lines instead of 64
   const float4* __restrict__ P = filt + s.off;
   const float4 q = sorted[s.off + i];
-  const int orig = __float_as_int(q.w);
   const int cnt = grid_knn(s.g, cell_start + s.cell_off, sorted + s.off, q.x, q.y, q.z, k, d2s + threadIdx.x,
                            idxs + threadIdx.x, kBlock);
   Moments m;
@@ -448,7 +446,37 @@ __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ 
   }
   double n[3];
   moments_normal(m, k, n);
-  normals[s.off + orig] = make_float4((float)n[0], (float)n[1], (float)n[2], 0.f);
+  normals[s.off + i] = make_double4(n[0], n[1], n[2], 0.0);  // CELL-SORTED order, double: see DESIGN.md "parity"
+}
+
+// k <= KMAX: the k best live in registers as sorted packed keys (s3d_core.h grid_knn_sorted).
+// Threads walk the cloud in CELL-SORTED order: the 64 lanes of a wave sit in adjacent grid cells,
+// so their cell_start / candidate loads fall into a handful of cache lines.
+template <int KMAX>
+__global__ void __launch_bounds__(kBlock) s3d_knn_normals_kernel(const SlotDev* __restrict__ slots,
+                                                                  const float4* __restrict__ filt,
+                                                                  const float4* __restrict__ sorted,
+                                                                  const uint32_t* __restrict__ cell_start,
+                                                                  double4* __restrict__ normals, int k) {
+  const SlotDev& s = slots[blockIdx.y];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= s.n) return;
+  const float4* __restrict__ P = filt + s.off;
+  const float4 q = sorted[s.off + i];
+  unsigned long long keys[KMAX];
+  const int cnt = grid_knn_sorted<KMAX>(s.g, cell_start + s.cell_off, sorted + s.off, q.x, q.y, q.z, k, keys);
+  Moments m;
+  moments_init(m);
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    if (j < cnt) {
+      const float4 p = P[(int)(uint32_t)(keys[j] & 0xFFFFFFFFull)];
+      moments_add(m, p.x, p.y, p.z);
+    }
+  }
+  double n[3];
+  moments_normal(m, k, n);
+  normals[s.off + i] = make_double4(n[0], n[1], n[2], 0.0);  // CELL-SORTED order, double: see DESIGN.md "parity"
 }
 
 // ------------------------------------------------------------------ pair state
@@ -483,8 +511,7 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
   const SlotDev& Ss = slots[P.slot_s];
   // queries are taken in the CELL-SORTED order of their own cloud (spatially coherent waves);
   // the result is stored at the point's index in filtered order
-  const float4 p0 = (dbg & 1) ? filt[St.off + i] : sorted[St.off + i];
-  const int orig = (dbg & 3) ? i : __float_as_int(p0.w);
+  const float4 p0 = sorted[St.off + i];
   F3 q;
   if (MODE == 0) {
     const F3 p = xf_pcl(P.guess, p0.x, p0.y, p0.z);
@@ -492,9 +519,241 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
   } else {
     q = xf_pcl(P.final_T, p0.x, p0.y, p0.z);
   }
-  const NNResult r = grid_nn1(Ss.g, cell_start + Ss.cell_off, sorted + Ss.off, q.x, q.y, q.z, max_d);
-  corr_idx[P.corr_off + orig] = r.idx;
-  corr_d2[P.corr_off + orig] = r.d2;
+  // radius hint: this query's distance in the previous pass (NaN-filled before the first one)
+  const float prev = corr_d2[P.corr_off + i];
+  NNResult r;
+  if (dbg & 4) {
+    r = grid_nn1(Ss.g, cell_start + Ss.cell_off, sorted + Ss.off, q.x, q.y, q.z, max_d);
+  } else {
+    // a large previous distance says little about the next one (the transform just moved): cap at one cell
+    const float hint = (prev >= 0.f && prev < 1.0e30f) ? fminf(sqrtf(prev) * 1.25f + 0.05f * Ss.g.h, Ss.g.h) : Ss.g.h;
+    r = grid_nn1_box(Ss.g, cell_start + Ss.cell_off, sorted + Ss.off, q.x, q.y, q.z, max_d, hint);
+  }
+  // results are kept in the query cloud's cell-sorted order and name the neighbour by its POSITION in
+  // the target's cell-sorted array: every later access (K6, fitness) is then coalesced or a local gather
+  corr_idx[P.corr_off + i] = r.pos;
+  corr_d2[P.corr_off + i] = r.d2;
+}
+
+// ------------------------------------------------------------------ K5 (LDS-tiled): transform + exact 1-NN
+// One WAVE = 64 consecutive queries of the query cloud's cell-sorted order = a short strip in
+// space (a few metres).  Per attempt the wave
+//   1. reduces the union (in target-grid cells) of its lanes' search boxes     [wave shuffles],
+//   2. stages the cell-table rows and the candidate points of that union into its private LDS
+//      slice with COALESCED loads (one 4-byte / 16-byte element per lane and load),
+//   3. lets every lane scan its own box out of LDS.
+// A lane is done when its best candidate is provably the nearest (d_best <= box radius); the
+// others retry with the exact radius (candidate found) or a doubled one.  Waves whose union does
+// not fit the LDS slice, and lanes left after kTileAttempts, fall back to the global-memory box
+// search (grid_nn1_box).  The per-lane arithmetic and tie rule are those of grid_nn1_box, so the
+// result is identical; only where the bytes come from differs: the un-tiled kernel is bound by the
+// L1 (TCP) access rate — ~17 distinct cache lines per wave-load — not by DRAM.  No block barrier is
+// needed: a wave only ever reads LDS that it wrote itself.
+constexpr int kTileTabCap = 1280;    // u32 entries of staged cell table per wave  (5 KiB)
+constexpr int kTilePtsCap = 320;     // staged candidate points per wave (float4)  (5 KiB)
+constexpr int kTileMaxRows = 64;
+constexpr int kTileAttempts = 3;
+
+struct WaveTile {
+  uint32_t tab[kTileTabCap];
+  float4 pts[kTilePtsCap];
+  int row_gs[kTileMaxRows];          // global sorted position of the row's first staged point minus its LDS offset
+  int row_off[kTileMaxRows + 1];     // LDS offset of the row's first staged point
+  int row_base[kTileMaxRows];        // index of the row's cell (bx0, y, z) in cell_start
+};
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+// LDS written by some lanes of this wave is read by others: order the accesses
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) s3d_nn_search_tiled_kernel(const PairDev* __restrict__ pairs,
+                                                                      const SlotDev* __restrict__ slots,
+                                                                      const float4* __restrict__ sorted,
+                                                                      const uint32_t* __restrict__ cell_start,
+                                                                      int* __restrict__ corr_idx,
+                                                                      float* __restrict__ corr_d2, float max_d,
+                                                                      int chunks_per_pair, int npairs) {
+  __shared__ WaveTile tiles[kBlock / kWave];
+  // XCD-aware block -> (pair, chunk) map: consecutive block ids are dealt round-robin to the 8 XCDs,
+  // so give every XCD whole pairs (pair % 8 == block % 8): a pair's cell table and points then stay
+  // in ONE 4 MiB L2 instead of being fetched into all eight.  (Speed only; any map is correct.)
+  int pair, chunk;
+  {
+    const int b = blockIdx.x;
+    if (npairs >= 8) {
+      const int xcd = b & 7, slot = b >> 3;
+      pair = (slot / chunks_per_pair) * 8 + xcd;
+      chunk = slot % chunks_per_pair;
+    } else {
+      pair = b / chunks_per_pair;
+      chunk = b % chunks_per_pair;
+    }
+  }
+  if (pair >= npairs) return;
+  const PairDev& P = pairs[pair];
+  if (MODE == 0 && !P.active) return;
+  const SlotDev& St = slots[P.slot_t];
+  const int lane = lane_id(), w = wave_id();
+  if (chunk * kBlock + w * kWave >= St.n) return;             // (wave-uniform)
+  const SlotDev& Ss = slots[P.slot_s];
+  const GridParams g = Ss.g;
+  const uint32_t* __restrict__ cs = cell_start + Ss.cell_off;
+  const float4* __restrict__ spts = sorted + Ss.off;
+  const int i = chunk * kBlock + threadIdx.x;
+  const bool valid = i < St.n;
+  WaveTile& W = tiles[w];
+
+  F3 q = {0.f, 0.f, 0.f};
+  float d = g.h;
+  if (valid) {
+    const float4 p0 = sorted[St.off + i];
+    if (MODE == 0) {
+      const F3 p = xf_pcl(P.guess, p0.x, p0.y, p0.z);
+      q = xf_eigen(P.T, p.x, p.y, p.z);
+    } else {
+      q = xf_pcl(P.final_T, p0.x, p0.y, p0.z);
+    }
+    const float prev = corr_d2[P.corr_off + i];
+    const float hint = (prev >= 0.f && prev < 1.0e30f) ? fminf(sqrtf(prev) * 1.25f + 0.05f * g.h, g.h) : g.h;
+    d = fminf(fmaxf(hint, 0.25f * g.h), max_d);
+  }
+  NNResult best;
+  best.idx = -1; best.d2 = 3.0e38f; best.pos = -1;
+  bool done = !valid;
+
+  for (int attempt = 0; attempt < kTileAttempts; ++attempt) {
+    if (__ballot(!done) == 0ull) break;                       // (wave-uniform)
+    // ---- 1. union of the active lanes' boxes, in cells
+    int x0 = 0, x1 = -1, y0 = 0, y1 = -1, z0 = 0, z1 = -1;
+    if (!done) {
+      const float m = d * 1.0001f + 2.0e-3f * g.h;
+      x0 = imax(grid_coord(g, 0, q.x - m), 0); x1 = imin(grid_coord(g, 0, q.x + m), g.dim[0] - 1);
+      y0 = imax(grid_coord(g, 1, q.y - m), 0); y1 = imin(grid_coord(g, 1, q.y + m), g.dim[1] - 1);
+      z0 = imax(grid_coord(g, 2, q.z - m), 0); z1 = imin(grid_coord(g, 2, q.z + m), g.dim[2] - 1);
+    }
+    const bool box = !done && x0 <= x1 && y0 <= y1 && z0 <= z1;
+    const int big = 0x3FFFFFFF;
+    const int bx0 = wave_min_i(box ? x0 : big), bx1 = wave_max_i(box ? x1 : -big);
+    const int by0 = wave_min_i(box ? y0 : big), by1 = wave_max_i(box ? y1 : -big);
+    const int bz0 = wave_min_i(box ? z0 : big), bz1 = wave_max_i(box ? z1 : -big);
+    const bool nonempty = bx0 <= bx1 && by0 <= by1 && bz0 <= bz1;
+    const long long nry_l = (long long)by1 - by0 + 1, nrz_l = (long long)bz1 - bz0 + 1, ncx_l = (long long)bx1 - bx0 + 2;
+    bool fits = nonempty && nry_l * nrz_l <= kTileMaxRows && nry_l * nrz_l * ncx_l <= kTileTabCap;
+    if (nonempty && !fits) break;                             // union too large for the slice: global fallback
+    if (fits) {
+      const int nry = (int)nry_l, nrows = (int)(nry_l * nrz_l), ncx1 = (int)ncx_l;
+      // ---- 2a. per-row extents and their prefix sum (one row per lane)
+      int cnt = 0, s_r = 0, rowbase = 0;
+      if (lane < nrows) {
+        rowbase = g.dim[0] * ((by0 + lane % nry) + g.dim[1] * (bz0 + lane / nry)) + bx0;
+        s_r = (int)cs[rowbase];
+        cnt = (int)cs[rowbase + ncx1 - 1] - s_r;
+      }
+      int incl = cnt;
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const int t = __shfl_up(incl, o, kWave);
+        if (lane >= o) incl += t;
+      }
+      const int total = __shfl(incl, kWave - 1, kWave);
+      if (total > kTilePtsCap) break;                         // too many candidate points: global fallback
+      if (lane < nrows) { W.row_off[lane] = incl - cnt; W.row_gs[lane] = s_r - (incl - cnt); W.row_base[lane] = rowbase; }
+      if (lane == 0) W.row_off[nrows] = total;
+      wave_lds_sync();
+      // ---- 2b. coalesced staging, four independent loads in flight per lane and step
+      {
+        const int ntab = nrows * ncx1;
+        for (int f = lane; f < ntab; f += 4 * kWave) {
+          int v[4], gsr[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int fu = f + u * kWave < ntab ? f + u * kWave : f;
+            const int r = fu / ncx1, c = fu - r * ncx1;
+            v[u] = (int)cs[W.row_base[r] + c];
+            gsr[u] = W.row_gs[r];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (f + u * kWave < ntab) W.tab[f + u * kWave] = (uint32_t)(v[u] - gsr[u]);
+        }
+        for (int j = lane; j < total; j += 2 * kWave) {
+          const int j2 = j + kWave < total ? j + kWave : j;
+          int lo1 = 0, lo2 = 0;                               // row of j: largest r with row_off[r] <= j
+#pragma unroll
+          for (int step = 32; step > 0; step >>= 1) {
+            if (lo1 + step < nrows && W.row_off[lo1 + step] <= j) lo1 += step;
+            if (lo2 + step < nrows && W.row_off[lo2 + step] <= j2) lo2 += step;
+          }
+          const float4 pa = spts[j + W.row_gs[lo1]], pb = spts[j2 + W.row_gs[lo2]];
+          W.pts[j] = pa;
+          if (j2 != j) W.pts[j2] = pb;
+        }
+      }
+      wave_lds_sync();
+      // ---- 3. every active lane scans its own box out of LDS
+      if (box) {
+        for (int cz = z0; cz <= z1; ++cz)
+          for (int cy = y0; cy <= y1; ++cy) {
+            const int r = (cz - bz0) * nry + (cy - by0);
+            const int gs = W.row_gs[r];
+            const uint32_t a = W.tab[r * ncx1 + (x0 - bx0)], b = W.tab[r * ncx1 + (x1 + 1 - bx0)];
+            for (uint32_t k = a; k < b; ++k) nn1_consider(best, W.pts[k], (uint32_t)((int)k + gs), q.x, q.y, q.z);
+          }
+      }
+      wave_lds_sync();                                        // the slice is re-staged by the next attempt
+    }
+    // ---- per-lane verdict (same rule as grid_nn1_box)
+    if (!done) {
+      if ((best.idx >= 0 && best.d2 <= d * d) || d >= max_d) done = true;
+      else d = best.idx >= 0 ? fminf(sqrtf(best.d2) * 1.0001f + 1.0e-6f, max_d) : fminf(2.0f * d, max_d);
+    }
+  }
+  if (valid) {
+    if (!done) {
+      const NNResult r = grid_nn1_box(g, cs, spts, q.x, q.y, q.z, max_d, d);
+      if (r.idx >= 0 && lex_less(r.d2, r.idx, best.d2, best.idx < 0 ? 2147483647 : best.idx)) best = r;
+    }
+    corr_idx[P.corr_off + i] = best.pos;
+    corr_d2[P.corr_off + i] = best.d2;
+  }
+}
+
+// API export (s3d_nn_search / s3d_knn_normals): back from cell-sorted order to the caller's point order
+__global__ void __launch_bounds__(kBlock) k_export_corr(const PairDev* __restrict__ pairs, const SlotDev* __restrict__ slots,
+                                                         const float4* __restrict__ sorted, const int* __restrict__ corr_idx,
+                                                         const float* __restrict__ corr_d2, int* __restrict__ out_idx,
+                                                         float* __restrict__ out_d2) {
+  const PairDev& P = pairs[blockIdx.y];
+  const SlotDev& St = slots[P.slot_t];
+  const SlotDev& Ss = slots[P.slot_s];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= St.n) return;
+  const int orig = __float_as_int(sorted[St.off + i].w);
+  const int pos = corr_idx[P.corr_off + i];
+  out_idx[P.corr_off + orig] = pos >= 0 ? __float_as_int(sorted[Ss.off + pos].w) : -1;
+  out_d2[P.corr_off + orig] = corr_d2[P.corr_off + i];
+}
+__global__ void __launch_bounds__(kBlock) k_export_normals(const SlotDev* __restrict__ slots, const float4* __restrict__ sorted,
+                                                            const double4* __restrict__ normals, float4* __restrict__ out) {
+  const SlotDev& s = slots[blockIdx.y];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= s.n) return;
+  const double4 n = normals[s.off + i];
+  out[s.off + __float_as_int(sorted[s.off + i].w)] = make_float4((float)n.x, (float)n.y, (float)n.z, 0.f);
 }
 
 // ------------------------------------------------------------------ K6: per-correspondence terms + reduction
@@ -517,7 +776,7 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
   }
 }
 
-__device__ __forceinline__ void unit3(const float4 nf, double n[3]) {
+__device__ __forceinline__ void unit3(const double4 nf, double n[3]) {
   const double x = nf.x, y = nf.y, z = nf.z;
   const double l = sqrt(x * x + y * y + z * z);
   if (l > 0) { n[0] = x / l; n[1] = y / l; n[2] = z / l; }
@@ -527,8 +786,8 @@ __device__ __forceinline__ void unit3(const float4 nf, double n[3]) {
 // GICP: Mahalanobis matrix + 73-term quadratic form (s3d_core.h "GICP quadratic form")
 __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairDev* __restrict__ pairs,
                                                                       const SlotDev* __restrict__ slots,
-                                                                      const float4* __restrict__ filt,
-                                                                      const float4* __restrict__ normals,
+                                                                      const float4* __restrict__ sorted,
+                                                                      const double4* __restrict__ normals,
                                                                       const int* __restrict__ corr_idx,
                                                                       const float* __restrict__ corr_d2,
                                                                       double* __restrict__ partials, RunParams rp) {
@@ -536,8 +795,12 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
   if (!P.active) return;
   const SlotDev& St = slots[P.slot_t];
   const SlotDev& Ss = slots[P.slot_s];
-  double R[9], S[6];
+  double R[9], S[6], Th0[12];
   gicp_rotation(P.T, P.guess, R, S);
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) Th0[c * 4 + a] = (double)S3D_M(P.T, c, a);
   double acc[GQ_NACC];
 #pragma unroll
   for (int c = 0; c < GQ_NACC; ++c) acc[c] = 0.0;
@@ -546,9 +809,9 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
     const int j = corr_idx[P.corr_off + i];
     const float d2 = corr_d2[P.corr_off + i];
     if (j < 0 || !((double)d2 < rp.dist_threshold)) continue;
-    const float4 p0 = filt[St.off + i];
+    const float4 p0 = sorted[St.off + i];
     const F3 pf = xf_pcl(P.guess, p0.x, p0.y, p0.z);
-    const float4 qf = filt[Ss.off + j];
+    const float4 qf = sorted[Ss.off + j];
     double n1[3], n2[3], n1r[3], Mm[6];
     unit3(normals[St.off + i], n1);
     unit3(normals[Ss.off + j], n2);
@@ -557,7 +820,7 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
     gicp_mahalanobis(S, n1r, n2, rp.gicp_epsilon, Mm);
     const double pd[3] = {pf.x, pf.y, pf.z};
     const double qd[3] = {qf.x, qf.y, qf.z};
-    gq_accumulate(acc, pd, qd, Mm);
+    gq_accumulate(acc, pd, qd, Mm, Th0);
   }
   block_reduce_store<GQ_NACC>(acc, partials + ((size_t)blockIdx.y * kAccumBlocks + blockIdx.x) * GQ_NACC);
 }
@@ -565,8 +828,8 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
 // point-to-plane: J^T J (21) + J^T r (6) + r^2 + count
 __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const PairDev* __restrict__ pairs,
                                                                          const SlotDev* __restrict__ slots,
-                                                                         const float4* __restrict__ filt,
-                                                                         const float4* __restrict__ normals,
+                                                                         const float4* __restrict__ sorted,
+                                                                         const double4* __restrict__ normals,
                                                                          const int* __restrict__ corr_idx,
                                                                          const float* __restrict__ corr_d2,
                                                                          double* __restrict__ partials, RunParams rp) {
@@ -582,11 +845,11 @@ __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const Pa
     const int j = corr_idx[P.corr_off + i];
     const float d2 = corr_d2[P.corr_off + i];
     if (j < 0 || !((double)d2 < rp.dist_threshold)) continue;
-    const float4 p0 = filt[St.off + i];
+    const float4 p0 = sorted[St.off + i];
     const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
     const F3 pq = xf_eigen(P.T, pg.x, pg.y, pg.z);
-    const float4 qf = filt[Ss.off + j];
-    const float4 nf = normals[Ss.off + j];
+    const float4 qf = sorted[Ss.off + j];
+    const double4 nf = normals[Ss.off + j];
     const double pd[3] = {pq.x, pq.y, pq.z};
     const double qd[3] = {qf.x, qf.y, qf.z};
     const double nd[3] = {nf.x, nf.y, nf.z};

@@ -97,24 +97,27 @@ Grid build_grid(const Cloud& c, float h0, int cells_per_point) {
   return G;
 }
 
-std::vector<F4> normals(const Cloud& c, const Grid& G, int k) {
-  std::vector<F4> out(c.pts.size());
+struct D3 { double x, y, z; };
+std::vector<D3> normals(const Cloud& c, const Grid& G, int k) {
+  std::vector<D3> out(c.pts.size());
   std::vector<float> d2(k);
   std::vector<int> idx(k);
   for (size_t i = 0; i < c.pts.size(); ++i) {
     const F4& q = c.pts[i];
-    int cnt = grid_knn(G.g, G.cell_start.data(), G.sorted.data(), q.x, q.y, q.z, k, d2.data(), idx.data(), 1);
+    unsigned long long keys[32];
+    int cnt = grid_knn_sorted<32>(G.g, G.cell_start.data(), G.sorted.data(), q.x, q.y, q.z, k, keys);
+    for (int j = 0; j < cnt; ++j) idx[j] = (int)(uint32_t)(keys[j] & 0xFFFFFFFFull);
     Moments m;
     moments_init(m);
     for (int j = 0; j < cnt; ++j) { const F4& p = c.pts[idx[j]]; moments_add(m, p.x, p.y, p.z); }
     double n[3];
     moments_normal(m, k, n);
-    out[i] = {(float)n[0], (float)n[1], (float)n[2], 0.f};
+    out[i] = {n[0], n[1], n[2]};
   }
   return out;
 }
 
-inline void unit3(const F4& nf, double n[3]) {
+inline void unit3(const D3& nf, double n[3]) {
   double x = nf.x, y = nf.y, z = nf.z, l = std::sqrt(x * x + y * y + z * z);
   if (l > 0) { n[0] = x / l; n[1] = y / l; n[2] = z / l; } else { n[0] = n[1] = 0; n[2] = 1; }
 }
@@ -145,11 +148,21 @@ void emu_nn(const float* tgt, int n, const float* qry, int m, float h0, int cpp,
     idx[i] = r.idx; d2[i] = r.d2;
   }
 }
+void emu_nn_box(const float* tgt, int n, const float* qry, int m, float h0, int cpp, float max_d, const float* hint,
+                int* idx, float* d2) {
+  Cloud c = voxel(tgt, n, 3, 0.0);
+  Grid G = build_grid(c, h0, cpp);
+  for (int i = 0; i < m; ++i) {
+    NNResult r = grid_nn1_box(G.g, G.cell_start.data(), G.sorted.data(), qry[i * 3], qry[i * 3 + 1], qry[i * 3 + 2],
+                              max_d, hint[i]);
+    idx[i] = r.idx; d2[i] = r.d2;
+  }
+}
 void emu_normals(const float* xyz, int n, int k, float h0, int cpp, float* out) {
   Cloud c = voxel(xyz, n, 3, 0.0);
   Grid G = build_grid(c, h0, cpp);
-  std::vector<F4> nr = normals(c, G, k);
-  for (int i = 0; i < n; ++i) { out[i * 3] = nr[i].x; out[i * 3 + 1] = nr[i].y; out[i * 3 + 2] = nr[i].z; }
+  std::vector<D3> nr = normals(c, G, k);
+  for (int i = 0; i < n; ++i) { out[i * 3] = (float)nr[i].x; out[i * 3 + 1] = (float)nr[i].y; out[i * 3 + 2] = (float)nr[i].z; }
 }
 
 // align() as the device pipeline runs it -------------------------------------------
@@ -171,7 +184,7 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
   if (k > (int)S.pts.size() || k > (int)T.pts.size()) return S3D_STATUS_INVALID_ARGUMENT;
   const float h0 = h0_for(cfg->point_cloud_density);
   Grid GS = build_grid(S, h0, cells_per_point);
-  std::vector<F4> NS = normals(S, GS, k), NT;
+  std::vector<D3> NS = normals(S, GS, k), NT;
   const bool gicp = (alg == S3D_ALG_GICP || alg == S3D_ALG_GICP_OMP);
   if (gicp) { Grid GT = build_grid(T, h0, cells_per_point); NT = normals(T, GT, k); }
 
@@ -181,15 +194,20 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
   const double thr = cfg->max_correspondence_distance * cfg->max_correspondence_distance;
   const float max_d = (float)cfg->max_correspondence_distance;
   int nr = 0, converged = 0, cnt = 0;
+  std::vector<float> hints(T.pts.size(), -1.f);
   while (!converged) {
-    double R[9], SS[6];
+    double R[9], SS[6], Th0[12];
     gicp_rotation(Tr, guess, R, SS);
+    for (int c = 0; c < 3; ++c)
+      for (int a = 0; a < 4; ++a) Th0[c * 4 + a] = (double)S3D_M(Tr, c, a);
     double acc[GQ_NACC] = {0};
     for (size_t i = 0; i < T.pts.size(); ++i) {
       const F4& p0 = T.pts[i];
       const F3 p = xf_pcl(guess, p0.x, p0.y, p0.z);
       const F3 q = xf_eigen(Tr, p.x, p.y, p.z);
-      NNResult r = grid_nn1(GS.g, GS.cell_start.data(), GS.sorted.data(), q.x, q.y, q.z, max_d);
+      const float hint = hints[i] >= 0.f ? std::sqrt(hints[i]) * 1.25f + 0.05f * GS.g.h : GS.g.h;
+      NNResult r = grid_nn1_box(GS.g, GS.cell_start.data(), GS.sorted.data(), q.x, q.y, q.z, max_d, hint);
+      hints[i] = r.idx >= 0 ? r.d2 : -1.f;
       if (r.idx < 0 || !((double)r.d2 < thr)) continue;
       const F4& t = S.pts[r.idx];
       const double td[3] = {t.x, t.y, t.z};
@@ -202,10 +220,9 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
         gicp_mahalanobis(SS, n1r, n2, 0.001, M);
         if (g_emu_perturb != 0.0) for (int a = 0; a < 6; ++a) M[a] *= 1.0 + g_emu_perturb * ((double)rand() / RAND_MAX - 0.5);
         const double pd[3] = {p.x, p.y, p.z};
-        gq_accumulate(acc, pd, td, M);
+        gq_accumulate(acc, pd, td, M, Th0);
       } else {
         const double qd[3] = {q.x, q.y, q.z};
-        // device stores float normals; use them as stored (no renormalisation) like the oracle
         const double nf[3] = {NS[r.idx].x, NS[r.idx].y, NS[r.idx].z};
         pp_accumulate(acc, qd, td, nf);
       }
@@ -250,11 +267,11 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
 
 // ---- unit hooks for the quadratic-form algebra (tests/test_core_math.py)
 extern "C" {
-void emu_gq_build(const double* p, const double* q, const double* M6, int m, double* acc /*GQ_NACC*/) {
+void emu_gq_build(const double* p, const double* q, const double* M6, int m, const double* th0, double* acc /*GQ_NACC*/) {
   for (int i = 0; i < GQ_NACC; ++i) acc[i] = 0;
-  for (int i = 0; i < m; ++i) gq_accumulate(acc, p + 3 * i, q + 3 * i, M6 + 6 * i);
+  for (int i = 0; i < m; ++i) gq_accumulate(acc, p + 3 * i, q + 3 * i, M6 + 6 * i, th0);
 }
-void emu_gq_eval(const double* acc, const double* x, double* f, double* g) { gq_eval(acc, x, f, g); }
+void emu_gq_eval(const double* acc, const double* th0, const double* x, double* f, double* g) { gq_eval(acc, th0, x, f, g); }
 void emu_apply_state(const double* x, float* T16) { Mat4f T; gicp_apply_state(x, T); for (int i = 0; i < 16; ++i) T16[i] = T.m[i]; }
 int emu_bfgs(const double* acc, int max_inner, float* T16, int* inner, int* evals) {
   Mat4f T; for (int i = 0; i < 16; ++i) T.m[i] = T16[i];

@@ -75,6 +75,25 @@ def test_device_grid_nn_is_exact(emu, oracle_mod, fixture_clouds, h0, cpp):
     assert np.all((idx[~m] == -1) | (d2[~m] >= 2.5 ** 2))
 
 
+@pytest.mark.parametrize("hint_kind", ["tiny", "exact", "huge", "random"])
+def test_device_box_nn_is_exact_for_any_hint(emu, oracle_mod, fixture_clouds, hint_kind):
+    """grid_nn1_box (the kernel's hot variant) must return the exact NN whatever the radius hint."""
+    v1, _ = oracle_mod.voxel_downsample(fixture_clouds[0], 0.2)
+    v2, _ = oracle_mod.voxel_downsample(fixture_clouds[1], 0.2)
+    rng = np.random.default_rng(2)
+    q = np.ascontiguousarray(np.concatenate([v2[::4], rng.uniform(-150, 150, (300, 3)).astype(np.float32)]))
+    oi, od = oracle_mod.nn_search(v1, q)
+    hint = {"tiny": np.full(len(q), 1e-4), "exact": np.sqrt(od), "huge": np.full(len(q), 50.0),
+            "random": rng.uniform(0.0, 3.0, len(q))}[hint_kind].astype(np.float32)
+    idx = np.empty(len(q), np.int32)
+    d2 = np.empty(len(q), np.float32)
+    emu.emu_nn_box(v1.ctypes.data_as(fp), len(v1), q.ctypes.data_as(fp), len(q), C.c_float(0.4), 16, C.c_float(2.5),
+                   hint.ctypes.data_as(fp), idx.ctypes.data_as(ip), d2.ctypes.data_as(fp))
+    m = od < 2.5 ** 2
+    assert np.array_equal(idx[m], oi[m]) and np.array_equal(d2[m], od[m])
+    assert np.all((idx[~m] == -1) | (d2[~m] >= 2.5 ** 2))
+
+
 def test_device_knn_normals_match_oracle(emu, oracle_mod, fixture_clouds):
     v1, _ = oracle_mod.voxel_downsample(fixture_clouds[0], 0.3)
     nr = np.empty((len(v1), 3), np.float32)
@@ -93,7 +112,8 @@ def test_quadratic_form_equals_direct_sum(emu):
     M = A @ A.transpose(0, 2, 1) + 0.1 * np.eye(3)
     M6 = np.ascontiguousarray(np.stack([M[:, 0, 0], M[:, 0, 1], M[:, 0, 2], M[:, 1, 1], M[:, 1, 2], M[:, 2, 2]], 1))
     acc = np.zeros(76)
-    emu.emu_gq_build(p.ctypes.data_as(dp), q.ctypes.data_as(dp), M6.ctypes.data_as(dp), m, acc.ctypes.data_as(dp))
+    # expansion point of the form: a transform near the solution (row-major 3x4)
+    x0 = np.array([0.28, -0.18, 0.04, 0.004, -0.012, 0.018])
 
     def rot(x):
         cph, sph, cth, sth, cps, sps = np.cos(x[3]), np.sin(x[3]), np.cos(x[4]), np.sin(x[4]), np.cos(x[5]), np.sin(x[5])
@@ -105,11 +125,15 @@ def test_quadratic_form_equals_direct_sum(emu):
         res = p @ rot(x).T + x[:3] - q
         return (res * np.einsum("nij,nj->ni", M, res)).sum() / m
 
+    th0 = np.ascontiguousarray(np.hstack([rot(x0), x0[:3, None]]))
+    emu.emu_gq_build(p.ctypes.data_as(dp), q.ctypes.data_as(dp), M6.ctypes.data_as(dp), m, th0.ctypes.data_as(dp),
+                     acc.ctypes.data_as(dp))
     x = np.array([0.25, -0.15, 0.01, 0.005, -0.01, 0.02])
     f = C.c_double()
     g = np.zeros(6)
-    emu.emu_gq_eval(acc.ctypes.data_as(dp), x.ctypes.data_as(dp), C.byref(f), g.ctypes.data_as(dp))
-    assert abs(f.value - direct(x)) < 1e-9 * abs(f.value)
+    emu.emu_gq_eval(acc.ctypes.data_as(dp), th0.ctypes.data_as(dp), x.ctypes.data_as(dp), C.byref(f),
+                    g.ctypes.data_as(dp))
+    assert abs(f.value - direct(x)) < 1e-12 * abs(f.value)      # expansion about the current transform: no cancellation
     gn = np.zeros(6)
     for i in range(6):
         h = 1e-6
