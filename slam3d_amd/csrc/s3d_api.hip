@@ -108,8 +108,8 @@ struct s3d_context {
   std::mutex mtx;
   s3d_profile prof{};
   // workspace (grown on demand, reused across calls)
-  DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, normals, cell_start, counts, blockcnt, corr_idx,
-      corr_d2, partials, n_active;
+  DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, normals, moments, cell_start, counts, blockcnt,
+      corr_idx, corr_d2, partials, n_active;
   int* h_active = nullptr;  // pinned
   hipEvent_t ev[8] = {};
   std::vector<hipEvent_t> nn_ev;
@@ -123,7 +123,7 @@ struct s3d_context {
     b.cap = want;
   }
   void release_all() {
-    DevBuf* all[] = {&slots, &pairs, &keysA, &keysB, &valsA, &valsB, &filt, &sorted, &normals, &cell_start,
+    DevBuf* all[] = {&slots, &pairs, &keysA, &keysB, &valsA, &valsB, &filt, &sorted, &normals, &moments, &cell_start,
                      &counts, &blockcnt, &corr_idx, &corr_d2, &partials, &n_active};
     for (DevBuf* b : all)
       if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
@@ -226,13 +226,17 @@ struct Batch {
       throw HipError{hipErrorInvalidValue, "batch too large for 32-bit offsets", __LINE__};
     nb_sort = std::max(1, cdiv(max_n, kSortTile));
     nb_head = std::max(1, cdiv(max_n, kBlock));
+    // blocks per pair in the accumulate kernels: enough blocks to fill the chip for small batches, few
+    // (long per-thread loops, one 76-value tree reduction per block) for large ones
     accum_blocks = std::min(kAccumBlocks, std::max(1, cdiv(max_n_t, kBlock * 8)));
+    accum_blocks = std::min(accum_blocks, std::max(4, cdiv(1024, std::max(1, P()))));
     const size_t np = std::max<size_t>(total_pts, 4);
     ctx->ensure(ctx->slots, sizeof(SlotDev) * std::max(1, C()));
     ctx->ensure(ctx->pairs, sizeof(PairDev) * std::max(1, P()));
     ctx->ensure(ctx->keysA, 4 * np); ctx->ensure(ctx->keysB, 4 * np);
     ctx->ensure(ctx->valsA, 4 * np); ctx->ensure(ctx->valsB, 4 * np);
     ctx->ensure(ctx->filt, 16 * np); ctx->ensure(ctx->sorted, 16 * np); ctx->ensure(ctx->normals, 32 * np);
+    ctx->ensure(ctx->moments, 80 * np);
     ctx->ensure(ctx->cell_start, 4 * std::max<size_t>(total_cells, 4));
     ctx->ensure(ctx->counts, 4 * (size_t)std::max(1, C()) * 256 * nb_sort);
     ctx->ensure(ctx->blockcnt, 4 * (size_t)std::max(1, C()) * nb_head);
@@ -299,43 +303,44 @@ struct Batch {
     hipStream_t st = ctx->stream;
     if (C() == 0) return;
     const int k = std::max(1, std::min(rp.k, 64));
-    dim3 grid(nb_head, C());
+    if (k > 32) {
+      k_normals<<<dim3(nb_head, C()), kBlock, (size_t)k * kBlock * 8, st>>>(d_slots(), filt(), sorted(), cells(), normals(), k);
+      return;
+    }
+    // the 9 moments of every point live in keysA..valsB?  no: they need 80 B/point -> own buffer
+    double* mom = (double*)ctx->moments.p;
+    const int slots8 = C() >= 8 ? cdiv(C(), 8) * 8 : C();
+    dim3 grid((unsigned)(slots8 * nb_head));
     if (k <= 8)
-      s3d_knn_normals_kernel<8><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), normals(), k);
+      s3d_knn_moments_kernel<8><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, k, nb_head, C());
     else if (k <= 16)
-      s3d_knn_normals_kernel<16><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), normals(), k);
+      s3d_knn_moments_kernel<16><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, k, nb_head, C());
     else if (k <= 20)
-      s3d_knn_normals_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), normals(), k);
-    else if (k <= 32)
-      s3d_knn_normals_kernel<32><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), normals(), k);
+      s3d_knn_moments_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, k, nb_head, C());
     else
-      k_normals<<<grid, kBlock, (size_t)k * kBlock * 8, st>>>(d_slots(), filt(), sorted(), cells(), normals(), k);
+      s3d_knn_moments_kernel<32><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, k, nb_head, C());
+    s3d_normals_from_moments_kernel<<<dim3(nb_head, C()), kBlock, 0, st>>>(d_slots(), mom, normals(), k);
   }
 
   int dbg_nn = getenv("S3D_DBG_NN") ? atoi(getenv("S3D_DBG_NN")) : 0;
   void launch_nn(int mode, float max_d) {
     hipStream_t st = ctx->stream;
+    const int chunks = cdiv(std::max(max_n_t, 1), kBlock);
+    const int pairs8 = P() >= 8 ? cdiv(P(), 8) * 8 : P();
+    dim3 grid((unsigned)(pairs8 * chunks));
+    int* ci = (int*)ctx->corr_idx.p;
+    float* cd = (float*)ctx->corr_d2.p;
     if (dbg_nn & 8) {      // opt-in (S3D_DBG_NN=8): LDS-tiled kernel; measured slower than the default, see DESIGN.md
-      const int chunks = cdiv(std::max(max_n_t, 1), kBlock);
-      const int pairs8 = P() >= 8 ? cdiv(P(), 8) * 8 : P();
-      dim3 grid((unsigned)(pairs8 * chunks));
       if (mode == 0)
-        s3d_nn_search_tiled_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(),
-                                                               (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, max_d,
-                                                               chunks, P());
+        s3d_nn_search_tiled_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), ci, cd, max_d, chunks, P());
       else
-        s3d_nn_search_tiled_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(),
-                                                               (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, max_d,
-                                                               chunks, P());
+        s3d_nn_search_tiled_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), ci, cd, max_d, chunks, P());
       return;
     }
-    dim3 grid(cdiv(std::max(max_n_t, 1), kBlock), P());
     if (mode == 0)
-      s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), filt(), sorted(), cells(),
-                                                        (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, max_d, dbg_nn);
+      s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), ci, cd, max_d, chunks, P(), dbg_nn);
     else
-      s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), filt(), sorted(), cells(),
-                                                        (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, max_d, dbg_nn);
+      s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), ci, cd, max_d, chunks, P(), dbg_nn);
   }
 
   // K5-K7 loop.  The host only polls the active-pair counter every check_interval iterations.

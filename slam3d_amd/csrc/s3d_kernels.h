@@ -103,6 +103,22 @@ __device__ __forceinline__ int block_excl_flag(bool flag, int* total, int* lds4 
   return before + inwave;
 }
 
+// XCD-aware block -> (pair, chunk) map shared by the NN kernels: consecutive block ids are dealt
+// round-robin to the 8 XCDs, so every XCD gets whole pairs (pair % 8 == block % 8) and a pair's cell
+// table and points stay in ONE 4 MiB L2 instead of being pulled into all eight.  Speed only: any
+// bijective map is correct, and nothing depends on the placement actually happening.
+__device__ __forceinline__ void nn_block_map(int chunks_per_pair, int npairs, int* pair, int* chunk) {
+  const int b = blockIdx.x;
+  if (npairs >= 8) {
+    const int xcd = b & 7, slot = b >> 3;
+    *pair = (slot / chunks_per_pair) * 8 + xcd;
+    *chunk = slot % chunks_per_pair;
+  } else {
+    *pair = b / chunks_per_pair;
+    *chunk = b % chunks_per_pair;
+  }
+}
+
 // ------------------------------------------------------------------ K1: bbox + voxel keys
 
 __global__ void __launch_bounds__(kBlock) k_slot_reset_bbox(SlotDev* slots) {
@@ -451,15 +467,22 @@ __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ 
 
 // k <= KMAX: the k best live in registers as sorted packed keys (s3d_core.h grid_knn_sorted).
 // Threads walk the cloud in CELL-SORTED order: the 64 lanes of a wave sit in adjacent grid cells,
-// so their cell_start / candidate loads fall into a handful of cache lines.
+// so their cell_start / candidate loads fall into a handful of cache lines.  The search kernel only
+// emits the neighbours' moments (9 doubles); the eigen-solve runs in its own kernel: keeping the
+// Jacobi iteration's registers out of the latency-bound search doubles its occupancy.
+// Slot -> XCD affinity as in nn_block_map: blocks of one cloud share one L2.
 template <int KMAX>
-__global__ void __launch_bounds__(kBlock) s3d_knn_normals_kernel(const SlotDev* __restrict__ slots,
+__global__ void __launch_bounds__(kBlock) s3d_knn_moments_kernel(const SlotDev* __restrict__ slots,
                                                                   const float4* __restrict__ filt,
                                                                   const float4* __restrict__ sorted,
                                                                   const uint32_t* __restrict__ cell_start,
-                                                                  double4* __restrict__ normals, int k) {
-  const SlotDev& s = slots[blockIdx.y];
-  const int i = blockIdx.x * kBlock + threadIdx.x;
+                                                                  double* __restrict__ moments, int k,
+                                                                  int chunks_per_slot, int nslots) {
+  int si, chunk;
+  nn_block_map(chunks_per_slot, nslots, &si, &chunk);
+  if (si >= nslots) return;
+  const SlotDev& s = slots[si];
+  const int i = chunk * kBlock + threadIdx.x;
   if (i >= s.n) return;
   const float4* __restrict__ P = filt + s.off;
   const float4 q = sorted[s.off + i];
@@ -474,6 +497,22 @@ __global__ void __launch_bounds__(kBlock) s3d_knn_normals_kernel(const SlotDev* 
       moments_add(m, p.x, p.y, p.z);
     }
   }
+  // SoA, 9 planes of total_pts doubles would need the batch size; keep AoS rows of 9 (+pad to 10 = 80 B)
+  double* o = moments + (size_t)(s.off + i) * 10;
+  o[0] = m.mean[0]; o[1] = m.mean[1]; o[2] = m.mean[2];
+  o[3] = m.c00; o[4] = m.c10; o[5] = m.c11; o[6] = m.c20; o[7] = m.c21; o[8] = m.c22;
+}
+
+__global__ void __launch_bounds__(kBlock) s3d_normals_from_moments_kernel(const SlotDev* __restrict__ slots,
+                                                                           const double* __restrict__ moments,
+                                                                           double4* __restrict__ normals, int k) {
+  const SlotDev& s = slots[blockIdx.y];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= s.n) return;
+  const double* o = moments + (size_t)(s.off + i) * 10;
+  Moments m;
+  m.mean[0] = o[0]; m.mean[1] = o[1]; m.mean[2] = o[2];
+  m.c00 = o[3]; m.c10 = o[4]; m.c11 = o[5]; m.c20 = o[6]; m.c21 = o[7]; m.c22 = o[8];
   double n[3];
   moments_normal(m, k, n);
   normals[s.off + i] = make_double4(n[0], n[1], n[2], 0.0);  // CELL-SORTED order, double: see DESIGN.md "parity"
@@ -498,19 +537,21 @@ __global__ void k_pair_init(PairDev* pairs, int npairs, int* n_active) {
 template <int MODE>
 __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __restrict__ pairs,
                                                                 const SlotDev* __restrict__ slots,
-                                                                const float4* __restrict__ filt,
                                                                 const float4* __restrict__ sorted,
                                                                 const uint32_t* __restrict__ cell_start,
                                                                 int* __restrict__ corr_idx, float* __restrict__ corr_d2,
-                                                                float max_d, int dbg) {
-  const PairDev& P = pairs[blockIdx.y];
+                                                                float max_d, int chunks_per_pair, int npairs, int dbg) {
+  int pair, chunk;
+  if (dbg & 16) { pair = blockIdx.x / chunks_per_pair; chunk = blockIdx.x % chunks_per_pair; }  // A/B: plain map
+  else nn_block_map(chunks_per_pair, npairs, &pair, &chunk);
+  if (pair >= npairs) return;
+  const PairDev& P = pairs[pair];
   if (MODE == 0 && !P.active) return;
   const SlotDev& St = slots[P.slot_t];
-  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const int i = chunk * kBlock + threadIdx.x;
   if (i >= St.n) return;
   const SlotDev& Ss = slots[P.slot_s];
-  // queries are taken in the CELL-SORTED order of their own cloud (spatially coherent waves);
-  // the result is stored at the point's index in filtered order
+  // queries are taken in the CELL-SORTED order of their own cloud (spatially coherent waves)
   const float4 p0 = sorted[St.off + i];
   F3 q;
   if (MODE == 0) {
@@ -588,21 +629,8 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_tiled_kernel(const PairD
                                                                       float* __restrict__ corr_d2, float max_d,
                                                                       int chunks_per_pair, int npairs) {
   __shared__ WaveTile tiles[kBlock / kWave];
-  // XCD-aware block -> (pair, chunk) map: consecutive block ids are dealt round-robin to the 8 XCDs,
-  // so give every XCD whole pairs (pair % 8 == block % 8): a pair's cell table and points then stay
-  // in ONE 4 MiB L2 instead of being fetched into all eight.  (Speed only; any map is correct.)
   int pair, chunk;
-  {
-    const int b = blockIdx.x;
-    if (npairs >= 8) {
-      const int xcd = b & 7, slot = b >> 3;
-      pair = (slot / chunks_per_pair) * 8 + xcd;
-      chunk = slot % chunks_per_pair;
-    } else {
-      pair = b / chunks_per_pair;
-      chunk = b % chunks_per_pair;
-    }
-  }
+  nn_block_map(chunks_per_pair, npairs, &pair, &chunk);
   if (pair >= npairs) return;
   const PairDev& P = pairs[pair];
   if (MODE == 0 && !P.active) return;

@@ -15,7 +15,7 @@ res={}
 for rnd in range(3):
     for cpp in cpps:
         for v in variants:
-            os.environ['S3D_DBG_NN']=v
+            os.environ[os.environ.get('VARKEY','S3D_DBG_NN')]=v
             o=s3d.ExecOptions(force_iterations=1, profile=1, grid_cells_per_point=cpp)
             t=time.perf_counter(); rec=ctx.align_batch(a,b,None,p,o); dt=(time.perf_counter()-t)*1e3
             pr=ctx.last_profile()
