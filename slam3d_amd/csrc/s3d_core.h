@@ -233,12 +233,54 @@ S3D_HD void nn1_consider(NNResult& best, const F4T& p, uint32_t k, float qx, flo
   }
 }
 
+// scan the (<= NR x NR) rows of a tight box with the memory accesses issued as three independent
+// BATCHES (all row ranges, then the first point of every row, then the rest) instead of one dependent
+// load per step: the kernel is bound by memory latency x chain length and by the L1 access rate.
+template <int NR, typename F4T>
+S3D_HD void nn1_scan_rows(NNResult& best, const GridParams& g, const uint32_t* __restrict__ cell_start,
+                          const F4T* __restrict__ pts, float qx, float qy, float qz, int x0, int x1, int y0, int ny,
+                          int z0, int nz) {
+  uint32_t rs[NR * NR], re[NR * NR];
+#pragma unroll
+  for (int r = 0; r < NR * NR; ++r) {
+    const int jy = r % NR, jz = r / NR;
+    const bool ok = jy < ny && jz < nz;
+    const int rowbase = g.dim[0] * ((y0 + (ok ? jy : 0)) + g.dim[1] * (z0 + (ok ? jz : 0)));
+    const uint32_t a = cell_start[rowbase + x0], b = cell_start[rowbase + x1 + 1];
+    rs[r] = a; re[r] = ok ? b : a;
+  }
+  F4T first[NR * NR];
+#pragma unroll
+  for (int r = 0; r < NR * NR; ++r) first[r] = pts[rs[r] < re[r] ? rs[r] : 0];
+#pragma unroll
+  for (int r = 0; r < NR * NR; ++r)
+    if (rs[r] < re[r]) nn1_consider(best, first[r], rs[r], qx, qy, qz);
+#pragma unroll
+  for (int r = 0; r < NR * NR; ++r) {
+    for (uint32_t k = rs[r] + 1; k < re[r]; k += 2) {
+      const F4T pa = pts[k];
+      const F4T pb = pts[k + 1 < re[r] ? k + 1 : k];
+      nn1_consider(best, pa, k, qx, qy, qz);
+      if (k + 1 < re[r]) nn1_consider(best, pb, k + 1, qx, qy, qz);
+    }
+  }
+}
+
+// seed_pos >= 0: position (in pts) of a point known to be near the query — the previous ICP
+// iteration's neighbour.  Its distance is then an exact upper bound of the NN distance: the box of
+// that radius is scanned once and the result is proven (the seed itself lies in the box).
 template <typename F4T>
 S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ cell_start,
-                             const F4T* __restrict__ pts, float qx, float qy, float qz, float max_d, float d_hint) {
+                             const F4T* __restrict__ pts, float qx, float qy, float qz, float max_d, float d_hint,
+                             int seed_pos = -1) {
   NNResult best;
   best.idx = -1; best.d2 = 3.0e38f; best.pos = -1;
   float d = fminf(fmaxf(d_hint, 0.25f * g.h), max_d);
+  if (seed_pos >= 0) {
+    nn1_consider(best, pts[seed_pos], (uint32_t)seed_pos, qx, qy, qz);
+    // (a seed that ended up far away — the transform just moved — must not blow the box up)
+    d = fminf(fminf(sqrtf(best.d2) * 1.0001f + 1.0e-6f, g.h), max_d);
+  }
   for (int attempt = 0; attempt < 64; ++attempt) {
     // margin: float rounding of the cell assignment of the points and of the box corners
     const float m = d * 1.0001f + 2.0e-3f * g.h;
@@ -247,34 +289,10 @@ S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ c
     const int z0 = imax(grid_coord(g, 2, qz - m), 0), z1 = imin(grid_coord(g, 2, qz + m), g.dim[2] - 1);
     const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
     if (x0 <= x1 && ny > 0 && nz > 0) {
-      if (ny <= 3 && nz <= 3) {
-        // hot path (tight box): the memory accesses are issued as three independent BATCHES
-        // (all row ranges, then the first point of every row, then the rest) instead of one
-        // dependent load per step: the kernel is bound by DRAM latency x chain length.
-        uint32_t rs[9], re[9];
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-          const int jy = r % 3, jz = r / 3;
-          const bool ok = jy < ny && jz < nz;
-          const int rowbase = g.dim[0] * ((y0 + (ok ? jy : 0)) + g.dim[1] * (z0 + (ok ? jz : 0)));
-          const uint32_t a = cell_start[rowbase + x0], b = cell_start[rowbase + x1 + 1];
-          rs[r] = a; re[r] = ok ? b : a;
-        }
-        F4T first[9];
-#pragma unroll
-        for (int r = 0; r < 9; ++r) first[r] = pts[rs[r] < re[r] ? rs[r] : 0];
-#pragma unroll
-        for (int r = 0; r < 9; ++r)
-          if (rs[r] < re[r]) nn1_consider(best, first[r], rs[r], qx, qy, qz);
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-          for (uint32_t k = rs[r] + 1; k < re[r]; k += 2) {
-            const F4T pa = pts[k];
-            const F4T pb = pts[k + 1 < re[r] ? k + 1 : k];
-            nn1_consider(best, pa, k, qx, qy, qz);
-            if (k + 1 < re[r]) nn1_consider(best, pb, k + 1, qx, qy, qz);
-          }
-        }
+      if (ny <= 2 && nz <= 2) {
+        nn1_scan_rows<2>(best, g, cell_start, pts, qx, qy, qz, x0, x1, y0, ny, z0, nz);
+      } else if (ny <= 3 && nz <= 3) {
+        nn1_scan_rows<3>(best, g, cell_start, pts, qx, qy, qz, x0, x1, y0, ny, z0, nz);
       } else {
         for (int cz = z0; cz <= z1; ++cz)
           for (int cy = y0; cy <= y1; ++cy) {

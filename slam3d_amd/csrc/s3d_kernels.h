@@ -566,9 +566,12 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
   if (dbg & 4) {
     r = grid_nn1(Ss.g, cell_start + Ss.cell_off, sorted + Ss.off, q.x, q.y, q.z, max_d);
   } else {
-    // a large previous distance says little about the next one (the transform just moved): cap at one cell
+    // seed: the neighbour found by the previous pass (its distance under the new transform bounds the
+    // search radius exactly), unless it was far away — then the transform has just moved a lot and a
+    // one-cell box is the better first guess.  dbg & 32: hint-only variant (A/B).
+    const int seed = (prev >= 0.f && prev < Ss.g.h * Ss.g.h && !(dbg & 32)) ? corr_idx[P.corr_off + i] : -1;
     const float hint = (prev >= 0.f && prev < 1.0e30f) ? fminf(sqrtf(prev) * 1.25f + 0.05f * Ss.g.h, Ss.g.h) : Ss.g.h;
-    r = grid_nn1_box(Ss.g, cell_start + Ss.cell_off, sorted + Ss.off, q.x, q.y, q.z, max_d, hint);
+    r = grid_nn1_box(Ss.g, cell_start + Ss.cell_off, sorted + Ss.off, q.x, q.y, q.z, max_d, hint, seed);
   }
   // results are kept in the query cloud's cell-sorted order and name the neighbour by its POSITION in
   // the target's cell-sorted array: every later access (K6, fitness) is then coalesced or a local gather

@@ -195,6 +195,7 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
   const float max_d = (float)cfg->max_correspondence_distance;
   int nr = 0, converged = 0, cnt = 0;
   std::vector<float> hints(T.pts.size(), -1.f);
+  std::vector<int> seeds(T.pts.size(), -1);
   while (!converged) {
     double R[9], SS[6], Th0[12];
     gicp_rotation(Tr, guess, R, SS);
@@ -206,8 +207,10 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
       const F3 p = xf_pcl(guess, p0.x, p0.y, p0.z);
       const F3 q = xf_eigen(Tr, p.x, p.y, p.z);
       const float hint = hints[i] >= 0.f ? std::sqrt(hints[i]) * 1.25f + 0.05f * GS.g.h : GS.g.h;
-      NNResult r = grid_nn1_box(GS.g, GS.cell_start.data(), GS.sorted.data(), q.x, q.y, q.z, max_d, hint);
+      const int seed = (hints[i] >= 0.f && hints[i] < GS.g.h * GS.g.h) ? seeds[i] : -1;
+      NNResult r = grid_nn1_box(GS.g, GS.cell_start.data(), GS.sorted.data(), q.x, q.y, q.z, max_d, hint, seed);
       hints[i] = r.idx >= 0 ? r.d2 : -1.f;
+      seeds[i] = r.pos;
       if (r.idx < 0 || !((double)r.d2 < thr)) continue;
       const F4& t = S.pts[r.idx];
       const double td[3] = {t.x, t.y, t.z};
