@@ -37,8 +37,8 @@ def _gen_pair(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=256, help="scan pairs per GPU and step")
     ap.add_argument("--points", type=int, default=100000)
     ap.add_argument("--iters", type=int, default=20)

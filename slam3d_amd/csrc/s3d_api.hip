@@ -307,7 +307,6 @@ struct Batch {
       k_normals<<<dim3(nb_head, C()), kBlock, (size_t)k * kBlock * 8, st>>>(d_slots(), filt(), sorted(), cells(), normals(), k);
       return;
     }
-    // the 9 moments of every point live in keysA..valsB?  no: they need 80 B/point -> own buffer
     double* mom = (double*)ctx->moments.p;
     const int slots8 = C() >= 8 ? cdiv(C(), 8) * 8 : C();
     dim3 grid((unsigned)(slots8 * nb_head));
