@@ -109,7 +109,7 @@ struct s3d_context {
   s3d_profile prof{};
   // workspace (grown on demand, reused across calls)
   DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, normals, moments, cell_start, counts, blockcnt,
-      corr_idx, corr_d2, partials, n_active;
+      corr_idx, corr_d2, corr_lb, partials, n_active;
   int* h_active = nullptr;  // pinned
   hipEvent_t ev[8] = {};
   std::vector<hipEvent_t> nn_ev;
@@ -124,7 +124,7 @@ struct s3d_context {
   }
   void release_all() {
     DevBuf* all[] = {&slots, &pairs, &keysA, &keysB, &valsA, &valsB, &filt, &sorted, &normals, &moments, &cell_start,
-                     &counts, &blockcnt, &corr_idx, &corr_d2, &partials, &n_active};
+                     &counts, &blockcnt, &corr_idx, &corr_d2, &corr_lb, &partials, &n_active};
     for (DevBuf* b : all)
       if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
   }
@@ -242,6 +242,7 @@ struct Batch {
     ctx->ensure(ctx->blockcnt, 4 * (size_t)std::max(1, C()) * nb_head);
     ctx->ensure(ctx->corr_idx, 4 * std::max<size_t>(total_corr, 4));
     ctx->ensure(ctx->corr_d2, 4 * std::max<size_t>(total_corr, 4));
+    ctx->ensure(ctx->corr_lb, 4 * std::max<size_t>(total_corr, 4));
     ctx->ensure(ctx->partials, 8 * (size_t)std::max(1, P()) * kAccumBlocks * GQ_NACC);
     ctx->ensure(ctx->n_active, 64);
     if (!ctx->h_active) HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
@@ -329,17 +330,18 @@ struct Batch {
     dim3 grid((unsigned)(pairs8 * chunks));
     int* ci = (int*)ctx->corr_idx.p;
     float* cd = (float*)ctx->corr_d2.p;
+    float* cl = (float*)ctx->corr_lb.p;
     if (dbg_nn & 8) {      // opt-in (S3D_DBG_NN=8): LDS-tiled kernel; measured slower than the default, see DESIGN.md
       if (mode == 0)
-        s3d_nn_search_tiled_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), ci, cd, max_d, chunks, P());
+        s3d_nn_search_tiled_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), ci, cd, cl, max_d, chunks, P());
       else
-        s3d_nn_search_tiled_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), ci, cd, max_d, chunks, P());
+        s3d_nn_search_tiled_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), ci, cd, cl, max_d, chunks, P());
       return;
     }
     if (mode == 0)
-      s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), ci, cd, max_d, chunks, P(), dbg_nn);
+      s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), ci, cd, cl, max_d, chunks, P(), dbg_nn);
     else
-      s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), ci, cd, max_d, chunks, P(), dbg_nn);
+      s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), ci, cd, cl, max_d, chunks, P(), dbg_nn);
   }
 
   // K5-K7 loop.  The host only polls the active-pair counter every check_interval iterations.
@@ -350,6 +352,7 @@ struct Batch {
     k_pair_init<<<cdiv(P(), 64), 64, 0, st>>>(d_pairs(), P(), d_active);
     // no radius hint for the first NN pass: fill the distances with NaN (0xFF bytes)
     HIPCHK(hipMemsetAsync(ctx->corr_d2.p, 0xFF, 4 * std::max<size_t>(total_corr, 4), st));
+    HIPCHK(hipMemsetAsync(ctx->corr_lb.p, 0, 4 * std::max<size_t>(total_corr, 4), st));
     const float max_d = (float)(rp.max_corr * 1.0001);
     double* part = (double*)ctx->partials.p;
     const bool prof = opts.profile != 0;
@@ -812,6 +815,7 @@ int s3d_nn_search(s3d_context* ctx, const float* target_xyz, int n, int stride_t
     b.stage_grid();
     k_pair_init<<<1, 64, 0, ctx->stream>>>(b.d_pairs(), 1, (int*)ctx->n_active.p);  // final_T = guess = I
     HIPCHK(hipMemsetAsync(ctx->corr_d2.p, 0xFF, 4 * std::max<size_t>(b.total_corr, 4), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->corr_lb.p, 0, 4 * std::max<size_t>(b.total_corr, 4), ctx->stream));
     b.launch_nn(1, (float)(max_distance * 1.0001));
     // back to the caller's query order / target indices (keysA, keysB are free at this point)
     k_export_corr<<<dim3(cdiv(std::max(m, 1), kBlock), 1), kBlock, 0, ctx->stream>>>(
@@ -886,6 +890,7 @@ int s3d_profile_nn_kernel(s3d_context* ctx, int n_pairs, s3d_cloud* const* sourc
     k_pair_init<<<cdiv(n_pairs, 64), 64, 0, ctx->stream>>>(b.d_pairs(), n_pairs, (int*)ctx->n_active.p);
     const float max_d = (float)(b.rp.max_corr * 1.0001);
     HIPCHK(hipMemsetAsync(ctx->corr_d2.p, 0xFF, 4 * std::max<size_t>(b.total_corr, 4), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->corr_lb.p, 0, 4 * std::max<size_t>(b.total_corr, 4), ctx->stream));
     b.launch_nn(0, max_d);  // warm-up (also leaves first-pass distances as radius hints)
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));

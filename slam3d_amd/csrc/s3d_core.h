@@ -155,13 +155,17 @@ S3D_HD int grid_cell_of_point(const GridParams& g, float x, float y, float z) {
 // Exact 1-NN by ring expansion.  pts: cell-sorted float4 (xyz, w = bit-cast index
 // in the un-sorted cloud); cell_start: ncells+1 entries.  Ties: lowest index.
 // max_d: only neighbours closer than this matter (search stops beyond it).
-struct NNResult { int idx; float d2; int pos; };
+struct NNResult {
+  int idx; float d2; int pos;
+  float second_d2;   // smallest d2 among the OTHER candidates examined (3e38 if none)
+  float radius;      // grid_nn1_box: every point within this distance of the query was examined
+};
 
 template <typename F4T>
 S3D_HD NNResult grid_nn1(const GridParams& g, const uint32_t* __restrict__ cell_start,
                          const F4T* __restrict__ pts, float qx, float qy, float qz, float max_d) {
   NNResult best;
-  best.idx = -1; best.d2 = 3.0e38f; best.pos = -1;
+  best.idx = -1; best.d2 = 3.0e38f; best.pos = -1; best.second_d2 = 3.0e38f; best.radius = 0.f;
   const float fx = (qx - g.origin[0]) * g.inv_h, fy = (qy - g.origin[1]) * g.inv_h,
               fz = (qz - g.origin[2]) * g.inv_h;
   const int ix = grid_coord(g, 0, qx), iy = grid_coord(g, 1, qy), iz = grid_coord(g, 2, qz);
@@ -228,8 +232,12 @@ template <typename F4T>
 S3D_HD void nn1_consider(NNResult& best, const F4T& p, uint32_t k, float qx, float qy, float qz) {
   const float d2 = dist2(qx, qy, qz, p.x, p.y, p.z);
   const int pi = __builtin_bit_cast(int, p.w);
+  if (pi == best.idx) return;  // (a rescan meets the incumbent again)
   if (lex_less(d2, pi, best.d2, best.idx < 0 ? 2147483647 : best.idx)) {
+    best.second_d2 = fminf(best.second_d2, best.d2);
     best.d2 = d2; best.idx = pi; best.pos = (int)k;
+  } else {
+    best.second_d2 = fminf(best.second_d2, d2);
   }
 }
 
@@ -269,17 +277,21 @@ S3D_HD void nn1_scan_rows(NNResult& best, const GridParams& g, const uint32_t* _
 // seed_pos >= 0: position (in pts) of a point known to be near the query — the previous ICP
 // iteration's neighbour.  Its distance is then an exact upper bound of the NN distance: the box of
 // that radius is scanned once and the result is proven (the seed itself lies in the box).
+constexpr float kNNRevalSlack = 0.25f;   // in cells
+
 template <typename F4T>
 S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ cell_start,
                              const F4T* __restrict__ pts, float qx, float qy, float qz, float max_d, float d_hint,
                              int seed_pos = -1) {
   NNResult best;
-  best.idx = -1; best.d2 = 3.0e38f; best.pos = -1;
+  best.idx = -1; best.d2 = 3.0e38f; best.pos = -1; best.second_d2 = 3.0e38f; best.radius = 0.f;
   float d = fminf(fmaxf(d_hint, 0.25f * g.h), max_d);
   if (seed_pos >= 0) {
     nn1_consider(best, pts[seed_pos], (uint32_t)seed_pos, qx, qy, qz);
+    // examine a little more than the seed's distance: the extra shell is what later lets
+    // nn_still_nearest() prove the correspondence without a search (lower bound of the other points).
     // (a seed that ended up far away — the transform just moved — must not blow the box up)
-    d = fminf(fminf(sqrtf(best.d2) * 1.0001f + 1.0e-6f, g.h), max_d);
+    d = fminf(fminf(sqrtf(best.d2) * 1.0001f + 1.0e-6f + kNNRevalSlack * g.h, g.h), max_d);
   }
   for (int attempt = 0; attempt < 64; ++attempt) {
     // margin: float rounding of the cell assignment of the points and of the box corners
@@ -302,11 +314,30 @@ S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ c
           }
       }
     }
+    best.radius = d;                               // everything within d of the query has been examined
     if (best.idx >= 0 && best.d2 <= d * d) break;  // nothing outside the box can be closer
     if (d >= max_d) break;                         // neighbours beyond max_d do not matter
     d = best.idx >= 0 ? fminf(sqrtf(best.d2) * 1.0001f + 1.0e-6f, max_d) : fminf(2.0f * d, max_d);
   }
   return best;
+}
+
+// ---- temporal coherence of ICP correspondences, with a proof ----
+// After a search at query position q_old we know the neighbour p* and a lower bound L on the distance
+// of EVERY OTHER point to q_old (the smaller of the runner-up's distance and the examined radius).
+// When the query moves to q_new, every other point is still farther than L - |q_new - q_old|
+// (triangle inequality), so p* is certainly still the unique nearest neighbour if
+//     |p* - q_new| + |q_new - q_old|  <  L (1 - 1e-5) - 1e-6.
+// The inequality is exact for the float-valued positions; the margin covers the rounding of the
+// three computed distances (coordinate differences are exact or 6e-8-relative, d2 and sqrt add
+// ~3e-7 relative: 30x below the margin).
+// Once ICP has converged the queries barely move and almost every correspondence is re-validated
+// without touching the grid; the result is the same point and the same float d2 as a full search.
+S3D_HD float nn_lower_bound_others(const NNResult& r) {
+  return fminf(sqrtf(r.second_d2), r.radius);
+}
+S3D_HD bool nn_still_nearest(float d_new, float move, float lb_others) {
+  return d_new + move < lb_others * 0.99999f - 1.0e-6f;
 }
 
 // Exact k-NN of a point among its own cloud by ring expansion.  The k best are

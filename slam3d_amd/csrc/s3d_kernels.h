@@ -46,6 +46,7 @@ struct PairDev {          // one align() job
   int   active, converged, iterations, correspondences;
   int   inner_total, evals_total;
   Mat4f guess, T, prev, final_T;
+  Mat4f T_nn;             // transformation_ the last correspondence pass ran with (see nn_still_nearest)
   double fitness;
   int   fit_count;
   int   pad;
@@ -527,7 +528,7 @@ __global__ void k_pair_init(PairDev* pairs, int npairs, int* n_active) {
   PairDev& P = pairs[p];
   P.active = 1; P.converged = 0; P.iterations = 0; P.correspondences = 0;
   P.inner_total = 0; P.evals_total = 0;
-  P.T = mat4f_identity(); P.prev = mat4f_identity(); P.final_T = P.guess;
+  P.T = mat4f_identity(); P.prev = mat4f_identity(); P.final_T = P.guess; P.T_nn = mat4f_identity();
   P.fitness = 0.0; P.fit_count = 0;
 }
 
@@ -540,7 +541,8 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
                                                                 const float4* __restrict__ sorted,
                                                                 const uint32_t* __restrict__ cell_start,
                                                                 int* __restrict__ corr_idx, float* __restrict__ corr_d2,
-                                                                float max_d, int chunks_per_pair, int npairs, int dbg) {
+                                                                float* __restrict__ corr_lb, float max_d,
+                                                                int chunks_per_pair, int npairs, int dbg) {
   int pair, chunk;
   if (dbg & 16) { pair = blockIdx.x / chunks_per_pair; chunk = blockIdx.x % chunks_per_pair; }  // A/B: plain map
   else nn_block_map(chunks_per_pair, npairs, &pair, &chunk);
@@ -553,15 +555,26 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
   const SlotDev& Ss = slots[P.slot_s];
   // queries are taken in the CELL-SORTED order of their own cloud (spatially coherent waves)
   const float4 p0 = sorted[St.off + i];
+  const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
   F3 q;
-  if (MODE == 0) {
-    const F3 p = xf_pcl(P.guess, p0.x, p0.y, p0.z);
-    q = xf_eigen(P.T, p.x, p.y, p.z);
-  } else {
-    q = xf_pcl(P.final_T, p0.x, p0.y, p0.z);
-  }
+  if (MODE == 0) q = xf_eigen(P.T, pg.x, pg.y, pg.z);
+  else q = xf_pcl(P.final_T, p0.x, p0.y, p0.z);
   // radius hint: this query's distance in the previous pass (NaN-filled before the first one)
   const float prev = corr_d2[P.corr_off + i];
+  const float lb = corr_lb[P.corr_off + i];      // lower bound of all OTHER points at the previous position (0: none)
+  if (lb > 0.f && prev >= 0.f && !(dbg & 64)) {
+    // re-validate the previous neighbour by the triangle inequality (s3d_core.h nn_still_nearest)
+    const int pos = corr_idx[P.corr_off + i];
+    const F3 qo = xf_eigen(P.T_nn, pg.x, pg.y, pg.z);   // where this query stood in the previous pass
+    const float4 ps = sorted[Ss.off + pos];
+    const float d2n = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z);
+    const float move = sqrtf(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
+    if (nn_still_nearest(sqrtf(d2n), move, lb)) {
+      corr_d2[P.corr_off + i] = d2n;                 // same point, its exact new distance
+      corr_lb[P.corr_off + i] = lb - move;           // still a lower bound for the others
+      return;
+    }
+  }
   NNResult r;
   if (dbg & 4) {
     r = grid_nn1(Ss.g, cell_start + Ss.cell_off, sorted + Ss.off, q.x, q.y, q.z, max_d);
@@ -577,6 +590,7 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
   // the target's cell-sorted array: every later access (K6, fitness) is then coalesced or a local gather
   corr_idx[P.corr_off + i] = r.pos;
   corr_d2[P.corr_off + i] = r.d2;
+  corr_lb[P.corr_off + i] = (r.idx >= 0 && !(dbg & 4)) ? nn_lower_bound_others(r) : 0.f;
 }
 
 // ------------------------------------------------------------------ K5 (LDS-tiled): transform + exact 1-NN
@@ -629,7 +643,8 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_tiled_kernel(const PairD
                                                                       const float4* __restrict__ sorted,
                                                                       const uint32_t* __restrict__ cell_start,
                                                                       int* __restrict__ corr_idx,
-                                                                      float* __restrict__ corr_d2, float max_d,
+                                                                      float* __restrict__ corr_d2,
+                                                                      float* __restrict__ corr_lb, float max_d,
                                                                       int chunks_per_pair, int npairs) {
   __shared__ WaveTile tiles[kBlock / kWave];
   int pair, chunk;
@@ -663,7 +678,7 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_tiled_kernel(const PairD
     d = fminf(fmaxf(hint, 0.25f * g.h), max_d);
   }
   NNResult best;
-  best.idx = -1; best.d2 = 3.0e38f; best.pos = -1;
+  best.idx = -1; best.d2 = 3.0e38f; best.pos = -1; best.second_d2 = 3.0e38f; best.radius = 0.f;
   bool done = !valid;
 
   for (int attempt = 0; attempt < kTileAttempts; ++attempt) {
@@ -760,6 +775,7 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_tiled_kernel(const PairD
     }
     corr_idx[P.corr_off + i] = best.pos;
     corr_d2[P.corr_off + i] = best.d2;
+    corr_lb[P.corr_off + i] = 0.f;     // (this variant does not keep the re-validation bound)
   }
 }
 
@@ -918,6 +934,7 @@ __global__ void __launch_bounds__(128) s3d_icp_control_kernel(PairDev* pairs, co
     rc = pp_update(acc, T);
   }
   P.prev = prev;
+  P.T_nn = prev;
   if (rc) {  // PCLException path: loop breaks, converged_ stays false
     P.active = 0; P.converged = 0;
     atomicSub(n_active, 1);

@@ -22,6 +22,8 @@
 using namespace s3d;
 
 static double g_emu_perturb = 0.0;
+static long long g_reval_hits = 0, g_reval_misses = 0, g_reval_mismatch = 0;
+extern "C" void emu_reval_stats(long long* out) { out[0] = g_reval_hits; out[1] = g_reval_misses; out[2] = g_reval_mismatch; }
 extern "C" void emu_set_perturb(double e) { g_emu_perturb = e; }
 namespace {
 
@@ -194,8 +196,9 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
   const double thr = cfg->max_correspondence_distance * cfg->max_correspondence_distance;
   const float max_d = (float)cfg->max_correspondence_distance;
   int nr = 0, converged = 0, cnt = 0;
-  std::vector<float> hints(T.pts.size(), -1.f);
+  std::vector<float> hints(T.pts.size(), -1.f), lbs(T.pts.size(), 0.f);
   std::vector<int> seeds(T.pts.size(), -1);
+  Mat4f T_nn = mat4f_identity();
   while (!converged) {
     double R[9], SS[6], Th0[12];
     gicp_rotation(Tr, guess, R, SS);
@@ -206,9 +209,30 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
       const F4& p0 = T.pts[i];
       const F3 p = xf_pcl(guess, p0.x, p0.y, p0.z);
       const F3 q = xf_eigen(Tr, p.x, p.y, p.z);
-      const float hint = hints[i] >= 0.f ? std::sqrt(hints[i]) * 1.25f + 0.05f * GS.g.h : GS.g.h;
+      const float hint = hints[i] >= 0.f ? std::fmin(std::sqrt(hints[i]) * 1.25f + 0.05f * GS.g.h, GS.g.h) : GS.g.h;
       const int seed = (hints[i] >= 0.f && hints[i] < GS.g.h * GS.g.h) ? seeds[i] : -1;
-      NNResult r = grid_nn1_box(GS.g, GS.cell_start.data(), GS.sorted.data(), q.x, q.y, q.z, max_d, hint, seed);
+      NNResult r;
+      bool revalidated = false;
+      if (lbs[i] > 0.f && hints[i] >= 0.f) {   // the kernel's triangle-inequality shortcut
+        const F3 qo = xf_eigen(T_nn, p.x, p.y, p.z);
+        const F4& ps = GS.sorted[seeds[i]];
+        const float d2n = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z);
+        const float move = std::sqrt(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
+        if (nn_still_nearest(std::sqrt(d2n), move, lbs[i])) {
+          r.idx = __builtin_bit_cast(int, ps.w); r.d2 = d2n; r.pos = seeds[i];
+          lbs[i] -= move;
+          revalidated = true;
+          ++g_reval_hits;
+          // the shortcut must agree with a full search, bit for bit
+          NNResult full = grid_nn1_box(GS.g, GS.cell_start.data(), GS.sorted.data(), q.x, q.y, q.z, max_d, hint, seed);
+          if (full.idx != r.idx || full.d2 != r.d2) ++g_reval_mismatch;
+        }
+      }
+      if (!revalidated) {
+        r = grid_nn1_box(GS.g, GS.cell_start.data(), GS.sorted.data(), q.x, q.y, q.z, max_d, hint, seed);
+        lbs[i] = r.idx >= 0 ? nn_lower_bound_others(r) : 0.f;
+        ++g_reval_misses;
+      }
       hints[i] = r.idx >= 0 ? r.d2 : -1.f;
       seeds[i] = r.pos;
       if (r.idx < 0 || !((double)r.d2 < thr)) continue;
@@ -231,6 +255,7 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
       }
     }
     prev = Tr;
+    T_nn = Tr;
     int rc;
     if (gicp) {
       cnt = (int)acc[GQ_CNT];
