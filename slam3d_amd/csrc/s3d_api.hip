@@ -168,7 +168,7 @@ struct Batch {
   void set_params(const s3d_reg_params* p, const s3d_exec_options* o) {
     if (o) opts = *o;
     if (opts.check_interval <= 0) opts.check_interval = 4;
-    if (opts.grid_cells_per_point <= 0) opts.grid_cells_per_point = 4;
+    if (opts.grid_cells_per_point <= 0) opts.grid_cells_per_point = 2;
     rp.algorithm = p->registration_algorithm == S3D_ALG_ICP ? 0 : 1;
     rp.k = p->correspondence_randomness;
     rp.max_iterations = p->maximum_iterations;

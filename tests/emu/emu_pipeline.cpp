@@ -22,6 +22,7 @@
 using namespace s3d;
 
 static double g_emu_perturb = 0.0;
+
 static long long g_reval_hits = 0, g_reval_misses = 0, g_reval_mismatch = 0;
 extern "C" void emu_reval_stats(long long* out) { out[0] = g_reval_hits; out[1] = g_reval_misses; out[2] = g_reval_mismatch; }
 extern "C" void emu_set_perturb(double e) { g_emu_perturb = e; }

@@ -94,13 +94,14 @@ def test_device_box_nn_is_exact_for_any_hint(emu, oracle_mod, fixture_clouds, hi
     assert np.all((idx[~m] == -1) | (d2[~m] >= 2.5 ** 2))
 
 
-def test_device_knn_normals_match_oracle(emu, oracle_mod, fixture_clouds):
+@pytest.mark.parametrize("h0,cpp,k", [(0.6, 16, 20), (0.6, 2, 20), (0.3, 64, 7)])
+def test_device_knn_normals_match_oracle(emu, oracle_mod, fixture_clouds, h0, cpp, k):
     v1, _ = oracle_mod.voxel_downsample(fixture_clouds[0], 0.3)
     nr = np.empty((len(v1), 3), np.float32)
-    emu.emu_normals(v1.ctypes.data_as(fp), len(v1), 20, C.c_float(0.6), 16, nr.ctypes.data_as(fp))
-    _, on = oracle_mod.gicp_covariances(v1, 20)
+    emu.emu_normals(v1.ctypes.data_as(fp), len(v1), k, C.c_float(h0), cpp, nr.ctypes.data_as(fp))
+    _, on = oracle_mod.gicp_covariances(v1, k)
     dots = np.abs((nr.astype(np.float64) * on).sum(1))
-    assert (dots < 1 - 1e-6).mean() < 1e-3        # identical k-NN sets -> identical normals (degenerate ties aside)
+    assert (dots < 1 - 1e-6).mean() < (1e-3 if k == 20 else 0.02)   # identical k-NN sets -> identical normals
 
 
 def test_quadratic_form_equals_direct_sum(emu):
