@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "lib", "libslam3d_hip.so")
+_LIB = os.environ.get("S3D_LIB_PATH") or os.path.join(_HERE, "lib", "libslam3d_hip.so")   # override: A/B of builds
 _CSRC = os.path.join(_HERE, "csrc")
 
 ALG_ICP, ALG_GICP, ALG_GICP_OMP, ALG_NDT, ALG_NDT_OMP = range(5)

@@ -423,7 +423,51 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
   float face = fminf(fminf(fminf(ox, 1.f - ox), fminf(oy, 1.f - oy)), fminf(oz, 1.f - oz));
   face = fmaxf(face - 2.0e-3f, 0.f);
   const int rmax = imax(imax(g.dim[0], g.dim[1]), g.dim[2]);
-  for (int r = 0; r <= rmax; ++r) {
+  // one candidate -> sorted list (unrolled min/max chain); `worst` mirrors keys[k-1]
+#define S3D_KNN_INSERT(P_, D2_)                                                                    \
+  {                                                                                                \
+    unsigned long long c = ((unsigned long long)__builtin_bit_cast(uint32_t, (D2_)) << 32) |       \
+                           (unsigned long long)__builtin_bit_cast(uint32_t, (P_).w);               \
+    if (c < worst) {                                                                               \
+      _Pragma("unroll") for (int j = 0; j < KMAX; ++j) {                                           \
+        const unsigned long long lo = keys[j] < c ? keys[j] : c;                                   \
+        c = keys[j] < c ? c : keys[j];                                                             \
+        keys[j] = lo;                                                                              \
+      }                                                                                            \
+      worst = kInf;                                                                                \
+      _Pragma("unroll") for (int j = 0; j < KMAX; ++j) worst = (j == k - 1) ? keys[j] : worst;     \
+      ++cnt;                                                                                       \
+    }                                                                                              \
+  }
+  // ---- rings 0 and 1 together = the 3x3x3 cells around the point: nine row ranges fetched as ONE
+  // batch, then the points two at a time (the search is bound by dependent-load latency)
+  {
+    const int cix = imin(imax(ix, -1), g.dim[0]);            // (a query outside the grid: clamp, rows below are masked)
+    const int xa = imax(cix - 1, 0), xb = imin(cix + 1, g.dim[0] - 1);
+    uint32_t rs[9], re[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const int cy = iy + (r % 3) - 1, cz = iz + (r / 3) - 1;
+      const bool ok = xa <= xb && cy >= 0 && cy < g.dim[1] && cz >= 0 && cz < g.dim[2];
+      const int rowbase = ok ? g.dim[0] * (cy + g.dim[1] * cz) : 0;
+      const uint32_t a = cell_start[rowbase + (ok ? xa : 0)], b = cell_start[rowbase + (ok ? xb + 1 : 0)];
+      rs[r] = a; re[r] = ok ? b : a;
+    }
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      for (uint32_t kk = rs[r]; kk < re[r]; kk += 2) {
+        const F4T pa = pts[kk];
+        const F4T pb = pts[kk + 1 < re[r] ? kk + 1 : kk];
+        const float da = dist2(qx, qy, qz, pa.x, pa.y, pa.z);
+        const float db = dist2(qx, qy, qz, pb.x, pb.y, pb.z);
+        S3D_KNN_INSERT(pa, da)
+        if (kk + 1 < re[r]) S3D_KNN_INSERT(pb, db)
+      }
+    }
+    const float bound = (1.0f + face) * g.h;
+    if (worst != kInf && __builtin_bit_cast(float, (uint32_t)(worst >> 32)) <= bound * bound) return cnt < k ? cnt : k;
+  }
+  for (int r = 2; r <= rmax; ++r) {
     const int z0 = imax(iz - r, 0), z1 = imin(iz + r, g.dim[2] - 1);
     const int y0 = imax(iy - r, 0), y1 = imin(iy + r, g.dim[1] - 1);
     const int xl = ix - r, xh = ix + r;
@@ -446,21 +490,7 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
           for (uint32_t kk = s; kk < e; ++kk) {
             const F4T p = pts[kk];
             const float d2 = dist2(qx, qy, qz, p.x, p.y, p.z);
-            unsigned long long c = ((unsigned long long)__builtin_bit_cast(uint32_t, d2) << 32) |
-                                   (unsigned long long)__builtin_bit_cast(uint32_t, p.w);
-            if (c < worst) {
-#pragma unroll
-              for (int j = 0; j < KMAX; ++j) {
-                const unsigned long long lo = keys[j] < c ? keys[j] : c;
-                c = keys[j] < c ? c : keys[j];
-                keys[j] = lo;
-              }
-              // worst = keys[k-1] without dynamic register indexing
-              worst = kInf;
-#pragma unroll
-              for (int j = 0; j < KMAX; ++j) worst = (j == k - 1) ? keys[j] : worst;
-              ++cnt;
-            }
+            S3D_KNN_INSERT(p, d2)
           }
         }
       }
@@ -471,6 +501,7 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
       if (dk <= bound * bound) break;
     }
   }
+#undef S3D_KNN_INSERT
   return cnt < k ? cnt : k;
 }
 
