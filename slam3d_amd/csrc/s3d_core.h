@@ -671,9 +671,9 @@ S3D_HD void gq_eval(const double* acc, const double* Th0, const double x[6], dou
   // the float rounding is applied once per outer iteration instead (gicp_apply_state),
   // where PCL stores transformation_ as Matrix4f.
   double Th[3][4];
+  const double cphi = cos(x[3]), sphi = sin(x[3]), cth = cos(x[4]), sth = sin(x[4]);
+  const double cpsi = cos(x[5]), spsi = sin(x[5]);
   {
-    const double cphi = cos(x[3]), sphi = sin(x[3]), cth = cos(x[4]), sth = sin(x[4]);
-    const double cpsi = cos(x[5]), spsi = sin(x[5]);
     Th[0][0] = cpsi * cth; Th[0][1] = cpsi * sth * sphi - spsi * cphi; Th[0][2] = cpsi * sth * cphi + spsi * sphi;
     Th[1][0] = spsi * cth; Th[1][1] = spsi * sth * sphi + cpsi * cphi; Th[1][2] = spsi * sth * cphi - cpsi * sphi;
     Th[2][0] = -sth; Th[2][1] = cth * sphi; Th[2][2] = cth * cphi;
@@ -706,9 +706,6 @@ S3D_HD void gq_eval(const double* acc, const double* Th0, const double x[6], dou
   for (int a = 0; a < 3; ++a)
     for (int c = 0; c < 3; ++c) Rs[a][c] = G[a][c] * sc;
   // PCL computeRDerivative: g[3+k] = sum_ij dR_k(j,i) Rs(i,j)
-  const double cphi = cos(x[3]), sphi = sin(x[3]);
-  const double cth = cos(x[4]), sth = sin(x[4]);
-  const double cpsi = cos(x[5]), spsi = sin(x[5]);
   const double dPhi[3][3] = {{0, sphi * spsi + cphi * cpsi * sth, cphi * spsi - cpsi * sphi * sth},
                              {0, -cpsi * sphi + cphi * spsi * sth, -cphi * cpsi - sphi * spsi * sth},
                              {0, cphi * cth, -cth * sphi}};

@@ -823,13 +823,6 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
   }
 }
 
-__device__ __forceinline__ void unit3(const double4 nf, double n[3]) {
-  const double x = nf.x, y = nf.y, z = nf.z;
-  const double l = sqrt(x * x + y * y + z * z);
-  if (l > 0) { n[0] = x / l; n[1] = y / l; n[2] = z / l; }
-  else { n[0] = 0; n[1] = 0; n[2] = 1; }
-}
-
 // GICP: Mahalanobis matrix + 73-term quadratic form (s3d_core.h "GICP quadratic form")
 __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairDev* __restrict__ pairs,
                                                                       const SlotDev* __restrict__ slots,
@@ -859,9 +852,10 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
     const float4 p0 = sorted[St.off + i];
     const F3 pf = xf_pcl(P.guess, p0.x, p0.y, p0.z);
     const float4 qf = sorted[Ss.off + j];
-    double n1[3], n2[3], n1r[3], Mm[6];
-    unit3(normals[St.off + i], n1);
-    unit3(normals[Ss.off + j], n2);
+    // normals are unit vectors in double (Jacobi eigenvectors): used as stored
+    const double4 na = normals[St.off + i], nb = normals[Ss.off + j];
+    const double n1[3] = {na.x, na.y, na.z}, n2[3] = {nb.x, nb.y, nb.z};
+    double n1r[3], Mm[6];
 #pragma unroll
     for (int a = 0; a < 3; ++a) n1r[a] = R[a * 3] * n1[0] + R[a * 3 + 1] * n1[1] + R[a * 3 + 2] * n1[2];
     gicp_mahalanobis(S, n1r, n2, rp.gicp_epsilon, Mm);

@@ -120,11 +120,6 @@ std::vector<D3> normals(const Cloud& c, const Grid& G, int k) {
   return out;
 }
 
-inline void unit3(const D3& nf, double n[3]) {
-  double x = nf.x, y = nf.y, z = nf.z, l = std::sqrt(x * x + y * y + z * z);
-  if (l > 0) { n[0] = x / l; n[1] = y / l; n[2] = z / l; } else { n[0] = n[1] = 0; n[2] = 1; }
-}
-
 float h0_for(double density) { return density > 0 ? (float)(2.0 * density) : 0.25f; }
 
 }  // namespace
@@ -239,11 +234,10 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
       if (r.idx < 0 || !((double)r.d2 < thr)) continue;
       const F4& t = S.pts[r.idx];
       const double td[3] = {t.x, t.y, t.z};
-      double n2[3];
-      unit3(NS[r.idx], n2);
+      const double n2[3] = {NS[r.idx].x, NS[r.idx].y, NS[r.idx].z};
       if (gicp) {
-        double n1[3], n1r[3], M[6];
-        unit3(NT[i], n1);
+        const double n1[3] = {NT[i].x, NT[i].y, NT[i].z};
+        double n1r[3], M[6];
         for (int a = 0; a < 3; ++a) n1r[a] = R[a * 3] * n1[0] + R[a * 3 + 1] * n1[1] + R[a * 3 + 2] * n1[2];
         gicp_mahalanobis(SS, n1r, n2, 0.001, M);
         if (g_emu_perturb != 0.0) for (int a = 0; a < 6; ++a) M[a] *= 1.0 + g_emu_perturb * ((double)rand() / RAND_MAX - 0.5);
