@@ -115,7 +115,8 @@ int  s3d_create_constraint(s3d_context* ctx, const float* source_xyz, int n_sour
                            double information[36], s3d_align_info* info);
 
 /* ---- measurement hook (bench.py roofline): time `reps` launches of the NN-search kernel
- *          (K5, one ICP iteration's correspondence pass at transformation_ = I) with HIP events
+ *          as a FIRST correspondence pass (transformation_ = I, no radius hints, no re-validation
+ *          of earlier correspondences — the most expensive pass of a registration) with HIP events
  *          on the context's stream.  n_queries / n_targets: points after the voxel filter. */
 int  s3d_profile_nn_kernel(s3d_context* ctx, int n_pairs, s3d_cloud* const* sources, s3d_cloud* const* targets,
                            const double* guesses, const s3d_reg_params* params, int reps, double* avg_ms,

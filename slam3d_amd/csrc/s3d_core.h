@@ -300,21 +300,51 @@ S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ c
     const int y0 = imax(grid_coord(g, 1, qy - m), 0), y1 = imin(grid_coord(g, 1, qy + m), g.dim[1] - 1);
     const int z0 = imax(grid_coord(g, 2, qz - m), 0), z1 = imin(grid_coord(g, 2, qz + m), g.dim[2] - 1);
     const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+    bool pruned = false;
     if (x0 <= x1 && ny > 0 && nz > 0) {
       if (ny <= 2 && nz <= 2) {
         nn1_scan_rows<2>(best, g, cell_start, pts, qx, qy, qz, x0, x1, y0, ny, z0, nz);
       } else if (ny <= 3 && nz <= 3) {
         nn1_scan_rows<3>(best, g, cell_start, pts, qx, qy, qz, x0, x1, y0, ny, z0, nz);
       } else {
-        for (int cz = z0; cz <= z1; ++cz)
-          for (int cy = y0; cy <= y1; ++cy) {
+        // wide box (badly aligned clouds, first passes): shrinking-ball scan.  Rows are visited from the
+        // query's own row outwards; a row whose slab is farther than the best distance so far is
+        // skipped, and inside a row only the cells within the remaining radius are read.  (Bounds are
+        // shrunk by 2e-3 cell; ties are never pruned: rows are skipped on strictly-greater only.)
+        const int cy0 = imin(imax(grid_coord(g, 1, qy), y0), y1), cz0 = imin(imax(grid_coord(g, 2, qz), z0), z1);
+        const float eps = 2.0e-3f * g.h;
+        pruned = true;
+        for (int oz = 0; oz <= 2 * (z1 - z0) + 1; ++oz) {
+          const int cz = cz0 + ((oz & 1) ? -((oz + 1) >> 1) : (oz >> 1));
+          if (cz < z0 || cz > z1) continue;
+          const float zlo = g.origin[2] + (float)cz * g.h, zhi = zlo + g.h;
+          const float dz = fmaxf(fmaxf(zlo - qz, qz - zhi) - eps, 0.f);
+          if (dz * dz > best.d2) continue;
+          for (int oy = 0; oy <= 2 * (y1 - y0) + 1; ++oy) {
+            const int cy = cy0 + ((oy & 1) ? -((oy + 1) >> 1) : (oy >> 1));
+            if (cy < y0 || cy > y1) continue;
+            const float ylo = g.origin[1] + (float)cy * g.h, yhi = ylo + g.h;
+            const float dy = fmaxf(fmaxf(ylo - qy, qy - yhi) - eps, 0.f);
+            const float rowd2 = dy * dy + dz * dz;
+            if (rowd2 > best.d2) continue;
+            int xa = x0, xb = x1;
+            if (best.idx >= 0) {   // only the cells within the remaining radius
+              const float rx = sqrtf(fmaxf(best.d2 - rowd2, 0.f)) * 1.0001f + eps;
+              xa = imax(x0, grid_coord(g, 0, qx - rx));
+              xb = imin(x1, grid_coord(g, 0, qx + rx));
+              if (xa > xb) continue;
+            }
             const int rowbase = g.dim[0] * (cy + g.dim[1] * cz);
-            const uint32_t s = cell_start[rowbase + x0], e = cell_start[rowbase + x1 + 1];
+            const uint32_t s = cell_start[rowbase + xa], e = cell_start[rowbase + xb + 1];
             for (uint32_t k = s; k < e; ++k) nn1_consider(best, pts[k], k, qx, qy, qz);
           }
+        }
       }
     }
-    best.radius = d;                               // everything within d of the query has been examined
+    // everything within `radius` of the query has been examined (after a pruned scan only the points
+    // up to the best distance are known: re-validation then fails once and the next, seeded search
+    // re-establishes a proper bound)
+    best.radius = (pruned && best.idx >= 0) ? fminf(d, sqrtf(best.d2)) : d;
     if (best.idx >= 0 && best.d2 <= d * d) break;  // nothing outside the box can be closer
     if (d >= max_d) break;                         // neighbours beyond max_d do not matter
     d = best.idx >= 0 ? fminf(sqrtf(best.d2) * 1.0001f + 1.0e-6f, max_d) : fminf(2.0f * d, max_d);
