@@ -433,18 +433,42 @@ S3D_HD int grid_knn(const GridParams& g, const uint32_t* __restrict__ cell_start
 }
 
 // Register-resident variant (the one the GPU runs for k <= 32): the k best are kept as a SORTED
-// list of packed 64-bit keys (float bits of d2 << 32 | index; d2 >= 0 so the integer order is the
-// lexicographic (d2, index) order).  An insertion is one unrolled min/max chain — no LDS, no
-// re-scan — and the list comes out in ascending distance, the order in which PCL sums the
-// neighbours.  keys[] must hold KMAX entries; returns the number of valid entries (<= k).
+// list of packed 64-bit keys ((float bits of d2 + 2^23) << 32 | index; d2 >= 0 so the integer order
+// is the lexicographic (d2, index) order).  The keys are held as DOUBLES: for positive, finite,
+// normal doubles the IEEE order equals the integer order of the bit patterns, so one chain step is
+// v_min_f64 + v_max_f64 instead of a 64-bit compare and four selects (the +2^23 keeps every key a
+// normal number, the sentinel is the largest finite pattern below it).  An insertion is one unrolled
+// min/max chain — no LDS, no re-scan — and the list comes out in ascending distance, the order in
+// which PCL sums the neighbours.  Returns the number of valid entries (<= k).
+// one chain step on double-held keys.  On the GPU the two instructions are emitted directly:
+// fmin()/fmax() would add a canonicalising v_max_f64 per operand (sNaN quieting) that the keys, which
+// are never NaN, do not need.
+S3D_HD void knn_chain_step(double& slot, double& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double lo, hi;
+  asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(slot), "v"(c));
+  asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(slot), "v"(c));
+  slot = lo; c = hi;
+#else
+  const double lo = slot < c ? slot : c;
+  c = slot < c ? c : slot;
+  slot = lo;
+#endif
+}
+
+S3D_HD float knn_key_d2(double key) {
+  return __builtin_bit_cast(float, (uint32_t)(__builtin_bit_cast(unsigned long long, key) >> 32) - 0x00800000u);
+}
+
 template <int KMAX, typename F4T>
 S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cell_start,
                            const F4T* __restrict__ pts, float qx, float qy, float qz, int k,
-                           unsigned long long (&keys)[KMAX]) {
-  const unsigned long long kInf = ~0ull;
+                           unsigned long long (&keys_out)[KMAX]) {
+  const double kInf = __builtin_bit_cast(double, 0x7FDFFFFFFFFFFFFFull);
+  double keys[KMAX];
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) keys[j] = kInf;
-  unsigned long long worst = kInf;  // == keys[k-1]
+  double worst = kInf;  // == keys[k-1]
   int cnt = 0;
   const float fx = (qx - g.origin[0]) * g.inv_h, fy = (qy - g.origin[1]) * g.inv_h,
               fz = (qz - g.origin[2]) * g.inv_h;
@@ -456,16 +480,17 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
   // one candidate -> sorted list (unrolled min/max chain); `worst` mirrors keys[k-1]
 #define S3D_KNN_INSERT(P_, D2_)                                                                    \
   {                                                                                                \
-    unsigned long long c = ((unsigned long long)__builtin_bit_cast(uint32_t, (D2_)) << 32) |       \
-                           (unsigned long long)__builtin_bit_cast(uint32_t, (P_).w);               \
+    double c = __builtin_bit_cast(double,                                                          \
+        ((unsigned long long)(__builtin_bit_cast(uint32_t, (D2_)) + 0x00800000u) << 32) |          \
+        (unsigned long long)__builtin_bit_cast(uint32_t, (P_).w));                                 \
     if (c < worst) {                                                                               \
-      _Pragma("unroll") for (int j = 0; j < KMAX; ++j) {                                           \
-        const unsigned long long lo = keys[j] < c ? keys[j] : c;                                   \
-        c = keys[j] < c ? c : keys[j];                                                             \
-        keys[j] = lo;                                                                              \
+      _Pragma("unroll") for (int j = 0; j < KMAX; ++j) knn_chain_step(keys[j], c);                 \
+      if (k == KMAX) {                                                                             \
+        worst = keys[KMAX - 1];                                                                    \
+      } else {                                                                                     \
+        worst = kInf;                                                                              \
+        _Pragma("unroll") for (int j = 0; j < KMAX; ++j) worst = (j == k - 1) ? keys[j] : worst;   \
       }                                                                                            \
-      worst = kInf;                                                                                \
-      _Pragma("unroll") for (int j = 0; j < KMAX; ++j) worst = (j == k - 1) ? keys[j] : worst;     \
       ++cnt;                                                                                       \
     }                                                                                              \
   }
@@ -495,7 +520,11 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
       }
     }
     const float bound = (1.0f + face) * g.h;
-    if (worst != kInf && __builtin_bit_cast(float, (uint32_t)(worst >> 32)) <= bound * bound) return cnt < k ? cnt : k;
+    if (worst != kInf && knn_key_d2(worst) <= bound * bound) {
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) keys_out[j] = __builtin_bit_cast(unsigned long long, keys[j]);
+      return cnt < k ? cnt : k;
+    }
   }
   for (int r = 2; r <= rmax; ++r) {
     const int z0 = imax(iz - r, 0), z1 = imin(iz + r, g.dim[2] - 1);
@@ -527,11 +556,13 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
     }
     const float bound = ((float)r + face) * g.h;
     if (worst != kInf) {
-      const float dk = __builtin_bit_cast(float, (uint32_t)(worst >> 32));
+      const float dk = knn_key_d2(worst);
       if (dk <= bound * bound) break;
     }
   }
 #undef S3D_KNN_INSERT
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) keys_out[j] = __builtin_bit_cast(unsigned long long, keys[j]);
   return cnt < k ? cnt : k;
 }
 
