@@ -508,16 +508,29 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
       const uint32_t a = cell_start[rowbase + (ok ? xa : 0)], b = cell_start[rowbase + (ok ? xb + 1 : 0)];
       rs[r] = a; re[r] = ok ? b : a;
     }
+    // ONE flattened loop over the candidates of all nine rows: with a loop per row the wave would run
+    // max-over-lanes steps for every row (and pay the insertion chain on each); flattened it runs
+    // max-over-lanes of the TOTAL.  cum[r] = candidates before row r, off[r] maps a flat index into it.
+    uint32_t cum[10];
+    cum[0] = 0;
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      for (uint32_t kk = rs[r]; kk < re[r]; kk += 2) {
-        const F4T pa = pts[kk];
-        const F4T pb = pts[kk + 1 < re[r] ? kk + 1 : kk];
-        const float da = dist2(qx, qy, qz, pa.x, pa.y, pa.z);
-        const float db = dist2(qx, qy, qz, pb.x, pb.y, pb.z);
-        S3D_KNN_INSERT(pa, da)
-        if (kk + 1 < re[r]) S3D_KNN_INSERT(pb, db)
+    for (int r = 0; r < 9; ++r) cum[r + 1] = cum[r] + (re[r] - rs[r]);
+    const uint32_t total = cum[9];
+    for (uint32_t t = 0; t < total; t += 2) {
+      const uint32_t t2 = t + 1 < total ? t + 1 : t;
+      uint32_t ba = rs[0], bb = rs[0];
+#pragma unroll
+      for (int r = 1; r < 9; ++r) {
+        const uint32_t off = rs[r] - cum[r];
+        ba = t >= cum[r] ? off : ba;
+        bb = t2 >= cum[r] ? off : bb;
       }
+      const F4T pa = pts[t + ba];
+      const F4T pb = pts[t2 + bb];
+      const float da = dist2(qx, qy, qz, pa.x, pa.y, pa.z);
+      const float db = dist2(qx, qy, qz, pb.x, pb.y, pb.z);
+      S3D_KNN_INSERT(pa, da)
+      if (t2 != t) S3D_KNN_INSERT(pb, db)
     }
     const float bound = (1.0f + face) * g.h;
     if (worst != kInf && knn_key_d2(worst) <= bound * bound) {
