@@ -148,9 +148,15 @@ def main():
         alg_bytes = 20.0 * nq + 12.0 * nt
         avg_ms = prof["nn_ms"] / n_launch
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        # HBM traffic per launch from the PMC counters (separate rocprofv3 --pmc passes of this same command,
+        # summary committed as profiles/nn_traffic.json; FETCH_SIZE doubled as the gfx950 guide prescribes)
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "nn_traffic.json")
+        if os.path.exists(tfile) and args.pairs == 256 and args.points == 100000 and args.iters == 20:
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
         roofline = {"kernel": "s3d_nn_search_kernel<0>", "bound": "hbm", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n_launch,
+                    "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n_launch,
                     "algorithmic_bytes_per_launch": int(alg_bytes),
                     "queries_per_launch": int(nq), "targets_per_launch": int(nt),
                     "gqueries_per_s": round(nq / (avg_ms * 1e-3) / 1e9, 3)}
