@@ -109,7 +109,7 @@ struct s3d_context {
   s3d_profile prof{};
   // workspace (grown on demand, reused across calls)
   DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, normals, moments, cell_start, counts, blockcnt,
-      corr_idx, corr_d2, corr_lb, partials, n_active;
+      corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active;
   int* h_active = nullptr;  // pinned
   hipEvent_t ev[8] = {};
   std::vector<hipEvent_t> nn_ev;
@@ -124,7 +124,7 @@ struct s3d_context {
   }
   void release_all() {
     DevBuf* all[] = {&slots, &pairs, &keysA, &keysB, &valsA, &valsB, &filt, &sorted, &normals, &moments, &cell_start,
-                     &counts, &blockcnt, &corr_idx, &corr_d2, &corr_lb, &partials, &n_active};
+                     &counts, &blockcnt, &corr_idx, &corr_d2, &corr_lb, &corr_q, &corr_n, &partials, &n_active};
     for (DevBuf* b : all)
       if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
   }
@@ -243,6 +243,8 @@ struct Batch {
     ctx->ensure(ctx->corr_idx, 4 * std::max<size_t>(total_corr, 4));
     ctx->ensure(ctx->corr_d2, 4 * std::max<size_t>(total_corr, 4));
     ctx->ensure(ctx->corr_lb, 4 * std::max<size_t>(total_corr, 4));
+    ctx->ensure(ctx->corr_q, 16 * std::max<size_t>(total_corr, 4));
+    ctx->ensure(ctx->corr_n, 16 * std::max<size_t>(total_corr, 4));
     ctx->ensure(ctx->partials, 8 * (size_t)std::max(1, P()) * kAccumBlocks * GQ_NACC);
     ctx->ensure(ctx->n_active, 64);
     if (!ctx->h_active) HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
@@ -331,17 +333,19 @@ struct Batch {
     int* ci = (int*)ctx->corr_idx.p;
     float* cd = (float*)ctx->corr_d2.p;
     float* cl = (float*)ctx->corr_lb.p;
+    float4* cq = (float4*)ctx->corr_q.p;
+    float4* cn = (float4*)ctx->corr_n.p;
     if (dbg_nn & 8) {      // opt-in (S3D_DBG_NN=8): LDS-tiled kernel; measured slower than the default, see DESIGN.md
       if (mode == 0)
-        s3d_nn_search_tiled_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), ci, cd, cl, max_d, chunks, P());
+        s3d_nn_search_tiled_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), normals(), ci, cd, cl, cq, cn, max_d, chunks, P());
       else
-        s3d_nn_search_tiled_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), ci, cd, cl, max_d, chunks, P());
+        s3d_nn_search_tiled_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), normals(), ci, cd, cl, cq, cn, max_d, chunks, P());
       return;
     }
     if (mode == 0)
-      s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), ci, cd, cl, max_d, chunks, P(), dbg_nn);
+      s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), normals(), ci, cd, cl, cq, cn, max_d, chunks, P(), dbg_nn);
     else
-      s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), ci, cd, cl, max_d, chunks, P(), dbg_nn);
+      s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), normals(), ci, cd, cl, cq, cn, max_d, chunks, P(), dbg_nn);
   }
 
   // K5-K7 loop.  The host only polls the active-pair counter every check_interval iterations.
@@ -369,10 +373,12 @@ struct Batch {
       if (prof) HIPCHK(hipEventRecord(ctx->nn_ev[2 * it + 1], st));
       if (rp.algorithm)
         s3d_gicp_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
-            d_pairs(), d_slots(), sorted(), normals(), (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, part, rp);
+            d_pairs(), d_slots(), sorted(), normals(), (float*)ctx->corr_d2.p, (float4*)ctx->corr_q.p,
+            (float4*)ctx->corr_n.p, part, rp);
       else
         s3d_p2plane_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
-            d_pairs(), d_slots(), sorted(), normals(), (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, part, rp);
+            d_pairs(), d_slots(), sorted(), (float*)ctx->corr_d2.p, (float4*)ctx->corr_q.p, (float4*)ctx->corr_n.p,
+            part, rp);
       s3d_icp_control_kernel<<<P(), 128, 0, st>>>(d_pairs(), part, accum_blocks, rp, d_active);
       ctx->prof.nn_launches = it + 1;
       if (!rp.force_iterations && (it + 1) % opts.check_interval == 0 && it + 1 < rp.max_iterations) {
@@ -390,8 +396,8 @@ struct Batch {
     k_pair_finalize<<<cdiv(P(), 64), 64, 0, st>>>(d_pairs(), P());
     launch_nn(1, (float)(std::sqrt(std::max(rp.fit_range, 0.0)) * 1.0001));
     double* part = (double*)ctx->partials.p;
-    s3d_fitness_partial_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(d_pairs(), d_slots(), (int*)ctx->corr_idx.p,
-                                                                           (float*)ctx->corr_d2.p, part, rp);
+    s3d_fitness_partial_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(d_pairs(), d_slots(), (float*)ctx->corr_d2.p,
+                                                                           part, rp);
     k_fitness_final<<<cdiv(P(), 64), 64, 0, st>>>(d_pairs(), part, accum_blocks, P());
   }
 

@@ -540,8 +540,10 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
                                                                 const SlotDev* __restrict__ slots,
                                                                 const float4* __restrict__ sorted,
                                                                 const uint32_t* __restrict__ cell_start,
+                                                                const float4* __restrict__ normals,
                                                                 int* __restrict__ corr_idx, float* __restrict__ corr_d2,
-                                                                float* __restrict__ corr_lb, float max_d,
+                                                                float* __restrict__ corr_lb, float4* __restrict__ corr_q,
+                                                                float4* __restrict__ corr_n, float max_d,
                                                                 int chunks_per_pair, int npairs, int dbg) {
   int pair, chunk;
   if (dbg & 16) { pair = blockIdx.x / chunks_per_pair; chunk = blockIdx.x % chunks_per_pair; }  // A/B: plain map
@@ -564,9 +566,8 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
   const float lb = corr_lb[P.corr_off + i];      // lower bound of all OTHER points at the previous position (0: none)
   if (lb > 0.f && prev >= 0.f && !(dbg & 64)) {
     // re-validate the previous neighbour by the triangle inequality (s3d_core.h nn_still_nearest)
-    const int pos = corr_idx[P.corr_off + i];
     const F3 qo = xf_eigen(P.T_nn, pg.x, pg.y, pg.z);   // where this query stood in the previous pass
-    const float4 ps = sorted[Ss.off + pos];
+    const float4 ps = corr_q[P.corr_off + i];           // the neighbour itself travels with the correspondence
     const float d2n = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z);
     const float move = sqrtf(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
     if (nn_still_nearest(sqrtf(d2n), move, lb)) {
@@ -583,7 +584,10 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
     // search radius exactly), unless it was far away — then the transform has just moved a lot and a
     // one-cell box is the better first guess.  dbg & 32: hint-only variant (A/B).
     const int seed = (prev >= 0.f && prev < Ss.g.h * Ss.g.h && !(dbg & 32)) ? corr_idx[P.corr_off + i] : -1;
-    const float hint = (prev >= 0.f && prev < 1.0e30f) ? fminf(sqrtf(prev) * 1.25f + 0.05f * Ss.g.h, Ss.g.h) : Ss.g.h;
+    // first pass (nothing known yet): a generous three-cell box — the shrinking-ball scan makes a large
+    // initial radius cheap, while a small one costs a second scan for every badly aligned query
+    const float first = 3.0f * Ss.g.h;
+    const float hint = (prev >= 0.f && prev < 1.0e30f) ? fminf(sqrtf(prev) * 1.25f + 0.05f * Ss.g.h, Ss.g.h) : first;
     r = grid_nn1_box(Ss.g, cell_start + Ss.cell_off, sorted + Ss.off, q.x, q.y, q.z, max_d, hint, seed);
   }
   // results are kept in the query cloud's cell-sorted order and name the neighbour by its POSITION in
@@ -591,6 +595,12 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
   corr_idx[P.corr_off + i] = r.pos;
   corr_d2[P.corr_off + i] = r.d2;
   corr_lb[P.corr_off + i] = (r.idx >= 0 && !(dbg & 4)) ? nn_lower_bound_others(r) : 0.f;
+  if (r.pos >= 0) {
+    // a copy of the matched point and of its normal is kept with the correspondence: the re-validation
+    // above and the accumulate kernel then stream them instead of gathering by index
+    corr_q[P.corr_off + i] = sorted[Ss.off + r.pos];
+    corr_n[P.corr_off + i] = normals[Ss.off + r.pos];
+  }
 }
 
 // ------------------------------------------------------------------ K5 (LDS-tiled): transform + exact 1-NN
@@ -642,9 +652,12 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_tiled_kernel(const PairD
                                                                       const SlotDev* __restrict__ slots,
                                                                       const float4* __restrict__ sorted,
                                                                       const uint32_t* __restrict__ cell_start,
+                                                                      const float4* __restrict__ normals,
                                                                       int* __restrict__ corr_idx,
                                                                       float* __restrict__ corr_d2,
-                                                                      float* __restrict__ corr_lb, float max_d,
+                                                                      float* __restrict__ corr_lb,
+                                                                      float4* __restrict__ corr_q,
+                                                                      float4* __restrict__ corr_n, float max_d,
                                                                       int chunks_per_pair, int npairs) {
   __shared__ WaveTile tiles[kBlock / kWave];
   int pair, chunk;
@@ -776,6 +789,10 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_tiled_kernel(const PairD
     corr_idx[P.corr_off + i] = best.pos;
     corr_d2[P.corr_off + i] = best.d2;
     corr_lb[P.corr_off + i] = 0.f;     // (this variant does not keep the re-validation bound)
+    if (best.pos >= 0) {
+      corr_q[P.corr_off + i] = spts[best.pos];
+      corr_n[P.corr_off + i] = normals[Ss.off + best.pos];
+    }
   }
 }
 
@@ -827,13 +844,13 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
                                                                       const SlotDev* __restrict__ slots,
                                                                       const float4* __restrict__ sorted,
                                                                       const float4* __restrict__ normals,
-                                                                      const int* __restrict__ corr_idx,
                                                                       const float* __restrict__ corr_d2,
+                                                                      const float4* __restrict__ corr_q,
+                                                                      const float4* __restrict__ corr_n,
                                                                       double* __restrict__ partials, RunParams rp) {
   const PairDev& P = pairs[blockIdx.y];
   if (!P.active) return;
   const SlotDev& St = slots[P.slot_t];
-  const SlotDev& Ss = slots[P.slot_s];
   double R[9], S[6], Th0[12];
   gicp_rotation(P.T, P.guess, R, S);
 #pragma unroll
@@ -845,15 +862,14 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
   for (int c = 0; c < GQ_NACC; ++c) acc[c] = 0.0;
   const int M = St.n;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < M; i += gridDim.x * kBlock) {
-    const int j = corr_idx[P.corr_off + i];
-    const float d2 = corr_d2[P.corr_off + i];
-    if (j < 0 || !((double)d2 < rp.dist_threshold)) continue;
+    const float d2 = corr_d2[P.corr_off + i];          // 3e38 when the query has no neighbour at all
+    if (!((double)d2 < rp.dist_threshold)) continue;
     const float4 p0 = sorted[St.off + i];
     const F3 pf = xf_pcl(P.guess, p0.x, p0.y, p0.z);
-    const float4 qf = sorted[Ss.off + j];
+    const float4 qf = corr_q[P.corr_off + i];
     // xyz + normal, both float4: the float-rounded unit normals are used as stored (measured effect on
     // the GICP result vs double normals: <= 2e-6 m)
-    const float4 na = normals[St.off + i], nb = normals[Ss.off + j];
+    const float4 na = normals[St.off + i], nb = corr_n[P.corr_off + i];
     const double n1[3] = {na.x, na.y, na.z}, n2[3] = {nb.x, nb.y, nb.z};
     double n1r[3], Mm[6];
 #pragma unroll
@@ -870,27 +886,25 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
 __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const PairDev* __restrict__ pairs,
                                                                          const SlotDev* __restrict__ slots,
                                                                          const float4* __restrict__ sorted,
-                                                                         const float4* __restrict__ normals,
-                                                                         const int* __restrict__ corr_idx,
                                                                          const float* __restrict__ corr_d2,
+                                                                         const float4* __restrict__ corr_q,
+                                                                         const float4* __restrict__ corr_n,
                                                                          double* __restrict__ partials, RunParams rp) {
   const PairDev& P = pairs[blockIdx.y];
   if (!P.active) return;
   const SlotDev& St = slots[P.slot_t];
-  const SlotDev& Ss = slots[P.slot_s];
   double acc[PP_NACC];
 #pragma unroll
   for (int c = 0; c < PP_NACC; ++c) acc[c] = 0.0;
   const int M = St.n;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < M; i += gridDim.x * kBlock) {
-    const int j = corr_idx[P.corr_off + i];
     const float d2 = corr_d2[P.corr_off + i];
-    if (j < 0 || !((double)d2 < rp.dist_threshold)) continue;
+    if (!((double)d2 < rp.dist_threshold)) continue;
     const float4 p0 = sorted[St.off + i];
     const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
     const F3 pq = xf_eigen(P.T, pg.x, pg.y, pg.z);
-    const float4 qf = sorted[Ss.off + j];
-    const float4 nf = normals[Ss.off + j];
+    const float4 qf = corr_q[P.corr_off + i];
+    const float4 nf = corr_n[P.corr_off + i];
     const double pd[3] = {pq.x, pq.y, pq.z};
     const double qd[3] = {qf.x, qf.y, qf.z};
     const double nd[3] = {nf.x, nf.y, nf.z};
@@ -954,7 +968,6 @@ __global__ void k_pair_finalize(PairDev* pairs, int npairs) {
 // ------------------------------------------------------------------ K8: fitness (masked mean of d2)
 __global__ void __launch_bounds__(kBlock) s3d_fitness_partial_kernel(const PairDev* __restrict__ pairs,
                                                                       const SlotDev* __restrict__ slots,
-                                                                      const int* __restrict__ corr_idx,
                                                                       const float* __restrict__ corr_d2,
                                                                       double* __restrict__ partials, RunParams rp) {
   __shared__ double red[kBlock / kWave][2];
@@ -963,7 +976,7 @@ __global__ void __launch_bounds__(kBlock) s3d_fitness_partial_kernel(const PairD
   double s = 0.0, c = 0.0;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < M; i += gridDim.x * kBlock) {
     const float d2 = corr_d2[P.corr_off + i];
-    if (corr_idx[P.corr_off + i] >= 0 && (double)d2 <= rp.fit_range) { s += (double)d2; c += 1.0; }
+    if ((double)d2 <= rp.fit_range) { s += (double)d2; c += 1.0; }   // (no neighbour at all: d2 = 3e38)
   }
   s = wave_sum(s); c = wave_sum(c);
   if (lane_id() == 0) { red[wave_id()][0] = s; red[wave_id()][1] = c; }
