@@ -14,6 +14,10 @@
 // must evaluate exactly as the oracle's; fma() is used explicitly elsewhere.
 #pragma once
 
+#ifndef S3D_KNN_PREFETCH
+#define S3D_KNN_PREFETCH 1
+#endif
+
 #include <math.h>
 #include <stdint.h>
 
@@ -445,15 +449,38 @@ S3D_HD int grid_knn(const GridParams& g, const uint32_t* __restrict__ cell_start
 // are never NaN, do not need.
 S3D_HD void knn_chain_step(double& slot, double& c) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  double lo, hi;
-  asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(slot), "v"(c));
-  asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(slot), "v"(c));
-  slot = lo; c = hi;
+  double hi;
+  asm("v_max_f64 %0, %1, %2" : "=&v"(hi) : "v"(slot), "v"(c));
+  asm("v_min_f64 %0, %0, %1" : "+v"(slot) : "v"(c));   // in place: no register copies around the chain
+  c = hi;
 #else
   const double lo = slot < c ? slot : c;
   c = slot < c ? c : slot;
   slot = lo;
 #endif
+}
+
+// the whole 20-step chain as ONE asm block (k <= 20 is the reference default): between separate asm
+// statements hipcc pads an s_nop it cannot prove unnecessary, i.e. 20 wasted issue slots per insertion
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void knn_chain20(double (&k)[20], double& c) {
+  double t;
+  asm("v_max_f64 %21, %0, %20\n\tv_min_f64 %0, %0, %20\n\tv_max_f64 %20, %1, %21\n\tv_min_f64 %1, %1, %21\n\tv_max_f64 %21, %2, %20\n\tv_min_f64 %2, %2, %20\n\tv_max_f64 %20, %3, %21\n\tv_min_f64 %3, %3, %21\n\tv_max_f64 %21, %4, %20\n\tv_min_f64 %4, %4, %20\n\tv_max_f64 %20, %5, %21\n\tv_min_f64 %5, %5, %21\n\tv_max_f64 %21, %6, %20\n\tv_min_f64 %6, %6, %20\n\tv_max_f64 %20, %7, %21\n\tv_min_f64 %7, %7, %21\n\tv_max_f64 %21, %8, %20\n\tv_min_f64 %8, %8, %20\n\tv_max_f64 %20, %9, %21\n\tv_min_f64 %9, %9, %21\n\tv_max_f64 %21, %10, %20\n\tv_min_f64 %10, %10, %20\n\tv_max_f64 %20, %11, %21\n\tv_min_f64 %11, %11, %21\n\tv_max_f64 %21, %12, %20\n\tv_min_f64 %12, %12, %20\n\tv_max_f64 %20, %13, %21\n\tv_min_f64 %13, %13, %21\n\tv_max_f64 %21, %14, %20\n\tv_min_f64 %14, %14, %20\n\tv_max_f64 %20, %15, %21\n\tv_min_f64 %15, %15, %21\n\tv_max_f64 %21, %16, %20\n\tv_min_f64 %16, %16, %20\n\tv_max_f64 %20, %17, %21\n\tv_min_f64 %17, %17, %21\n\tv_max_f64 %21, %18, %20\n\tv_min_f64 %18, %18, %20\n\tv_max_f64 %20, %19, %21\n\tv_min_f64 %19, %19, %21"
+      : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]), "+v"(k[4]), "+v"(k[5]), "+v"(k[6]), "+v"(k[7]), "+v"(k[8]),
+        "+v"(k[9]), "+v"(k[10]), "+v"(k[11]), "+v"(k[12]), "+v"(k[13]), "+v"(k[14]), "+v"(k[15]), "+v"(k[16]),
+        "+v"(k[17]), "+v"(k[18]), "+v"(k[19]), "+v"(c), "=&v"(t));
+}
+#endif
+template <int KMAX>
+S3D_HD void knn_chain(double (&keys)[KMAX], double& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (KMAX == 20) {
+    knn_chain20(keys, c);
+    return;
+  }
+#endif
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) knn_chain_step(keys[j], c);
 }
 
 S3D_HD float knn_key_d2(double key) {
@@ -484,7 +511,7 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
         ((unsigned long long)(__builtin_bit_cast(uint32_t, (D2_)) + 0x00800000u) << 32) |          \
         (unsigned long long)__builtin_bit_cast(uint32_t, (P_).w));                                 \
     if (c < worst) {                                                                               \
-      _Pragma("unroll") for (int j = 0; j < KMAX; ++j) knn_chain_step(keys[j], c);                 \
+      knn_chain<KMAX>(keys, c);                                                                    \
       if (k == KMAX) {                                                                             \
         worst = keys[KMAX - 1];                                                                    \
       } else {                                                                                     \
@@ -516,22 +543,45 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
 #pragma unroll
     for (int r = 0; r < 9; ++r) cum[r + 1] = cum[r] + (re[r] - rs[r]);
     const uint32_t total = cum[9];
+    // flat index -> position in pts (select chain over the nine row offsets, no register indexing)
+#define S3D_KNN_FLATPOS(T_, OUT_)                                         \
+    {                                                                     \
+      uint32_t b_ = rs[0];                                                \
+      _Pragma("unroll") for (int r = 1; r < 9; ++r)                       \
+        b_ = (T_) >= cum[r] ? rs[r] - cum[r] : b_;                        \
+      OUT_ = (T_) + b_;                                                   \
+    }
+    // software-pipelined: the two points of step t+2 are requested before the insertion chains of
+    // step t run, so the chains (~200 instructions) cover the load latency
+    F4T na = pts[0], nb = pts[0];
+    if (total > 0) {
+      uint32_t ka, kb;
+      S3D_KNN_FLATPOS(0u, ka)
+      S3D_KNN_FLATPOS((total > 1 ? 1u : 0u), kb)
+      na = pts[ka]; nb = pts[kb];
+    }
     for (uint32_t t = 0; t < total; t += 2) {
-      const uint32_t t2 = t + 1 < total ? t + 1 : t;
-      uint32_t ba = rs[0], bb = rs[0];
-#pragma unroll
-      for (int r = 1; r < 9; ++r) {
-        const uint32_t off = rs[r] - cum[r];
-        ba = t >= cum[r] ? off : ba;
-        bb = t2 >= cum[r] ? off : bb;
+      F4T pa = na, pb = nb;
+      const bool two = t + 1 < total;
+      if (!S3D_KNN_PREFETCH && t > 0) {
+        uint32_t ka, kb;
+        S3D_KNN_FLATPOS(t, ka)
+        S3D_KNN_FLATPOS((two ? t + 1 : t), kb)
+        pa = pts[ka]; pb = pts[kb];
       }
-      const F4T pa = pts[t + ba];
-      const F4T pb = pts[t2 + bb];
+      if (S3D_KNN_PREFETCH && t + 2 < total) {
+        uint32_t ka, kb;
+        const uint32_t t3 = t + 3 < total ? t + 3 : t + 2;
+        S3D_KNN_FLATPOS(t + 2, ka)
+        S3D_KNN_FLATPOS(t3, kb)
+        na = pts[ka]; nb = pts[kb];
+      }
       const float da = dist2(qx, qy, qz, pa.x, pa.y, pa.z);
       const float db = dist2(qx, qy, qz, pb.x, pb.y, pb.z);
       S3D_KNN_INSERT(pa, da)
-      if (t2 != t) S3D_KNN_INSERT(pb, db)
+      if (two) S3D_KNN_INSERT(pb, db)
     }
+#undef S3D_KNN_FLATPOS
     const float bound = (1.0f + face) * g.h;
     if (worst != kInf && knn_key_d2(worst) <= bound * bound) {
 #pragma unroll

@@ -395,3 +395,22 @@ def test_nn_revalidation_shortcut_is_bitwise_neutral(gpu_ctx, fixture_clouds, mo
         st1, T1, i1 = gpu_ctx.align(fixture_clouds[1], fixture_clouds[2], np.eye(4), p, opts)
         monkeypatch.delenv("S3D_DBG_NN", raising=False)
         assert st0 == st1 == 0 and np.array_equal(T0, T1) and i0 == i1
+
+
+def test_million_point_pair(gpu_ctx, oracle_mod):
+    """BASELINE.json configs[4] scale (1M-point scans): exact NN against the kd-tree oracle on a sample of
+    the queries, and a 50-iteration registration that recovers the ground truth and is deterministic."""
+    import slam3d_amd as s3d
+    src, tgt, T_true = s3d.make_pair(1_000_000, 7)
+    idx, d2 = gpu_ctx.nn_search(src, tgt[::50], 2.5)
+    oi, od = oracle_mod.nn_search(src, tgt[::50])
+    m = od < 2.5 ** 2
+    assert m.mean() > 0.99 and np.array_equal(idx[m], oi[m]) and np.array_equal(d2[m], od[m])
+    opts = s3d.ExecOptions(force_iterations=1)
+    p = s3d.default_params(point_cloud_density=0.01, maximum_iterations=50)
+    st, T, info = gpu_ctx.align(src, tgt, np.eye(4), p, opts)
+    st2, T2, info2 = gpu_ctx.align(src, tgt, np.eye(4), p, opts)
+    dt, dr = transform_delta(T_true, T)
+    assert st == 0 and info["iterations"] == 50 and info["n_target_filtered"] > 900_000
+    assert dt < 2e-3 and dr < 3e-4, (dt, dr)
+    assert np.array_equal(T, T2) and info == info2
