@@ -472,8 +472,11 @@ __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ 
 // emits the neighbours' moments (9 doubles); the eigen-solve runs in its own kernel: keeping the
 // Jacobi iteration's registers out of the latency-bound search doubles its occupancy.
 // Slot -> XCD affinity as in nn_block_map: blocks of one cloud share one L2.
+#ifndef S3D_KNN_WAVES
+#define S3D_KNN_WAVES 5
+#endif
 template <int KMAX>
-__global__ void __launch_bounds__(kBlock) s3d_knn_moments_kernel(const SlotDev* __restrict__ slots,
+__global__ void __launch_bounds__(kBlock, S3D_KNN_WAVES) s3d_knn_moments_kernel(const SlotDev* __restrict__ slots,
                                                                   const float4* __restrict__ filt,
                                                                   const float4* __restrict__ sorted,
                                                                   const uint32_t* __restrict__ cell_start,
