@@ -114,19 +114,30 @@ struct s3d_context {
   hipEvent_t ev[8] = {};
   std::vector<hipEvent_t> nn_ev;
 
-  void ensure(DevBuf& b, size_t bytes) {
-    if (bytes <= b.cap) return;
-    if (b.p) HIPCHK(hipFree(b.p));
-    b.p = nullptr; b.cap = 0;
-    size_t want = bytes + bytes / 8 + 256;
-    HIPCHK(hipMalloc(&b.p, want));
-    b.cap = want;
+  // ONE device allocation for the whole workspace, carved at 2 MiB boundaries: a few hundred MB per
+  // array in separate hipMallocs left some processes with 3x slower streaming kernels on this pool
+  // (fragmented page mappings); one large arena gets the driver's largest fragments.
+  DevBuf arena;
+  void carve(std::initializer_list<std::pair<DevBuf*, size_t>> reqs) {
+    const size_t gran = (size_t)2 << 20;
+    size_t total = 0;
+    for (auto& r : reqs) total += (r.second + gran - 1) / gran * gran;
+    if (total > arena.cap) {
+      if (arena.p) HIPCHK(hipFree(arena.p));
+      arena.p = nullptr; arena.cap = 0;
+      const size_t want = total + total / 8;
+      HIPCHK(hipMalloc(&arena.p, want));
+      arena.cap = want;
+    }
+    size_t off = 0;
+    for (auto& r : reqs) {
+      r.first->p = (char*)arena.p + off;
+      r.first->cap = r.second;
+      off += (r.second + gran - 1) / gran * gran;
+    }
   }
   void release_all() {
-    DevBuf* all[] = {&slots, &pairs, &keysA, &keysB, &valsA, &valsB, &filt, &sorted, &normals, &moments, &cell_start,
-                     &counts, &blockcnt, &corr_idx, &corr_d2, &corr_lb, &corr_q, &corr_n, &partials, &n_active};
-    for (DevBuf* b : all)
-      if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    if (arena.p) { (void)hipFree(arena.p); arena.p = nullptr; arena.cap = 0; }
   }
 };
 
@@ -231,22 +242,18 @@ struct Batch {
     accum_blocks = std::min(kAccumBlocks, std::max(1, cdiv(max_n_t, kBlock * 8)));
     accum_blocks = std::min(accum_blocks, std::max(4, cdiv(1024, std::max(1, P()))));
     const size_t np = std::max<size_t>(total_pts, 4);
-    ctx->ensure(ctx->slots, sizeof(SlotDev) * std::max(1, C()));
-    ctx->ensure(ctx->pairs, sizeof(PairDev) * std::max(1, P()));
-    ctx->ensure(ctx->keysA, 4 * np); ctx->ensure(ctx->keysB, 4 * np);
-    ctx->ensure(ctx->valsA, 4 * np); ctx->ensure(ctx->valsB, 4 * np);
-    ctx->ensure(ctx->filt, 16 * np); ctx->ensure(ctx->sorted, 16 * np); ctx->ensure(ctx->normals, 16 * np);
-    ctx->ensure(ctx->moments, 80 * np);
-    ctx->ensure(ctx->cell_start, 4 * std::max<size_t>(total_cells, 4));
-    ctx->ensure(ctx->counts, 4 * (size_t)std::max(1, C()) * 256 * nb_sort);
-    ctx->ensure(ctx->blockcnt, 4 * (size_t)std::max(1, C()) * nb_head);
-    ctx->ensure(ctx->corr_idx, 4 * std::max<size_t>(total_corr, 4));
-    ctx->ensure(ctx->corr_d2, 4 * std::max<size_t>(total_corr, 4));
-    ctx->ensure(ctx->corr_lb, 4 * std::max<size_t>(total_corr, 4));
-    ctx->ensure(ctx->corr_q, 16 * std::max<size_t>(total_corr, 4));
-    ctx->ensure(ctx->corr_n, 16 * std::max<size_t>(total_corr, 4));
-    ctx->ensure(ctx->partials, 8 * (size_t)std::max(1, P()) * kAccumBlocks * GQ_NACC);
-    ctx->ensure(ctx->n_active, 64);
+    const size_t nc = std::max<size_t>(total_corr, 4);
+    ctx->carve({{&ctx->slots, sizeof(SlotDev) * std::max(1, C())},
+                {&ctx->pairs, sizeof(PairDev) * std::max(1, P())},
+                {&ctx->keysA, 4 * np}, {&ctx->keysB, 4 * np}, {&ctx->valsA, 4 * np}, {&ctx->valsB, 4 * np},
+                {&ctx->filt, 16 * np}, {&ctx->sorted, 16 * np}, {&ctx->normals, 16 * np}, {&ctx->moments, 80 * np},
+                {&ctx->cell_start, 4 * std::max<size_t>(total_cells, 4)},
+                {&ctx->counts, 4 * (size_t)std::max(1, C()) * 256 * nb_sort},
+                {&ctx->blockcnt, 4 * (size_t)std::max(1, C()) * nb_head},
+                {&ctx->corr_idx, 4 * nc}, {&ctx->corr_d2, 4 * nc}, {&ctx->corr_lb, 4 * nc},
+                {&ctx->corr_q, 16 * nc}, {&ctx->corr_n, 16 * nc},
+                {&ctx->partials, 8 * (size_t)std::max(1, P()) * kAccumBlocks * GQ_NACC},
+                {&ctx->n_active, 64}});
     if (!ctx->h_active) HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
     hipStream_t st = ctx->stream;
     if (C()) HIPCHK(hipMemcpyAsync(ctx->slots.p, h_slots.data(), sizeof(SlotDev) * C(), hipMemcpyHostToDevice, st));
