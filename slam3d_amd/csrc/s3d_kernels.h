@@ -254,53 +254,77 @@ __global__ void __launch_bounds__(kBlock) k_sort_scan(const SlotDev* __restrict_
   }
 }
 
+// Stable scatter of one 1024-element tile.  Every wave owns a CONTIGUOUS quarter of the tile (4 rounds
+// of 64 elements), so the output order (wave, round, lane) is the input order and the per-digit ranks
+// can be accumulated per wave without a block barrier per round: lanes holding the same digit find
+// each other with 8 ballots, the first of them bumps the wave's private LDS counter.  Two block
+// barriers in all (the first version needed twelve).
 __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restrict__ slots,
                                                           const uint32_t* __restrict__ keys_in,
                                                           const uint32_t* __restrict__ vals_in,
                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                           const uint32_t* __restrict__ counts, int shift, int nb_max) {
-  __shared__ unsigned int digit_base[256];
-  __shared__ unsigned int wave_cnt[kBlock / kWave][256];
+  __shared__ unsigned int wave_cnt[kBlock / kWave][256];   // per wave: elements of each digit seen so far
   const SlotDev& s = slots[blockIdx.y];
   const int n = s.n_sort;
   const int nb = (n + kSortTile - 1) / kSortTile;
   if ((int)blockIdx.x >= nb) return;
-  digit_base[threadIdx.x] = counts[((size_t)blockIdx.y * 256 + threadIdx.x) * nb_max + blockIdx.x];
-#pragma unroll
-  for (int w = 0; w < kBlock / kWave; ++w) wave_cnt[w][threadIdx.x] = 0;
-  __syncthreads();
   const int lane = lane_id(), w = wave_id();
-  const int base = blockIdx.x * kSortTile;
-  for (int r = 0; r < kSortTile / kBlock; ++r) {
-    const int i = base + r * kBlock + threadIdx.x;
+  constexpr int kRounds = kSortTile / kBlock;               // 4
+#pragma unroll
+  for (int ww = 0; ww < kBlock / kWave; ++ww) wave_cnt[ww][threadIdx.x] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * kSortTile + w * (kSortTile / (kBlock / kWave));
+  uint32_t key[kRounds], val[kRounds];
+  unsigned int rank[kRounds];
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {                       // all loads up front (independent)
+    const int i = base + r * kWave + lane;
+    key[r] = 0; val[r] = 0;
+    if (i < n) { key[r] = keys_in[s.off + i]; val[r] = vals_in[s.off + i]; }
+  }
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int i = base + r * kWave + lane;
     const bool act = i < n;
-    uint32_t key = 0, val = 0;
-    if (act) { key = keys_in[s.off + i]; val = vals_in[s.off + i]; }
-    const unsigned int d = (key >> shift) & 255u;
-    // lanes of this wave holding the same digit
+    const unsigned int d = (key[r] >> shift) & 255u;
     unsigned long long peers = __ballot(act);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
       const unsigned long long m = __ballot(act && ((d >> b) & 1u));
       peers &= ((d >> b) & 1u) ? m : ~m;
     }
-    const int rank = __popcll(peers & ((1ull << lane) - 1ull));
-    if (act && rank == 0) wave_cnt[w][d] = (unsigned int)__popcll(peers);
-    __syncthreads();
-    if (act) {
-      unsigned int pos = digit_base[d] + (unsigned int)rank;
-      for (int ww = 0; ww < w; ++ww) pos += wave_cnt[ww][d];
-      keys_out[s.off + pos] = key;
-      vals_out[s.off + pos] = val;
-    }
-    __syncthreads();
-    {
-      unsigned int add = 0;
+    const int in_round = __popcll(peers & ((1ull << lane) - 1ull));
+    unsigned int before = 0;
+    if (act) before = wave_cnt[w][d];                       // same value for all peers
+    __builtin_amdgcn_wave_barrier();
+    if (act && in_round == 0) wave_cnt[w][d] = before + (unsigned int)__popcll(peers);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    rank[r] = before + (unsigned int)in_round;
+  }
+  __syncthreads();
+  // exclusive prefix over the waves for digit = threadIdx.x, on top of the block's global offset
+  {
+    unsigned int run = counts[((size_t)blockIdx.y * 256 + threadIdx.x) * nb_max + blockIdx.x];
 #pragma unroll
-      for (int ww = 0; ww < kBlock / kWave; ++ww) { add += wave_cnt[ww][threadIdx.x]; wave_cnt[ww][threadIdx.x] = 0; }
-      digit_base[threadIdx.x] += add;
+    for (int ww = 0; ww < kBlock / kWave; ++ww) {
+      const unsigned int c = wave_cnt[ww][threadIdx.x];
+      wave_cnt[ww][threadIdx.x] = run;
+      run += c;
     }
-    __syncthreads();
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int i = base + r * kWave + lane;
+    if (i < n) {
+      const unsigned int d = (key[r] >> shift) & 255u;
+      const unsigned int pos = wave_cnt[w][d] + rank[r];
+      keys_out[s.off + pos] = key[r];
+      vals_out[s.off + pos] = val[r];
+    }
   }
 }
 
