@@ -786,28 +786,78 @@ S3D_HD void gicp_apply_state(const double x[6], Mat4f& T) {
   S3D_M(T, 2, 3) = (float)x[2];
 }
 
+// sin and cos of an Euler angle of the BFGS state.  The state is a correction about the current
+// transform, so |x| is far below pi/4 in every evaluation that matters: there the fdlibm kernel
+// polynomials (|error| < 1 ulp on [-pi/4, pi/4], no argument reduction) replace the library calls,
+// which are ~10x longer dependent chains for the single wave that runs the optimiser.
+S3D_HD void gq_sincos(double x, double* s, double* c) {
+  if (fabs(x) > 0.78) { *s = sin(x); *c = cos(x); return; }
+  const double z = x * x;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                               2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                             8.33333333332248946124e-03), -1.66666666666666324348e-01);
+  *s = fma(x * z, ps, x);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                               -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                             -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  *c = fma(z * z, pc, fma(z, -0.5, 1.0));
+}
+
 // f(x) and gradient from the quadratic form (PCL OptimizationFunctorWithIndices::fdf)
-// Th0: the expansion point used by gq_accumulate (3x4 row-major)
+// Th0: the expansion point used by gq_accumulate (3x4 row-major).
+// On the GPU this is called by ALL 64 lanes of the controller's wave with identical arguments (the
+// BFGS around it runs redundantly on every lane, so control flow stays uniform): the three sincos and
+// the twelve 12-term dot products of G are then spread over the lanes and exchanged by shuffles,
+// which makes one evaluation ~3x shorter than the scalar form the CPU emulation uses.
 S3D_HD void gq_eval(const double* acc, const double* Th0, const double x[6], double* f, double g[6]) {
+  double cphi, sphi, cth, sth, cpsi, spsi;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int wl = (int)(threadIdx.x & 63);
+  {
+    const int j = wl % 3;
+    const double ang = j == 0 ? x[3] : (j == 1 ? x[4] : x[5]);
+    double sv, cv;
+    gq_sincos(ang, &sv, &cv);
+    sphi = __shfl(sv, 0, 64); cphi = __shfl(cv, 0, 64);
+    sth = __shfl(sv, 1, 64);  cth = __shfl(cv, 1, 64);
+    spsi = __shfl(sv, 2, 64); cpsi = __shfl(cv, 2, 64);
+  }
+#else
+  gq_sincos(x[3], &sphi, &cphi); gq_sincos(x[4], &sth, &cth); gq_sincos(x[5], &spsi, &cpsi);
+#endif
   // Theta = [Rz(x5) Ry(x4) Rx(x3) | x0..2] carried in DOUBLE.  PCL's applyState rounds
   // Theta to float before every evaluation, which turns f(x) into a 1e-7-level staircase
   // and makes the line search terminate on rounding noise ("conditioning");
   // the float rounding is applied once per outer iteration instead (gicp_apply_state),
   // where PCL stores transformation_ as Matrix4f.
   double Th[3][4];
-  const double cphi = cos(x[3]), sphi = sin(x[3]), cth = cos(x[4]), sth = sin(x[4]);
-  const double cpsi = cos(x[5]), spsi = sin(x[5]);
-  {
-    Th[0][0] = cpsi * cth; Th[0][1] = cpsi * sth * sphi - spsi * cphi; Th[0][2] = cpsi * sth * cphi + spsi * sphi;
-    Th[1][0] = spsi * cth; Th[1][1] = spsi * sth * sphi + cpsi * cphi; Th[1][2] = spsi * sth * cphi - cpsi * sphi;
-    Th[2][0] = -sth; Th[2][1] = cth * sphi; Th[2][2] = cth * cphi;
-    Th[0][3] = x[0]; Th[1][3] = x[1]; Th[2][3] = x[2];
-    for (int c = 0; c < 3; ++c)
-      for (int a = 0; a < 4; ++a) Th[c][a] -= Th0[c * 4 + a];  // dTheta about the expansion point
-  }
+  Th[0][0] = cpsi * cth; Th[0][1] = cpsi * sth * sphi - spsi * cphi; Th[0][2] = cpsi * sth * cphi + spsi * sphi;
+  Th[1][0] = spsi * cth; Th[1][1] = spsi * sth * sphi + cpsi * cphi; Th[1][2] = spsi * sth * cphi - cpsi * sphi;
+  Th[2][0] = -sth; Th[2][1] = cth * sphi; Th[2][2] = cth * cphi;
+  Th[0][3] = x[0]; Th[1][3] = x[1]; Th[2][3] = x[2];
+  for (int c = 0; c < 3; ++c)
+    for (int a = 0; a < 4; ++a) Th[c][a] -= Th0[c * 4 + a];  // dTheta about the expansion point
   // G[a][c] = sum_{d,b} Th[d][b] A[ab][cd] - B[c][a]   ( = sum_i P_a (M res_i)_c )
   double G[4][3];
-  double fsum = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  {
+    const int l12 = wl < 12 ? wl : 0, a = l12 / 3, c = l12 % 3;
+    double sgc = 0.0;
+    for (int b = 0; b < 4; ++b) {
+      const int pr = a <= b ? gq_pair(a, b) : gq_pair(b, a);
+      for (int d = 0; d < 3; ++d) {
+        const int sm = c <= d ? gq_sym(c, d) : gq_sym(d, c);
+        // Th[d][b] with lane-dependent (d, b) only through the loop counters: static indices
+        sgc = fma(Th[d][b], acc[pr * 6 + sm], sgc);
+      }
+    }
+    sgc -= acc[GQ_B + c * 4 + a];
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) G[aa][cc] = __shfl(sgc, aa * 3 + cc, 64);
+  }
+#else
   for (int a = 0; a < 4; ++a)
     for (int c = 0; c < 3; ++c) {
       double s = 0.0;
@@ -818,10 +868,12 @@ S3D_HD void gq_eval(const double* acc, const double* Th0, const double x[6], dou
           s = fma(Th[d][b], acc[pr * 6 + sm], s);
         }
       }
-      const double Bca = acc[GQ_B + c * 4 + a];
-      G[a][c] = s - Bca;
-      fsum += Th[c][a] * (G[a][c] - Bca);
+      G[a][c] = s - acc[GQ_B + c * 4 + a];
     }
+#endif
+  double fsum = 0.0;
+  for (int a = 0; a < 4; ++a)
+    for (int c = 0; c < 3; ++c) fsum += Th[c][a] * (G[a][c] - acc[GQ_B + c * 4 + a]);
   const double m = acc[GQ_CNT];
   *f = (fsum + acc[GQ_C0]) / m;
   const double sc = 2.0 / m;

@@ -234,7 +234,13 @@ __global__ void __launch_bounds__(kBlock) k_sort_scan(const SlotDev* __restrict_
   const int nb = (s.n_sort + kSortTile - 1) / kSortTile;
   uint32_t* c = counts + ((size_t)blockIdx.x * 256 + threadIdx.x) * nb_max;
   unsigned int sum = 0;
-  for (int b = 0; b < nb; ++b) sum += c[b];
+  for (int b0 = 0; b0 < nb; b0 += 8) {   // 8 loads in flight: the loop is pure latency for a lone slot
+    unsigned int t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = (b0 + j < nb) ? c[b0 + j] : 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += t[j];
+  }
   tot[threadIdx.x] = sum;
   __syncthreads();
   // exclusive scan over the 256 digit totals (Hillis-Steele, 8 steps)
@@ -247,10 +253,15 @@ __global__ void __launch_bounds__(kBlock) k_sort_scan(const SlotDev* __restrict_
     __syncthreads();
   }
   unsigned int run = v - sum;
-  for (int b = 0; b < nb; ++b) {
-    const unsigned int t = c[b];
-    c[b] = run;
-    run += t;
+  for (int b0 = 0; b0 < nb; b0 += 8) {
+    unsigned int t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = (b0 + j < nb) ? c[b0 + j] : 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (b0 + j < nb) c[b0 + j] = run;
+      run += t[j];
+    }
   }
 }
 
@@ -957,17 +968,25 @@ __global__ void __launch_bounds__(128) s3d_icp_control_kernel(PairDev* pairs, co
     acc[threadIdx.x] = v;
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
+  // Wave 0 runs the optimiser redundantly on all 64 lanes (identical inputs -> identical, uniform
+  // control flow) so that gq_eval can spread its transcendental and dot-product work over the lanes;
+  // lane 0 alone writes the pair state back.
+  if (threadIdx.x >= kWave) return;
+  const bool writer = threadIdx.x == 0;
   Mat4f T = P.T;
   const Mat4f prev = T;
-  int rc, inner = 0, evals = 0;
+  const int it = P.iterations + 1;
+  int rc, inner = 0, evals = 0, corr;
   if (gicp) {
-    P.correspondences = (int)acc[GQ_CNT];
+    corr = (int)acc[GQ_CNT];
     rc = gicp_estimate_bfgs(acc, rp.max_inner, T, &inner, &evals);
   } else {
-    P.correspondences = (int)acc[PP_CNT];
+    corr = (int)acc[PP_CNT];
     rc = pp_update(acc, T);
   }
+  const double delta = rc ? 0.0 : icp_delta(prev, T, rp.rotation_epsilon, rp.transformation_epsilon);
+  if (!writer) return;
+  P.correspondences = corr;
   P.prev = prev;
   P.T_nn = prev;
   if (rc) {  // PCLException path: loop breaks, converged_ stays false
@@ -977,8 +996,7 @@ __global__ void __launch_bounds__(128) s3d_icp_control_kernel(PairDev* pairs, co
   }
   P.inner_total += inner; P.evals_total += evals;
   P.T = T;
-  const double delta = icp_delta(prev, T, rp.rotation_epsilon, rp.transformation_epsilon);
-  const int it = ++P.iterations;
+  P.iterations = it;
   if (it >= rp.max_iterations || (!rp.force_iterations && delta < 1.0)) {
     P.converged = 1; P.active = 0; P.prev = T;
     atomicSub(n_active, 1);
