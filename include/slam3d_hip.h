@@ -114,6 +114,50 @@ int  s3d_create_constraint(s3d_context* ctx, const float* source_xyz, int n_sour
                            double covariance_scale, const s3d_exec_options* opts, double relative_pose[16],
                            double information[36], s3d_align_info* info);
 
+/* ==== the callers either side of the registration path ===================== */
+
+/* copy a device-resident cloud back to the host: n * stride floats, xyz first (stride 4: w = 1) */
+int  s3d_cloud_download(s3d_context* ctx, const s3d_cloud* c, float* xyz, int stride);
+
+/* ---- B1  PointCloudSensor::getAccumulatedCloud (PointCloudSensor.cpp:235-256): every cloud transformed by
+ *          its pose (correctedPose * sensorPose, formed by the caller; PointCloudSensor::transform, :228-233 =
+ *          pcl::transformPointCloud with a Matrix4d) and appended in list order.  frame != NULL adds
+ *          createCombinedMeasurement (:258-266): the accumulated cloud shifted by frame.inverse().  The result
+ *          stays in HBM and is a valid source/target for s3d_align_batch / s3d_create_constraint_clouds, so a
+ *          loop-closure patch (ScanSensor.cpp:150-151) never visits the host.
+ *          poses: 16 * n_clouds doubles, column-major.  *out is owned by the caller (s3d_cloud_release). */
+int  s3d_cloud_accumulate(s3d_context* ctx, int n_clouds, s3d_cloud* const* clouds, const double* poses,
+                          const double frame[16], s3d_cloud** out);
+
+/* ---- A1 on device-resident clouds (patches built by s3d_cloud_accumulate): same contract as
+ *          s3d_create_constraint. */
+int  s3d_create_constraint_clouds(s3d_context* ctx, s3d_cloud* source, const double source_sensor_pose[16],
+                                  s3d_cloud* target, const double target_sensor_pose[16], const double odometry[16],
+                                  int loop, const s3d_reg_params* fine, const s3d_reg_params* coarse,
+                                  double covariance_scale, const s3d_exec_options* opts, double relative_pose[16],
+                                  double information[36], s3d_align_info* info);
+
+/* ---- B2  PointCloudSensor::removeOutliers (:211-226, pcl::RadiusOutlierRemoval): keeps, in input order, the
+ *          points with at least min_neighbors OTHER points within `radius` (float d2 <= r*r as PCL compares
+ *          it).  radius <= 0 or min_neighbors == 0: the input comes back unchanged (:214).
+ *          out_xyz: capacity 3*n floats (packed). */
+int  s3d_remove_outliers(s3d_context* ctx, const float* xyz, int n, int stride, double radius, unsigned min_neighbors,
+                         float* out_xyz, int* n_out);
+int  s3d_remove_outliers_cloud(s3d_context* ctx, const s3d_cloud* in, double radius, unsigned min_neighbors,
+                               s3d_cloud** out);
+/* A3 on a device-resident cloud */
+int  s3d_voxel_downsample_cloud(s3d_context* ctx, const s3d_cloud* in, double leaf_size, s3d_cloud** out);
+
+/* ---- B3  PointCloudSensor::buildMap (:301-318): accumulate, removeOutliers(outlier_radius,
+ *          outlier_neighbors), downsample(map_resolution) — all in HBM; *out_map is device-resident. */
+typedef struct s3d_map_profile {   /* milliseconds, HIP events; counts of points between the stages */
+  double accumulate_ms, grid_ms, count_ms, compact_ms, voxel_ms, total_ms;
+  long long n_accumulated, n_kept, n_map;
+} s3d_map_profile;
+int  s3d_build_map(s3d_context* ctx, int n_clouds, s3d_cloud* const* clouds, const double* poses,
+                   double outlier_radius, unsigned outlier_neighbors, double map_resolution, s3d_cloud** out_map);
+int  s3d_last_map_profile(const s3d_context* ctx, s3d_map_profile* out);
+
 /* ---- measurement hook (bench.py roofline): time `reps` launches of the NN-search kernel
  *          as a FIRST correspondence pass (transformation_ = I, no radius hints, no re-validation
  *          of earlier correspondences — the most expensive pass of a registration) with HIP events

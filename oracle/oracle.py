@@ -93,6 +93,14 @@ def lib():
                                             C.POINTER(RegParams), C.POINTER(RegParams), C.c_double, dp, dp,
                                             C.POINTER(AlignInfo)]
         L.s3o_default_params.argtypes = [C.POINTER(RegParams)]
+        fpp = C.POINTER(fp)
+        L.s3o_transform_cloud.argtypes = [fp, C.c_int, C.c_int, dp, fp]
+        L.s3o_accumulate_clouds.restype = C.c_int
+        L.s3o_accumulate_clouds.argtypes = [fpp, ip, ip, C.c_int, dp, dp, fp]
+        L.s3o_remove_outliers.restype = C.c_int
+        L.s3o_remove_outliers.argtypes = [fp, C.c_int, C.c_int, C.c_double, C.c_uint, fp]
+        L.s3o_build_map.restype = C.c_int
+        L.s3o_build_map.argtypes = [fpp, ip, ip, C.c_int, dp, C.c_double, C.c_uint, C.c_double, fp]
         L.s3o_sym_eig3.argtypes = [dp, dp, dp]
         L.s3o_rotation_angle.restype = C.c_double
         L.s3o_rotation_angle.argtypes = [dp]
@@ -243,6 +251,51 @@ def create_constraint(source, source_pose, target, target_pose, odometry, loop=F
                                          int(loop), C.byref(fine), C.byref(coarse), float(covariance_scale),
                                          _dptr(rel), _dptr(inf), C.byref(info))
     return status, from_colmajor(rel), inf.reshape(6, 6), {k: getattr(info, k) for k, _ in AlignInfo._fields_}
+
+
+def transform_cloud(xyz, T):
+    """PointCloudSensor::transform (PointCloudSensor.cpp:228-233)."""
+    a, n, stride = _cloud(xyz)
+    out = np.empty((n, 3), np.float32)
+    tf = colmajor(T)
+    lib().s3o_transform_cloud(_fptr(a), n, stride, _dptr(tf), _fptr(out))
+    return out
+
+
+def _cloud_list(clouds, poses):
+    arrs = [_cloud(c) for c in clouds]
+    ptrs = (C.POINTER(C.c_float) * len(arrs))(*[_fptr(a[0]) for a in arrs])
+    sizes = np.array([a[1] for a in arrs], np.int32)
+    strides = np.array([a[2] for a in arrs], np.int32)
+    P = np.ascontiguousarray(np.concatenate([colmajor(T) for T in poses])) if len(arrs) else np.zeros(16)
+    return arrs, ptrs, sizes, strides, P
+
+
+def accumulate_clouds(clouds, poses, frame=None):
+    """getAccumulatedCloud (:235-256); with `frame`, createCombinedMeasurement (:258-266)."""
+    arrs, ptrs, sizes, strides, P = _cloud_list(clouds, poses)
+    out = np.empty((max(int(sizes.sum()), 1), 3), np.float32)
+    fr = colmajor(frame) if frame is not None else None
+    n = lib().s3o_accumulate_clouds(ptrs, _iptr(sizes), _iptr(strides), len(arrs), _dptr(P),
+                                    _dptr(fr) if fr is not None else None, _fptr(out))
+    return out[:n].copy()
+
+
+def remove_outliers(xyz, radius, min_neighbors):
+    """removeOutliers (:211-226), pcl::RadiusOutlierRemoval."""
+    a, n, stride = _cloud(xyz)
+    out = np.empty((max(n, 1), 3), np.float32)
+    m = lib().s3o_remove_outliers(_fptr(a), n, stride, float(radius), int(min_neighbors), _fptr(out))
+    return out[:m].copy()
+
+
+def build_map(clouds, poses, outlier_radius=0.2, outlier_neighbors=3, map_resolution=0.1):
+    """buildMap (:301-318) with the constructor defaults of PointCloudSensor.cpp:176-183."""
+    arrs, ptrs, sizes, strides, P = _cloud_list(clouds, poses)
+    out = np.empty((max(int(sizes.sum()), 1), 3), np.float32)
+    n = lib().s3o_build_map(ptrs, _iptr(sizes), _iptr(strides), len(arrs), _dptr(P), float(outlier_radius),
+                            int(outlier_neighbors), float(map_resolution), _fptr(out))
+    return out[:n].copy()
 
 
 def set_eval_precision(mode):

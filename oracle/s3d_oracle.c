@@ -1266,3 +1266,94 @@ int s3o_create_constraint(const float* source, int n_source, int stride_source, 
   for (int i = 0; i < 6; ++i) information[i * 6 + i] = 1.0 / covariance_scale; /* :296-298 (I*scale)^-1 */
   return S3D_STATUS_OK;
 }
+
+/* ------------------------------------------------------------------ patch accumulation (B1) and map building (B2, B3)
+ * the callers either side of the registration path. */
+
+/* PointCloudSensor::transform (PCS.cpp:228-233) = pcl::transformPointCloud(in, out, tf.matrix()) with a
+ * Matrix4d: pcl::detail::Transformer<double>::se3, carried in double and rounded to float once per
+ * coordinate.  Summation order of the SSE2/AVX specialisation PCL compiles on x86-64:
+ * (x*c0 + y*c1) + (z*c2 + c3).  tf: 4x4 column-major. */
+void s3o_transform_cloud(const float* xyz, int n, int stride, const double tf[16], float* out) {
+  for (int i = 0; i < n; ++i) {
+    const float* p = xyz + (size_t)i * stride;
+    const double x = p[0], y = p[1], z = p[2];
+    for (int r = 0; r < 3; ++r)
+      out[(size_t)i * 3 + r] = (float)((x * tf[0 * 4 + r] + y * tf[1 * 4 + r]) + (z * tf[2 * 4 + r] + tf[3 * 4 + r]));
+  }
+}
+
+/* getAccumulatedCloud (PCS.cpp:235-256): every cloud transformed by its pose (= correctedPose * sensorPose,
+ * formed by the caller) and appended; the reference appends in OpenMP completion order, restated here in
+ * vertex order (the single-thread order).  frame != NULL adds createCombinedMeasurement (PCS.cpp:258-266):
+ * the accumulated cloud — already rounded to float — transformed again by frame.inverse().
+ * out: capacity 3 * sum(sizes).  Returns the number of points. */
+int s3o_accumulate_clouds(const float* const* clouds, const int* sizes, const int* strides, int n_clouds,
+                          const double* poses, const double* frame, float* out) {
+  size_t off = 0;
+  for (int c = 0; c < n_clouds; ++c) {
+    s3o_transform_cloud(clouds[c], sizes[c], strides[c], poses + (size_t)c * 16, out + off * 3);
+    off += (size_t)sizes[c];
+  }
+  if (frame) {
+    double inv[16];
+    s3o_mat4d_inverse_isometry(frame, inv);
+    s3o_transform_cloud(out, (int)off, 3, inv, out);
+  }
+  return (int)off;
+}
+
+/* removeOutliers (PCS.cpp:211-226) -> pcl::RadiusOutlierRemoval::applyFilterIndices, dense-cloud branch
+ * (PCL 1.12 radius_outlier_removal.hpp): k = min_neighbors + 1 nearest neighbours of the point (the point
+ * itself included, FLANN float distances); the point stays iff all k exist and r*r >= d2[k-1].
+ * radius <= 0 or min_neighbors == 0 or an empty cloud: the input is returned unchanged (:214).
+ * out: capacity 3*n.  Returns the number of points kept, in input order. */
+int s3o_remove_outliers(const float* xyz, int n, int stride, double radius, unsigned min_neighbors, float* out) {
+  if (n <= 0) return 0;
+  float* packed = (float*)malloc(sizeof(float) * 3 * (size_t)n);
+  for (int i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a) packed[(size_t)i * 3 + a] = xyz[(size_t)i * stride + a];
+  if (!(radius > 0) || min_neighbors == 0) {
+    memcpy(out, packed, sizeof(float) * 3 * (size_t)n);
+    free(packed);
+    return n;
+  }
+  const int mean_k = (int)min_neighbors + 1;
+  const double nn_dists_max = radius * radius;
+  s3o_kdtree* t = s3o_kdtree_build(packed, n);
+  int* idx = (int*)malloc(sizeof(int) * (size_t)mean_k);
+  float* d2 = (float*)malloc(sizeof(float) * (size_t)mean_k);
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    const int k = s3o_kdtree_knn(t, packed + (size_t)i * 3, mean_k, idx, d2);
+    int keep = 1;
+    if (k == mean_k) {
+      if (nn_dists_max < (double)d2[k - 1]) keep = 0;
+    } else {
+      keep = 0;
+    }
+    if (!keep) continue;
+    for (int a = 0; a < 3; ++a) out[(size_t)m * 3 + a] = packed[(size_t)i * 3 + a];
+    ++m;
+  }
+  free(idx); free(d2);
+  s3o_kdtree_free(t);
+  free(packed);
+  return m;
+}
+
+/* buildMap (PCS.cpp:301-318): accumulate, removeOutliers(mMapOutlierRadius, mMapOutlierNeighbors),
+ * downsample(mMapResolution).  out: capacity 3 * sum(sizes). */
+int s3o_build_map(const float* const* clouds, const int* sizes, const int* strides, int n_clouds, const double* poses,
+                  double outlier_radius, unsigned outlier_neighbors, double map_resolution, float* out) {
+  size_t total = 0;
+  for (int c = 0; c < n_clouds; ++c) total += (size_t)sizes[c];
+  if (total == 0) return 0;
+  float* accu = (float*)malloc(sizeof(float) * 3 * total);
+  float* kept = (float*)malloc(sizeof(float) * 3 * total);
+  const int n = s3o_accumulate_clouds(clouds, sizes, strides, n_clouds, poses, NULL, accu);
+  const int m = s3o_remove_outliers(accu, n, 3, outlier_radius, outlier_neighbors, kept);
+  const int r = s3o_voxel_downsample(kept, m, 3, map_resolution, out, NULL);
+  free(accu); free(kept);
+  return r;
+}

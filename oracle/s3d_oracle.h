@@ -103,6 +103,17 @@ int s3o_create_constraint(const float* source, int n_source, int stride_source, 
                           double covariance_scale,
                           double relative_pose[16], double information[36], s3o_align_info* info);
 
+/* ---- B1: PointCloudSensor::transform (PointCloudSensor.cpp:228-233),
+ * getAccumulatedCloud (:235-256), createCombinedMeasurement (:258-266).
+ * tf / poses / frame: 4x4 double column-major.  out: packed xyz. */
+void s3o_transform_cloud(const float* xyz, int n, int stride, const double tf[16], float* out);
+int  s3o_accumulate_clouds(const float* const* clouds, const int* sizes, const int* strides, int n_clouds,
+                           const double* poses, const double* frame /* NULL: no re-framing */, float* out);
+/* ---- B2 (rank 2): removeOutliers (:211-226) -> pcl::RadiusOutlierRemoval; B3: buildMap (:301-318) */
+int  s3o_remove_outliers(const float* xyz, int n, int stride, double radius, unsigned min_neighbors, float* out);
+int  s3o_build_map(const float* const* clouds, const int* sizes, const int* strides, int n_clouds, const double* poses,
+                   double outlier_radius, unsigned outlier_neighbors, double map_resolution, float* out);
+
 /* ---- variants / diagnostics (process-global; defaults = PCL-literal behaviour)
  * eval_precision 0: the BFGS functor transforms points with a float 4x4 in float, as PCL does
  *                   (f(x) is then piecewise constant at the 1e-7 level: "float staircase");

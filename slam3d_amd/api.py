@@ -60,6 +60,15 @@ class Profile(C.Structure):
         return d
 
 
+class MapProfile(C.Structure):
+    _fields_ = [("accumulate_ms", C.c_double), ("grid_ms", C.c_double), ("count_ms", C.c_double),
+                ("compact_ms", C.c_double), ("voxel_ms", C.c_double), ("total_ms", C.c_double),
+                ("n_accumulated", C.c_longlong), ("n_kept", C.c_longlong), ("n_map", C.c_longlong)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 def lib_path():
     return _LIB
 
@@ -108,6 +117,15 @@ def load_library():
                                       C.POINTER(AlignInfo)]),
         "s3d_create_constraint": (C.c_int, [vp, fp, C.c_int, C.c_int, dp, fp, C.c_int, C.c_int, dp, dp, C.c_int, pp, pp,
                                             C.c_double, op, dp, dp, C.POINTER(AlignInfo)]),
+        "s3d_cloud_download": (C.c_int, [vp, vp, fp, C.c_int]),
+        "s3d_cloud_accumulate": (C.c_int, [vp, C.c_int, C.POINTER(vp), dp, dp, C.POINTER(vp)]),
+        "s3d_create_constraint_clouds": (C.c_int, [vp, vp, dp, vp, dp, dp, C.c_int, pp, pp, C.c_double, op, dp, dp,
+                                                   C.POINTER(AlignInfo)]),
+        "s3d_remove_outliers": (C.c_int, [vp, fp, C.c_int, C.c_int, C.c_double, C.c_uint, fp, ip]),
+        "s3d_remove_outliers_cloud": (C.c_int, [vp, vp, C.c_double, C.c_uint, C.POINTER(vp)]),
+        "s3d_voxel_downsample_cloud": (C.c_int, [vp, vp, C.c_double, C.POINTER(vp)]),
+        "s3d_build_map": (C.c_int, [vp, C.c_int, C.POINTER(vp), dp, C.c_double, C.c_uint, C.c_double, C.POINTER(vp)]),
+        "s3d_last_map_profile": (C.c_int, [vp, C.POINTER(MapProfile)]),
         "s3d_profile_nn_kernel": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, pp, C.c_int, dp,
                                             C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     }
@@ -167,6 +185,10 @@ class Cloud:
 
     def __init__(self, ctx, handle, n):
         self.ctx, self.handle, self.n = ctx, handle, n
+
+    def download(self):
+        """(n, 3) float32 copy of the device-resident points."""
+        return self.ctx.download(self)
 
     def release(self):
         if self.handle:
@@ -321,6 +343,86 @@ class Context:
         if st:
             raise ValueError(STATUS_NAMES[st])
         return dict(avg_ms=ms.value, n_queries=nq.value, n_targets=nt.value)
+
+    # ---- patches and maps, device-resident -----------------------
+    def _new_cloud(self, h):
+        return Cloud(self, h, int(self._L.s3d_cloud_size(h)))
+
+    def _poses(self, poses):
+        P = np.asarray(poses, np.float64).reshape(-1, 4, 4)
+        return np.ascontiguousarray(P.transpose(0, 2, 1).reshape(-1, 16))
+
+    def download(self, cloud):
+        out = np.empty((max(cloud.n, 1), 3), np.float32)
+        st = self._check(self._L.s3d_cloud_download(self._h, cloud.handle, _fp(out), 3))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
+        return out[:cloud.n]
+
+    def accumulate(self, clouds, poses, frame=None):
+        """getAccumulatedCloud (PointCloudSensor.cpp:235-256); with `frame` createCombinedMeasurement (:258-266)."""
+        P = self._poses(poses) if len(clouds) else np.zeros((1, 16))
+        fr = _colmajor(frame) if frame is not None else None
+        h = C.c_void_p()
+        st = self._check(self._L.s3d_cloud_accumulate(self._h, len(clouds), self._handles(clouds), _dp(P),
+                                                      _dp(fr) if fr is not None else None, C.byref(h)))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
+        return self._new_cloud(h)
+
+    def create_constraint_clouds(self, source, source_pose, target, target_pose, odometry, loop=False, fine=None,
+                                 coarse=None, covariance_scale=1.0, opts=None):
+        fine = fine or default_params()
+        coarse = coarse or default_params()
+        rel = np.empty(16, np.float64)
+        inf = np.empty(36, np.float64)
+        info = AlignInfo()
+        sp, tp, od = _colmajor(source_pose), _colmajor(target_pose), _colmajor(odometry)
+        st = self._check(self._L.s3d_create_constraint_clouds(
+            self._h, source.handle, _dp(sp), target.handle, _dp(tp), _dp(od), int(loop), C.byref(fine),
+            C.byref(coarse), float(covariance_scale), C.byref(opts) if opts else None, _dp(rel), _dp(inf),
+            C.byref(info)))
+        return st, _from_colmajor(rel), inf.reshape(6, 6), info.asdict()
+
+    def remove_outliers(self, xyz, radius, min_neighbors):
+        """removeOutliers (:211-226).  numpy in -> numpy out; Cloud in -> Cloud out."""
+        if isinstance(xyz, Cloud):
+            h = C.c_void_p()
+            st = self._check(self._L.s3d_remove_outliers_cloud(self._h, xyz.handle, float(radius), int(min_neighbors),
+                                                               C.byref(h)))
+            if st:
+                raise ValueError(STATUS_NAMES[st])
+            return self._new_cloud(h)
+        a, n, stride = _cloud(xyz)
+        out = np.empty((max(n, 1), 3), np.float32)
+        m = C.c_int(0)
+        st = self._check(self._L.s3d_remove_outliers(self._h, _fp(a), n, stride, float(radius), int(min_neighbors),
+                                                     _fp(out), C.byref(m)))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
+        return out[:m.value].copy()
+
+    def voxel_downsample_cloud(self, cloud, leaf):
+        h = C.c_void_p()
+        st = self._check(self._L.s3d_voxel_downsample_cloud(self._h, cloud.handle, float(leaf), C.byref(h)))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
+        return self._new_cloud(h)
+
+    def build_map(self, clouds, poses, outlier_radius=0.2, outlier_neighbors=3, map_resolution=0.1):
+        """buildMap (:301-318); defaults = PointCloudSensor constructor (:176-183)."""
+        P = self._poses(poses) if len(clouds) else np.zeros((1, 16))
+        h = C.c_void_p()
+        st = self._check(self._L.s3d_build_map(self._h, len(clouds), self._handles(clouds), _dp(P), float(outlier_radius),
+                                               int(outlier_neighbors), float(map_resolution), C.byref(h)))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
+        return self._new_cloud(h)
+
+    def last_map_profile(self):
+        p = MapProfile()
+        self._L.s3d_last_map_profile(self._h, C.byref(p))
+        return p.asdict()
 
     def last_profile(self):
         p = Profile()

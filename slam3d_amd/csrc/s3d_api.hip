@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -107,6 +108,7 @@ struct s3d_context {
   std::string err;
   std::mutex mtx;
   s3d_profile prof{};
+  s3d_map_profile map_prof{};
   // workspace (grown on demand, reused across calls)
   DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, normals, moments, cell_start, counts, blockcnt,
       corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active;
@@ -161,6 +163,8 @@ struct Batch {
   std::vector<SlotDev> h_slots;
   std::vector<PairDev> h_pairs;
   int max_n = 0, max_n_t = 0, nb_sort = 0, nb_head = 0, accum_blocks = 1;
+  long long cell_cap_max = 1ll << 24;  // 24-bit cell ids sort in 3 radix passes; map jobs raise it (4 passes)
+  long long max_cell_cap = 0;
   size_t total_pts = 0, total_cells = 0, total_corr = 0;
 
   SlotDev* d_slots() { return (SlotDev*)ctx->slots.p; }
@@ -205,8 +209,9 @@ struct Batch {
     s.off = (int)total_pts;
     total_pts += (size_t)((c->n + 3) & ~3);
     const long long cap =
-        std::min<long long>(std::max<long long>((long long)opts.grid_cells_per_point * c->n, 64), 1ll << 24);
+        std::min<long long>(std::max<long long>((long long)opts.grid_cells_per_point * c->n, 64), cell_cap_max);
     s.cell_cap = (int)cap;
+    max_cell_cap = std::max(max_cell_cap, cap);
     s.cell_off = (int)total_cells;
     total_cells += (size_t)cap + 1;
     max_n = std::max(max_n, c->n);
@@ -232,7 +237,8 @@ struct Batch {
     }
   }
 
-  void allocate() {
+  // icp_buffers = false: voxel filter / search grid only (map building), no normals or correspondences
+  void allocate(bool icp_buffers = true) {
     if (total_pts > (size_t)0x7FFFFFF0 || total_cells > (size_t)0x7FFFFFF0 || total_corr > (size_t)0x7FFFFFF0)
       throw HipError{hipErrorInvalidValue, "batch too large for 32-bit offsets", __LINE__};
     nb_sort = std::max(1, cdiv(max_n, kSortTile));
@@ -243,10 +249,11 @@ struct Batch {
     accum_blocks = std::min(accum_blocks, std::max(4, cdiv(1024, std::max(1, P()))));
     const size_t np = std::max<size_t>(total_pts, 4);
     const size_t nc = std::max<size_t>(total_corr, 4);
+    const size_t npi = icp_buffers ? np : 4;
     ctx->carve({{&ctx->slots, sizeof(SlotDev) * std::max(1, C())},
                 {&ctx->pairs, sizeof(PairDev) * std::max(1, P())},
                 {&ctx->keysA, 4 * np}, {&ctx->keysB, 4 * np}, {&ctx->valsA, 4 * np}, {&ctx->valsB, 4 * np},
-                {&ctx->filt, 16 * np}, {&ctx->sorted, 16 * np}, {&ctx->normals, 16 * np}, {&ctx->moments, 80 * np},
+                {&ctx->filt, 16 * np}, {&ctx->sorted, 16 * np}, {&ctx->normals, 16 * npi}, {&ctx->moments, 80 * npi},
                 {&ctx->cell_start, 4 * std::max<size_t>(total_cells, 4)},
                 {&ctx->counts, 4 * (size_t)std::max(1, C()) * 256 * nb_sort},
                 {&ctx->blockcnt, 4 * (size_t)std::max(1, C()) * nb_head},
@@ -303,9 +310,10 @@ struct Batch {
     k_bbox<1><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), C()), kBlock, 0, st>>>(d_slots(), filt());
     k_grid_params<<<cdiv(C(), 64), 64, 0, st>>>(d_slots(), rp, C());
     k_cell_keys<<<dim3(nb_head, C()), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA());
-    sort(3);  // cell ids < 2^24
-    k_grid_finalize<<<dim3(cdiv(max_n + 1, kBlock), C()), kBlock, 0, st>>>(d_slots(), filt(), kB(), vB(), sorted(),
-                                                                           cells());
+    const bool wide = max_cell_cap > (1ll << 24);
+    sort(wide ? 4 : 3);  // cell ids < 2^24 unless a map job raised the cap
+    k_grid_finalize<<<dim3(cdiv(max_n + 1, kBlock), C()), kBlock, 0, st>>>(d_slots(), filt(), wide ? kA() : kB(),
+                                                                           wide ? vA() : vB(), sorted(), cells());
   }
 
   // K4
@@ -519,6 +527,189 @@ void free_cloud(s3d_cloud* c) {
   c->d = nullptr;
 }
 
+// ---- device-resident helpers shared by the map / patch entry points --------------------------------
+
+void alloc_cloud(s3d_cloud* c, int n) {
+  c->n = n; c->owned = true; c->d = nullptr;
+  HIPCHK(hipMalloc((void**)&c->d, sizeof(float4) * (size_t)std::max(n, 1)));
+}
+
+void rowmajor3x4(const double colmajor[16], double out[12]) {
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) out[r * 4 + c] = colmajor[c * 4 + r];
+}
+
+// B1: transform + concatenate into a new owned cloud
+void accumulate_dev(s3d_context* ctx, int n_clouds, s3d_cloud* const* clouds, const double* poses, const double* frame,
+                    s3d_cloud* out) {
+  size_t total = 0;
+  std::vector<XformJob> jobs((size_t)std::max(n_clouds, 1));
+  int max_n = 0;
+  for (int i = 0; i < n_clouds; ++i) {
+    XformJob& J = jobs[i];
+    J.src = clouds[i]->d; J.n = clouds[i]->n; J.out_off = (int)total;
+    rowmajor3x4(poses + (size_t)i * 16, J.T);
+    total += (size_t)clouds[i]->n;
+    max_n = std::max(max_n, clouds[i]->n);
+  }
+  if (total > (size_t)0x7FFFFFF0) throw HipError{hipErrorInvalidValue, "accumulated cloud too large for 32-bit offsets", __LINE__};
+  alloc_cloud(out, (int)total);
+  if (total == 0) return;
+  Xf3x4d fr{};
+  if (frame) {
+    double inv[16];
+    mat4d_inverse_isometry(frame, inv);   // pose.inverse() (PointCloudSensor.cpp:262)
+    rowmajor3x4(inv, fr.m);
+    fr.enabled = 1;
+  }
+  XformJob* d_jobs = nullptr;
+  HIPCHK(hipMalloc((void**)&d_jobs, sizeof(XformJob) * jobs.size()));
+  HIPCHK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(XformJob) * jobs.size(), hipMemcpyHostToDevice, ctx->stream));
+  // enough blocks per cloud to fill the chip even for a two-cloud patch; grid-stride inside
+  const int bx = std::max(1, std::min(cdiv(max_n, kBlock), std::max(8, cdiv(4096, n_clouds))));
+  s3d_transform_concat_kernel<<<dim3(bx, n_clouds), kBlock, 0, ctx->stream>>>(d_jobs, out->d, fr);
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // jobs[] (pageable) and d_jobs are released here
+  (void)hipFree(d_jobs);
+  HIPCHK(hipGetLastError());
+}
+
+void copy_cloud_dev(s3d_context* ctx, const s3d_cloud* in, s3d_cloud* out) {
+  alloc_cloud(out, in->n);
+  if (in->n > 0)
+    HIPCHK(hipMemcpyAsync(out->d, in->d, sizeof(float4) * (size_t)in->n, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+}
+
+struct StageTimer {   // optional HIP-event stopwatch on the context's stream
+  s3d_context* ctx; hipEvent_t a = nullptr, b = nullptr;
+  explicit StageTimer(s3d_context* c) : ctx(c) { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); }
+  ~StageTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  void start() { HIPCHK(hipEventRecord(a, ctx->stream)); }
+  double stop() {
+    HIPCHK(hipEventRecord(b, ctx->stream));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b));
+    return (double)ms;
+  }
+};
+
+// B2: pcl::RadiusOutlierRemoval on the search grid
+void remove_outliers_dev(s3d_context* ctx, const s3d_cloud* in, double radius, unsigned min_neighbors, s3d_cloud* out,
+                         s3d_map_profile* mp) {
+  if (in->n == 0 || !(radius > 0) || min_neighbors == 0) {   // PointCloudSensor.cpp:214: returns `in`
+    copy_cloud_dev(ctx, in, out);
+    return;
+  }
+  StageTimer tm(ctx);
+  Batch b;
+  b.ctx = ctx;
+  b.opts.grid_cells_per_point = 2;
+  b.opts.check_interval = 4;
+  b.cell_cap_max = 1ll << 30;
+  b.rp.leaf = 0.f;                 // search the cloud as given
+  b.rp.h0 = (float)radius;         // the ball of one query then spans at most 3 cells per axis
+  std::map<const s3d_cloud*, int> index;
+  b.add_slot(in, index);
+  b.allocate(false);
+  hipStream_t st = ctx->stream;
+  tm.start();
+  b.stage_voxel();
+  b.stage_grid();
+  if (mp) mp->grid_ms = tm.stop();
+  // PCL compares double(r*r) < double(d2f): the largest float not above r*r gives the same verdicts in float
+  const double r2 = radius * radius;
+  float r2f = (float)r2;
+  if ((double)r2f > r2) r2f = std::nextafterf(r2f, 0.f);
+  const float reach = (float)(radius * 1.00001) + 1e-30f;
+  const long long need_ll = (long long)min_neighbors + 1;   // the query itself is one of the k neighbours
+  const int need = (int)std::min<long long>(need_ll, 0x7FFFFFFF);
+  uint32_t* flags = b.vA();   // free after the grid build unless the wide sort left its result there
+  if (b.max_cell_cap > (1ll << 24)) flags = b.vB();
+  tm.start();
+  s3d_radius_count_kernel<<<dim3(b.nb_head, 1), kBlock, 0, st>>>(b.d_slots(), b.sorted(), b.cells(), flags, reach, r2f, need);
+  if (mp) mp->count_ms = tm.stop();
+  alloc_cloud(out, in->n);
+  uint32_t* bc = (uint32_t*)ctx->blockcnt.p;
+  tm.start();
+  k_flags_count<<<dim3(b.nb_head, 1), kBlock, 0, st>>>(b.d_slots(), flags, bc, b.nb_head);
+  k_heads_scan<<<1, kBlock, 0, st>>>(b.d_slots(), bc, b.nb_head);   // slot.n = number kept
+  k_flags_compact<<<dim3(b.nb_head, 1), kBlock, 0, st>>>(b.d_slots(), flags, bc, b.filt(), out->d, b.nb_head);
+  if (mp) mp->compact_ms = tm.stop();
+  b.download();
+  out->n = b.h_slots[0].n;
+}
+
+// A3 on a device-resident cloud
+void voxel_dev(s3d_context* ctx, const s3d_cloud* in, double leaf_size, s3d_cloud* out, s3d_map_profile* mp) {
+  if (in->n == 0 || !(leaf_size > 0)) {
+    copy_cloud_dev(ctx, in, out);
+    return;
+  }
+  StageTimer tm(ctx);
+  Batch b;
+  b.ctx = ctx;
+  b.opts.grid_cells_per_point = 2;
+  b.opts.check_interval = 4;
+  b.rp.leaf = (float)leaf_size;   // PointCloudSensor.cpp:196 setLeafSize(double -> float)
+  b.rp.h0 = 0.25f;
+  std::map<const s3d_cloud*, int> index;
+  b.add_slot(in, index);
+  b.allocate(false);
+  tm.start();
+  b.stage_voxel();
+  if (mp) mp->voxel_ms = tm.stop();
+  b.download();
+  const int m = b.h_slots[0].n;
+  alloc_cloud(out, m);
+  if (m > 0)
+    HIPCHK(hipMemcpyAsync(out->d, b.filt() + b.h_slots[0].off, sizeof(float4) * (size_t)m, hipMemcpyDeviceToDevice,
+                          ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+}
+
+void download_packed(s3d_context* ctx, const s3d_cloud* c, float* xyz, int stride) {
+  const int n = c->n;
+  if (n <= 0) return;
+  std::vector<float4> tmp((size_t)n);
+  HIPCHK(hipMemcpyAsync(tmp.data(), c->d, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < n; ++i) {
+    float* o = xyz + (size_t)i * stride;
+    o[0] = tmp[i].x; o[1] = tmp[i].y; o[2] = tmp[i].z;
+    if (stride >= 4) o[3] = 1.f;
+  }
+}
+
+// align() of two device-resident clouds (PointCloudSensor.cpp:119-174)
+int align_dev(s3d_context* ctx, s3d_cloud* ps, s3d_cloud* pt, const double guess[16], const s3d_reg_params* params,
+              const s3d_exec_options* opts, double result[16], s3d_align_info* info) {
+  const int alg = check_algorithm(params);
+  Batch b;
+  b.ctx = ctx;
+  int status;
+  if (alg != S3D_STATUS_OK) {
+    // the reference downsamples and applies the 100-point gate before it dispatches (:127-135)
+    s3d_reg_params tmp = *params;
+    tmp.registration_algorithm = S3D_ALG_GICP;
+    tmp.maximum_iterations = 0;
+    b.set_params(&tmp, opts);
+    b.add_pairs(1, &ps, &pt, guess);
+    b.allocate();
+    b.stage_voxel();
+    b.download();
+    status = (b.h_slots[0].n < 100 || b.h_slots[b.h_pairs[0].slot_t].n < 100) ? S3D_STATUS_TOO_FEW_POINTS : alg;
+    if (info) { info->n_source_filtered = b.h_slots[0].n; info->n_target_filtered = b.h_slots[b.h_pairs[0].slot_t].n; }
+  } else {
+    b.set_params(params, opts);
+    b.add_pairs(1, &ps, &pt, guess);
+    b.allocate();
+    b.run_all();
+    status = b.finish_pair(0, params, guess, result, info);
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return status;
+}
+
 struct ScopedDevice {
   explicit ScopedDevice(s3d_context* ctx) : lock(ctx->mtx) { HIPCHK(hipSetDevice(ctx->device)); }
   std::lock_guard<std::mutex> lock;
@@ -695,36 +886,13 @@ int s3d_align(s3d_context* ctx, const float* source_xyz, int n_source, int strid
     return S3D_STATUS_INVALID_ARGUMENT;
   for (int i = 0; i < 16; ++i) result[i] = (i % 5 == 0) ? 1.0 : 0.0;
   if (info) std::memset(info, 0, sizeof *info);
-  const int alg = check_algorithm(params);
   s3d_cloud cs, ct;
   int status = S3D_STATUS_OK;
   try {
     ScopedDevice sd(ctx);
     upload_cloud(ctx, source_xyz, n_source, stride_source, &cs);
     upload_cloud(ctx, target_xyz, n_target, stride_target, &ct);
-    Batch b;
-    b.ctx = ctx;
-    s3d_cloud* ps = &cs; s3d_cloud* pt = &ct;
-    if (alg != S3D_STATUS_OK) {
-      // the reference downsamples and applies the 100-point gate before it dispatches (:127-135)
-      s3d_reg_params tmp = *params;
-      tmp.registration_algorithm = S3D_ALG_GICP;
-      tmp.maximum_iterations = 0;
-      b.set_params(&tmp, opts);
-      b.add_pairs(1, &ps, &pt, guess);
-      b.allocate();
-      b.stage_voxel();
-      b.download();
-      status = (b.h_slots[0].n < 100 || b.h_slots[1].n < 100) ? S3D_STATUS_TOO_FEW_POINTS : alg;
-      if (info) { info->n_source_filtered = b.h_slots[0].n; info->n_target_filtered = b.h_slots[1].n; }
-    } else {
-      b.set_params(params, opts);
-      b.add_pairs(1, &ps, &pt, guess);
-      b.allocate();
-      b.run_all();
-      status = b.finish_pair(0, params, guess, result, info);
-    }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    status = align_dev(ctx, &cs, &ct, guess, params, opts, result, info);
     free_cloud(&cs);
     free_cloud(&ct);
   } catch (const HipError& e) {
@@ -742,30 +910,27 @@ int s3d_create_constraint(s3d_context* ctx, const float* source_xyz, int n_sourc
                           const s3d_exec_options* opts, double relative_pose[16], double information[36],
                           s3d_align_info* info) {
   if (!ctx || !source_sensor_pose || !target_sensor_pose || !odometry || !fine || (loop && !coarse) ||
-      !relative_pose || !information)
+      !relative_pose || !information || n_source < 0 || n_target < 0 || stride_source < 3 || stride_target < 3)
     return S3D_STATUS_INVALID_ARGUMENT;
-  double sinv[16], tinv[16], guess[16], tmp[16];
-  mat4d_inverse_isometry(source_sensor_pose, sinv);
-  mat4d_inverse_isometry(target_sensor_pose, tinv);
-  mat4d_mul(sinv, odometry, tmp);              // PointCloudSensor.cpp:274
-  mat4d_mul(tmp, target_sensor_pose, guess);
-  int st;
-  if (loop) {                                  // :286-289
-    double coarse_result[16];
-    st = s3d_align(ctx, source_xyz, n_source, stride_source, target_xyz, n_target, stride_target, guess, coarse, opts,
-                   coarse_result, info);
-    if (st != S3D_STATUS_OK) return st;
-    std::memcpy(guess, coarse_result, sizeof guess);
+  s3d_cloud cs, ct;   // both clouds go up once, the coarse and the fine align() share them
+  try {
+    ScopedDevice sd(ctx);
+    upload_cloud(ctx, source_xyz, n_source, stride_source, &cs);
+    upload_cloud(ctx, target_xyz, n_target, stride_target, &ct);
+  } catch (const HipError& e) {
+    free_cloud(&cs);
+    free_cloud(&ct);
+    return fail(ctx, e);
   }
-  double icp_result[16];
-  st = s3d_align(ctx, source_xyz, n_source, stride_source, target_xyz, n_target, stride_target, guess, fine, opts,
-                 icp_result, info);           // :292
-  if (st != S3D_STATUS_OK) return st;
-  mat4d_mul(source_sensor_pose, icp_result, tmp);  // :295
-  mat4d_mul(tmp, tinv, relative_pose);
-  for (int i = 0; i < 36; ++i) information[i] = 0.0;
-  for (int i = 0; i < 6; ++i) information[i * 6 + i] = 1.0 / covariance_scale;  // :296-298
-  return S3D_STATUS_OK;
+  const int st = s3d_create_constraint_clouds(ctx, &cs, source_sensor_pose, &ct, target_sensor_pose, odometry, loop, fine,
+                                              coarse, covariance_scale, opts, relative_pose, information, info);
+  {
+    std::lock_guard<std::mutex> lock(ctx->mtx);
+    (void)hipSetDevice(ctx->device);
+    free_cloud(&cs);
+    free_cloud(&ct);
+  }
+  return st;
 }
 
 int s3d_voxel_downsample(s3d_context* ctx, const float* xyz, int n, int stride, double leaf_size, float* out_xyz,
@@ -883,6 +1048,166 @@ int s3d_knn_normals(s3d_context* ctx, const float* xyz, int n, int stride, int k
     free_cloud(&c);
     return fail(ctx, e);
   }
+  return S3D_STATUS_OK;
+}
+
+int s3d_cloud_download(s3d_context* ctx, const s3d_cloud* c, float* xyz, int stride) {
+  if (!ctx || !c || stride < 3 || (c->n > 0 && !xyz)) return S3D_STATUS_INVALID_ARGUMENT;
+  try {
+    ScopedDevice sd(ctx);
+    download_packed(ctx, c, xyz, stride);
+  } catch (const HipError& e) {
+    return fail(ctx, e);
+  }
+  return S3D_STATUS_OK;
+}
+
+int s3d_cloud_accumulate(s3d_context* ctx, int n_clouds, s3d_cloud* const* clouds, const double* poses,
+                         const double frame[16], s3d_cloud** out) {
+  if (!ctx || !out || n_clouds < 0 || (n_clouds > 0 && (!clouds || !poses))) return S3D_STATUS_INVALID_ARGUMENT;
+  for (int i = 0; i < n_clouds; ++i)
+    if (!clouds[i]) return S3D_STATUS_INVALID_ARGUMENT;
+  s3d_cloud* c = new s3d_cloud();
+  try {
+    ScopedDevice sd(ctx);
+    accumulate_dev(ctx, n_clouds, clouds, poses, frame, c);
+  } catch (const HipError& e) {
+    free_cloud(c);
+    delete c;
+    return fail(ctx, e);
+  }
+  *out = c;
+  return S3D_STATUS_OK;
+}
+
+int s3d_create_constraint_clouds(s3d_context* ctx, s3d_cloud* source, const double source_sensor_pose[16],
+                                 s3d_cloud* target, const double target_sensor_pose[16], const double odometry[16],
+                                 int loop, const s3d_reg_params* fine, const s3d_reg_params* coarse,
+                                 double covariance_scale, const s3d_exec_options* opts, double relative_pose[16],
+                                 double information[36], s3d_align_info* info) {
+  if (!ctx || !source || !target || !source_sensor_pose || !target_sensor_pose || !odometry || !fine ||
+      (loop && !coarse) || !relative_pose || !information)
+    return S3D_STATUS_INVALID_ARGUMENT;
+  if (info) std::memset(info, 0, sizeof *info);
+  double sinv[16], tinv[16], guess[16], tmp[16];
+  mat4d_inverse_isometry(source_sensor_pose, sinv);
+  mat4d_inverse_isometry(target_sensor_pose, tinv);
+  mat4d_mul(sinv, odometry, tmp);              // PointCloudSensor.cpp:274
+  mat4d_mul(tmp, target_sensor_pose, guess);
+  try {
+    ScopedDevice sd(ctx);
+    int st;
+    double result[16];
+    if (loop) {                                // :286-289
+      st = align_dev(ctx, source, target, guess, coarse, opts, result, info);
+      if (st != S3D_STATUS_OK) return st;
+      std::memcpy(guess, result, sizeof guess);
+    }
+    st = align_dev(ctx, source, target, guess, fine, opts, result, info);   // :292
+    if (st != S3D_STATUS_OK) return st;
+    mat4d_mul(source_sensor_pose, result, tmp);   // :295
+    mat4d_mul(tmp, tinv, relative_pose);
+  } catch (const HipError& e) {
+    return fail(ctx, e);
+  }
+  for (int i = 0; i < 36; ++i) information[i] = 0.0;
+  for (int i = 0; i < 6; ++i) information[i * 6 + i] = 1.0 / covariance_scale;  // :296-298
+  return S3D_STATUS_OK;
+}
+
+int s3d_remove_outliers_cloud(s3d_context* ctx, const s3d_cloud* in, double radius, unsigned min_neighbors,
+                              s3d_cloud** out) {
+  if (!ctx || !in || !out) return S3D_STATUS_INVALID_ARGUMENT;
+  s3d_cloud* c = new s3d_cloud();
+  try {
+    ScopedDevice sd(ctx);
+    remove_outliers_dev(ctx, in, radius, min_neighbors, c, nullptr);
+  } catch (const HipError& e) {
+    free_cloud(c);
+    delete c;
+    return fail(ctx, e);
+  }
+  *out = c;
+  return S3D_STATUS_OK;
+}
+
+int s3d_remove_outliers(s3d_context* ctx, const float* xyz, int n, int stride, double radius, unsigned min_neighbors,
+                        float* out_xyz, int* n_out) {
+  if (!ctx || !n_out || n < 0 || stride < 3 || (n > 0 && (!xyz || !out_xyz))) return S3D_STATUS_INVALID_ARGUMENT;
+  *n_out = 0;
+  if (n == 0) return S3D_STATUS_OK;
+  s3d_cloud in, kept;
+  try {
+    ScopedDevice sd(ctx);
+    upload_cloud(ctx, xyz, n, stride, &in);
+    remove_outliers_dev(ctx, &in, radius, min_neighbors, &kept, nullptr);
+    download_packed(ctx, &kept, out_xyz, 3);
+    *n_out = kept.n;
+    free_cloud(&in);
+    free_cloud(&kept);
+  } catch (const HipError& e) {
+    free_cloud(&in);
+    free_cloud(&kept);
+    return fail(ctx, e);
+  }
+  return S3D_STATUS_OK;
+}
+
+int s3d_voxel_downsample_cloud(s3d_context* ctx, const s3d_cloud* in, double leaf_size, s3d_cloud** out) {
+  if (!ctx || !in || !out) return S3D_STATUS_INVALID_ARGUMENT;
+  s3d_cloud* c = new s3d_cloud();
+  try {
+    ScopedDevice sd(ctx);
+    voxel_dev(ctx, in, leaf_size, c, nullptr);
+  } catch (const HipError& e) {
+    free_cloud(c);
+    delete c;
+    return fail(ctx, e);
+  }
+  *out = c;
+  return S3D_STATUS_OK;
+}
+
+int s3d_build_map(s3d_context* ctx, int n_clouds, s3d_cloud* const* clouds, const double* poses, double outlier_radius,
+                  unsigned outlier_neighbors, double map_resolution, s3d_cloud** out_map) {
+  if (!ctx || !out_map || n_clouds < 0 || (n_clouds > 0 && (!clouds || !poses))) return S3D_STATUS_INVALID_ARGUMENT;
+  for (int i = 0; i < n_clouds; ++i)
+    if (!clouds[i]) return S3D_STATUS_INVALID_ARGUMENT;
+  s3d_cloud accu, kept;
+  s3d_cloud* map = new s3d_cloud();
+  try {
+    ScopedDevice sd(ctx);
+    s3d_map_profile mp{};
+    const auto t0 = std::chrono::steady_clock::now();
+    {
+      StageTimer tm(ctx);
+      tm.start();
+      accumulate_dev(ctx, n_clouds, clouds, poses, nullptr, &accu);    // PointCloudSensor.cpp:305
+      mp.accumulate_ms = tm.stop();
+    }
+    mp.n_accumulated = accu.n;
+    remove_outliers_dev(ctx, &accu, outlier_radius, outlier_neighbors, &kept, &mp);   // :308
+    free_cloud(&accu);
+    mp.n_kept = kept.n;
+    voxel_dev(ctx, &kept, map_resolution, map, &mp);                   // :309
+    free_cloud(&kept);
+    mp.n_map = map->n;
+    mp.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ctx->map_prof = mp;
+  } catch (const HipError& e) {
+    free_cloud(&accu);
+    free_cloud(&kept);
+    free_cloud(map);
+    delete map;
+    return fail(ctx, e);
+  }
+  *out_map = map;
+  return S3D_STATUS_OK;
+}
+
+int s3d_last_map_profile(const s3d_context* ctx, s3d_map_profile* out) {
+  if (!ctx || !out) return S3D_STATUS_INVALID_ARGUMENT;
+  *out = ctx->map_prof;
   return S3D_STATUS_OK;
 }
 

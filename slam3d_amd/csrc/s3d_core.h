@@ -76,6 +76,17 @@ S3D_HD float dist2(float ax, float ay, float az, float bx, float by, float bz) {
   return (dx * dx + dy * dy) + dz * dz;
 }
 
+// pcl::transformPointCloud with a Matrix4d (pcl::detail::Transformer<double>::se3): the product is carried in
+// double and rounded to float once per coordinate, (x c0 + y c1) + (z c2 + c3).  T: 3x4 ROW-major.
+S3D_HD F3 xf_pcl_d(const double* T, float xf, float yf, float zf) {
+  const double x = xf, y = yf, z = zf;
+  F3 o;
+  o.x = (float)((x * T[0] + y * T[1]) + (z * T[2] + T[3]));
+  o.y = (float)((x * T[4] + y * T[5]) + (z * T[6] + T[7]));
+  o.z = (float)((x * T[8] + y * T[9]) + (z * T[10] + T[11]));
+  return o;
+}
+
 S3D_HD bool lex_less(float d2a, int ia, float d2b, int ib) { return d2a < d2b || (d2a == d2b && ia < ib); }
 
 S3D_HD int imin(int a, int b) { return a < b ? a : b; }
@@ -154,6 +165,31 @@ S3D_HD int grid_cell_of_point(const GridParams& g, float x, float y, float z) {
   int iy = imin(imax(grid_coord(g, 1, y), 0), g.dim[1] - 1);
   int iz = imin(imax(grid_coord(g, 2, z), 0), g.dim[2] - 1);
   return ix + g.dim[0] * (iy + g.dim[1] * iz);
+}
+
+// pcl::RadiusOutlierRemoval on the search grid: how many points p of the cloud (the query itself included)
+// have float d2(q, p) <= r2f; the scan stops as soon as `need` are found.  reach >= sqrt(r2f) * (1 + 1e-5): the
+// box of cells that can hold such a point.
+template <typename F4T>
+S3D_HD int grid_radius_count(const GridParams& g, const uint32_t* __restrict__ cell_start, const F4T* __restrict__ pts,
+                             float qx, float qy, float qz, float reach, float r2f, int need) {
+  const int x0 = imin(imax(grid_coord(g, 0, qx - reach), 0), g.dim[0] - 1);
+  const int x1 = imin(imax(grid_coord(g, 0, qx + reach), 0), g.dim[0] - 1);
+  const int y0 = imin(imax(grid_coord(g, 1, qy - reach), 0), g.dim[1] - 1);
+  const int y1 = imin(imax(grid_coord(g, 1, qy + reach), 0), g.dim[1] - 1);
+  const int z0 = imin(imax(grid_coord(g, 2, qz - reach), 0), g.dim[2] - 1);
+  const int z1 = imin(imax(grid_coord(g, 2, qz + reach), 0), g.dim[2] - 1);
+  int count = 0;
+  for (int z = z0; z <= z1; ++z)
+    for (int y = y0; y <= y1; ++y) {
+      const int row = g.dim[0] * (y + g.dim[1] * z);
+      const int b = (int)cell_start[row + x0], e = (int)cell_start[row + x1 + 1];
+      for (int j = b; j < e; ++j) {
+        const F4T p = pts[j];
+        if (dist2(qx, qy, qz, p.x, p.y, p.z) <= r2f && ++count >= need) return count;
+      }
+    }
+  return count;
 }
 
 // Exact 1-NN by ring expansion.  pts: cell-sorted float4 (xyz, w = bit-cast index

@@ -1045,4 +1045,78 @@ __global__ void k_fitness_final(PairDev* pairs, const double* __restrict__ parti
   pairs[p].fit_count = (int)c;
 }
 
+// ------------------------------------------------------------------ B1: patch accumulation
+// PointCloudSensor::getAccumulatedCloud / createCombinedMeasurement (PointCloudSensor.cpp:235-266): every
+// cloud of the patch through its own pose, appended in vertex order; with `frame` the float result goes
+// through the second transform (pose.inverse()) in the same thread, rounded to float in between exactly
+// as the reference's two transformPointCloud passes do.  16 B in, 16 B out per point.
+struct XformJob {
+  const float4* src;
+  int n, out_off;
+  double T[12];  // 3x4 row-major
+};
+struct Xf3x4d { double m[12]; int enabled; };
+
+__global__ void __launch_bounds__(kBlock) s3d_transform_concat_kernel(const XformJob* __restrict__ jobs,
+                                                                       float4* __restrict__ out, Xf3x4d frame) {
+  const XformJob& J = jobs[blockIdx.y];
+  const int n = J.n;
+  const float4* __restrict__ src = J.src;
+  float4* __restrict__ dst = out + J.out_off;
+  double T[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) T[i] = J.T[i];
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 p = src[i];
+    F3 q = xf_pcl_d(T, p.x, p.y, p.z);
+    if (frame.enabled) q = xf_pcl_d(frame.m, q.x, q.y, q.z);
+    dst[i] = make_float4(q.x, q.y, q.z, 1.f);
+  }
+}
+
+// ------------------------------------------------------------------ B2: radius outlier removal
+// One thread per point in CELL order (neighbouring lanes scan the same rows); the keep flag lands at the
+// point's original index so that the compaction below preserves the input order like pcl::FilterIndices.
+__global__ void __launch_bounds__(kBlock) s3d_radius_count_kernel(const SlotDev* __restrict__ slots,
+                                                                   const float4* __restrict__ sorted,
+                                                                   const uint32_t* __restrict__ cell_start,
+                                                                   uint32_t* __restrict__ flags, float reach, float r2f,
+                                                                   int need) {
+  const SlotDev& s = slots[blockIdx.y];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= s.n) return;
+  const float4 q = sorted[s.off + i];
+  const int c = grid_radius_count(s.g, cell_start + s.cell_off, sorted + s.off, q.x, q.y, q.z, reach, r2f, need);
+  flags[s.off + (int)__float_as_uint(q.w)] = c >= need ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(kBlock) k_flags_count(const SlotDev* __restrict__ slots, const uint32_t* __restrict__ flags,
+                                                         uint32_t* __restrict__ blockcnt, int nb_max) {
+  __shared__ int lds4[4];
+  const SlotDev& s = slots[blockIdx.y];
+  const int base = blockIdx.x * kBlock;
+  if (base >= s.n_raw) return;
+  const int i = base + threadIdx.x;
+  const bool keep = i < s.n_raw && flags[s.off + i] != 0u;
+  int total;
+  block_excl_flag(keep, &total, lds4);
+  if (threadIdx.x == 0) blockcnt[(size_t)blockIdx.y * nb_max + blockIdx.x] = (uint32_t)total;
+}
+
+// after k_heads_scan: out[pos] = point i for every kept i, input order preserved
+__global__ void __launch_bounds__(kBlock) k_flags_compact(const SlotDev* __restrict__ slots, const uint32_t* __restrict__ flags,
+                                                           const uint32_t* __restrict__ blockcnt,
+                                                           const float4* __restrict__ filt, float4* __restrict__ out,
+                                                           int nb_max) {
+  __shared__ int lds4[4];
+  const SlotDev& s = slots[blockIdx.y];
+  const int base = blockIdx.x * kBlock;
+  if (base >= s.n_raw) return;
+  const int i = base + threadIdx.x;
+  const bool keep = i < s.n_raw && flags[s.off + i] != 0u;
+  int total;
+  const int pos = block_excl_flag(keep, &total, lds4) + (int)blockcnt[(size_t)blockIdx.y * nb_max + blockIdx.x];
+  if (keep) out[pos] = filt[s.off + i];
+}
+
 }  // namespace s3d

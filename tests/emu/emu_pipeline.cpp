@@ -163,6 +163,36 @@ void emu_normals(const float* xyz, int n, int k, float h0, int cpp, float* out) 
   for (int i = 0; i < n; ++i) { out[i * 3] = (float)nr[i].x; out[i * 3 + 1] = (float)nr[i].y; out[i * 3 + 2] = (float)nr[i].z; }
 }
 
+// B1/B2 (patch accumulation, radius outlier removal) as the kernels run them ---------------------
+void emu_transform(const float* xyz, int n, const double* tf_colmajor, float* out) {
+  double T[12];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) T[r * 4 + c] = tf_colmajor[c * 4 + r];
+  for (int i = 0; i < n; ++i) {
+    F3 q = xf_pcl_d(T, xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]);
+    out[i * 3] = q.x; out[i * 3 + 1] = q.y; out[i * 3 + 2] = q.z;
+  }
+}
+int emu_remove_outliers(const float* xyz, int n, double radius, unsigned min_neighbors, int cpp, float* out) {
+  Cloud c = voxel(xyz, n, 3, 0.0);
+  Grid G = build_grid(c, (float)radius, cpp);
+  const double r2 = radius * radius;
+  float r2f = (float)r2;
+  if ((double)r2f > r2) r2f = std::nextafterf(r2f, 0.f);
+  const float reach = (float)(radius * 1.00001) + 1e-30f;
+  const int need = (int)min_neighbors + 1;
+  std::vector<char> keep(c.pts.size(), 0);
+  for (size_t i = 0; i < G.sorted.size(); ++i) {
+    const F4& q = G.sorted[i];
+    const int cnt = grid_radius_count(G.g, G.cell_start.data(), G.sorted.data(), q.x, q.y, q.z, reach, r2f, need);
+    keep[__builtin_bit_cast(int, q.w)] = cnt >= need;
+  }
+  int m = 0;
+  for (size_t i = 0; i < c.pts.size(); ++i)
+    if (keep[i]) { out[m * 3] = c.pts[i].x; out[m * 3 + 1] = c.pts[i].y; out[m * 3 + 2] = c.pts[i].z; ++m; }
+  return m;
+}
+
 // align() as the device pipeline runs it -------------------------------------------
 int emu_align(const float* source, int n_source, int stride_source, const float* target, int n_target,
               int stride_target, const double guess_d[16], const s3d_reg_params* cfg, int force_iterations,
