@@ -110,7 +110,7 @@ struct s3d_context {
   s3d_profile prof{};
   s3d_map_profile map_prof{};
   // workspace (grown on demand, reused across calls)
-  DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, normals, moments, cell_start, counts, blockcnt,
+  DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, normals, moments, cell_start, counts, digit_tot, blockcnt,
       corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active;
   int* h_active = nullptr;  // pinned
   hipEvent_t ev[8] = {};
@@ -256,6 +256,7 @@ struct Batch {
                 {&ctx->filt, 16 * np}, {&ctx->sorted, 16 * np}, {&ctx->normals, 16 * npi}, {&ctx->moments, 80 * npi},
                 {&ctx->cell_start, 4 * std::max<size_t>(total_cells, 4)},
                 {&ctx->counts, 4 * (size_t)std::max(1, C()) * 256 * nb_sort},
+                {&ctx->digit_tot, 4 * (size_t)std::max(1, C()) * 256},
                 {&ctx->blockcnt, 4 * (size_t)std::max(1, C()) * nb_head},
                 {&ctx->corr_idx, 4 * nc}, {&ctx->corr_d2, 4 * nc}, {&ctx->corr_lb, 4 * nc},
                 {&ctx->corr_q, 16 * nc}, {&ctx->corr_n, 16 * nc},
@@ -273,11 +274,13 @@ struct Batch {
     hipStream_t st = ctx->stream;
     uint32_t *ki = kA(), *vi = vA(), *ko = kB(), *vo = vB();
     uint32_t* cnt = (uint32_t*)ctx->counts.p;
+    uint32_t* dtot = (uint32_t*)ctx->digit_tot.p;
     for (int p = 0; p < passes; ++p) {
       const int shift = 8 * p;
       k_sort_hist<<<dim3(nb_sort, C()), kBlock, 0, st>>>(d_slots(), ki, cnt, shift, nb_sort);
-      k_sort_scan<<<C(), kBlock, 0, st>>>(d_slots(), cnt, nb_sort);
-      k_sort_scatter<<<dim3(nb_sort, C()), kBlock, 0, st>>>(d_slots(), ki, vi, ko, vo, cnt, shift, nb_sort);
+      k_sort_scan_rows<<<dim3(256 / (kBlock / kWave), C()), kBlock, 0, st>>>(d_slots(), cnt, dtot, nb_sort);
+      k_sort_scan_digits<<<C(), kBlock, 0, st>>>(dtot);
+      k_sort_scatter<<<dim3(nb_sort, C()), kBlock, 0, st>>>(d_slots(), ki, vi, ko, vo, cnt, dtot, shift, nb_sort);
       std::swap(ki, ko);
       std::swap(vi, vo);
     }

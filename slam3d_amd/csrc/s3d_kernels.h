@@ -157,12 +157,22 @@ __global__ void __launch_bounds__(kBlock) k_bbox(SlotDev* slots, const float4* _
       mx[a] = max(mx[a], (unsigned int)__shfl_down((int)mx[a], o, kWave));
     }
   }
+  // one candidate per block and axis, and only if it would move the bound: a lone 10^7-point slot otherwise
+  // queues ~2*10^5 atomics on the same six words (2.5 ms)
+  __shared__ unsigned int red[kBlock / kWave][6];
   if (lane_id() == 0) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      atomicMin(&s.bb[a], mn[a]);
-      atomicMax(&s.bb[3 + a], mx[a]);
-    }
+    for (int a = 0; a < 3; ++a) { red[wave_id()][a] = mn[a]; red[wave_id()][3 + a] = mx[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    unsigned int v = red[0][a];
+#pragma unroll
+    for (int w = 1; w < kBlock / kWave; ++w) v = a < 3 ? min(v, red[w][a]) : max(v, red[w][a]);
+    const unsigned int cur = __atomic_load_n(&s.bb[a], __ATOMIC_RELAXED);
+    if (a < 3) { if (v < cur) atomicMin(&s.bb[a], v); }
+    else       { if (v > cur) atomicMax(&s.bb[a], v); }
   }
 }
 
@@ -227,42 +237,57 @@ __global__ void __launch_bounds__(kBlock) k_sort_hist(const SlotDev* __restrict_
   counts[((size_t)blockIdx.y * 256 + threadIdx.x) * nb_max + blockIdx.x] = hist[threadIdx.x];
 }
 
-__global__ void __launch_bounds__(kBlock) k_sort_scan(const SlotDev* __restrict__ slots, uint32_t* __restrict__ counts,
-                                                       int nb_max) {
-  __shared__ unsigned int tot[256];
-  const SlotDev& s = slots[blockIdx.x];
+// Offsets of one pass in two steps.  (1) one WAVE per (slot, digit) row of tile counts: exclusive scan of the row
+// in place, 64 tiles per step (four steps' loads in flight), row total -> digit_tot.  (2) one block per slot:
+// exclusive scan of the 256 row totals; the scatter adds that base to its tile's row offset.  A lone 10^7-point
+// slot (map building) has ~10^4 tiles per row: the first version walked each row with one thread and took 5 ms
+// per pass there.
+__global__ void __launch_bounds__(kBlock) k_sort_scan_rows(const SlotDev* __restrict__ slots, uint32_t* __restrict__ counts,
+                                                            uint32_t* __restrict__ digit_tot, int nb_max) {
+  const SlotDev& s = slots[blockIdx.y];
   const int nb = (s.n_sort + kSortTile - 1) / kSortTile;
-  uint32_t* c = counts + ((size_t)blockIdx.x * 256 + threadIdx.x) * nb_max;
-  unsigned int sum = 0;
-  for (int b0 = 0; b0 < nb; b0 += 8) {   // 8 loads in flight: the loop is pure latency for a lone slot
-    unsigned int t[8];
+  const int digit = blockIdx.x * (kBlock / kWave) + wave_id();
+  const int lane = lane_id();
+  uint32_t* __restrict__ c = counts + ((size_t)blockIdx.y * 256 + digit) * nb_max;
+  unsigned int carry = 0;
+  for (int b0 = 0; b0 < nb; b0 += 4 * kWave) {
+    unsigned int v[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = (b0 + j < nb) ? c[b0 + j] : 0u;
+    for (int j = 0; j < 4; ++j) {
+      const int b = b0 + j * kWave + lane;
+      v[j] = b < nb ? c[b] : 0u;
+    }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sum += t[j];
+    for (int j = 0; j < 4; ++j) {
+      unsigned int incl = v[j];
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const unsigned int t = __shfl_up(incl, o, kWave);
+        if (lane >= o) incl += t;
+      }
+      const int b = b0 + j * kWave + lane;
+      if (b < nb) c[b] = carry + incl - v[j];
+      carry += __shfl(incl, kWave - 1, kWave);
+    }
   }
-  tot[threadIdx.x] = sum;
+  if (lane == 0) digit_tot[(size_t)blockIdx.y * 256 + digit] = carry;
+}
+
+__global__ void __launch_bounds__(kBlock) k_sort_scan_digits(uint32_t* __restrict__ digit_tot) {
+  __shared__ unsigned int tot[256];
+  uint32_t* t = digit_tot + (size_t)blockIdx.x * 256;
+  const unsigned int own = t[threadIdx.x];
+  tot[threadIdx.x] = own;
   __syncthreads();
-  // exclusive scan over the 256 digit totals (Hillis-Steele, 8 steps)
-  unsigned int v = sum;
-  for (int o = 1; o < 256; o <<= 1) {
-    unsigned int t = (threadIdx.x >= (unsigned)o) ? tot[threadIdx.x - o] : 0u;
+  unsigned int v = own;
+  for (int o = 1; o < 256; o <<= 1) {   // Hillis-Steele, 8 steps
+    const unsigned int u = (threadIdx.x >= (unsigned)o) ? tot[threadIdx.x - o] : 0u;
     __syncthreads();
-    v += t;
+    v += u;
     tot[threadIdx.x] = v;
     __syncthreads();
   }
-  unsigned int run = v - sum;
-  for (int b0 = 0; b0 < nb; b0 += 8) {
-    unsigned int t[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = (b0 + j < nb) ? c[b0 + j] : 0u;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (b0 + j < nb) c[b0 + j] = run;
-      run += t[j];
-    }
-  }
+  t[threadIdx.x] = v - own;
 }
 
 // Stable scatter of one 1024-element tile.  Every wave owns a CONTIGUOUS quarter of the tile (4 rounds
@@ -274,7 +299,8 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
                                                           const uint32_t* __restrict__ keys_in,
                                                           const uint32_t* __restrict__ vals_in,
                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                          const uint32_t* __restrict__ counts, int shift, int nb_max) {
+                                                          const uint32_t* __restrict__ counts,
+                                                          const uint32_t* __restrict__ digit_base, int shift, int nb_max) {
   __shared__ unsigned int wave_cnt[kBlock / kWave][256];   // per wave: elements of each digit seen so far
   const SlotDev& s = slots[blockIdx.y];
   const int n = s.n_sort;
@@ -318,7 +344,8 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
   __syncthreads();
   // exclusive prefix over the waves for digit = threadIdx.x, on top of the block's global offset
   {
-    unsigned int run = counts[((size_t)blockIdx.y * 256 + threadIdx.x) * nb_max + blockIdx.x];
+    unsigned int run = counts[((size_t)blockIdx.y * 256 + threadIdx.x) * nb_max + blockIdx.x] +
+                       digit_base[(size_t)blockIdx.y * 256 + threadIdx.x];
 #pragma unroll
     for (int ww = 0; ww < kBlock / kWave; ++ww) {
       const unsigned int c = wave_cnt[ww][threadIdx.x];
