@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstring>
 #include <exception>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -70,12 +71,16 @@ struct Covariance {  // Eigen::Matrix<double,N,N>, row/col symmetric use only
 };
 
 // Types.hpp:108-135
+typedef std::string Uuid;  // reference: boost::uuids::uuid (random); here a process-unique string
+Uuid generateUuid();        // defined in sensor/hip/PointCloudSensor.cpp
+
 class Measurement {
  public:
   typedef std::shared_ptr<Measurement> Ptr;  // reference: boost::shared_ptr
   Measurement(const std::string& r, const std::string& s, const Transform& p)
-      : mRobotName(r), mSensorName(s), mSensorPose(p), mInverseSensorPose(p.inverse()) {}
+      : mRobotName(r), mSensorName(s), mSensorPose(p), mInverseSensorPose(p.inverse()), mUniqueId(generateUuid()) {}
   virtual ~Measurement() {}
+  Uuid getUniqueId() const { return mUniqueId; }
   std::string getRobotName() const { return mRobotName; }
   std::string getSensorName() const { return mSensorName; }
   Transform getSensorPose() const { return mSensorPose; }
@@ -84,6 +89,35 @@ class Measurement {
  protected:
   std::string mRobotName, mSensorName;
   Transform mSensorPose, mInverseSensorPose;
+  Uuid mUniqueId;
+};
+
+// slam3d/core/Types.hpp:305-330: what the pose graph attaches to a vertex
+struct VertexObject {
+  void init(const Measurement::Ptr m, IdType i) {
+    index = i;
+    robotName = m->getRobotName();
+    sensorName = m->getSensorName();
+    typeName = m->getTypeName();
+    measurementUuid = m->getUniqueId();
+    label = robotName + ":" + sensorName + "(" + std::to_string(index) + ")";
+  }
+  IdType index = 0;
+  std::string label, robotName, sensorName, typeName;
+  Transform correctedPose;
+  Uuid measurementUuid;
+};
+typedef std::vector<VertexObject> VertexObjectList;
+
+// slam3d/core/MeasurementStorage.hpp:16-53
+class MeasurementStorage {
+ public:
+  virtual ~MeasurementStorage() {}
+  virtual void add(Measurement::Ptr m) { mMeasurements[m->getUniqueId()] = m; }
+  virtual Measurement::Ptr get(const Uuid& key) { return mMeasurements.at(key); }   // std::out_of_range if absent
+  virtual bool contains(const Uuid& key) { return mMeasurements.count(key) != 0; }
+ private:
+  std::map<Uuid, Measurement::Ptr> mMeasurements;
 };
 
 enum ConstraintType { TENTATIVE, SE3, GRAVITY, POSITION, ORIENTATION, POSE };

@@ -4,6 +4,7 @@
 // reference's messages.
 #include "PointCloudSensor.hpp"
 
+#include <atomic>
 #include <cstdio>
 #include <iostream>
 
@@ -13,6 +14,13 @@ void Logger::message(LogLevel lvl, const std::string& msg) {
   if (lvl < mLogLevel) return;
   static const char* names[] = {"[DEBUG] ", "[INFO] ", "[WARN] ", "[ERROR] ", "[FATAL] "};
   std::cerr << names[lvl] << msg << std::endl;
+}
+
+Uuid generateUuid() {
+  static std::atomic<unsigned long long> counter{0};
+  char buf[48];
+  std::snprintf(buf, sizeof buf, "s3d-%016llx", counter.fetch_add(1) + 1);
+  return buf;
 }
 
 namespace {
@@ -65,25 +73,125 @@ PointCloud::Ptr PointCloudSensor::downsampleScan(PointCloud::Ptr source) {
 }
 
 PointCloud::Ptr PointCloudSensor::transform(PointCloud::ConstPtr source, const Transform tf) const {
-  PointCloud::Ptr out(new PointCloud(*source));  // pcl::transformPointCloud with a double matrix (:228-233)
+  // pcl::transformPointCloud with a Matrix4d (:228-233): double product, one rounding per coordinate, in the
+  // summation order the device kernel (s3d_cloud_accumulate) uses
+  PointCloud::Ptr out(new PointCloud(*source));
   for (PointType& p : out->points) {
     const double x = p.x, y = p.y, z = p.z;
-    p.x = (float)(tf(0, 0) * x + tf(0, 1) * y + tf(0, 2) * z + tf(0, 3));
-    p.y = (float)(tf(1, 0) * x + tf(1, 1) * y + tf(1, 2) * z + tf(1, 3));
-    p.z = (float)(tf(2, 0) * x + tf(2, 1) * y + tf(2, 2) * z + tf(2, 3));
+    p.x = (float)((x * tf(0, 0) + y * tf(0, 1)) + (z * tf(0, 2) + tf(0, 3)));
+    p.y = (float)((x * tf(1, 0) + y * tf(1, 1)) + (z * tf(1, 2) + tf(1, 3)));
+    p.z = (float)((x * tf(2, 0) + y * tf(2, 1)) + (z * tf(2, 2) + tf(2, 3)));
   }
   return out;
 }
 
+std::shared_ptr<DeviceCloud> PointCloudSensor::deviceCloudOf(const PointCloudMeasurement::Ptr& m) const {
+  std::shared_ptr<DeviceCloud> d = m->getDeviceCloud();
+  if (d) return d;
+  const PointCloud::Ptr c = m->getPointCloud();
+  static const float dummy[4] = {0, 0, 0, 0};
+  s3d_cloud* h = nullptr;
+  if (s3d_cloud_upload(mContext, c->size() ? &c->points[0].x : dummy, (int)c->size(), 4, &h) != S3D_STATUS_OK)
+    throw std::runtime_error(std::string("HIP back-end error: ") + s3d_last_error(mContext));
+  d = std::make_shared<DeviceCloud>(h);
+  m->setDeviceCloud(d);
+  return d;
+}
+
+PointCloud::Ptr PointCloudSensor::download(s3d_cloud* c) const {
+  PointCloud::Ptr out(new PointCloud);
+  const int n = s3d_cloud_size(c);
+  out->points.resize(n);
+  if (n > 0 && s3d_cloud_download(mContext, c, &out->points[0].x, 4) != S3D_STATUS_OK)
+    throw std::runtime_error(std::string("HIP back-end error: ") + s3d_last_error(mContext));
+  out->width = (uint32_t)n;
+  out->height = 1;
+  out->is_dense = true;
+  return out;
+}
+
+PointCloud::Ptr PointCloudSensor::removeOutliers(PointCloud::Ptr in, double radius, unsigned min_neighbors) const {
+  if (!(in->size() > 0 && radius > 0 && min_neighbors > 0)) return in;   // PointCloudSensor.cpp:214, :224
+  std::vector<float> packed(in->size() * 3);
+  int n_out = 0;
+  if (s3d_remove_outliers(mContext, &in->points[0].x, (int)in->size(), 4, radius, min_neighbors, packed.data(), &n_out) !=
+      S3D_STATUS_OK)
+    throw std::runtime_error(std::string("HIP back-end error: ") + s3d_last_error(mContext));
+  PointCloud::Ptr out(new PointCloud);
+  out->points.resize(n_out);
+  for (int i = 0; i < n_out; ++i) out->points[i] = PointType{packed[3 * i], packed[3 * i + 1], packed[3 * i + 2], 1.f};
+  out->width = (uint32_t)n_out;
+  return out;
+}
+
+void PointCloudSensor::gather(const VertexObjectList& vertices, std::vector<std::shared_ptr<DeviceCloud>>& keep,
+                              std::vector<s3d_cloud*>& clouds, std::vector<double>& poses) const {
+  if (!mStorage) throw std::runtime_error("PointCloudSensor: no MeasurementStorage set (setMeasurementStorage)");
+  for (const VertexObject& v : vertices) {
+    Measurement::Ptr m = mStorage->get(v.measurementUuid);   // reference: mMapper->getGraph()->getMeasurement(uuid)
+    PointCloudMeasurement::Ptr pcl = std::dynamic_pointer_cast<PointCloudMeasurement>(m);
+    if (!pcl) {   // PointCloudSensor.cpp:243-247
+      mLogger->message(ERROR, "Measurement in getAccumulatedCloud() is not a point cloud!");
+      throw BadMeasurementType();
+    }
+    keep.push_back(deviceCloudOf(pcl));
+    clouds.push_back(keep.back()->cloud);
+    const Transform tf = v.correctedPose * pcl->getSensorPose();   // :249
+    poses.insert(poses.end(), tf.data(), tf.data() + 16);
+  }
+}
+
+PointCloud::Ptr PointCloudSensor::getAccumulatedCloud(const VertexObjectList& vertices) const {
+  std::vector<std::shared_ptr<DeviceCloud>> keep;
+  std::vector<s3d_cloud*> clouds;
+  std::vector<double> poses;
+  gather(vertices, keep, clouds, poses);
+  s3d_cloud* accu = nullptr;
+  if (s3d_cloud_accumulate(mContext, (int)clouds.size(), clouds.data(), poses.data(), nullptr, &accu) != S3D_STATUS_OK)
+    throw std::runtime_error(std::string("HIP back-end error: ") + s3d_last_error(mContext));
+  DeviceCloud guard(accu);
+  return download(accu);
+}
+
+Measurement::Ptr PointCloudSensor::createCombinedMeasurement(const VertexObjectList& vertices, Transform pose) const {
+  std::vector<std::shared_ptr<DeviceCloud>> keep;
+  std::vector<s3d_cloud*> clouds;
+  std::vector<double> poses;
+  gather(vertices, keep, clouds, poses);
+  s3d_cloud* shifted = nullptr;   // accumulate + pose.inverse() in one pass over the points (:260-262)
+  if (s3d_cloud_accumulate(mContext, (int)clouds.size(), clouds.data(), poses.data(), pose.data(), &shifted) !=
+      S3D_STATUS_OK)
+    throw std::runtime_error(std::string("HIP back-end error: ") + s3d_last_error(mContext));
+  std::shared_ptr<DeviceCloud> dev = std::make_shared<DeviceCloud>(shifted);
+  PointCloud::Ptr cloud = download(shifted);
+  mLogger->message(DEBUG, "Patch pointcloud has " + std::to_string(cloud->size()) + " points.");
+  PointCloudMeasurement::Ptr m(new PointCloudMeasurement(cloud, "AccumulatedPointcloud", mName, Transform::Identity()));
+  m->setDeviceCloud(dev);   // the patch stays in HBM for the createConstraint that follows (ScanSensor.cpp:150-156)
+  return m;
+}
+
+PointCloud::Ptr PointCloudSensor::buildMap(const VertexObjectList& vertices) const {
+  std::vector<std::shared_ptr<DeviceCloud>> keep;
+  std::vector<s3d_cloud*> clouds;
+  std::vector<double> poses;
+  gather(vertices, keep, clouds, poses);
+  s3d_cloud* map = nullptr;   // :305-309: accumulate, removeOutliers, downsample — all in HBM
+  if (s3d_build_map(mContext, (int)clouds.size(), clouds.data(), poses.data(), mMapOutlierRadius, mMapOutlierNeighbors,
+                    mMapResolution, &map) != S3D_STATUS_OK)
+    throw std::runtime_error(std::string("HIP back-end error: ") + s3d_last_error(mContext));
+  DeviceCloud guard(map);
+  mLogger->message(INFO, "Generated Pointcloud from " + std::to_string(vertices.size()) + " scans.");
+  return download(map);
+}
+
 Transform PointCloudSensor::align(const PointCloudMeasurement::Ptr& source, const PointCloudMeasurement::Ptr& target,
                                   const Transform& guess, const RegistrationParameters& config) {
-  const PointCloud::Ptr s = source->getPointCloud(), t = target->getPointCloud();
+  // each cloud is uploaded once per measurement and reused by every later align() it takes part in
+  std::shared_ptr<DeviceCloud> s = deviceCloudOf(source), t = deviceCloudOf(target);
   Transform result;
   s3d_align_info info;
-  static const float dummy[4] = {0, 0, 0, 0};
-  const int st = s3d_align(mContext, s->size() ? &s->points[0].x : dummy, (int)s->size(), 4,
-                           t->size() ? &t->points[0].x : dummy, (int)t->size(), 4, guess.data(),
-                           reinterpret_cast<const s3d_reg_params*>(&config), nullptr, result.data(), &info);
+  const int st = s3d_align_clouds(mContext, s->cloud, t->cloud, guess.data(),
+                                  reinterpret_cast<const s3d_reg_params*>(&config), nullptr, result.data(), &info);
   switch (st) {
     case S3D_STATUS_OK: return result;
     case S3D_STATUS_TOO_FEW_POINTS:   // PointCloudSensor.cpp:135

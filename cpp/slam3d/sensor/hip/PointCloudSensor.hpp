@@ -43,6 +43,17 @@ class PointCloud {
 };
 
 // PointCloudSensor.hpp:50-100
+// The HBM copy of a measurement's cloud.  Not in the reference: it is what lets a scan be uploaded once and
+// then registered against every neighbour (ScanSensor::linkToNeighbors), and a loop-closure patch go from
+// createCombinedMeasurement into createConstraint without visiting the host.
+struct DeviceCloud {
+  explicit DeviceCloud(s3d_cloud* c) : cloud(c) {}
+  ~DeviceCloud() { s3d_cloud_release(nullptr, cloud); }
+  DeviceCloud(const DeviceCloud&) = delete;
+  DeviceCloud& operator=(const DeviceCloud&) = delete;
+  s3d_cloud* cloud;
+};
+
 class PointCloudMeasurement : public Measurement {
  public:
   typedef std::shared_ptr<PointCloudMeasurement> Ptr;
@@ -50,8 +61,13 @@ class PointCloudMeasurement : public Measurement {
       : Measurement(r, s, p), mPointCloud(cloud) {}
   const PointCloud::Ptr getPointCloud() const { return mPointCloud; }
   const char* getTypeName() const override { return "slam3d::PointCloudMeasurement"; }
+  // device-resident copy, attached lazily by the sensor (the host cloud must not be modified afterwards)
+  std::shared_ptr<DeviceCloud> getDeviceCloud() const { std::lock_guard<std::mutex> l(mDeviceMutex); return mDeviceCloud; }
+  void setDeviceCloud(std::shared_ptr<DeviceCloud> d) const { std::lock_guard<std::mutex> l(mDeviceMutex); mDeviceCloud = d; }
  protected:
   PointCloud::Ptr mPointCloud;
+  mutable std::mutex mDeviceMutex;
+  mutable std::shared_ptr<DeviceCloud> mDeviceCloud;
 };
 
 // the part of Sensor / ScanSensor (Sensor.hpp:84-168, ScanSensor.hpp:35-158) the path needs
@@ -90,6 +106,14 @@ class PointCloudSensor : public ScanSensor {
   PointCloud::Ptr downsampleScan(PointCloud::Ptr source);
   PointCloud::Ptr transform(PointCloud::ConstPtr source, const Transform tf) const;
 
+  // ---- patches and maps (reference: PointCloudSensor.hpp:127, :200-216).  The reference reaches the
+  // measurements through mMapper->getGraph(); the mirror has no Mapper/Graph, the storage is handed in directly.
+  void setMeasurementStorage(MeasurementStorage* s) { mStorage = s; }
+  PointCloud::Ptr removeOutliers(PointCloud::Ptr source, double radius, unsigned min_neighbors) const;
+  PointCloud::Ptr getAccumulatedCloud(const VertexObjectList& vertices) const;
+  Measurement::Ptr createCombinedMeasurement(const VertexObjectList& vertices, Transform pose) const;
+  PointCloud::Ptr buildMap(const VertexObjectList& vertices) const;
+
   // the same align() the reference keeps file-local (PointCloudSensor.cpp:119-174), exposed for tests
   Transform align(const PointCloudMeasurement::Ptr& source, const PointCloudMeasurement::Ptr& target,
                   const Transform& guess, const RegistrationParameters& config);
@@ -103,6 +127,13 @@ class PointCloudSensor : public ScanSensor {
   unsigned mMapOutlierNeighbors;
 
  private:
+  // upload-once cache: the device copy of a measurement's cloud
+  std::shared_ptr<DeviceCloud> deviceCloudOf(const PointCloudMeasurement::Ptr& m) const;
+  // clouds + poses (correctedPose * sensorPose) of the vertices, as the C ABI takes them
+  void gather(const VertexObjectList& vertices, std::vector<std::shared_ptr<DeviceCloud>>& keep,
+              std::vector<s3d_cloud*>& clouds, std::vector<double>& poses) const;
+  PointCloud::Ptr download(s3d_cloud* c) const;
+  MeasurementStorage* mStorage = nullptr;
   s3d_context* mContext;   // one HIP device + stream; calls are serialised inside the library,
                            // so createConstraint may be entered from the link thread (ScanSensor.cpp:210)
 };

@@ -129,8 +129,11 @@ int  s3d_cloud_download(s3d_context* ctx, const s3d_cloud* c, float* xyz, int st
 int  s3d_cloud_accumulate(s3d_context* ctx, int n_clouds, s3d_cloud* const* clouds, const double* poses,
                           const double frame[16], s3d_cloud** out);
 
-/* ---- A1 on device-resident clouds (patches built by s3d_cloud_accumulate): same contract as
- *          s3d_create_constraint. */
+/* ---- A2 / A1 on device-resident clouds (scans uploaded once, patches built by s3d_cloud_accumulate): same
+ *          contracts as s3d_align / s3d_create_constraint. */
+int  s3d_align_clouds(s3d_context* ctx, s3d_cloud* source, s3d_cloud* target, const double guess[16],
+                      const s3d_reg_params* params, const s3d_exec_options* opts, double result[16],
+                      s3d_align_info* info);
 int  s3d_create_constraint_clouds(s3d_context* ctx, s3d_cloud* source, const double source_sensor_pose[16],
                                   s3d_cloud* target, const double target_sensor_pose[16], const double odometry[16],
                                   int loop, const s3d_reg_params* fine, const s3d_reg_params* coarse,

@@ -119,6 +119,7 @@ def load_library():
                                             C.c_double, op, dp, dp, C.POINTER(AlignInfo)]),
         "s3d_cloud_download": (C.c_int, [vp, vp, fp, C.c_int]),
         "s3d_cloud_accumulate": (C.c_int, [vp, C.c_int, C.POINTER(vp), dp, dp, C.POINTER(vp)]),
+        "s3d_align_clouds": (C.c_int, [vp, vp, vp, dp, pp, op, dp, C.POINTER(AlignInfo)]),
         "s3d_create_constraint_clouds": (C.c_int, [vp, vp, dp, vp, dp, dp, C.c_int, pp, pp, C.c_double, op, dp, dp,
                                                    C.POINTER(AlignInfo)]),
         "s3d_remove_outliers": (C.c_int, [vp, fp, C.c_int, C.c_int, C.c_double, C.c_uint, fp, ip]),
@@ -369,6 +370,15 @@ class Context:
         if st:
             raise ValueError(STATUS_NAMES[st])
         return self._new_cloud(h)
+
+    def align_clouds(self, source, target, guess=np.eye(4), params=None, opts=None):
+        params = params or default_params()
+        g = _colmajor(guess)
+        res = np.empty(16, np.float64)
+        info = AlignInfo()
+        st = self._check(self._L.s3d_align_clouds(self._h, source.handle, target.handle, _dp(g), C.byref(params),
+                                                  C.byref(opts) if opts else None, _dp(res), C.byref(info)))
+        return st, _from_colmajor(res), info.asdict()
 
     def create_constraint_clouds(self, source, source_pose, target, target_pose, odometry, loop=False, fine=None,
                                  coarse=None, covariance_scale=1.0, opts=None):

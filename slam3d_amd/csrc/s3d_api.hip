@@ -1083,6 +1083,20 @@ int s3d_cloud_accumulate(s3d_context* ctx, int n_clouds, s3d_cloud* const* cloud
   return S3D_STATUS_OK;
 }
 
+int s3d_align_clouds(s3d_context* ctx, s3d_cloud* source, s3d_cloud* target, const double guess[16],
+                     const s3d_reg_params* params, const s3d_exec_options* opts, double result[16],
+                     s3d_align_info* info) {
+  if (!ctx || !source || !target || !guess || !params || !result) return S3D_STATUS_INVALID_ARGUMENT;
+  for (int i = 0; i < 16; ++i) result[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  if (info) std::memset(info, 0, sizeof *info);
+  try {
+    ScopedDevice sd(ctx);
+    return align_dev(ctx, source, target, guess, params, opts, result, info);
+  } catch (const HipError& e) {
+    return fail(ctx, e);
+  }
+}
+
 int s3d_create_constraint_clouds(s3d_context* ctx, s3d_cloud* source, const double source_sensor_pose[16],
                                  s3d_cloud* target, const double target_sensor_pose[16], const double odometry[16],
                                  int loop, const s3d_reg_params* fine, const s3d_reg_params* coarse,

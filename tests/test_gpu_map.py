@@ -215,3 +215,47 @@ def test_map_of_ten_million_points_properties(gpu_ctx):
     assert len(M) == n_vox
     mjk = np.floor(M * inv).astype(np.int64)
     assert len(np.unique(mjk, axis=0)) >= int(0.999 * n_vox)   # centroids stay in their voxel up to float rounding
+
+
+def test_cpp_mirror_build_map_and_patch_link(gpu_ctx, oracle_mod, fixture_clouds, golden, tmp_path):
+    """slam3d::PointCloudSensor::buildMap / getAccumulatedCloud / createCombinedMeasurement + createConstraint through
+    the C++ mirror (cpp/example_build_map.cpp) == the golden map and the C ABI called from Python."""
+    import subprocess
+    import slam3d_amd as s3d
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "cpp", "example_build_map")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "cpp")])
+    poses = [np.array(p) for p in golden["poses"]]
+    with open(tmp_path / "poses.txt", "w") as f:
+        for T in poses:
+            f.write(" ".join("%.17g" % v for v in T.reshape(-1)) + "\n")
+    files = []
+    for i, c in enumerate(fixture_clouds):
+        fn = tmp_path / ("scan%d.bin" % i)
+        c.astype(np.float32).tofile(fn)
+        files.append(str(fn))
+    out = subprocess.check_output([exe, str(tmp_path / "poses.txt"), *files], stderr=subprocess.DEVNULL).decode().splitlines()
+    assert out[0].startswith("MAP ")
+    n_map, sx, sy, sz = out[0].split()[1:]
+    rec = golden["build_map"]["0.2/3/0.10"]   # the sensor's constructor defaults (PointCloudSensor.cpp:179-182)
+    want = oracle_mod.build_map(fixture_clouds, poses, 0.2, 3, 0.1)
+    assert int(n_map) == rec["n"] == len(want)
+    assert np.allclose([float(sx), float(sy), float(sz)], want.astype(np.float64).sum(0), rtol=1e-9)
+    assert out[1] == "ACCU %d" % golden["accumulate"]["n"]
+    # the loop-closure link of the two device-resident patches == the same call from Python
+    dev = [gpu_ctx.upload(c) for c in fixture_clouds]
+    pa = gpu_ctx.accumulate(dev[:2], poses[:2], poses[0])
+    pb = gpu_ctx.accumulate(dev[2:], poses[2:], poses[2])
+    assert out[2] == "PATCH %d %d" % (pa.n, pb.n)
+    fine = s3d.default_params(registration_algorithm=s3d.ALG_ICP)
+    coarse = s3d.default_params(registration_algorithm=s3d.ALG_ICP, point_cloud_density=0.5,
+                                max_correspondence_distance=5.0)
+    guess = np.linalg.inv(poses[0]) @ poses[2]
+    st, rel, _, _ = gpu_ctx.create_constraint_clouds(pa, np.eye(4), pb, np.eye(4), guess, True, fine, coarse)
+    if st == 0:
+        assert out[3] == "OK SE(3)"
+        T_cpp = np.array([[float(x) for x in line.split()] for line in out[4:8]])
+        assert np.allclose(T_cpp, rel, atol=1e-9)
+    else:
+        assert out[3].startswith("NoMatch")
