@@ -36,7 +36,8 @@ typedef struct s3d_exec_options {
   int force_iterations;     /* != 0: run exactly maximum_iterations outer iterations (bench mode, no early exit) */
   int check_interval;       /* host polls "all pairs converged" every N outer iterations (0 = default 2)          */
   int grid_cells_per_point; /* search-grid budget, cells per input point (0 = default 2)                         */
-  int profile;              /* != 0: record per-stage HIP-event timings, read with s3d_last_profile()            */
+  int profile;              /* != 0: record per-stage HIP-event timings, read with s3d_last_profile();
+                               >= 2: also count the searched queries per NN launch (slows the first passes)      */
 } s3d_exec_options;
 
 typedef struct s3d_align_info {   /* diagnostics of one align() */
@@ -52,6 +53,8 @@ typedef struct s3d_profile {      /* milliseconds, HIP events on the context's s
   int    nn_launches;
   long long nn_queries, nn_targets; /* summed over launches: queries searched, target points indexed */
   float  nn_launch_ms[64];          /* duration of the first 64 NN launches of the ICP loop, in order */
+  int    nn_searched[64];           /* profile >= 2: queries of launch i that needed a grid search (not re-validated) */
+  int    nn_unseeded[64];           /* ... of which without a usable previous neighbour (wide search)            */
 } s3d_profile;
 
 /* ---- context ------------------------------------------------------------------ */

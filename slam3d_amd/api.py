@@ -52,10 +52,13 @@ class EdgeRecord(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("voxel_ms", C.c_double), ("grid_ms", C.c_double), ("normals_ms", C.c_double), ("icp_ms", C.c_double),
                 ("fitness_ms", C.c_double), ("total_ms", C.c_double), ("nn_ms", C.c_double), ("nn_launches", C.c_int),
-                ("nn_queries", C.c_longlong), ("nn_targets", C.c_longlong), ("nn_launch_ms", C.c_float * 64)]
+                ("nn_queries", C.c_longlong), ("nn_targets", C.c_longlong), ("nn_launch_ms", C.c_float * 64),
+                ("nn_searched", C.c_int * 64), ("nn_unseeded", C.c_int * 64)]
 
     def asdict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "nn_launch_ms"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("nn_launch_ms", "nn_searched", "nn_unseeded")}
+        d["nn_searched"] = list(self.nn_searched[:max(min(self.nn_launches, 64), 0)])
+        d["nn_unseeded"] = list(self.nn_unseeded[:max(min(self.nn_launches, 64), 0)])
         d["nn_launch_ms"] = [round(float(x), 4) for x in self.nn_launch_ms[:max(self.nn_launch_ms and self.nn_launches, 0)]][:64]
         return d
 

@@ -130,6 +130,7 @@ struct s3d_context {
       const size_t want = total + total / 8;
       HIPCHK(hipMalloc(&arena.p, want));
       arena.cap = want;
+      if (getenv("S3D_DBG_ARENA")) std::fprintf(stderr, "[s3d] arena %p + %zu MiB\n", arena.p, want >> 20);
     }
     size_t off = 0;
     for (auto& r : reqs) {
@@ -261,7 +262,7 @@ struct Batch {
                 {&ctx->corr_idx, 4 * nc}, {&ctx->corr_d2, 4 * nc}, {&ctx->corr_lb, 4 * nc},
                 {&ctx->corr_q, 16 * nc}, {&ctx->corr_n, 16 * nc},
                 {&ctx->partials, 8 * (size_t)std::max(1, P()) * kAccumBlocks * GQ_NACC},
-                {&ctx->n_active, 64}});
+                {&ctx->n_active, 64 + 2 * 64 * sizeof(int)}});
     if (!ctx->h_active) HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
     hipStream_t st = ctx->stream;
     if (C()) HIPCHK(hipMemcpyAsync(ctx->slots.p, h_slots.data(), sizeof(SlotDev) * C(), hipMemcpyHostToDevice, st));
@@ -343,7 +344,8 @@ struct Batch {
   }
 
   int dbg_nn = getenv("S3D_DBG_NN") ? atoi(getenv("S3D_DBG_NN")) : 0;
-  void launch_nn(int mode, float max_d) {
+  // prof_slot >= 0: count searched / unseeded queries of this launch into the profile counters
+  void launch_nn(int mode, float max_d, int prof_slot = -1) {
     hipStream_t st = ctx->stream;
     const int chunks = cdiv(std::max(max_n_t, 1), kBlock);
     const int pairs8 = P() >= 8 ? cdiv(P(), 8) * 8 : P();
@@ -353,6 +355,7 @@ struct Batch {
     float* cl = (float*)ctx->corr_lb.p;
     float4* cq = (float4*)ctx->corr_q.p;
     float4* cn = (float4*)ctx->corr_n.p;
+    int* pc = (prof_slot >= 0 && prof_slot < 64) ? (int*)ctx->n_active.p + 16 + 2 * prof_slot : nullptr;
     if (dbg_nn & 8) {      // opt-in (S3D_DBG_NN=8): LDS-tiled kernel; measured slower than the default, see DESIGN.md
       if (mode == 0)
         s3d_nn_search_tiled_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), normals(), ci, cd, cl, cq, cn, max_d, chunks, P());
@@ -361,9 +364,9 @@ struct Batch {
       return;
     }
     if (mode == 0)
-      s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), normals(), ci, cd, cl, cq, cn, max_d, chunks, P(), dbg_nn);
+      s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), normals(), ci, cd, cl, cq, cn, max_d, chunks, P(), dbg_nn, pc);
     else
-      s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), normals(), ci, cd, cl, cq, cn, max_d, chunks, P(), dbg_nn);
+      s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), normals(), ci, cd, cl, cq, cn, max_d, chunks, P(), dbg_nn, pc);
   }
 
   // K5-K7 loop.  The host only polls the active-pair counter every check_interval iterations.
@@ -378,6 +381,7 @@ struct Batch {
     const float max_d = (float)(rp.max_corr * 1.0001);
     double* part = (double*)ctx->partials.p;
     const bool prof = opts.profile != 0;
+    if (prof) HIPCHK(hipMemsetAsync((int*)ctx->n_active.p + 16, 0, 2 * 64 * sizeof(int), st));
     for (int it = 0; it < rp.max_iterations; ++it) {
       if (prof) {
         if ((int)ctx->nn_ev.size() < 2 * (it + 1)) {
@@ -387,7 +391,7 @@ struct Batch {
         }
         HIPCHK(hipEventRecord(ctx->nn_ev[2 * it], st));
       }
-      launch_nn(0, max_d);
+      launch_nn(0, max_d, opts.profile >= 2 ? it : -1);   // the counters cost two atomics per searching wave
       if (prof) HIPCHK(hipEventRecord(ctx->nn_ev[2 * it + 1], st));
       if (rp.algorithm)
         s3d_gicp_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
@@ -460,6 +464,9 @@ struct Batch {
         ctx->prof.nn_ms += ms;
         if (i < 64) ctx->prof.nn_launch_ms[i] = ms;
       }
+      int counts[128];
+      HIPCHK(hipMemcpy(counts, (int*)ctx->n_active.p + 16, sizeof counts, hipMemcpyDeviceToHost));
+      for (int i = 0; i < 64; ++i) { ctx->prof.nn_searched[i] = counts[2 * i]; ctx->prof.nn_unseeded[i] = counts[2 * i + 1]; }
       ctx->prof.nn_queries = nq * ctx->prof.nn_launches;
       ctx->prof.nn_targets = nt * ctx->prof.nn_launches;
     }
@@ -771,6 +778,12 @@ int s3d_context_create(int device, void* hip_stream, s3d_context** out) {
     } else {
       HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
       ctx->own_stream = true;
+    }
+    if (const char* pre = getenv("S3D_ARENA_PREALLOC_MB")) {   // experiment: reserve the workspace before any cloud upload
+      const size_t want = (size_t)atoll(pre) << 20;
+      HIPCHK(hipMalloc(&ctx->arena.p, want));
+      ctx->arena.cap = want;
+      if (getenv("S3D_DBG_ARENA")) std::fprintf(stderr, "[s3d] arena (prealloc) %p + %zu MiB\n", ctx->arena.p, want >> 20);
     }
   } catch (const HipError& e) {
     fail(ctx, e);

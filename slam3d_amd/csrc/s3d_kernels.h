@@ -609,7 +609,8 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
                                                                 int* __restrict__ corr_idx, float* __restrict__ corr_d2,
                                                                 float* __restrict__ corr_lb, float4* __restrict__ corr_q,
                                                                 float4* __restrict__ corr_n, float max_d,
-                                                                int chunks_per_pair, int npairs, int dbg) {
+                                                                int chunks_per_pair, int npairs, int dbg,
+                                                                int* __restrict__ prof_counts) {
   int pair, chunk;
   if (dbg & 16) { pair = blockIdx.x / chunks_per_pair; chunk = blockIdx.x % chunks_per_pair; }  // A/B: plain map
   else nn_block_map(chunks_per_pair, npairs, &pair, &chunk);
@@ -629,37 +630,58 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
   // radius hint: this query's distance in the previous pass (NaN-filled before the first one)
   const float prev = corr_d2[P.corr_off + i];
   const float lb = corr_lb[P.corr_off + i];      // lower bound of all OTHER points at the previous position (0: none)
+  float move = 3.0e38f;                          // how far this query moved since the previous pass (if known)
   if (lb > 0.f && prev >= 0.f && !(dbg & 64)) {
-    // re-validate the previous neighbour by the triangle inequality (s3d_core.h nn_still_nearest)
+    // re-validate the previous result by the triangle inequality (s3d_core.h nn_still_nearest)
     const F3 qo = xf_eigen(P.T_nn, pg.x, pg.y, pg.z);   // where this query stood in the previous pass
-    const float4 ps = corr_q[P.corr_off + i];           // the neighbour itself travels with the correspondence
-    const float d2n = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z);
-    const float move = sqrtf(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
-    if (nn_still_nearest(sqrtf(d2n), move, lb)) {
-      corr_d2[P.corr_off + i] = d2n;                 // same point, its exact new distance
-      corr_lb[P.corr_off + i] = lb - move;           // still a lower bound for the others
+    move = sqrtf(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
+    if (prev < 1.0e30f) {
+      const float4 ps = corr_q[P.corr_off + i];         // the neighbour itself travels with the correspondence
+      const float d2n = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z);
+      if (nn_still_nearest(sqrtf(d2n), move, lb)) {
+        corr_d2[P.corr_off + i] = d2n;                 // same point, its exact new distance
+        corr_lb[P.corr_off + i] = lb - move;           // still a lower bound for the others
+        return;
+      }
+    } else if (nn_still_nearest(max_d, move, lb)) {
+      // no point at all within lb of the previous position, lb > max_d: still none within max_d
+      corr_lb[P.corr_off + i] = lb - move;
       return;
     }
   }
   NNResult r;
+  if (prof_counts) {   // profile mode only: how many queries search, how many of them without a seed
+    const bool unseeded = !(prev >= 0.f && prev < Ss.g.h * Ss.g.h);
+    const unsigned long long all = __ballot(1), un = __ballot(unseeded);
+    if (lane_id() == __ffsll((long long)all) - 1) {
+      atomicAdd(&prof_counts[0], (int)__popcll(all));
+      atomicAdd(&prof_counts[1], (int)__popcll(un));
+    }
+  }
   if (dbg & 4) {
     r = grid_nn1(Ss.g, cell_start + Ss.cell_off, sorted + Ss.off, q.x, q.y, q.z, max_d);
   } else {
     // seed: the neighbour found by the previous pass (its distance under the new transform bounds the
-    // search radius exactly), unless it was far away — then the transform has just moved a lot and a
-    // one-cell box is the better first guess.  dbg & 32: hint-only variant (A/B).
-    const int seed = (prev >= 0.f && prev < Ss.g.h * Ss.g.h && !(dbg & 32)) ? corr_idx[P.corr_off + i] : -1;
+    // search radius exactly).  A NEAR neighbour (< one cell) is always used.  A FAR one — a query in a part of
+    // the scan the other cloud does not cover — is trusted only when the query has barely moved since the
+    // previous pass: right after a large transform update a one-cell box is the better first guess, once the
+    // registration settles the old neighbour is still the nearest and the search must cover its ball anyway.
+    // dbg & 32: hint-only variant (A/B).
+    const bool has_prev = prev >= 0.f && prev < 1.0e30f;
+    const bool near_seed = has_prev && prev < Ss.g.h * Ss.g.h;
+    const bool far_seed = has_prev && !near_seed && move < kNNRevalSlack * Ss.g.h && !(dbg & 128);
+    const int seed = ((near_seed || far_seed) && !(dbg & 32)) ? corr_idx[P.corr_off + i] : -1;
     // first pass (nothing known yet): a generous three-cell box — the shrinking-ball scan makes a large
     // initial radius cheap, while a small one costs a second scan for every badly aligned query
-    const float first = 3.0f * Ss.g.h;
-    const float hint = (prev >= 0.f && prev < 1.0e30f) ? fminf(sqrtf(prev) * 1.25f + 0.05f * Ss.g.h, Ss.g.h) : first;
-    r = grid_nn1_box(Ss.g, cell_start + Ss.cell_off, sorted + Ss.off, q.x, q.y, q.z, max_d, hint, seed);
+    const float first = ((dbg & 256) ? 1.0f : (dbg & 512) ? 1.5f : (dbg & 1024) ? 2.0f : 3.0f) * Ss.g.h;
+    const float hint = has_prev ? fminf(sqrtf(prev) * 1.25f + 0.05f * Ss.g.h, Ss.g.h) : first;
+    r = grid_nn1_box(Ss.g, cell_start + Ss.cell_off, sorted + Ss.off, q.x, q.y, q.z, max_d, hint, seed, far_seed);
   }
   // results are kept in the query cloud's cell-sorted order and name the neighbour by its POSITION in
   // the target's cell-sorted array: every later access (K6, fitness) is then coalesced or a local gather
   corr_idx[P.corr_off + i] = r.pos;
   corr_d2[P.corr_off + i] = r.d2;
-  corr_lb[P.corr_off + i] = (r.idx >= 0 && !(dbg & 4)) ? nn_lower_bound_others(r) : 0.f;
+  corr_lb[P.corr_off + i] = !(dbg & 4) ? nn_lower_bound_others(r) : 0.f;   // no neighbour at all: the scanned radius
   if (r.pos >= 0) {
     // a copy of the matched point and of its normal is kept with the correspondence: the re-validation
     // above and the accumulate kernel then stream them instead of gathering by index

@@ -70,6 +70,12 @@ def make_pair(n, pair_index=0):
     T = np.eye(4)
     T[:3, :3] = _rpy(*rpy)
     T[:3, 3] = t
-    Tinv = np.linalg.inv(T)
-    b_local = (b.astype(np.float64) @ Tinv[:3, :3].T + Tinv[:3, 3]).astype(np.float32)
-    return a, b_local, T
+    # rigid inverse and the per-point products are written out element-wise: a BLAS matmul here is neither
+    # bit-reproducible across thread counts nor — observed with 16 generator threads on a 256-core host and
+    # OpenBLAS 0.3.29 (MAX_THREADS=64) — always correct
+    R, t3 = T[:3, :3], T[:3, 3]
+    Ri = R.T.copy()
+    ti = -(Ri[:, 0] * t3[0] + Ri[:, 1] * t3[1] + Ri[:, 2] * t3[2])
+    x, y, z = (b[:, k].astype(np.float64) for k in range(3))
+    b_local = np.stack([(x * Ri[r, 0] + y * Ri[r, 1]) + (z * Ri[r, 2] + ti[r]) for r in range(3)], axis=1)
+    return a, b_local.astype(np.float32), T

@@ -23,8 +23,8 @@ using namespace s3d;
 
 static double g_emu_perturb = 0.0;
 
-static long long g_reval_hits = 0, g_reval_misses = 0, g_reval_mismatch = 0;
-extern "C" void emu_reval_stats(long long* out) { out[0] = g_reval_hits; out[1] = g_reval_misses; out[2] = g_reval_mismatch; }
+static long long g_reval_hits = 0, g_reval_misses = 0, g_reval_mismatch = 0, g_far_seeded = 0;
+extern "C" void emu_reval_stats(long long* out) { out[0] = g_reval_hits; out[1] = g_reval_misses; out[2] = g_reval_mismatch; out[3] = g_far_seeded; }
 extern "C" void emu_set_perturb(double e) { g_emu_perturb = e; }
 namespace {
 
@@ -220,7 +220,7 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
   for (int i = 0; i < 16; ++i) guess.m[i] = (float)guess_d[i];
   Mat4f Tr = mat4f_identity(), prev = mat4f_identity();
   const double thr = cfg->max_correspondence_distance * cfg->max_correspondence_distance;
-  const float max_d = (float)cfg->max_correspondence_distance;
+  const float max_d_search = (float)(cfg->max_correspondence_distance * 1.0001);   // what Batch::stage_icp passes to K5
   int nr = 0, converged = 0, cnt = 0;
   std::vector<float> hints(T.pts.size(), -1.f), lbs(T.pts.size(), 0.f);
   std::vector<int> seeds(T.pts.size(), -1);
@@ -235,31 +235,53 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
       const F4& p0 = T.pts[i];
       const F3 p = xf_pcl(guess, p0.x, p0.y, p0.z);
       const F3 q = xf_eigen(Tr, p.x, p.y, p.z);
-      const float hint = hints[i] >= 0.f ? std::fmin(std::sqrt(hints[i]) * 1.25f + 0.05f * GS.g.h, GS.g.h) : GS.g.h;
-      const int seed = (hints[i] >= 0.f && hints[i] < GS.g.h * GS.g.h) ? seeds[i] : -1;
+      // the same decisions as s3d_nn_search_kernel<0> (hints[i]: previous d2, 3e38 = searched but none, -1 = never)
+      const float prevd = hints[i];
+      const bool has_prev = prevd >= 0.f && prevd < 1.0e30f;
       NNResult r;
+      r.idx = -1; r.d2 = 3.0e38f; r.pos = -1;
       bool revalidated = false;
-      if (lbs[i] > 0.f && hints[i] >= 0.f) {   // the kernel's triangle-inequality shortcut
+      float move = 3.0e38f;
+      if (lbs[i] > 0.f && prevd >= 0.f) {   // the kernel's triangle-inequality shortcut
         const F3 qo = xf_eigen(T_nn, p.x, p.y, p.z);
-        const F4& ps = GS.sorted[seeds[i]];
-        const float d2n = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z);
-        const float move = std::sqrt(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
-        if (nn_still_nearest(std::sqrt(d2n), move, lbs[i])) {
-          r.idx = __builtin_bit_cast(int, ps.w); r.d2 = d2n; r.pos = seeds[i];
+        move = std::sqrt(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
+        if (has_prev) {
+          const F4& ps = GS.sorted[seeds[i]];
+          const float d2n = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z);
+          if (nn_still_nearest(std::sqrt(d2n), move, lbs[i])) {
+            r.idx = __builtin_bit_cast(int, ps.w); r.d2 = d2n; r.pos = seeds[i];
+            revalidated = true;
+          }
+        } else if (nn_still_nearest(max_d_search, move, lbs[i])) {
+          revalidated = true;                 // still no point within max_d
+        }
+        if (revalidated) {
           lbs[i] -= move;
-          revalidated = true;
           ++g_reval_hits;
-          // the shortcut must agree with a full search, bit for bit
-          NNResult full = grid_nn1_box(GS.g, GS.cell_start.data(), GS.sorted.data(), q.x, q.y, q.z, max_d, hint, seed);
-          if (full.idx != r.idx || full.d2 != r.d2) ++g_reval_mismatch;
+          // the shortcut must agree with a full, unseeded search, bit for bit (within max_d)
+          NNResult full = grid_nn1_box(GS.g, GS.cell_start.data(), GS.sorted.data(), q.x, q.y, q.z, max_d_search, GS.g.h);
+          const bool full_in = full.idx >= 0 && full.d2 <= max_d_search * max_d_search;
+          const bool r_in = r.idx >= 0 && r.d2 <= max_d_search * max_d_search;
+          if (full_in != r_in || (full_in && (full.idx != r.idx || full.d2 != r.d2))) ++g_reval_mismatch;
         }
       }
       if (!revalidated) {
-        r = grid_nn1_box(GS.g, GS.cell_start.data(), GS.sorted.data(), q.x, q.y, q.z, max_d, hint, seed);
-        lbs[i] = r.idx >= 0 ? nn_lower_bound_others(r) : 0.f;
+        const bool near_seed = has_prev && prevd < GS.g.h * GS.g.h;
+        const bool far_seed = has_prev && !near_seed && move < kNNRevalSlack * GS.g.h;
+        const int seed = (near_seed || far_seed) ? seeds[i] : -1;
+        const float hint = has_prev ? std::fmin(std::sqrt(prevd) * 1.25f + 0.05f * GS.g.h, GS.g.h) : 3.0f * GS.g.h;
+        r = grid_nn1_box(GS.g, GS.cell_start.data(), GS.sorted.data(), q.x, q.y, q.z, max_d_search, hint, seed, far_seed);
+        lbs[i] = nn_lower_bound_others(r);
         ++g_reval_misses;
+        if (far_seed) {   // a trusted far seed must give what an unseeded search gives
+          ++g_far_seeded;
+          NNResult full = grid_nn1_box(GS.g, GS.cell_start.data(), GS.sorted.data(), q.x, q.y, q.z, max_d_search, GS.g.h);
+          const bool full_in = full.idx >= 0 && full.d2 <= max_d_search * max_d_search;
+          const bool r_in = r.idx >= 0 && r.d2 <= max_d_search * max_d_search;
+          if (full_in != r_in || (full_in && (full.idx != r.idx || full.d2 != r.d2))) ++g_reval_mismatch;
+        }
       }
-      hints[i] = r.idx >= 0 ? r.d2 : -1.f;
+      hints[i] = r.d2;
       seeds[i] = r.pos;
       if (r.idx < 0 || !((double)r.d2 < thr)) continue;
       const F4& t = S.pts[r.idx];

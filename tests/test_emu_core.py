@@ -209,12 +209,13 @@ def test_correspondence_revalidation_is_exact(emu, oracle_mod, fixture_clouds):
     """The triangle-inequality shortcut of the NN kernel (nn_still_nearest) must return exactly what a
     full search returns; the emulation harness checks every shortcut hit against a full search."""
     p = oracle_mod.default_params(registration_algorithm=oracle_mod.ALG_ICP, maximum_iterations=30)
-    before = (C.c_longlong * 3)()
+    before = (C.c_longlong * 4)()
     emu.emu_reval_stats(before)
     for a, b in ((0, 1), (2, 3)):
         emu_align(emu, oracle_mod, fixture_clouds[a], fixture_clouds[b], params=p, force=1)
-    stats = (C.c_longlong * 3)()
+    stats = (C.c_longlong * 4)()
     emu.emu_reval_stats(stats)
-    hits, misses, mismatch = (stats[i] - before[i] for i in range(3))
-    assert stats[2] == 0                # no shortcut hit of the whole module run ever disagreed with a full search
+    hits, misses, mismatch, far_seeded = (stats[i] - before[i] for i in range(4))
+    assert stats[2] == 0                # no shortcut hit / trusted far seed of the whole module run ever disagreed with a full search
+    assert far_seeded > 100             # queries without a near neighbour (partial overlap) do take the trusted-seed path
     assert hits > 2 * misses, (hits, misses)   # once ICP has converged nearly every correspondence is re-validated
