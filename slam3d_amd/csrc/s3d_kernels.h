@@ -598,6 +598,108 @@ __global__ void k_pair_init(PairDev* pairs, int npairs, int* n_active) {
 }
 
 // ------------------------------------------------------------------ K5: transform + exact 1-NN
+// ---- wave-cooperative wide search -------------------------------------------------------------------
+// A query without a near neighbour (a part of the scan the other cloud does not cover, a badly aligned first
+// guess) has to examine a ball of many cells: one lane walking its rows one dependent load after the other is a
+// chain of hundreds of memory latencies, and the 63 other lanes of its wave wait for it.  When only a few lanes
+// of a wave are in that situation the wave serves them one at a time instead: every lane takes one ROW of the
+// query's box (slab test, row range look-up, scan of the row's points), a lexicographic (d2, index) wave
+// reduction picks the winner, and the loop of grid_nn1_box (exact radius / doubling) runs on wave-uniform
+// values.  Same neighbour, same float d2 and the same tie rule as the per-lane search; the lower bound it
+// reports for the re-validation is computed from what was examined and may differ (both are valid bounds).
+constexpr int kCoopMaxLanes = 16;   // more wide lanes than this: the per-lane search is the faster one
+
+__device__ __forceinline__ NNResult wave_nn1_coop(const GridParams& g, const uint32_t* __restrict__ cell_start,
+                                                  const float4* __restrict__ pts, float qx, float qy, float qz,
+                                                  float max_d, float d_hint, int seed_pos, bool seed_trusted) {
+  // all arguments are wave-uniform
+  const int lane = lane_id();
+  NNResult best;
+  best.idx = -1; best.d2 = 3.0e38f; best.pos = -1; best.second_d2 = 3.0e38f; best.radius = 0.f;
+  const float cap = max_d + kNNRevalSlack * g.h;
+  const float shell = seed_trusted ? kNNRevalSlack * g.h : 0.f;
+  float d = fminf(fmaxf(d_hint, 0.25f * g.h), cap);
+  if (seed_pos >= 0) {
+    nn1_consider(best, pts[seed_pos], (uint32_t)seed_pos, qx, qy, qz);
+    d = sqrtf(best.d2) * 1.0001f + 1.0e-6f + kNNRevalSlack * g.h;
+    d = fminf(seed_trusted ? d : fminf(d, g.h), cap);
+  }
+  const float eps = 2.0e-3f * g.h;
+  for (int attempt = 0; attempt < 64; ++attempt) {
+    const float m = d * 1.0001f + 2.0e-3f * g.h;
+    const int x0 = imax(grid_coord(g, 0, qx - m), 0), x1 = imin(grid_coord(g, 0, qx + m), g.dim[0] - 1);
+    const int y0 = imax(grid_coord(g, 1, qy - m), 0), y1 = imin(grid_coord(g, 1, qy + m), g.dim[1] - 1);
+    const int z0 = imax(grid_coord(g, 2, qz - m), 0), z1 = imin(grid_coord(g, 2, qz + m), g.dim[2] - 1);
+    const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+    // rows farther than the best so far (+ shell) cannot matter; the limit is fixed for the whole round
+    float lim2 = 3.0e38f;
+    if (best.idx >= 0) {
+      const float l = sqrtf(best.d2) * 1.0001f + shell;
+      lim2 = shell > 0.f ? l * l : best.d2;
+    }
+    NNResult mine;   // this lane's rows
+    mine.idx = -1; mine.d2 = 3.0e38f; mine.pos = -1; mine.second_d2 = 3.0e38f; mine.radius = 0.f;
+    if (x0 <= x1 && ny > 0 && nz > 0) {
+      const int nrows = ny * nz;
+      for (int r = lane; r < nrows; r += kWave) {
+        const int cy = y0 + r % ny, cz = z0 + r / ny;
+        const float ylo = g.origin[1] + (float)cy * g.h, zlo = g.origin[2] + (float)cz * g.h;
+        const float dy = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.h)) - eps, 0.f);
+        const float dz = fmaxf(fmaxf(zlo - qz, qz - (zlo + g.h)) - eps, 0.f);
+        const float rowd2 = dy * dy + dz * dz;
+        if (rowd2 > lim2) continue;
+        int xa = x0, xb = x1;
+        if (lim2 < 1.0e30f) {
+          const float rx = sqrtf(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
+          xa = imax(x0, grid_coord(g, 0, qx - rx));
+          xb = imin(x1, grid_coord(g, 0, qx + rx));
+          if (xa > xb) continue;
+        }
+        const int rowbase = g.dim[0] * (cy + g.dim[1] * cz);
+        const uint32_t s = cell_start[rowbase + xa], e = cell_start[rowbase + xb + 1];
+        for (uint32_t k = s; k < e; k += 2) {
+          const float4 pa = pts[k];
+          const float4 pb = pts[k + 1 < e ? k + 1 : k];
+          nn1_consider(mine, pa, k, qx, qy, qz);
+          if (k + 1 < e) nn1_consider(mine, pb, k + 1, qx, qy, qz);
+        }
+      }
+    }
+    // merge: the incumbent (wave-uniform) competes as lane 0's extra candidate
+    if (lane == 0 && best.idx >= 0) {
+      if (mine.idx == best.idx) { /* met again */ }
+      else if (lex_less(best.d2, best.idx, mine.d2, mine.idx < 0 ? 2147483647 : mine.idx)) {
+        mine.second_d2 = fminf(mine.second_d2, mine.d2);
+        mine.d2 = best.d2; mine.idx = best.idx; mine.pos = best.pos;
+      } else {
+        mine.second_d2 = fminf(mine.second_d2, best.d2);
+      }
+      mine.second_d2 = fminf(mine.second_d2, best.second_d2);
+    }
+    // lexicographic (d2, idx) minimum over the wave
+    float wd2 = mine.d2; int widx = mine.idx < 0 ? 2147483647 : mine.idx; int wpos = mine.pos;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float od2 = __shfl_xor(wd2, o, kWave);
+      const int oidx = __shfl_xor(widx, o, kWave);
+      const int opos = __shfl_xor(wpos, o, kWave);
+      if (lex_less(od2, oidx, wd2, widx)) { wd2 = od2; widx = oidx; wpos = opos; }
+    }
+    // runner-up: every lane's second, and the best of every lane that did not win
+    float sec = mine.second_d2;
+    if (mine.idx >= 0 && mine.idx != widx) sec = fminf(sec, mine.d2);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sec = fminf(sec, __shfl_xor(sec, o, kWave));
+    if (widx != 2147483647) { best.idx = widx; best.d2 = wd2; best.pos = wpos; }
+    best.second_d2 = fminf(best.second_d2, sec);
+    best.radius = lim2 < 1.0e30f ? fminf(d, sqrtf(lim2) * 0.9999f) : d;
+    if (best.idx >= 0 && best.d2 <= d * d) break;   // nothing outside the box can be closer
+    if (d >= cap) break;
+    d = best.idx >= 0 ? fminf(sqrtf(best.d2) * 1.0001f + 1.0e-6f + shell, cap) : fminf(2.0f * d, cap);
+  }
+  return best;
+}
+
 // MODE 0: ICP iteration  q = transformation_ * (guess * p)   (Eigen product of the PCL-transformed point)
 // MODE 1: fitness pass   q = final_transformation * p        (pcl::transformPointCloud)
 template <int MODE>
@@ -619,74 +721,95 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
   if (MODE == 0 && !P.active) return;
   const SlotDev& St = slots[P.slot_t];
   const int i = chunk * kBlock + threadIdx.x;
-  if (i >= St.n) return;
+  if (chunk * kBlock >= St.n) return;
   const SlotDev& Ss = slots[P.slot_s];
+  // lanes past the end of the cloud stay in the wave (the cooperative search needs all of them) but own no query
+  bool need = i < St.n;
+  const int ci = P.corr_off + (need ? i : 0);
   // queries are taken in the CELL-SORTED order of their own cloud (spatially coherent waves)
-  const float4 p0 = sorted[St.off + i];
+  const float4 p0 = sorted[St.off + (need ? i : 0)];
   const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
   F3 q;
   if (MODE == 0) q = xf_eigen(P.T, pg.x, pg.y, pg.z);
   else q = xf_pcl(P.final_T, p0.x, p0.y, p0.z);
   // radius hint: this query's distance in the previous pass (NaN-filled before the first one)
-  const float prev = corr_d2[P.corr_off + i];
-  const float lb = corr_lb[P.corr_off + i];      // lower bound of all OTHER points at the previous position (0: none)
+  const float prev = corr_d2[ci];
+  const float lb = corr_lb[ci];                  // lower bound of all OTHER points at the previous position (0: none)
   float move = 3.0e38f;                          // how far this query moved since the previous pass (if known)
-  if (lb > 0.f && prev >= 0.f && !(dbg & 64)) {
+  if (need && lb > 0.f && prev >= 0.f && !(dbg & 64)) {
     // re-validate the previous result by the triangle inequality (s3d_core.h nn_still_nearest)
     const F3 qo = xf_eigen(P.T_nn, pg.x, pg.y, pg.z);   // where this query stood in the previous pass
     move = sqrtf(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
     if (prev < 1.0e30f) {
-      const float4 ps = corr_q[P.corr_off + i];         // the neighbour itself travels with the correspondence
+      const float4 ps = corr_q[ci];                     // the neighbour itself travels with the correspondence
       const float d2n = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z);
       if (nn_still_nearest(sqrtf(d2n), move, lb)) {
-        corr_d2[P.corr_off + i] = d2n;                 // same point, its exact new distance
-        corr_lb[P.corr_off + i] = lb - move;           // still a lower bound for the others
-        return;
+        corr_d2[ci] = d2n;                             // same point, its exact new distance
+        corr_lb[ci] = lb - move;                       // still a lower bound for the others
+        need = false;
       }
     } else if (nn_still_nearest(max_d, move, lb)) {
       // no point at all within lb of the previous position, lb > max_d: still none within max_d
-      corr_lb[P.corr_off + i] = lb - move;
-      return;
+      corr_lb[ci] = lb - move;
+      need = false;
     }
   }
-  NNResult r;
-  if (prof_counts) {   // profile mode only: how many queries search, how many of them without a seed
-    const bool unseeded = !(prev >= 0.f && prev < Ss.g.h * Ss.g.h);
-    const unsigned long long all = __ballot(1), un = __ballot(unseeded);
-    if (lane_id() == __ffsll((long long)all) - 1) {
+  if (__ballot(need) == 0ull) return;
+  // seed: the neighbour found by the previous pass (its distance under the new transform bounds the
+  // search radius exactly).  A NEAR neighbour (< one cell) is always used.  A FAR one — a query in a part of
+  // the scan the other cloud does not cover — is trusted only when the query has barely moved since the
+  // previous pass: right after a large transform update a one-cell box is the better first guess, once the
+  // registration settles the old neighbour is still the nearest and the search must cover its ball anyway.
+  // dbg & 32: hint-only variant (A/B).
+  const bool has_prev = prev >= 0.f && prev < 1.0e30f;
+  const bool near_seed = has_prev && prev < Ss.g.h * Ss.g.h;
+  const bool far_seed = has_prev && !near_seed && move < kNNRevalSlack * Ss.g.h && !(dbg & 128);
+  const int seed = ((near_seed || far_seed) && !(dbg & 32)) ? corr_idx[ci] : -1;
+  // first pass (nothing known yet): a generous three-cell box — the shrinking-ball scan makes a large
+  // initial radius cheap, while a small one costs a second scan for every badly aligned query
+  const float first = ((dbg & 256) ? 1.0f : (dbg & 512) ? 1.5f : (dbg & 1024) ? 2.0f : 3.0f) * Ss.g.h;
+  const float hint = has_prev ? fminf(sqrtf(prev) * 1.25f + 0.05f * Ss.g.h, Ss.g.h) : first;
+  if (prof_counts) {   // profile >= 2 only: how many queries search, how many of them without a near seed
+    const unsigned long long all = __ballot(need), un = __ballot(need && !near_seed);
+    if (lane_id() == 0) {
       atomicAdd(&prof_counts[0], (int)__popcll(all));
       atomicAdd(&prof_counts[1], (int)__popcll(un));
     }
   }
+  NNResult r;
+  r.idx = -1; r.d2 = 3.0e38f; r.pos = -1; r.second_d2 = 3.0e38f; r.radius = 0.f;
+  const uint32_t* __restrict__ cs = cell_start + Ss.cell_off;
+  const float4* __restrict__ tp = sorted + Ss.off;
   if (dbg & 4) {
-    r = grid_nn1(Ss.g, cell_start + Ss.cell_off, sorted + Ss.off, q.x, q.y, q.z, max_d);
+    if (need) r = grid_nn1(Ss.g, cs, tp, q.x, q.y, q.z, max_d);
   } else {
-    // seed: the neighbour found by the previous pass (its distance under the new transform bounds the
-    // search radius exactly).  A NEAR neighbour (< one cell) is always used.  A FAR one — a query in a part of
-    // the scan the other cloud does not cover — is trusted only when the query has barely moved since the
-    // previous pass: right after a large transform update a one-cell box is the better first guess, once the
-    // registration settles the old neighbour is still the nearest and the search must cover its ball anyway.
-    // dbg & 32: hint-only variant (A/B).
-    const bool has_prev = prev >= 0.f && prev < 1.0e30f;
-    const bool near_seed = has_prev && prev < Ss.g.h * Ss.g.h;
-    const bool far_seed = has_prev && !near_seed && move < kNNRevalSlack * Ss.g.h && !(dbg & 128);
-    const int seed = ((near_seed || far_seed) && !(dbg & 32)) ? corr_idx[P.corr_off + i] : -1;
-    // first pass (nothing known yet): a generous three-cell box — the shrinking-ball scan makes a large
-    // initial radius cheap, while a small one costs a second scan for every badly aligned query
-    const float first = ((dbg & 256) ? 1.0f : (dbg & 512) ? 1.5f : (dbg & 1024) ? 2.0f : 3.0f) * Ss.g.h;
-    const float hint = has_prev ? fminf(sqrtf(prev) * 1.25f + 0.05f * Ss.g.h, Ss.g.h) : first;
-    r = grid_nn1_box(Ss.g, cell_start + Ss.cell_off, sorted + Ss.off, q.x, q.y, q.z, max_d, hint, seed, far_seed);
+    // queries that will walk a wide box: served by the whole wave, one after the other, when they are few
+    const bool wide = need && !near_seed;
+    unsigned long long wmask = __ballot(wide);
+    const bool coop = wmask != 0ull && __popcll(wmask) <= kCoopMaxLanes && !(dbg & 2048);
+    if (need && !(coop && wide)) r = grid_nn1_box(Ss.g, cs, tp, q.x, q.y, q.z, max_d, hint, seed, far_seed);
+    if (coop) {
+      while (wmask) {
+        const int src = __ffsll((long long)wmask) - 1;
+        wmask &= wmask - 1ull;
+        const NNResult w = wave_nn1_coop(Ss.g, cs, tp, __shfl(q.x, src, kWave), __shfl(q.y, src, kWave),
+                                         __shfl(q.z, src, kWave), max_d, __shfl(hint, src, kWave),
+                                         __shfl(seed, src, kWave), __shfl((int)far_seed, src, kWave) != 0);
+        if (lane_id() == src) r = w;
+      }
+    }
   }
+  if (!need) return;
   // results are kept in the query cloud's cell-sorted order and name the neighbour by its POSITION in
   // the target's cell-sorted array: every later access (K6, fitness) is then coalesced or a local gather
-  corr_idx[P.corr_off + i] = r.pos;
-  corr_d2[P.corr_off + i] = r.d2;
-  corr_lb[P.corr_off + i] = !(dbg & 4) ? nn_lower_bound_others(r) : 0.f;   // no neighbour at all: the scanned radius
+  corr_idx[ci] = r.pos;
+  corr_d2[ci] = r.d2;
+  corr_lb[ci] = !(dbg & 4) ? nn_lower_bound_others(r) : 0.f;   // no neighbour at all: the scanned radius
   if (r.pos >= 0) {
     // a copy of the matched point and of its normal is kept with the correspondence: the re-validation
     // above and the accumulate kernel then stream them instead of gathering by index
-    corr_q[P.corr_off + i] = sorted[Ss.off + r.pos];
-    corr_n[P.corr_off + i] = normals[Ss.off + r.pos];
+    corr_q[ci] = sorted[Ss.off + r.pos];
+    corr_n[ci] = normals[Ss.off + r.pos];
   }
 }
 

@@ -384,17 +384,20 @@ def test_cpp_point_cloud_sensor_create_constraint(gpu_ctx, fixture_clouds, tmp_p
 
 
 def test_nn_revalidation_shortcut_is_bitwise_neutral(gpu_ctx, fixture_clouds, monkeypatch):
-    """S3D_DBG_NN=64 disables the triangle-inequality shortcut of the NN kernel: results must not change."""
+    """The NN kernel's shortcuts (triangle-inequality re-validation, trusted far seeds, wave-cooperative wide
+    search) can be switched off one by one with S3D_DBG_NN: results must not change by a bit."""
     import slam3d_amd as s3d
     opts = s3d.ExecOptions(force_iterations=1)
     for alg in (s3d.ALG_ICP, s3d.ALG_GICP):
         p = s3d.default_params(registration_algorithm=alg, maximum_iterations=25)
         monkeypatch.delenv("S3D_DBG_NN", raising=False)
         st0, T0, i0 = gpu_ctx.align(fixture_clouds[1], fixture_clouds[2], np.eye(4), p, opts)
-        monkeypatch.setenv("S3D_DBG_NN", "64")
-        st1, T1, i1 = gpu_ctx.align(fixture_clouds[1], fixture_clouds[2], np.eye(4), p, opts)
-        monkeypatch.delenv("S3D_DBG_NN", raising=False)
-        assert st0 == st1 == 0 and np.array_equal(T0, T1) and i0 == i1
+        # 64: no re-validation; 128: no trusted far seeds; 2048: no wave-cooperative wide search
+        for flags in ("64", "128", "2048", str(64 + 128 + 2048)):
+            monkeypatch.setenv("S3D_DBG_NN", flags)
+            st1, T1, i1 = gpu_ctx.align(fixture_clouds[1], fixture_clouds[2], np.eye(4), p, opts)
+            monkeypatch.delenv("S3D_DBG_NN", raising=False)
+            assert st0 == st1 == 0 and np.array_equal(T0, T1) and i0 == i1, flags
 
 
 def test_million_point_pair(gpu_ctx, oracle_mod):
