@@ -654,6 +654,55 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
       return cnt < k ? cnt : k;
     }
   }
+  // ---- ring 2, pruned: the list is full, so the k-th distance so far bounds the true one.  If that ball lies
+  // inside the 5x5x5 cells around the point, only the ring-2 cells the ball reaches can still contribute:
+  // rows are slab-tested against the (shrinking) k-th distance and cut to the x-range the ball covers, the
+  // 3x3x3 cells already examined are skipped.  On surface-like clouds this reads a handful of cells instead of
+  // the 98 of the full shell (the un-pruned ring loop below was most of the kernel's time).
+  if (worst != kInf) {
+    const float b2 = (2.0f + face) * g.h;
+    float lim2 = knn_key_d2(worst);
+    if (lim2 <= b2 * b2) {
+      const float eps = 2.0e-3f * g.h;
+      for (int dz = -2; dz <= 2; ++dz) {
+        const int cz = iz + dz;
+        if (cz < 0 || cz >= g.dim[2]) continue;
+        const float zlo = g.origin[2] + (float)cz * g.h;
+        const float fz2 = fmaxf(fmaxf(zlo - qz, qz - (zlo + g.h)) - eps, 0.f);
+        if (fz2 * fz2 > lim2) continue;
+        for (int dy = -2; dy <= 2; ++dy) {
+          const int cy = iy + dy;
+          if (cy < 0 || cy >= g.dim[1]) continue;
+          const float ylo = g.origin[1] + (float)cy * g.h;
+          const float fy2 = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.h)) - eps, 0.f);
+          const float rowd2 = fy2 * fy2 + fz2 * fz2;
+          if (rowd2 > lim2) continue;
+          const float rx = sqrtf(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
+          const int xa = imax(imax(ix - 2, grid_coord(g, 0, qx - rx)), 0);
+          const int xb = imin(imin(ix + 2, grid_coord(g, 0, qx + rx)), g.dim[0] - 1);
+          const bool inner = dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
+          const int rowbase = g.dim[0] * (cy + g.dim[1] * cz);
+          for (int part = 0; part < 2; ++part) {
+            int sa, sb;
+            if (!inner) { if (part) break; sa = xa; sb = xb; }
+            else if (part == 0) { sa = xa; sb = imin(xb, ix - 2); }    // left of the examined cells
+            else { sa = imax(xa, ix + 2); sb = xb; }                  // right of them
+            if (sa > sb) continue;
+            const uint32_t s = cell_start[rowbase + sa], e = cell_start[rowbase + sb + 1];
+            for (uint32_t kk = s; kk < e; ++kk) {
+              const F4T p = pts[kk];
+              const float d2 = dist2(qx, qy, qz, p.x, p.y, p.z);
+              S3D_KNN_INSERT(p, d2)
+            }
+          }
+          lim2 = fminf(lim2, knn_key_d2(worst));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) keys_out[j] = __builtin_bit_cast(unsigned long long, keys[j]);
+      return cnt < k ? cnt : k;
+    }
+  }
   for (int r = 2; r <= rmax; ++r) {
     const int z0 = imax(iz - r, 0), z1 = imin(iz + r, g.dim[2] - 1);
     const int y0 = imax(iy - r, 0), y1 = imin(iy + r, g.dim[1] - 1);
