@@ -142,18 +142,18 @@ struct GridParams {
   int   ncells;
 };
 
-// h0: wanted cell edge; the edge is grown (x 2^(1/3)) until the cell count fits `cap`
+// h0: wanted cell edge; the edge is grown (x 2^(1/6)) until the cell count fits `cap`
 S3D_HD GridParams grid_params_from_bbox(const float mn[3], const float mx[3], float h0, int cap) {
   GridParams g;
   float h = h0;
-  for (int it = 0; it < 200; ++it) {
+  for (int it = 0; it < 400; ++it) {
     int64_t nc = 1;
     for (int a = 0; a < 3; ++a) {
       g.dim[a] = (int)floorf((mx[a] - mn[a]) / h) + 1;
       nc *= g.dim[a];
     }
     if (nc <= (int64_t)cap) break;
-    h *= 1.2599210f;
+    h *= 1.1224620f;   // 2^(1/6): the cell count lands within sqrt(2) of the budget
   }
   g.h = h;
   g.inv_h = 1.0f / h;

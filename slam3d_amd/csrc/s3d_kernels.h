@@ -1071,23 +1071,39 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
 #pragma unroll
   for (int c = 0; c < GQ_NACC; ++c) acc[c] = 0.0;
   const int M = St.n;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < M; i += gridDim.x * kBlock) {
-    const float d2 = corr_d2[P.corr_off + i];          // 3e38 when the query has no neighbour at all
-    if (!((double)d2 < rp.dist_threshold)) continue;
-    const float4 p0 = sorted[St.off + i];
-    const F3 pf = xf_pcl(P.guess, p0.x, p0.y, p0.z);
-    const float4 qf = corr_q[P.corr_off + i];
-    // xyz + normal, both float4: the float-rounded unit normals are used as stored (measured effect on
-    // the GICP result vs double normals: <= 2e-6 m)
-    const float4 na = normals[St.off + i], nb = corr_n[P.corr_off + i];
-    const double n1[3] = {na.x, na.y, na.z}, n2[3] = {nb.x, nb.y, nb.z};
-    double n1r[3], Mm[6];
+  // software-pipelined stream: the five loads of element i + stride are in flight while element i is folded
+  // into the 73 accumulators (three waves per SIMD fit beside them: the loads of ONE element per lane do not
+  // cover the HBM latency-bandwidth product)
+  const int stride = gridDim.x * kBlock;
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  float d2 = 3.0e38f;
+  float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), qf = p0, na = p0, nb = p0;
+  if (i < M) {
+    d2 = corr_d2[P.corr_off + i];          // 3e38 when the query has no neighbour at all
+    p0 = sorted[St.off + i]; qf = corr_q[P.corr_off + i];
+    na = normals[St.off + i]; nb = corr_n[P.corr_off + i];
+  }
+  while (i < M) {
+    const int in = i + stride;
+    const int j = in < M ? in : i;         // (the last step re-reads its own element: no branch around the loads)
+    const float d2n = corr_d2[P.corr_off + j];
+    const float4 p0n = sorted[St.off + j], qfn = corr_q[P.corr_off + j];
+    const float4 nan_ = normals[St.off + j], nbn = corr_n[P.corr_off + j];
+    if ((double)d2 < rp.dist_threshold) {
+      const F3 pf = xf_pcl(P.guess, p0.x, p0.y, p0.z);
+      // xyz + normal, both float4: the float-rounded unit normals are used as stored (measured effect on
+      // the GICP result vs double normals: <= 2e-6 m)
+      const double n1[3] = {na.x, na.y, na.z}, n2[3] = {nb.x, nb.y, nb.z};
+      double n1r[3], Mm[6];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) n1r[a] = R[a * 3] * n1[0] + R[a * 3 + 1] * n1[1] + R[a * 3 + 2] * n1[2];
-    gicp_mahalanobis(S, n1r, n2, rp.gicp_epsilon, Mm);
-    const double pd[3] = {pf.x, pf.y, pf.z};
-    const double qd[3] = {qf.x, qf.y, qf.z};
-    gq_accumulate(acc, pd, qd, Mm, Th0);
+      for (int a = 0; a < 3; ++a) n1r[a] = R[a * 3] * n1[0] + R[a * 3 + 1] * n1[1] + R[a * 3 + 2] * n1[2];
+      gicp_mahalanobis(S, n1r, n2, rp.gicp_epsilon, Mm);
+      const double pd[3] = {pf.x, pf.y, pf.z};
+      const double qd[3] = {qf.x, qf.y, qf.z};
+      gq_accumulate(acc, pd, qd, Mm, Th0);
+    }
+    d2 = d2n; p0 = p0n; qf = qfn; na = nan_; nb = nbn;
+    i = in;
   }
   block_reduce_store<GQ_NACC>(acc, partials + ((size_t)blockIdx.y * kAccumBlocks + blockIdx.x) * GQ_NACC);
 }

@@ -13,7 +13,7 @@ for r in range(REP):
         src.append(dev[a]); tgt.append(dev[b])
 for alg in (s3d.ALG_GICP, s3d.ALG_ICP):
     p=s3d.default_params(registration_algorithm=alg, maximum_iterations=20)
-    o=s3d.ExecOptions(force_iterations=1, profile=int(os.environ.get('PROFILE','1')))
+    o=s3d.ExecOptions(force_iterations=1, profile=int(os.environ.get('PROFILE','1')), grid_cells_per_point=int(os.environ.get('CPP','0')))
     for i in range(3): rec=ctx.align_batch(src,tgt,None,p,o); pr=ctx.last_profile()
     print('alg',alg,'pairs',len(src),'total %.2f voxel %.2f grid %.2f normals %.2f icp %.2f nn %.2f'%(pr['total_ms'],pr['voxel_ms'],pr['grid_ms'],pr['normals_ms'],pr['icp_ms'],pr['nn_ms']))
     print('  nn ms', [round(x,3) for x in pr['nn_launch_ms']])
