@@ -607,7 +607,8 @@ __global__ void k_pair_init(PairDev* pairs, int npairs, int* n_active) {
 // reduction picks the winner, and the loop of grid_nn1_box (exact radius / doubling) runs on wave-uniform
 // values.  Same neighbour, same float d2 and the same tie rule as the per-lane search; the lower bound it
 // reports for the re-validation is computed from what was examined and may differ (both are valid bounds).
-constexpr int kCoopMaxLanes = 16;   // more wide lanes than this: the per-lane search is the faster one
+constexpr int kCoopMaxLanes = 6;    // more wide lanes than this: the per-lane search is the faster one
+constexpr int kCoopAllLanes = 3;    // this few searching lanes in a wave: serve all of them cooperatively
 
 __device__ __forceinline__ NNResult wave_nn1_coop(const GridParams& g, const uint32_t* __restrict__ cell_start,
                                                   const float4* __restrict__ pts, float qx, float qy, float qz,
@@ -617,7 +618,8 @@ __device__ __forceinline__ NNResult wave_nn1_coop(const GridParams& g, const uin
   NNResult best;
   best.idx = -1; best.d2 = 3.0e38f; best.pos = -1; best.second_d2 = 3.0e38f; best.radius = 0.f;
   const float cap = max_d + kNNRevalSlack * g.h;
-  const float shell = seed_trusted ? kNNRevalSlack * g.h : 0.f;
+  // every seeded search examines a shell beyond the neighbour: that is what the next pass re-validates against
+  const float shell = seed_pos >= 0 ? kNNRevalSlack * g.h : 0.f;
   float d = fminf(fmaxf(d_hint, 0.25f * g.h), cap);
   if (seed_pos >= 0) {
     nn1_consider(best, pts[seed_pos], (uint32_t)seed_pos, qx, qy, qz);
@@ -637,31 +639,57 @@ __device__ __forceinline__ NNResult wave_nn1_coop(const GridParams& g, const uin
       const float l = sqrtf(best.d2) * 1.0001f + shell;
       lim2 = shell > 0.f ? l * l : best.d2;
     }
-    NNResult mine;   // this lane's rows
+    NNResult mine;   // this lane's share of the candidates
     mine.idx = -1; mine.d2 = 3.0e38f; mine.pos = -1; mine.second_d2 = 3.0e38f; mine.radius = 0.f;
     if (x0 <= x1 && ny > 0 && nz > 0) {
       const int nrows = ny * nz;
-      for (int r = lane; r < nrows; r += kWave) {
-        const int cy = y0 + r % ny, cz = z0 + r / ny;
-        const float ylo = g.origin[1] + (float)cy * g.h, zlo = g.origin[2] + (float)cz * g.h;
-        const float dy = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.h)) - eps, 0.f);
-        const float dz = fmaxf(fmaxf(zlo - qz, qz - (zlo + g.h)) - eps, 0.f);
-        const float rowd2 = dy * dy + dz * dz;
-        if (rowd2 > lim2) continue;
-        int xa = x0, xb = x1;
-        if (lim2 < 1.0e30f) {
-          const float rx = sqrtf(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
-          xa = imax(x0, grid_coord(g, 0, qx - rx));
-          xb = imin(x1, grid_coord(g, 0, qx + rx));
-          if (xa > xb) continue;
+      for (int base = 0; base < nrows; base += kWave) {
+        // step 1: one ROW per lane — slab test and range look-up (one memory latency for up to 64 rows)
+        const int r = base + lane;
+        uint32_t rs = 0, len = 0;
+        if (r < nrows) {
+          const int cy = y0 + r % ny, cz = z0 + r / ny;
+          const float ylo = g.origin[1] + (float)cy * g.h, zlo = g.origin[2] + (float)cz * g.h;
+          const float dy = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.h)) - eps, 0.f);
+          const float dz = fmaxf(fmaxf(zlo - qz, qz - (zlo + g.h)) - eps, 0.f);
+          const float rowd2 = dy * dy + dz * dz;
+          if (rowd2 <= lim2) {
+            int xa = x0, xb = x1;
+            if (lim2 < 1.0e30f) {
+              const float rx = sqrtf(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
+              xa = imax(x0, grid_coord(g, 0, qx - rx));
+              xb = imin(x1, grid_coord(g, 0, qx + rx));
+            }
+            if (xa <= xb) {
+              const int rowbase = g.dim[0] * (cy + g.dim[1] * cz);
+              rs = cell_start[rowbase + xa];
+              len = cell_start[rowbase + xb + 1] - rs;
+            }
+          }
         }
-        const int rowbase = g.dim[0] * (cy + g.dim[1] * cz);
-        const uint32_t s = cell_start[rowbase + xa], e = cell_start[rowbase + xb + 1];
-        for (uint32_t k = s; k < e; k += 2) {
-          const float4 pa = pts[k];
-          const float4 pb = pts[k + 1 < e ? k + 1 : k];
-          nn1_consider(mine, pa, k, qx, qy, qz);
-          if (k + 1 < e) nn1_consider(mine, pb, k + 1, qx, qy, qz);
+        // step 2: the candidates of all those rows dealt out one per lane and round (second latency)
+        uint32_t incl = len;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+          const uint32_t t = __shfl_up(incl, o, kWave);
+          if (lane >= o) incl += t;
+        }
+        const uint32_t total = __shfl(incl, kWave - 1, kWave);
+        for (uint32_t t0 = 0; t0 < total; t0 += kWave) {
+          const uint32_t t = t0 + lane;
+          int lo = 0, hi = kWave - 1;      // first lane whose inclusive count exceeds t
+#pragma unroll
+          for (int step = 0; step < 6; ++step) {
+            const int mid = (lo + hi) >> 1;
+            const uint32_t v = __shfl(incl, mid, kWave);
+            if (t >= v) lo = mid + 1; else hi = mid;
+          }
+          const uint32_t row_incl = __shfl(incl, lo, kWave), row_len = __shfl(len, lo, kWave);
+          const uint32_t row_rs = __shfl(rs, lo, kWave);
+          if (t < total) {
+            const uint32_t k = row_rs + (t - (row_incl - row_len));
+            nn1_consider(mine, pts[k], k, qx, qy, qz);
+          }
         }
       }
     }
@@ -783,8 +811,12 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
   if (dbg & 4) {
     if (need) r = grid_nn1(Ss.g, cs, tp, q.x, q.y, q.z, max_d);
   } else {
-    // queries that will walk a wide box: served by the whole wave, one after the other, when they are few
-    const bool wide = need && !near_seed;
+    // served by the whole wave, one query after the other: the queries that will walk a wide box when they are
+    // few, and every searching query when the wave has only a handful (a converging registration: most lanes
+    // were re-validated, the wave would otherwise idle through the ~10 dependent loads of one lane's box scan)
+    const unsigned long long nmask = __ballot(need);
+    const bool all_coop = __popcll(nmask) <= kCoopAllLanes && !(dbg & 2048);
+    const bool wide = need && (all_coop || !near_seed);
     unsigned long long wmask = __ballot(wide);
     const bool coop = wmask != 0ull && __popcll(wmask) <= kCoopMaxLanes && !(dbg & 2048);
     if (need && !(coop && wide)) r = grid_nn1_box(Ss.g, cs, tp, q.x, q.y, q.z, max_d, hint, seed, far_seed);
