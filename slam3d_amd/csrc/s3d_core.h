@@ -790,6 +790,50 @@ S3D_HD void sym3_smallest_eigvec(double a00, double a01, double a02, double a11,
   n[2] = m == 0 ? V[2][0] : (m == 1 ? V[2][1] : V[2][2]);
 }
 
+// Closed-form variant for the common, well-conditioned case (a surface patch: lambda_min well separated):
+// eigenvalues by the trigonometric solution of the characteristic cubic, eigenvector = the largest cross
+// product of two rows of (A - lambda_min I).  ~4x fewer operations than the Jacobi sweeps and no loop.
+// Returns false — caller falls back to the Jacobi iteration, whose tie rules the oracle shares — when the
+// matrix is (nearly) isotropic or lambda_min is not separated from the middle eigenvalue by 1e-6 of the
+// spread: there the closed form loses digits and the choice of vector is a convention, not a number.
+S3D_HD bool sym3_smallest_eigvec_direct(double a00, double a01, double a02, double a11, double a12, double a22,
+                                        double n[3]) {
+  const double scale = fmax(fmax(fabs(a00), fabs(a11)), fmax(fmax(fabs(a22), fabs(a01)), fmax(fabs(a02), fabs(a12))));
+  if (!(scale > 1e-300)) return false;
+  const double is = 1.0 / scale;
+  a00 *= is; a01 *= is; a02 *= is; a11 *= is; a12 *= is; a22 *= is;
+  const double q = (a00 + a11 + a22) / 3.0;
+  const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+  const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+  const double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1;
+  const double pp = sqrt(p2 / 6.0);
+  if (!(pp > 1e-9)) return false;
+  const double ip = 1.0 / pp;
+  const double c00 = b00 * ip, c01 = a01 * ip, c02 = a02 * ip, c11 = b11 * ip, c12 = a12 * ip, c22 = b22 * ip;
+  double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
+  r = fmin(fmax(r, -1.0), 1.0);
+  const double phi = acos(r) / 3.0;
+  const double emax = q + 2.0 * pp * cos(phi);
+  const double emin = q + 2.0 * pp * cos(phi + 2.0943951023931953);   // + 2 pi / 3
+  const double emid = 3.0 * q - emax - emin;
+  if (!(emid - emin > 1e-6 * (emax - emin))) return false;
+  // rows of A - emin I
+  const double r0[3] = {a00 - emin, a01, a02}, r1[3] = {a01, a11 - emin, a12}, r2[3] = {a02, a12, a22 - emin};
+  const double x0[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
+  const double x1[3] = {r0[1] * r2[2] - r0[2] * r2[1], r0[2] * r2[0] - r0[0] * r2[2], r0[0] * r2[1] - r0[1] * r2[0]};
+  const double x2[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+  const double m0 = x0[0] * x0[0] + x0[1] * x0[1] + x0[2] * x0[2];
+  const double m1 = x1[0] * x1[0] + x1[1] * x1[1] + x1[2] * x1[2];
+  const double m2 = x2[0] * x2[0] + x2[1] * x2[1] + x2[2] * x2[2];
+  double v0 = x0[0], v1 = x0[1], v2 = x0[2], mm = m0;
+  if (m1 > mm) { v0 = x1[0]; v1 = x1[1]; v2 = x1[2]; mm = m1; }
+  if (m2 > mm) { v0 = x2[0]; v1 = x2[1]; v2 = x2[2]; mm = m2; }
+  if (!(mm > 1e-24)) return false;
+  const double inv = 1.0 / sqrt(mm);
+  n[0] = v0 * inv; n[1] = v1 * inv; n[2] = v2 * inv;
+  return true;
+}
+
 // PCL computeCovariances moments of the k neighbours: float products, double sums
 struct Moments { double mean[3]; double c00, c10, c11, c20, c21, c22; };
 S3D_HD void moments_init(Moments& m) {
@@ -804,7 +848,8 @@ S3D_HD void moments_normal(const Moments& m, int k, double n[3]) {
   const double mx = m.mean[0] / kd, my = m.mean[1] / kd, mz = m.mean[2] / kd;
   const double c00 = m.c00 / kd - mx * mx, c10 = m.c10 / kd - my * mx, c11 = m.c11 / kd - my * my;
   const double c20 = m.c20 / kd - mz * mx, c21 = m.c21 / kd - mz * my, c22 = m.c22 / kd - mz * mz;
-  sym3_smallest_eigvec(c00, c10, c20, c11, c21, c22, n);
+  if (!sym3_smallest_eigvec_direct(c00, c10, c20, c11, c21, c22, n))
+    sym3_smallest_eigvec(c00, c10, c20, c11, c21, c22, n);
 }
 
 // ------------------------------------------------------------------ GICP quadratic form (K6/K7)
