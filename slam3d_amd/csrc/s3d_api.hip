@@ -336,7 +336,9 @@ struct Batch {
       s3d_knn_moments_kernel<8><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, k, nb_head, C());
     else if (k <= 16)
       s3d_knn_moments_kernel<16><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, k, nb_head, C());
-    else if (k <= 20)
+    else if (k == 20)   // the reference default (correspondence_randomness = 20): list length known at compile time
+      s3d_knn_moments_kernel<20, true><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, k, nb_head, C());
+    else if (k < 20)
       s3d_knn_moments_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, k, nb_head, C());
     else
       s3d_knn_moments_kernel<32><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, k, nb_head, C());

@@ -552,7 +552,10 @@ S3D_HD float knn_key_d2(double key) {
   return __builtin_bit_cast(float, (uint32_t)(__builtin_bit_cast(unsigned long long, key) >> 32) - 0x00800000u);
 }
 
-template <int KMAX, typename F4T>
+// FULL: k == KMAX is known at compile time (the default k = 20 on the <20> instantiation): `worst` is then simply
+// the last slot; with a run-time k the compiler evaluates the 20-way select chain after EVERY insertion
+// (80 v_cndmask per insertion, a fifth of the kernel's instructions).
+template <int KMAX, bool FULL = false, typename F4T = void>
 S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cell_start,
                            const F4T* __restrict__ pts, float qx, float qy, float qz, int k,
                            unsigned long long (&keys_out)[KMAX]) {
@@ -577,7 +580,7 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
         (unsigned long long)__builtin_bit_cast(uint32_t, (P_).w));                                 \
     if (c < worst) {                                                                               \
       knn_chain<KMAX>(keys, c);                                                                    \
-      if (k == KMAX) {                                                                             \
+      if (FULL || k == KMAX) {                                                                     \
         worst = keys[KMAX - 1];                                                                    \
       } else {                                                                                     \
         worst = kInf;                                                                              \
@@ -594,7 +597,11 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
     uint32_t rs[9], re[9];
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
-      const int cy = iy + (r % 3) - 1, cz = iz + (r / 3) - 1;
+      // the point's own row first, then the four rows sharing a face with it, then the corner rows: the list
+      // fills with near points early and most later candidates fail the one-compare pre-check instead of
+      // running the 40-instruction insertion chain (the result does not depend on the order)
+      const int rr = r == 0 ? 4 : (r <= 4 ? 2 * r - 1 : (r == 5 ? 0 : (r == 6 ? 2 : (r == 7 ? 6 : 8))));
+      const int cy = iy + (rr % 3) - 1, cz = iz + (rr / 3) - 1;
       const bool ok = xa <= xb && cy >= 0 && cy < g.dim[1] && cz >= 0 && cz < g.dim[2];
       const int rowbase = ok ? g.dim[0] * (cy + g.dim[1] * cz) : 0;
       const uint32_t a = cell_start[rowbase + (ok ? xa : 0)], b = cell_start[rowbase + (ok ? xb + 1 : 0)];

@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ 
 #ifndef S3D_KNN_WAVES
 #define S3D_KNN_WAVES 5
 #endif
-template <int KMAX>
+template <int KMAX, bool FULL = false>
 __global__ void __launch_bounds__(kBlock, S3D_KNN_WAVES) s3d_knn_moments_kernel(const SlotDev* __restrict__ slots,
                                                                   const float4* __restrict__ filt,
                                                                   const float4* __restrict__ sorted,
@@ -553,7 +553,7 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_WAVES) s3d_knn_moments_kernel(
   const float4* __restrict__ P = filt + s.off;
   const float4 q = sorted[s.off + i];
   unsigned long long keys[KMAX];
-  const int cnt = grid_knn_sorted<KMAX>(s.g, cell_start + s.cell_off, sorted + s.off, q.x, q.y, q.z, k, keys);
+  const int cnt = grid_knn_sorted<KMAX, FULL>(s.g, cell_start + s.cell_off, sorted + s.off, q.x, q.y, q.z, k, keys);
   Moments m;
   moments_init(m);
 #pragma unroll
