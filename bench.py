@@ -64,7 +64,8 @@ def main():
     import slam3d_amd as s3d
 
     dist = None
-    if world > 1:
+    # S3D_BENCH_FORCE_DIST=1: take the RCCL path with a single rank too (smoke test of the collective on a 1-GPU box)
+    if world > 1 or os.environ.get("S3D_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29513")

@@ -342,27 +342,55 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
     rank[r] = before + (unsigned int)in_round;
   }
   __syncthreads();
-  // exclusive prefix over the waves for digit = threadIdx.x, on top of the block's global offset
+  // digit = threadIdx.x: exclusive prefix over the waves (tile-local), the digit's first position inside the
+  // tile (exclusive scan of the tile histogram over the 256 digits) and in the output (this tile's row offset
+  // + the digit base of the pass)
+  __shared__ unsigned int dig_local[256], dig_global[256], wave_tot[kBlock / kWave];
+  __shared__ uint32_t lkey[kSortTile], lval[kSortTile];
   {
-    unsigned int run = counts[((size_t)blockIdx.y * 256 + threadIdx.x) * nb_max + blockIdx.x] +
-                       digit_base[(size_t)blockIdx.y * 256 + threadIdx.x];
+    unsigned int run = 0;
 #pragma unroll
     for (int ww = 0; ww < kBlock / kWave; ++ww) {
       const unsigned int c = wave_cnt[ww][threadIdx.x];
-      wave_cnt[ww][threadIdx.x] = run;
+      wave_cnt[ww][threadIdx.x] = run;      // elements of this digit in earlier waves of the tile
       run += c;
     }
+    unsigned int incl = run;                // tile histogram -> inclusive scan over the digits
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const unsigned int t = __shfl_up(incl, o, kWave);
+      if (lane >= o) incl += t;
+    }
+    if (lane == kWave - 1) wave_tot[w] = incl;
+    __syncthreads();
+    unsigned int before = 0;
+#pragma unroll
+    for (int ww = 0; ww < kBlock / kWave; ++ww) before += ww < w ? wave_tot[ww] : 0u;
+    dig_local[threadIdx.x] = before + incl - run;
+    dig_global[threadIdx.x] = counts[((size_t)blockIdx.y * 256 + threadIdx.x) * nb_max + blockIdx.x] +
+                              digit_base[(size_t)blockIdx.y * 256 + threadIdx.x];
   }
   __syncthreads();
+  // the tile is first put in digit order in LDS, then written out with consecutive threads on consecutive
+  // addresses of each digit run (a direct scatter issues 64 unrelated 4-byte stores per wave and array)
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const int i = base + r * kWave + lane;
     if (i < n) {
       const unsigned int d = (key[r] >> shift) & 255u;
-      const unsigned int pos = wave_cnt[w][d] + rank[r];
-      keys_out[s.off + pos] = key[r];
-      vals_out[s.off + pos] = val[r];
+      const unsigned int lp = dig_local[d] + wave_cnt[w][d] + rank[r];
+      lkey[lp] = key[r];
+      lval[lp] = val[r];
     }
+  }
+  __syncthreads();
+  const int tile_n = min(kSortTile, n - (int)blockIdx.x * kSortTile);
+  for (int j = threadIdx.x; j < tile_n; j += kBlock) {
+    const uint32_t kk = lkey[j];
+    const unsigned int d = (kk >> shift) & 255u;
+    const unsigned int pos = dig_global[d] + ((unsigned int)j - dig_local[d]);
+    keys_out[s.off + pos] = kk;
+    vals_out[s.off + pos] = lval[j];
   }
 }
 
