@@ -1,6 +1,6 @@
 """dev tool: in-process A/B of kernel variants selected by env vars (timing noise between processes is ~2x)."""
 import os, sys, time, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import slam3d_amd as s3d
 from multiprocessing.pool import ThreadPool
 NP=int(os.environ.get('NPAIRS','64'))

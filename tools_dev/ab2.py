@@ -1,6 +1,6 @@
 """dev tool: two-library A/B (old vs new build) — run as two processes alternating, reports step/icp/single-pair."""
 import os, sys, time, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import slam3d_amd as s3d
 from multiprocessing.pool import ThreadPool
 NP=int(os.environ.get('NPAIRS','256'))

@@ -1,6 +1,6 @@
 """dev tool: is the batch result bitwise identical across processes, and does the steady NN time follow it?"""
 import os, sys, hashlib, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import slam3d_amd as s3d
 from multiprocessing.pool import ThreadPool
 NP=int(os.environ.get('NPAIRS','128'))

@@ -1,6 +1,6 @@
 """dev tool: real-data batch (the reference's fixture scans, default parameters): per-launch NN time and search counts."""
 import os, sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import slam3d_amd as s3d
 G='tests/golden'
 clouds=[np.load(os.path.join(G,'cloud%d.npz'%i))['xyzi'].astype(np.float32) for i in range(1,5)]

@@ -1,6 +1,6 @@
 """dev tool: run only the k-NN normals stage a few times (for PMC collection)."""
 import os, sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import slam3d_amd as s3d
 from multiprocessing.pool import ThreadPool
 NP=64

@@ -1,6 +1,6 @@
 """dev tool: how much does each pair's transform still move per outer iteration at the end of the forced 20?"""
 import os, sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import slam3d_amd as s3d
 from multiprocessing.pool import ThreadPool
 NP=int(os.environ.get('NPAIRS','256'))

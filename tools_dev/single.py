@@ -1,5 +1,5 @@
 import os, sys, time, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import slam3d_amd as s3d
 pairs=[s3d.make_pair(100000,0)]
 ctx=s3d.Context(0)

@@ -1,7 +1,7 @@
 """dev tool: does the NN steady-state launch time depend on the arena placement? re-create context in one process."""
 import os, sys, time, numpy as np
 import torch; torch.cuda.init(); torch.zeros(1, device="cuda")
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import slam3d_amd as s3d
 from multiprocessing.pool import ThreadPool
 NP=int(os.environ.get('NPAIRS','256'))
