@@ -358,13 +358,6 @@ struct Batch {
     float4* cq = (float4*)ctx->corr_q.p;
     float4* cn = (float4*)ctx->corr_n.p;
     int* pc = (prof_slot >= 0 && prof_slot < 64) ? (int*)ctx->n_active.p + 16 + 2 * prof_slot : nullptr;
-    if (dbg_nn & 8) {      // opt-in (S3D_DBG_NN=8): LDS-tiled kernel; measured slower than the default, see DESIGN.md
-      if (mode == 0)
-        s3d_nn_search_tiled_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), normals(), ci, cd, cl, cq, cn, max_d, chunks, P());
-      else
-        s3d_nn_search_tiled_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), normals(), ci, cd, cl, cq, cn, max_d, chunks, P());
-      return;
-    }
     if (mode == 0)
       s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), normals(), ci, cd, cl, cq, cn, max_d, chunks, P(), dbg_nn, pc);
     else

@@ -873,198 +873,6 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
   }
 }
 
-// ------------------------------------------------------------------ K5 (LDS-tiled): transform + exact 1-NN
-// One WAVE = 64 consecutive queries of the query cloud's cell-sorted order = a short strip in
-// space (a few metres).  Per attempt the wave
-//   1. reduces the union (in target-grid cells) of its lanes' search boxes     [wave shuffles],
-//   2. stages the cell-table rows and the candidate points of that union into its private LDS
-//      slice with COALESCED loads (one 4-byte / 16-byte element per lane and load),
-//   3. lets every lane scan its own box out of LDS.
-// A lane is done when its best candidate is provably the nearest (d_best <= box radius); the
-// others retry with the exact radius (candidate found) or a doubled one.  Waves whose union does
-// not fit the LDS slice, and lanes left after kTileAttempts, fall back to the global-memory box
-// search (grid_nn1_box).  The per-lane arithmetic and tie rule are those of grid_nn1_box, so the
-// result is identical; only where the bytes come from differs: the un-tiled kernel is bound by the
-// L1 (TCP) access rate — ~17 distinct cache lines per wave-load — not by DRAM.  No block barrier is
-// needed: a wave only ever reads LDS that it wrote itself.
-constexpr int kTileTabCap = 1280;    // u32 entries of staged cell table per wave  (5 KiB)
-constexpr int kTilePtsCap = 320;     // staged candidate points per wave (float4)  (5 KiB)
-constexpr int kTileMaxRows = 64;
-constexpr int kTileAttempts = 3;
-
-struct WaveTile {
-  uint32_t tab[kTileTabCap];
-  float4 pts[kTilePtsCap];
-  int row_gs[kTileMaxRows];          // global sorted position of the row's first staged point minus its LDS offset
-  int row_off[kTileMaxRows + 1];     // LDS offset of the row's first staged point
-  int row_base[kTileMaxRows];        // index of the row's cell (bx0, y, z) in cell_start
-};
-
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, kWave));
-  return v;
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, kWave));
-  return v;
-}
-// LDS written by some lanes of this wave is read by others: order the accesses
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <int MODE>
-__global__ void __launch_bounds__(kBlock) s3d_nn_search_tiled_kernel(const PairDev* __restrict__ pairs,
-                                                                      const SlotDev* __restrict__ slots,
-                                                                      const float4* __restrict__ sorted,
-                                                                      const uint32_t* __restrict__ cell_start,
-                                                                      const float4* __restrict__ normals,
-                                                                      int* __restrict__ corr_idx,
-                                                                      float* __restrict__ corr_d2,
-                                                                      float* __restrict__ corr_lb,
-                                                                      float4* __restrict__ corr_q,
-                                                                      float4* __restrict__ corr_n, float max_d,
-                                                                      int chunks_per_pair, int npairs) {
-  __shared__ WaveTile tiles[kBlock / kWave];
-  int pair, chunk;
-  nn_block_map(chunks_per_pair, npairs, &pair, &chunk);
-  if (pair >= npairs) return;
-  const PairDev& P = pairs[pair];
-  if (MODE == 0 && !P.active) return;
-  const SlotDev& St = slots[P.slot_t];
-  const int lane = lane_id(), w = wave_id();
-  if (chunk * kBlock + w * kWave >= St.n) return;             // (wave-uniform)
-  const SlotDev& Ss = slots[P.slot_s];
-  const GridParams g = Ss.g;
-  const uint32_t* __restrict__ cs = cell_start + Ss.cell_off;
-  const float4* __restrict__ spts = sorted + Ss.off;
-  const int i = chunk * kBlock + threadIdx.x;
-  const bool valid = i < St.n;
-  WaveTile& W = tiles[w];
-
-  F3 q = {0.f, 0.f, 0.f};
-  float d = g.h;
-  if (valid) {
-    const float4 p0 = sorted[St.off + i];
-    if (MODE == 0) {
-      const F3 p = xf_pcl(P.guess, p0.x, p0.y, p0.z);
-      q = xf_eigen(P.T, p.x, p.y, p.z);
-    } else {
-      q = xf_pcl(P.final_T, p0.x, p0.y, p0.z);
-    }
-    const float prev = corr_d2[P.corr_off + i];
-    const float hint = (prev >= 0.f && prev < 1.0e30f) ? fminf(sqrtf(prev) * 1.25f + 0.05f * g.h, g.h) : g.h;
-    d = fminf(fmaxf(hint, 0.25f * g.h), max_d);
-  }
-  NNResult best;
-  best.idx = -1; best.d2 = 3.0e38f; best.pos = -1; best.second_d2 = 3.0e38f; best.radius = 0.f;
-  bool done = !valid;
-
-  for (int attempt = 0; attempt < kTileAttempts; ++attempt) {
-    if (__ballot(!done) == 0ull) break;                       // (wave-uniform)
-    // ---- 1. union of the active lanes' boxes, in cells
-    int x0 = 0, x1 = -1, y0 = 0, y1 = -1, z0 = 0, z1 = -1;
-    if (!done) {
-      const float m = d * 1.0001f + 2.0e-3f * g.h;
-      x0 = imax(grid_coord(g, 0, q.x - m), 0); x1 = imin(grid_coord(g, 0, q.x + m), g.dim[0] - 1);
-      y0 = imax(grid_coord(g, 1, q.y - m), 0); y1 = imin(grid_coord(g, 1, q.y + m), g.dim[1] - 1);
-      z0 = imax(grid_coord(g, 2, q.z - m), 0); z1 = imin(grid_coord(g, 2, q.z + m), g.dim[2] - 1);
-    }
-    const bool box = !done && x0 <= x1 && y0 <= y1 && z0 <= z1;
-    const int big = 0x3FFFFFFF;
-    const int bx0 = wave_min_i(box ? x0 : big), bx1 = wave_max_i(box ? x1 : -big);
-    const int by0 = wave_min_i(box ? y0 : big), by1 = wave_max_i(box ? y1 : -big);
-    const int bz0 = wave_min_i(box ? z0 : big), bz1 = wave_max_i(box ? z1 : -big);
-    const bool nonempty = bx0 <= bx1 && by0 <= by1 && bz0 <= bz1;
-    const long long nry_l = (long long)by1 - by0 + 1, nrz_l = (long long)bz1 - bz0 + 1, ncx_l = (long long)bx1 - bx0 + 2;
-    bool fits = nonempty && nry_l * nrz_l <= kTileMaxRows && nry_l * nrz_l * ncx_l <= kTileTabCap;
-    if (nonempty && !fits) break;                             // union too large for the slice: global fallback
-    if (fits) {
-      const int nry = (int)nry_l, nrows = (int)(nry_l * nrz_l), ncx1 = (int)ncx_l;
-      // ---- 2a. per-row extents and their prefix sum (one row per lane)
-      int cnt = 0, s_r = 0, rowbase = 0;
-      if (lane < nrows) {
-        rowbase = g.dim[0] * ((by0 + lane % nry) + g.dim[1] * (bz0 + lane / nry)) + bx0;
-        s_r = (int)cs[rowbase];
-        cnt = (int)cs[rowbase + ncx1 - 1] - s_r;
-      }
-      int incl = cnt;
-#pragma unroll
-      for (int o = 1; o < kWave; o <<= 1) {
-        const int t = __shfl_up(incl, o, kWave);
-        if (lane >= o) incl += t;
-      }
-      const int total = __shfl(incl, kWave - 1, kWave);
-      if (total > kTilePtsCap) break;                         // too many candidate points: global fallback
-      if (lane < nrows) { W.row_off[lane] = incl - cnt; W.row_gs[lane] = s_r - (incl - cnt); W.row_base[lane] = rowbase; }
-      if (lane == 0) W.row_off[nrows] = total;
-      wave_lds_sync();
-      // ---- 2b. coalesced staging, four independent loads in flight per lane and step
-      {
-        const int ntab = nrows * ncx1;
-        for (int f = lane; f < ntab; f += 4 * kWave) {
-          int v[4], gsr[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int fu = f + u * kWave < ntab ? f + u * kWave : f;
-            const int r = fu / ncx1, c = fu - r * ncx1;
-            v[u] = (int)cs[W.row_base[r] + c];
-            gsr[u] = W.row_gs[r];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (f + u * kWave < ntab) W.tab[f + u * kWave] = (uint32_t)(v[u] - gsr[u]);
-        }
-        for (int j = lane; j < total; j += 2 * kWave) {
-          const int j2 = j + kWave < total ? j + kWave : j;
-          int lo1 = 0, lo2 = 0;                               // row of j: largest r with row_off[r] <= j
-#pragma unroll
-          for (int step = 32; step > 0; step >>= 1) {
-            if (lo1 + step < nrows && W.row_off[lo1 + step] <= j) lo1 += step;
-            if (lo2 + step < nrows && W.row_off[lo2 + step] <= j2) lo2 += step;
-          }
-          const float4 pa = spts[j + W.row_gs[lo1]], pb = spts[j2 + W.row_gs[lo2]];
-          W.pts[j] = pa;
-          if (j2 != j) W.pts[j2] = pb;
-        }
-      }
-      wave_lds_sync();
-      // ---- 3. every active lane scans its own box out of LDS
-      if (box) {
-        for (int cz = z0; cz <= z1; ++cz)
-          for (int cy = y0; cy <= y1; ++cy) {
-            const int r = (cz - bz0) * nry + (cy - by0);
-            const int gs = W.row_gs[r];
-            const uint32_t a = W.tab[r * ncx1 + (x0 - bx0)], b = W.tab[r * ncx1 + (x1 + 1 - bx0)];
-            for (uint32_t k = a; k < b; ++k) nn1_consider(best, W.pts[k], (uint32_t)((int)k + gs), q.x, q.y, q.z);
-          }
-      }
-      wave_lds_sync();                                        // the slice is re-staged by the next attempt
-    }
-    // ---- per-lane verdict (same rule as grid_nn1_box)
-    if (!done) {
-      if ((best.idx >= 0 && best.d2 <= d * d) || d >= max_d) done = true;
-      else d = best.idx >= 0 ? fminf(sqrtf(best.d2) * 1.0001f + 1.0e-6f, max_d) : fminf(2.0f * d, max_d);
-    }
-  }
-  if (valid) {
-    if (!done) {
-      const NNResult r = grid_nn1_box(g, cs, spts, q.x, q.y, q.z, max_d, d);
-      if (r.idx >= 0 && lex_less(r.d2, r.idx, best.d2, best.idx < 0 ? 2147483647 : best.idx)) best = r;
-    }
-    corr_idx[P.corr_off + i] = best.pos;
-    corr_d2[P.corr_off + i] = best.d2;
-    corr_lb[P.corr_off + i] = 0.f;     // (this variant does not keep the re-validation bound)
-    if (best.pos >= 0) {
-      corr_q[P.corr_off + i] = spts[best.pos];
-      corr_n[P.corr_off + i] = normals[Ss.off + best.pos];
-    }
-  }
-}
 
 // API export (s3d_nn_search / s3d_knn_normals): back from cell-sorted order to the caller's point order
 __global__ void __launch_bounds__(kBlock) k_export_corr(const PairDev* __restrict__ pairs, const SlotDev* __restrict__ slots,
