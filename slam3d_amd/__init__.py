@@ -10,3 +10,4 @@ from .api import (  # noqa: F401
     EdgeRecord, ExecOptions, Profile, RegParams, backend_info, build, default_params, lib_path, load_library,
     EDGE_RECORD_DOUBLES)
 from .synthetic import make_pair, make_scene_cloud  # noqa: F401
+from . import posegraph  # noqa: F401

@@ -259,3 +259,54 @@ def test_cpp_mirror_build_map_and_patch_link(gpu_ctx, oracle_mod, fixture_clouds
         assert np.allclose(T_cpp, rel, atol=1e-9)
     else:
         assert out[3].startswith("NoMatch")
+
+
+def test_pose_graph_loop_closure_sweep(gpu_ctx):
+    """a pose graph (drifted trajectory around the synthetic scene) -> linkToNeighbors candidates
+    -> device-resident patches -> batched coarse + fine registration.  The batch must equal the one-by-one
+    createConstraint on the same patches bit for bit, and recover the true relative poses."""
+    import slam3d_amd as s3d
+    from slam3d_amd.posegraph import LinkPolicy, PoseGraph, build_patch, register_links, sweep_candidates
+    n = 24
+    rng = np.random.default_rng(5)
+    g = PoseGraph()
+    truth = {}
+    for i in range(n):   # two laps of a small circle inside the canyon: lap 2 revisits lap 1
+        a = 4 * np.pi * i / n
+        T = np.eye(4)
+        T[:2, :2] = [[np.cos(0.2 * a), -np.sin(0.2 * a)], [np.sin(0.2 * a), np.cos(0.2 * a)]]
+        T[:3, 3] = [3.0 * np.cos(a), 2.0 * np.sin(a), 0.0]
+        truth[i] = T
+        world = s3d.make_scene_cloud(30000, 900 + i).astype(np.float64)
+        Ti = np.linalg.inv(T)
+        local = (world @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
+        drift = np.eye(4)
+        drift[:3, 3] = rng.normal(0, 0.08, 3) * (i > 0)
+        g.add_vertex(i, T @ drift, "velodyne", gpu_ctx.upload(local))
+    for i in range(n - 1):
+        g.add_edge(i, i + 1)
+    pol = LinkPolicy(neighbor_radius=1.2, max_neighbor_links=2, min_loop_length=6, patch_building_range=1)
+    pairs = sweep_candidates(g, pol)
+    assert 4 <= len(pairs) <= 2 * n
+    fine = s3d.default_params(registration_algorithm=s3d.ALG_ICP, point_cloud_density=0.1)
+    coarse = s3d.default_params(registration_algorithm=s3d.ALG_ICP, point_cloud_density=0.4,
+                                max_correspondence_distance=5.0)
+    rec, status = register_links(gpu_ctx, g, pairs, pol, fine, coarse)
+    assert sum(1 for st in status if st == 0) >= len(pairs) // 2
+    errs = []
+    for (s, t), r, st in zip(pairs[:6], rec, status):
+        ps, _ = build_patch(gpu_ctx, g, s, pol)
+        pt, _ = build_patch(gpu_ctx, g, t, pol)
+        st1, rel, _, _ = gpu_ctx.create_constraint_clouds(ps, np.eye(4), pt, np.eye(4), g.get_transform(s, t), True,
+                                                          fine, coarse)
+        assert st1 == st
+        if st == 0:
+            assert np.array_equal(s3d.api.record_transform(r), rel)
+            # the patches were assembled with the DRIFTED neighbour poses, so the truth is recovered only to the
+            # drift level of the patch members; the source/target scans themselves dominate
+            dt, dr = transform_delta(np.linalg.inv(truth[s]) @ truth[t], rel)
+            dg, _ = transform_delta(np.linalg.inv(truth[s]) @ truth[t], g.get_transform(s, t))
+            errs.append((dt, dg))
+            assert dt < 0.25 and dr < 0.05
+    errs = np.array(errs)
+    assert len(errs) >= 2 and errs[:, 0].mean() < errs[:, 1].mean()   # the links correct the drifted graph estimate

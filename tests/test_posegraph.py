@@ -1,0 +1,107 @@
+"""Candidate generation: slam3d_amd/posegraph.py against independent scipy restatements of
+the graph queries and against the rules of ScanSensor::linkToNeighbors read off the reference source.  CPU only."""
+import numpy as np
+import pytest
+from scipy.sparse import csr_matrix
+from scipy.sparse.csgraph import dijkstra
+
+from slam3d_amd.posegraph import SE3, TENTATIVE, LinkPolicy, PoseGraph, link_candidates, sweep_candidates
+
+
+def pose(x, y, yaw=0.0):
+    T = np.eye(4)
+    T[:2, :2] = [[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]]
+    T[:2, 3] = [x, y]
+    return T
+
+
+def loop_graph(n=40, radius=10.0, extra=()):
+    """n vertices on a circle of `radius`, odometry edges between consecutive ones, the loop NOT closed."""
+    g = PoseGraph()
+    for i in range(n):
+        a = 2 * np.pi * i / n
+        g.add_vertex(i, pose(radius * np.cos(a), radius * np.sin(a), a + np.pi / 2))
+    for i in range(n - 1):
+        g.add_edge(i, i + 1, "velodyne", SE3)
+    for s, t, sensor, ty in extra:
+        g.add_edge(s, t, sensor, ty)
+    return g
+
+
+def scipy_dist(g, weights=(1.0, 10000.0)):
+    idx = {v: k for k, v in enumerate(g.ids)}
+    rows, cols, w = [], [], []
+    for u in g.ids:
+        for t, _, ty in g.out[u]:
+            rows.append(idx[u]); cols.append(idx[t]); w.append(weights[0] if ty == SE3 else weights[1])
+    m = csr_matrix((w, (rows, cols)), shape=(len(g.ids),) * 2)
+    return dijkstra(m, directed=True), idx
+
+
+def test_nearby_vertices_is_the_linear_scan():
+    g = loop_graph(40)
+    g.add_vertex(100, pose(10.0, 0.3), sensor="other")
+    tf = pose(10.0, 0.0)
+    got = g.get_nearby_vertices(tf, 3.5, {"velodyne"})
+    want = [v for v in g.ids if g.sensor[v] == "velodyne" and np.linalg.norm(g.pose[v][:3, 3] - tf[:3, 3]) < 3.5]
+    assert got == want and 0 in got and 100 not in got
+    assert 100 in g.get_nearby_vertices(tf, 3.5, ())           # empty sensor set = all sensors (BoostGraph.cpp:107)
+    assert g.get_nearby_vertices(tf, 0.0) == []                 # strict <
+
+
+def test_graph_distance_is_dijkstra_with_the_reference_weights():
+    g = loop_graph(30, extra=[(2, 20, "velodyne", TENTATIVE), (5, 12, "gps", SE3)])
+    d, idx = scipy_dist(g)
+    for a, b in [(0, 29), (3, 19), (5, 12), (4, 13), (29, 0), (7, 7)]:
+        assert g.calculate_graph_distance(a, b) == d[idx[a], idx[b]]
+    assert g.calculate_graph_distance(2, 20) == 12.0           # 3 + 1 (the SE(3) edge of another sensor) + 8 hops beat the 10000-weight tentative edge
+    g2 = PoseGraph()
+    g2.add_vertex(0, np.eye(4)); g2.add_vertex(1, np.eye(4))
+    assert g2.calculate_graph_distance(0, 1) > 1e30            # unreachable
+
+
+@pytest.mark.parametrize("rng", [0, 1, 2, 5])
+def test_vertices_in_range_is_bfs_depth(rng):
+    g = loop_graph(30, extra=[(2, 20, "velodyne", TENTATIVE), (5, 12, "gps", SE3)])
+    d, idx = scipy_dist(g, weights=(1.0, np.inf))               # SE(3) edges only, hop count
+    for src in (0, 5, 12, 29):
+        want = [v for v in g.ids if d[idx[src], idx[v]] <= rng]
+        assert g.get_vertices_in_range(src, rng) == want
+
+
+def test_link_candidates_follow_the_reference_policy():
+    n = 40
+    g = loop_graph(n)
+    pol = LinkPolicy(neighbor_radius=3.5, max_neighbor_links=1, min_loop_length=10)
+    # the last vertex sees the start of the loop again: one candidate, the LAST nearby vertex in graph order that
+    # passes the gates (reverse iteration), as source, the queried vertex as target
+    c = link_candidates(g, n - 1, pol)
+    near = g.get_nearby_vertices(g.pose[n - 1], 3.5, {"velodyne"})
+    passing = [v for v in near if v != n - 1 and g.calculate_graph_distance(v, n - 1) >= 10]
+    assert c == [(passing[-1], n - 1)]
+    # more links allowed: reverse graph order, capped
+    pol3 = LinkPolicy(neighbor_radius=3.5, max_neighbor_links=3, min_loop_length=10)
+    assert link_candidates(g, n - 1, pol3) == [(v, n - 1) for v in reversed(passing)][:3]
+    # max_neighbor_links = 0 -> nothing; a vertex in the middle of the open loop has only close-by neighbours
+    assert link_candidates(g, n - 1, LinkPolicy(neighbor_radius=3.5, max_neighbor_links=0)) == []
+    assert link_candidates(g, 20, pol3) == []
+    # an existing edge vertex -> index of this sensor suppresses the candidate (another sensor's does not)
+    g.add_edge(n - 1, passing[-1], "velodyne", SE3)
+    assert passing[-1] not in [s for s, _ in link_candidates(g, n - 1, pol3)]
+    g2 = loop_graph(n, extra=[(n - 1, 0, "gps", SE3)])
+    # ... but that gps edge shortens the graph distance to 1 hop: below min_loop_length, no candidate at all
+    assert link_candidates(g2, n - 1, pol) == []
+    # patch_building_range: dist <= 2 * range is excluded even when min_loop_length would allow it
+    polp = LinkPolicy(neighbor_radius=3.5, max_neighbor_links=5, min_loop_length=0, patch_building_range=1)
+    for s, t in link_candidates(g, 20, polp):
+        assert g.calculate_graph_distance(s, t) > 2
+
+
+def test_sweep_candidates_deduplicates_both_directions():
+    g = loop_graph(40)
+    pol = LinkPolicy(neighbor_radius=3.5, max_neighbor_links=2, min_loop_length=10)
+    c = sweep_candidates(g, pol)
+    assert len(c) == len(set(c)) and all((t, s) not in c for s, t in c) and len(c) > 0
+    for s, t in c:
+        assert np.linalg.norm(g.pose[s][:3, 3] - g.pose[t][:3, 3]) < 3.5
+        assert g.calculate_graph_distance(s, t) >= 10
