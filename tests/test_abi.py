@@ -30,9 +30,9 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header(tmp_path):
     import slam3d_amd
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "slam3d_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "slam3d_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(s3d_reg_params),sizeof(s3d_edge_record),sizeof(s3d_exec_options),sizeof(s3d_align_info),'
-                   'sizeof(s3d_profile),offsetof(s3d_reg_params,rotation_epsilon));return 0;}\n')
+                   'sizeof(s3d_profile),offsetof(s3d_reg_params,rotation_epsilon),sizeof(s3d_map_profile));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
@@ -42,6 +42,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     assert sizes[3] == ctypes.sizeof(slam3d_amd.AlignInfo)
     assert sizes[4] == ctypes.sizeof(slam3d_amd.Profile)
     assert sizes[5] == slam3d_amd.RegParams.rotation_epsilon.offset
+    assert sizes[6] == ctypes.sizeof(slam3d_amd.api.MapProfile)
 
 
 def test_default_params_match_reference_defaults():
