@@ -346,22 +346,24 @@ struct Batch {
   }
 
   int dbg_nn = getenv("S3D_DBG_NN") ? atoi(getenv("S3D_DBG_NN")) : 0;
-  // prof_slot >= 0: count searched / unseeded queries of this launch into the profile counters
-  void launch_nn(int mode, float max_d, int prof_slot = -1) {
+  // prof_slot >= 0: count searched / unseeded queries of this launch into the profile counters.
+  // compact: the block-compacting variant of the kernel (see s3d_nn_search_compact_kernel).
+  void launch_nn(int mode, float max_d, int prof_slot = -1, bool compact = false) {
     hipStream_t st = ctx->stream;
     const int chunks = cdiv(std::max(max_n_t, 1), kBlock);
     const int pairs8 = P() >= 8 ? cdiv(P(), 8) * 8 : P();
     dim3 grid((unsigned)(pairs8 * chunks));
-    int* ci = (int*)ctx->corr_idx.p;
-    float* cd = (float*)ctx->corr_d2.p;
-    float* cl = (float*)ctx->corr_lb.p;
-    float4* cq = (float4*)ctx->corr_q.p;
-    float4* cn = (float4*)ctx->corr_n.p;
+    NNArrays A;
+    A.sorted = sorted(); A.cell_start = cells(); A.normals = normals();
+    A.corr_idx = (int*)ctx->corr_idx.p; A.corr_d2 = (float*)ctx->corr_d2.p; A.corr_lb = (float*)ctx->corr_lb.p;
+    A.corr_q = (float4*)ctx->corr_q.p; A.corr_n = (float4*)ctx->corr_n.p;
     int* pc = (prof_slot >= 0 && prof_slot < 64) ? (int*)ctx->n_active.p + 16 + 2 * prof_slot : nullptr;
-    if (mode == 0)
-      s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), normals(), ci, cd, cl, cq, cn, max_d, chunks, P(), dbg_nn, pc);
+    if (compact && mode == 0 && !(dbg_nn & 65536))
+      s3d_nn_search_compact_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc);
+    else if (mode == 0)
+      s3d_nn_search_kernel<0, 0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc);
     else
-      s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted(), cells(), normals(), ci, cd, cl, cq, cn, max_d, chunks, P(), dbg_nn, pc);
+      s3d_nn_search_kernel<1, 0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc);
   }
 
   // K5-K7 loop.  The host only polls the active-pair counter every check_interval iterations.
@@ -386,7 +388,8 @@ struct Batch {
         }
         HIPCHK(hipEventRecord(ctx->nn_ev[2 * it], st));
       }
-      launch_nn(0, max_d, opts.profile >= 2 ? it : -1);   // the counters cost two atomics per searching wave
+      // passes 3-5: a third of the lanes still search, scattered over all waves -> block-compacting variant
+      launch_nn(0, max_d, opts.profile >= 2 ? it : -1, it >= 2 && it <= 4);   // (the counters cost two atomics per searching wave)
       if (prof) HIPCHK(hipEventRecord(ctx->nn_ev[2 * it + 1], st));
       if (rp.algorithm)
         s3d_gicp_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(

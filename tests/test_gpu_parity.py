@@ -392,8 +392,9 @@ def test_nn_revalidation_shortcut_is_bitwise_neutral(gpu_ctx, fixture_clouds, mo
         p = s3d.default_params(registration_algorithm=alg, maximum_iterations=25)
         monkeypatch.delenv("S3D_DBG_NN", raising=False)
         st0, T0, i0 = gpu_ctx.align(fixture_clouds[1], fixture_clouds[2], np.eye(4), p, opts)
-        # 64: no re-validation; 128: no trusted far seeds; 2048: no wave-cooperative wide search
-        for flags in ("64", "128", "2048", str(64 + 128 + 2048)):
+        # 64: no re-validation; 128: no trusted far seeds; 2048: no wave-cooperative wide search;
+        # 65536: no block-compacting kernel in passes 3-5
+        for flags in ("64", "128", "2048", "65536", str(64 + 128 + 2048 + 65536)):
             monkeypatch.setenv("S3D_DBG_NN", flags)
             st1, T1, i1 = gpu_ctx.align(fixture_clouds[1], fixture_clouds[2], np.eye(4), p, opts)
             monkeypatch.delenv("S3D_DBG_NN", raising=False)
