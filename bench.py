@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--algorithm", default="gicp", choices=["gicp", "icp"])
     ap.add_argument("--density", type=float, default=0.02)
     ap.add_argument("--cpu-pairs", type=int, default=3, help="pairs timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-threads", type=int, default=32,
+                    help="also time this many pairs on as many oracle threads at once (cpu_baseline_parallel; 0/1 = off)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--nn-reps", type=int, default=20)
     ap.add_argument("--cells-per-point", type=int, default=0, help="search-grid budget (0 = library default)")
@@ -176,6 +178,7 @@ def main():
                       "first_iteration_nn_launch_ms_full_batch": round(nn0["avg_ms"], 4)}
         # ---- CPU baseline: the oracle (a port of the reference path), one thread, same inputs/iterations
         cpu = None
+        cpu_par = None
         if not args.no_cpu and world == 1:
             import oracle
             op = oracle.default_params(registration_algorithm=alg, point_cloud_density=args.density,
@@ -186,6 +189,19 @@ def main():
                 tc = time.perf_counter()
                 oracle.align(pairs[i][0], pairs[i][1], np.eye(4), op, force_iterations=True)
                 times.append(time.perf_counter() - tc)
+            # the same port on many cores at once (independent pairs, one thread each; ctypes releases the GIL)
+            nthr = max(1, min(args.cpu_threads, os.cpu_count() or 1, args.pairs))
+            cpu_par = None
+            if nthr > 1:
+                def _one(i):
+                    oracle.align(pairs[i][0], pairs[i][1], np.eye(4), op, force_iterations=True)
+                tp0 = time.perf_counter()
+                with ThreadPool(nthr) as pool:
+                    pool.map(_one, range(nthr))
+                tpar = time.perf_counter() - tp0
+                cpu_par = {"value": round(nthr / tpar, 3), "unit": "registrations/s", "cores": nthr, "kind": "port",
+                           "sample": "%d pairs of this workload registered concurrently, one oracle thread each, %.1f s"
+                                     % (nthr, tpar)}
             cpu = {"value": round(1.0 / float(np.median(times)), 4), "unit": "registrations/s", "cores": 1,
                    "kind": "port",
                    "sample": "%d of the %d pairs of this workload, oracle/s3d_oracle.c align() (kd-tree + "
@@ -208,6 +224,7 @@ def main():
                        "collective": "all_gather of 128-B edge records (RCCL)" if world > 1 else "none"},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "cpu_baseline_parallel": cpu_par,
             "single_pair": single,
             "step_ms": step_ms,
             "stage_ms": {k: round(v, 3) for k, v in prof.items() if k.endswith("_ms") and k != "nn_launch_ms"},
