@@ -347,7 +347,7 @@ struct Batch {
 
   int dbg_nn = getenv("S3D_DBG_NN") ? atoi(getenv("S3D_DBG_NN")) : 0;
   // prof_slot >= 0: count searched / unseeded queries of this launch into the profile counters.
-  // compact: the block-compacting variant of the kernel (see s3d_nn_search_compact_kernel).
+  // compact: the block-compacting mode of the kernel (see s3d_nn_search_kernel).
   void launch_nn(int mode, float max_d, int prof_slot = -1, bool compact = false) {
     hipStream_t st = ctx->stream;
     const int chunks = cdiv(std::max(max_n_t, 1), kBlock);
@@ -358,12 +358,11 @@ struct Batch {
     A.corr_idx = (int*)ctx->corr_idx.p; A.corr_d2 = (float*)ctx->corr_d2.p; A.corr_lb = (float*)ctx->corr_lb.p;
     A.corr_q = (float4*)ctx->corr_q.p; A.corr_n = (float4*)ctx->corr_n.p;
     int* pc = (prof_slot >= 0 && prof_slot < 64) ? (int*)ctx->n_active.p + 16 + 2 * prof_slot : nullptr;
-    if (compact && mode == 0 && !(dbg_nn & 65536))
-      s3d_nn_search_compact_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc);
-    else if (mode == 0)
-      s3d_nn_search_kernel<0, 0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc);
+    const int cmp = (compact && mode == 0 && !(dbg_nn & 65536)) ? 1 : 0;
+    if (mode == 0)
+      s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc, cmp);
     else
-      s3d_nn_search_kernel<1, 0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc);
+      s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc, 0);
   }
 
   // K5-K7 loop.  The host only polls the active-pair counter every check_interval iterations.

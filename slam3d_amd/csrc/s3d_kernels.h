@@ -760,7 +760,7 @@ __device__ __forceinline__ NNResult wave_nn1_coop(const GridParams& g, const uin
 // MODE 1: fitness pass   q = final_transformation * p        (pcl::transformPointCloud)
 // One query of the correspondence pass.  PHASE 0: everything in one go (s3d_nn_search_kernel).  PHASE 3:
 // re-validate and classify only (0: still needs a search and has a near seed, 1: will walk a wide box, 2: done);
-// PHASE 2: search a query that PHASE 3 left open (s3d_nn_search_compact_kernel packs those to the front of the
+// PHASE 2: search a query that PHASE 3 left open (the compact mode of s3d_nn_search_kernel packs those to the front of the
 // block in between).
 struct NNArrays {
   const float4* __restrict__ sorted;
@@ -876,12 +876,23 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   }
 }
 
-// one thread per query of the pair, everything in one kernel
-template <int MODE, int PHASE>
+// One thread per query of the pair.  compact = 0: every lane re-validates and, if it must, searches its own query.
+// compact = 1, block-level compaction: the 256 queries of a block are re-validated and classified, the ones that
+// still need a search are packed to the front of the block — near-seeded first, wide ones after them — and
+// searched by the first waves; the others leave.  In the third to fifth pass of a registration a third of the
+// lanes search while the rest are done, scattered over all waves: without compaction a wave pays for the search
+// with most of its lanes masked off.  Neighbouring queries stay together (a block is 256 consecutive points of
+// the cell order), no atomics are involved.  Measured per pass on 256 x 100k pairs (plain -> compacted):
+// 3.39 -> 3.49, 2.77 -> 2.17, 1.06 -> 0.94, then 0.25 -> 0.29 ms once nearly every query re-validates (five block
+// barriers on a streaming kernel): the host asks for it in passes 3 to 5 only.  A global worklist (atomics, second
+// kernel) loses the spatial order of the queries and was 2x slower.  Same results either way, bit for bit.
+template <int MODE>
 __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __restrict__ pairs,
                                                                 const SlotDev* __restrict__ slots, NNArrays A,
                                                                 float max_d, int chunks_per_pair, int npairs, int dbg,
-                                                                int* __restrict__ prof_counts) {
+                                                                int* __restrict__ prof_counts, int compact) {
+  __shared__ int order[kBlock];
+  __shared__ int lds4[4];
   int pair, chunk;
   if (dbg & 16) { pair = blockIdx.x / chunks_per_pair; chunk = blockIdx.x % chunks_per_pair; }  // A/B: plain map
   else nn_block_map(chunks_per_pair, npairs, &pair, &chunk);
@@ -891,35 +902,12 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __
   const SlotDev& St = slots[P.slot_t];
   const int i = chunk * kBlock + threadIdx.x;
   if (chunk * kBlock >= St.n) return;
-  // lanes past the end of the cloud stay in the wave (the cooperative search needs all of them) but own no query
-  nn_query<MODE, PHASE>(P, St, slots[P.slot_s], pair, i, i < St.n, A, max_d, dbg, prof_counts);
-}
-
-// Block-level compaction: the 256 queries of a block are re-validated and classified, the ones that still need a
-// search are packed to the front of the block — near-seeded first, wide ones after them — and searched by the first
-// waves; the others leave.  In the third to fifth pass of a registration a third of the lanes search while the rest
-// are done, scattered over all waves: a fused wave pays for the search with most of its lanes masked off.
-// Neighbouring queries stay together (a block is 256 consecutive points of the cell order), no atomics are
-// involved.  Measured per pass on 256 x 100k pairs (fused -> compacted): 3.39 -> 3.49, 2.77 -> 2.17, 1.06 -> 0.94,
-// then 0.25 -> 0.29 ms once nearly every query re-validates (five block barriers on a streaming kernel): the
-// host uses it for passes 3 to 5 only.  A global worklist (atomics, second kernel) loses the spatial order of
-// the queries and was 2x slower.
-template <int MODE>
-__global__ void __launch_bounds__(kBlock) s3d_nn_search_compact_kernel(const PairDev* __restrict__ pairs,
-                                                                        const SlotDev* __restrict__ slots, NNArrays A,
-                                                                        float max_d, int chunks_per_pair, int npairs,
-                                                                        int dbg, int* __restrict__ prof_counts) {
-  __shared__ int order[kBlock];
-  __shared__ int lds4[4];
-  int pair, chunk;
-  nn_block_map(chunks_per_pair, npairs, &pair, &chunk);
-  if (pair >= npairs) return;
-  const PairDev& P = pairs[pair];
-  if (MODE == 0 && !P.active) return;
-  const SlotDev& St = slots[P.slot_t];
-  if (chunk * kBlock >= St.n) return;
   const SlotDev& Ss = slots[P.slot_s];
-  const int i = chunk * kBlock + threadIdx.x;
+  // lanes past the end of the cloud stay in the wave (the cooperative search needs all of them) but own no query
+  if (!compact) {
+    nn_query<MODE, 0>(P, St, Ss, pair, i, i < St.n, A, max_d, dbg, prof_counts);
+    return;
+  }
   int cls = 2;
   nn_query<MODE, 3>(P, St, Ss, pair, i, i < St.n, A, max_d, dbg, nullptr, &cls);
   int n0, n1;
