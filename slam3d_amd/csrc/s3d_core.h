@@ -381,19 +381,23 @@ S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ c
           return best.d2 < 1.0e30f ? l * l : 3.0e38f;
         };
         float lim2 = limit2();
-        for (int oz = 0; oz <= 2 * (z1 - z0) + 1; ++oz) {
+        // (layers / rows are visited centre-out, alternating sides: once BOTH sides have produced a slab beyond
+        // the limit, every later one is beyond it too and the loop ends)
+        int zfar = 0;
+        for (int oz = 0; oz <= 2 * (z1 - z0) + 1 && zfar != 3; ++oz) {
           const int cz = cz0 + ((oz & 1) ? -((oz + 1) >> 1) : (oz >> 1));
-          if (cz < z0 || cz > z1) continue;
+          if (cz < z0 || cz > z1) { zfar |= (oz & 1) ? 1 : 2; continue; }
           const float zlo = g.origin[2] + (float)cz * g.h, zhi = zlo + g.h;
           const float dz = fmaxf(fmaxf(zlo - qz, qz - zhi) - eps, 0.f);
-          if (dz * dz > lim2) continue;
-          for (int oy = 0; oy <= 2 * (y1 - y0) + 1; ++oy) {
+          if (dz * dz > lim2) { zfar |= (oz & 1) ? 1 : 2; continue; }
+          int yfar = 0;
+          for (int oy = 0; oy <= 2 * (y1 - y0) + 1 && yfar != 3; ++oy) {
             const int cy = cy0 + ((oy & 1) ? -((oy + 1) >> 1) : (oy >> 1));
-            if (cy < y0 || cy > y1) continue;
+            if (cy < y0 || cy > y1) { yfar |= (oy & 1) ? 1 : 2; continue; }
             const float ylo = g.origin[1] + (float)cy * g.h, yhi = ylo + g.h;
             const float dy = fmaxf(fmaxf(ylo - qy, qy - yhi) - eps, 0.f);
             const float rowd2 = dy * dy + dz * dz;
-            if (rowd2 > lim2) continue;
+            if (rowd2 > lim2) { yfar |= (oy & 1) ? 1 : 2; continue; }
             int xa = x0, xb = x1;
             if (best.idx >= 0) {   // only the cells within the remaining radius
               const float rx = sqrtf(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
