@@ -569,14 +569,16 @@ void accumulate_dev(s3d_context* ctx, int n_clouds, s3d_cloud* const* clouds, co
     rowmajor3x4(inv, fr.m);
     fr.enabled = 1;
   }
-  XformJob* d_jobs = nullptr;
-  HIPCHK(hipMalloc((void**)&d_jobs, sizeof(XformJob) * jobs.size()));
-  HIPCHK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(XformJob) * jobs.size(), hipMemcpyHostToDevice, ctx->stream));
+  struct DevJobs {   // freed on every exit path
+    XformJob* p = nullptr;
+    ~DevJobs() { if (p) (void)hipFree(p); }
+  } d_jobs;
+  HIPCHK(hipMalloc((void**)&d_jobs.p, sizeof(XformJob) * jobs.size()));
+  HIPCHK(hipMemcpyAsync(d_jobs.p, jobs.data(), sizeof(XformJob) * jobs.size(), hipMemcpyHostToDevice, ctx->stream));
   // enough blocks per cloud to fill the chip even for a two-cloud patch; grid-stride inside
   const int bx = std::max(1, std::min(cdiv(max_n, kBlock), std::max(8, cdiv(4096, n_clouds))));
-  s3d_transform_concat_kernel<<<dim3(bx, n_clouds), kBlock, 0, ctx->stream>>>(d_jobs, out->d, fr);
-  HIPCHK(hipStreamSynchronize(ctx->stream));   // jobs[] (pageable) and d_jobs are released here
-  (void)hipFree(d_jobs);
+  s3d_transform_concat_kernel<<<dim3(bx, n_clouds), kBlock, 0, ctx->stream>>>(d_jobs.p, out->d, fr);
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // jobs[] (pageable) must outlive the copy, d_jobs the kernel
   HIPCHK(hipGetLastError());
 }
 
