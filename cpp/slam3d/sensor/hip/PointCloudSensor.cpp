@@ -197,12 +197,15 @@ Transform PointCloudSensor::align(const PointCloudMeasurement::Ptr& source, cons
     case S3D_STATUS_TOO_FEW_POINTS:   // PointCloudSensor.cpp:135
       throw NoMatch("Too few points after filtering, you may have to decrease 'point_cloud_density'.");
     case S3D_STATUS_NOT_CONVERGED:
-    case S3D_STATUS_FITNESS_EXCEEDED:  // :76
-      throw NoMatch(fmt("ICP failed with Fitness-Score %g > %g", info.fitness, config.max_fitness_score));
+    case S3D_STATUS_FITNESS_EXCEEDED:  // :76 (doICP) / :110 (doNDT)
+      throw NoMatch(fmt(config.registration_algorithm == NDT || config.registration_algorithm == NDT_OMP
+                            ? "NDT failed with Fitness-Score %g > %g"
+                            : "ICP failed with Fitness-Score %g > %g",
+                        info.fitness, config.max_fitness_score));
     case S3D_STATUS_TOO_FAR_FROM_GUESS:  // :171
       throw NoMatch("ICP result is to far away from guess");
-    case S3D_STATUS_UNSUPPORTED_ALGORITHM:  // NDT: not on the accelerated path (cf. :161)
-      throw std::runtime_error("NDT is not available in the MI355X build, use GICP or ICP.");
+    case S3D_STATUS_UNSUPPORTED_ALGORITHM:  // (no enumerator maps to this any more; kept for older libraries)
+      throw std::runtime_error("Registration algorithm not available in this build.");
     case S3D_STATUS_UNKNOWN_ALGORITHM:  // :164
       throw std::runtime_error("Unknown registration algorithm specified.");
     default:

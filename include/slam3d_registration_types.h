@@ -23,7 +23,8 @@ enum s3d_registration_algorithm {
                            Gauss-Newton ICP (the north-star's 6x6 reduction). */
   S3D_ALG_GICP     = 1, /* reference default: pcl::GeneralizedIterativeClosestPoint */
   S3D_ALG_GICP_OMP = 2, /* reference: pclomp variant, same arithmetic as GICP */
-  S3D_ALG_NDT      = 3, /* not on the hot path: S3D_STATUS_UNSUPPORTED_ALGORITHM */
+  S3D_ALG_NDT      = 3, /* doNDT (:84-117): voxel statistics + derivative passes on the device, Newton /
+                           More-Thuente on the host; one pair at a time */
   S3D_ALG_NDT_OMP  = 4
 };
 
@@ -58,7 +59,7 @@ enum s3d_status {
   S3D_STATUS_FITNESS_EXCEEDED      = 3, /* :74 score > max_fitness_score -> same NoMatch */
   S3D_STATUS_TOO_FAR_FROM_GUESS    = 4, /* :169-172 NoMatch("ICP result is to far away from guess") */
   S3D_STATUS_UNKNOWN_ALGORITHM     = 5, /* :163-164 std::runtime_error("Unknown registration algorithm specified.") */
-  S3D_STATUS_UNSUPPORTED_ALGORITHM = 6, /* NDT / NDT_OMP: not on this path (cf. :159-161 runtime_error) */
+  S3D_STATUS_UNSUPPORTED_ALGORITHM = 6, /* reserved (NDT / NDT_OMP returned it before they were implemented) */
   S3D_STATUS_INVALID_ARGUMENT      = 7,
   S3D_STATUS_BACKEND_ERROR         = 8  /* HIP runtime error; message via s3d_last_error() */
 };

@@ -1173,6 +1173,438 @@ done:
   return rc;
 }
 
+/* ------------------------------------------------------------------ NDT
+ * doNDT (PCS.cpp:84-117) -> pcl::NormalDistributionsTransform (PCL 1.12 ndt.hpp, voxel_grid_covariance.hpp),
+ * restated from the published algorithm (Magnusson 2009, Algorithm 2 + More-Thuente 1994 line search as PCL
+ * codes them).  PARITY UNPINNED like the rest of this file.  Deliberate simplifications, all below the 1e-4 bar:
+ *   - the voxel centroid used for the radius query is the (double) mean rounded to float, PCL accumulates a
+ *     separate float centroid;
+ *   - voxels whose covariance cannot be inverted are dropped (PCL keeps them in the kd-tree);
+ *   - Eigen's Transform::rotation() (an SVD clean-up) is taken as the 3x3 block of the guess;
+ *   - the angle-derivative vectors j_ang / h_ang are formed as products of the elementary rotation matrices and
+ *     their derivatives (the same numbers as PCL's closed forms up to rounding);
+ *   - NDT_OMP (pclomp, DIRECT7 neighbourhood) is served by the same code. */
+
+typedef struct {
+  int n;            /* valid cells */
+  double* mean;     /* n * 3 */
+  double* icov;     /* n * 9 */
+  float* centroid;  /* n * 3 */
+  s3o_kdtree* tree; /* over centroid */
+} ndt_cells;
+
+static void ndt_cells_free(ndt_cells* c) {
+  free(c->mean); free(c->icov); free(c->centroid);
+  if (c->tree) s3o_kdtree_free(c->tree);
+  memset(c, 0, sizeof *c);
+}
+
+/* VoxelGridCovariance::applyFilter: leaf layout as pcl::VoxelGrid, >= 6 points per voxel, unbiased covariance,
+ * eigenvalues below 0.01 * the largest are raised to it, inverse covariance */
+static void ndt_build_cells(const float* xyz, int n, double resolution, ndt_cells* out) {
+  memset(out, 0, sizeof *out);
+  if (n <= 0) return;
+  const float leaf = (float)resolution, inv = 1.0f / leaf;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a) {
+      const float v = xyz[(size_t)i * 3 + a];
+      if (v < mn[a]) mn[a] = v;
+      if (v > mx[a]) mx[a] = v;
+    }
+  int min_b[3], max_b[3], div_b[3];
+  for (int a = 0; a < 3; ++a) {
+    min_b[a] = (int)floorf(mn[a] * inv);
+    max_b[a] = (int)floorf(mx[a] * inv);
+    div_b[a] = max_b[a] - min_b[a] + 1;
+  }
+  key_idx* kv = (key_idx*)malloc(sizeof(key_idx) * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const float* p = xyz + (size_t)i * 3;
+    const int ijk0 = (int)floorf(p[0] * inv) - min_b[0], ijk1 = (int)floorf(p[1] * inv) - min_b[1],
+              ijk2 = (int)floorf(p[2] * inv) - min_b[2];
+    kv[i].key = (unsigned)(ijk0 + ijk1 * div_b[0] + ijk2 * div_b[0] * div_b[1]);
+    kv[i].idx = i;
+  }
+  qsort(kv, (size_t)n, sizeof(key_idx), cmp_key_idx);
+  out->mean = (double*)malloc(sizeof(double) * 3 * (size_t)n);
+  out->icov = (double*)malloc(sizeof(double) * 9 * (size_t)n);
+  out->centroid = (float*)malloc(sizeof(float) * 3 * (size_t)n);
+  int m = 0;
+  for (int i = 0; i < n;) {
+    int j = i;
+    double s[3] = {0, 0, 0}, c[3][3] = {{0}};
+    while (j < n && kv[j].key == kv[i].key) {
+      const float* p = xyz + (size_t)kv[j].idx * 3;
+      const double pd[3] = {p[0], p[1], p[2]};
+      for (int a = 0; a < 3; ++a) {
+        s[a] += pd[a];
+        for (int b = 0; b < 3; ++b) c[a][b] += pd[a] * pd[b];
+      }
+      ++j;
+    }
+    const int np = j - i;
+    i = j;
+    if (np < 6) continue;                                   /* min_points_per_voxel_ */
+    double mean[3] = {s[0] / np, s[1] / np, s[2] / np};
+    double cov[9];
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) cov[a * 3 + b] = (c[a][b] - s[a] * mean[b]) / (np - 1.0);
+    double ev[3], V[9];                                     /* descending, eigenvectors in columns */
+    s3o_sym_eig3(cov, ev, V);
+    if (ev[2] < -1e-12 || ev[1] < -1e-12 || ev[0] <= 0) continue;
+    const double floor_ev = 0.01 * ev[0];                   /* min_covar_eigvalue_mult_ */
+    if (ev[2] < floor_ev) {
+      ev[2] = floor_ev;
+      if (ev[1] < floor_ev) ev[1] = floor_ev;
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+          double v = 0;
+          for (int k = 0; k < 3; ++k) v += V[a * 3 + k] * ev[k] * V[b * 3 + k];
+          cov[a * 3 + b] = v;
+        }
+    }
+    double cm[3][3], ci[3][3];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) cm[a][b] = cov[a * 3 + b];
+    mat3_inverse(cm, ci);
+    int bad = 0;
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) if (!isfinite(ci[a][b])) bad = 1;
+    if (bad) continue;
+    for (int a = 0; a < 3; ++a) {
+      out->mean[(size_t)m * 3 + a] = mean[a];
+      out->centroid[(size_t)m * 3 + a] = (float)mean[a];
+      for (int b = 0; b < 3; ++b) out->icov[(size_t)m * 9 + a * 3 + b] = ci[a][b];
+    }
+    ++m;
+  }
+  free(kv);
+  out->n = m;
+  out->tree = s3o_kdtree_build(out->centroid, m);
+}
+
+typedef struct {
+  const float* input;   /* the registration's source cloud (pcl input_), packed */
+  int m;
+  const ndt_cells* cells;
+  double resolution, d1, d2;
+  int evaluations;
+} ndt_problem;
+
+static void m3mul(const double a[3][3], const double b[3][3], double o[3][3]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) o[i][j] = a[i][0] * b[0][j] + a[i][1] * b[1][j] + a[i][2] * b[2][j];
+}
+
+/* point_gradient_ columns 3..5 = dR[k] x, point_hessian_ block (k, l) = d2R[k][l] x with R = Rx Ry Rz;
+ * computeAngleDerivatives snaps angles below 10e-5 to cos = 1, sin = 0 */
+static void ndt_angle_derivatives(const double p[6], double dR[3][3][3], double d2R[3][3][3][3]) {
+  double cs[3], sn[3];
+  for (int k = 0; k < 3; ++k) {
+    if (fabs(p[3 + k]) < 10e-5) { cs[k] = 1.0; sn[k] = 0.0; }
+    else { cs[k] = cos(p[3 + k]); sn[k] = sin(p[3 + k]); }
+  }
+  double E[3][3][3][3];   /* E[axis][order 0..2] */
+  for (int ax = 0; ax < 3; ++ax) {
+    const double c = cs[ax], s = sn[ax];
+    const int u = (ax + 1) % 3, v = (ax + 2) % 3;
+    for (int o = 0; o < 3; ++o) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) E[ax][o][i][j] = 0;
+    E[ax][0][ax][ax] = 1;
+    E[ax][0][u][u] = c;  E[ax][0][u][v] = -s; E[ax][0][v][u] = s;  E[ax][0][v][v] = c;
+    E[ax][1][u][u] = -s; E[ax][1][u][v] = -c; E[ax][1][v][u] = c;  E[ax][1][v][v] = -s;
+    E[ax][2][u][u] = -c; E[ax][2][u][v] = s;  E[ax][2][v][u] = -s; E[ax][2][v][v] = -c;
+  }
+  for (int k = 0; k < 3; ++k) {
+    int o[3] = {0, 0, 0};
+    o[k] = 1;
+    double t[3][3];
+    m3mul(E[0][o[0]], E[1][o[1]], t);
+    m3mul(t, E[2][o[2]], dR[k]);
+    for (int l = 0; l < 3; ++l) {
+      int q[3] = {0, 0, 0};
+      q[k] += 1; q[l] += 1;
+      m3mul(E[0][q[0]], E[1][q[1]], t);
+      m3mul(t, E[2][q[2]], d2R[k][l]);
+    }
+  }
+}
+
+/* convertTransform: (Translation * AngleAxis(x) * AngleAxis(y) * AngleAxis(z)).matrix() in float */
+static void ndt_convert_transform(const double p[6], float T[16]) {
+  const float a = (float)p[3], b = (float)p[4], c = (float)p[5];
+  const float ca = cosf(a), sa = sinf(a), cb = cosf(b), sb = sinf(b), cc = cosf(c), sc = sinf(c);
+  const float Rx[3][3] = {{1, 0, 0}, {0, ca, -sa}, {0, sa, ca}};
+  const float Ry[3][3] = {{cb, 0, sb}, {0, 1, 0}, {-sb, 0, cb}};
+  const float Rz[3][3] = {{cc, -sc, 0}, {sc, cc, 0}, {0, 0, 1}};
+  float t[3][3], R[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) t[i][j] = (Rx[i][0] * Ry[0][j] + Rx[i][1] * Ry[1][j]) + Rx[i][2] * Ry[2][j];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[i][j] = (t[i][0] * Rz[0][j] + t[i][1] * Rz[1][j]) + t[i][2] * Rz[2][j];
+  for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.f : 0.f;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) T[j * 4 + i] = R[i][j];
+    T[12 + i] = (float)p[i];
+  }
+}
+
+/* computeDerivatives / computeHessian / updateDerivatives.  Returns the score. */
+static double ndt_derivatives(ndt_problem* P, const float T[16], const double p[6], double g[6], double H[36],
+                              int want_hessian) {
+  double dR[3][3][3], d2R[3][3][3][3];
+  ndt_angle_derivatives(p, dR, d2R);
+  for (int i = 0; i < 6; ++i) g[i] = 0;
+  for (int i = 0; i < 36; ++i) H[i] = 0;
+  double score = 0;
+  P->evaluations++;
+  int nn_i[27];
+  float nn_d[27];
+  const float r2 = (float)(P->resolution * P->resolution);
+  for (int i = 0; i < P->m; ++i) {
+    const float* xf = P->input + (size_t)i * 3;
+    float xt[3];
+    xf_pcl(T, xf, xt);
+    const int k = s3o_kdtree_knn(P->cells->tree, xt, 27, nn_i, nn_d);
+    const double x[3] = {xf[0], xf[1], xf[2]};
+    double J[3][6];   /* point_gradient_ */
+    int have_j = 0;
+    for (int c = 0; c < k; ++c) {
+      if (!(nn_d[c] < r2)) break;                            /* sorted ascending; FLANN radius search is strict */
+      if (!have_j) {
+        for (int a = 0; a < 3; ++a) {
+          for (int b = 0; b < 3; ++b) J[a][b] = a == b ? 1.0 : 0.0;
+          for (int kk = 0; kk < 3; ++kk) J[a][3 + kk] = dR[kk][a][0] * x[0] + dR[kk][a][1] * x[1] + dR[kk][a][2] * x[2];
+        }
+        have_j = 1;
+      }
+      const double* mu = P->cells->mean + (size_t)nn_i[c] * 3;
+      const double* Ci = P->cells->icov + (size_t)nn_i[c] * 9;
+      const double xq[3] = {(double)xt[0] - mu[0], (double)xt[1] - mu[1], (double)xt[2] - mu[2]};
+      double Cx[3];
+      for (int a = 0; a < 3; ++a) Cx[a] = Ci[a * 3] * xq[0] + Ci[a * 3 + 1] * xq[1] + Ci[a * 3 + 2] * xq[2];
+      double e = exp(-P->d2 * (xq[0] * Cx[0] + xq[1] * Cx[1] + xq[2] * Cx[2]) / 2);
+      const double score_inc = -P->d1 * e;
+      e = P->d2 * e;
+      if (e > 1 || e < 0 || e != e) continue;                /* updateDerivatives returns 0 */
+      score += score_inc;
+      e *= P->d1;
+      double CJ[3][6], xCJ[6];
+      for (int col = 0; col < 6; ++col) {
+        for (int a = 0; a < 3; ++a) CJ[a][col] = Ci[a * 3] * J[0][col] + Ci[a * 3 + 1] * J[1][col] + Ci[a * 3 + 2] * J[2][col];
+        xCJ[col] = xq[0] * CJ[0][col] + xq[1] * CJ[1][col] + xq[2] * CJ[2][col];
+        g[col] += xCJ[col] * e;
+      }
+      if (!want_hessian) continue;
+      for (int ii = 0; ii < 6; ++ii)
+        for (int jj = 0; jj < 6; ++jj) {
+          double hx = 0;                                     /* x^T C^-1 (d2 x / dp_i dp_j) */
+          if (ii >= 3 && jj >= 3) {
+            double hv[3];
+            for (int a = 0; a < 3; ++a)
+              hv[a] = d2R[ii - 3][jj - 3][a][0] * x[0] + d2R[ii - 3][jj - 3][a][1] * x[1] + d2R[ii - 3][jj - 3][a][2] * x[2];
+            hx = Cx[0] * hv[0] + Cx[1] * hv[1] + Cx[2] * hv[2];
+          }
+          const double jcj = J[0][jj] * CJ[0][ii] + J[1][jj] * CJ[1][ii] + J[2][jj] * CJ[2][ii];
+          H[ii * 6 + jj] += e * (-P->d2 * xCJ[ii] * xCJ[jj] + hx + jcj);
+        }
+    }
+  }
+  return score;
+}
+
+/* symmetric 6x6 Jacobi eigen-decomposition; solve H d = b in the least-squares sense (= JacobiSVD::solve) */
+static void ndt_solve6(const double Hin[36], const double b[6], double d[6]) {
+  double A[6][6], V[6][6];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) { A[i][j] = 0.5 * (Hin[i * 6 + j] + Hin[j * 6 + i]); V[i][j] = i == j; }
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0, diag = 0;
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { if (i != j) off += A[i][j] * A[i][j]; else diag += A[i][i] * A[i][i]; }
+    if (off <= 1e-300 || off <= 1e-32 * diag) break;
+    for (int p = 0; p < 5; ++p)
+      for (int q = p + 1; q < 6; ++q) {
+        if (A[p][q] == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 6; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq; }
+        for (int k = 0; k < 6; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk; }
+        for (int k = 0; k < 6; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
+      }
+  }
+  double lmax = 0;
+  for (int i = 0; i < 6; ++i) if (fabs(A[i][i]) > lmax) lmax = fabs(A[i][i]);
+  const double thr = 6 * DBL_EPSILON * lmax;                 /* Eigen's default SVD threshold: eps * max(rows, cols) */
+  for (int i = 0; i < 6; ++i) d[i] = 0;
+  for (int k = 0; k < 6; ++k) {
+    if (!(fabs(A[k][k]) > thr)) continue;
+    double vb = 0;
+    for (int i = 0; i < 6; ++i) vb += V[i][k] * b[i];
+    vb /= A[k][k];
+    for (int i = 0; i < 6; ++i) d[i] += V[i][k] * vb;
+  }
+}
+
+static double ndt_trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t,
+                              double f_t, double g_t) {
+  if (f_t > f_l) {                                           /* case 1 */
+    const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = sqrt(z * z - g_t * g_l);
+    const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    const double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+    return fabs(a_c - a_l) < fabs(a_q - a_l) ? a_c : 0.5 * (a_q + a_c);
+  }
+  if (g_t * g_l < 0) {                                       /* case 2 */
+    const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = sqrt(z * z - g_t * g_l);
+    const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    return fabs(a_c - a_t) >= fabs(a_s - a_t) ? a_c : a_s;
+  }
+  if (fabs(g_t) <= fabs(g_l)) {                              /* case 3 */
+    const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l, w = sqrt(z * z - g_t * g_l);
+    const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    const double a_n = fabs(a_c - a_t) < fabs(a_s - a_t) ? a_c : a_s;
+    return a_t > a_l ? fmin(a_t + 0.66 * (a_u - a_t), a_n) : fmax(a_t + 0.66 * (a_u - a_t), a_n);
+  }
+  {                                                          /* case 4 */
+    const double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u, w = sqrt(z * z - g_t * g_u);
+    return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+  }
+}
+
+static int ndt_update_interval(double* a_l, double* f_l, double* g_l, double* a_u, double* f_u, double* g_u, double a_t,
+                               double f_t, double g_t) {
+  if (f_t > *f_l) { *a_u = a_t; *f_u = f_t; *g_u = g_t; return 0; }
+  if (g_t * (*a_l - a_t) > 0) { *a_l = a_t; *f_l = f_t; *g_l = g_t; return 0; }
+  if (g_t * (*a_l - a_t) < 0) { *a_u = *a_l; *f_u = *f_l; *g_u = *g_l; *a_l = a_t; *f_l = f_t; *g_l = g_t; return 0; }
+  return 1;
+}
+
+/* computeStepLengthMT.  x: current parameters; dir: unit direction (may be flipped); on return T / score / g / H
+ * describe the accepted trial point. */
+static double ndt_step_length(ndt_problem* P, const double x[6], double dir[6], double step_init, double step_max,
+                              double step_min, double* score, double g[6], double H[36], float T[16]) {
+  const double phi_0 = -*score;
+  double d_phi_0 = -vdot6(g, dir);
+  if (d_phi_0 >= 0) {
+    if (d_phi_0 == 0) return 0;
+    d_phi_0 = -d_phi_0;
+    for (int i = 0; i < 6; ++i) dir[i] = -dir[i];
+  }
+  const int max_step_iterations = 10;
+  int step_iterations = 0;
+  const double mu = 1.e-4, nu = 0.9;
+  double a_l = 0, a_u = 0;
+  double f_l = 0 /* psi(0) */, g_l = d_phi_0 - mu * d_phi_0, f_u = f_l, g_u = g_l;
+  int interval_converged = (step_max - step_min) < 0, open_interval = 1;
+  double a_t = step_init;
+  a_t = fmin(a_t, step_max);
+  a_t = fmax(a_t, step_min);
+  double x_t[6];
+  for (int i = 0; i < 6; ++i) x_t[i] = x[i] + dir[i] * a_t;
+  ndt_convert_transform(x_t, T);
+  *score = ndt_derivatives(P, T, x_t, g, H, 1);
+  double phi_t = -*score, d_phi_t = -vdot6(g, dir);
+  double psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t, d_psi_t = d_phi_t - mu * d_phi_0;
+  while (!interval_converged && step_iterations < max_step_iterations && !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
+    if (open_interval) a_t = ndt_trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t);
+    else a_t = ndt_trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
+    a_t = fmin(a_t, step_max);
+    a_t = fmax(a_t, step_min);
+    for (int i = 0; i < 6; ++i) x_t[i] = x[i] + dir[i] * a_t;
+    ndt_convert_transform(x_t, T);
+    double Htmp[36];
+    *score = ndt_derivatives(P, T, x_t, g, Htmp, 0);
+    phi_t = -*score;
+    d_phi_t = -vdot6(g, dir);
+    psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t;
+    d_psi_t = d_phi_t - mu * d_phi_0;
+    if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
+      open_interval = 0;
+      f_l += phi_0 - mu * d_phi_0 * a_l;
+      g_l += mu * d_phi_0;
+      f_u += phi_0 - mu * d_phi_0 * a_u;
+      g_u += mu * d_phi_0;
+    }
+    if (open_interval) interval_converged = ndt_update_interval(&a_l, &f_l, &g_l, &a_u, &f_u, &g_u, a_t, psi_t, d_psi_t);
+    else interval_converged = ndt_update_interval(&a_l, &f_l, &g_l, &a_u, &f_u, &g_u, a_t, phi_t, d_phi_t);
+    step_iterations++;
+  }
+  if (step_iterations) {                                     /* computeHessian at the accepted point */
+    double gtmp[6];
+    ndt_derivatives(P, T, x_t, gtmp, H, 1);
+  }
+  return a_t;
+}
+
+/* Eigen Matrix3f::eulerAngles(0, 1, 2) */
+static void ndt_euler_xyz(const float R[3][3], float res[3]) {
+  res[0] = atan2f(R[1][2], R[2][2]);
+  const float c2 = sqrtf(R[0][0] * R[0][0] + R[0][1] * R[0][1]);
+  if (res[0] > 0.f) {
+    res[0] -= 3.14159265358979323846f;
+    res[1] = atan2f(-R[0][2], -c2);
+  } else {
+    res[1] = atan2f(-R[0][2], c2);
+  }
+  const float s1 = sinf(res[0]), c1 = cosf(res[0]);
+  res[2] = atan2f(s1 * R[2][0] - c1 * R[1][0], c1 * R[1][1] - s1 * R[2][1]);
+  res[0] = -res[0]; res[1] = -res[1]; res[2] = -res[2];
+}
+
+int s3o_ndt(const float* input, int m, const float* target, int n, const float guess[16], const s3d_reg_params* cfg,
+            s3o_icp_result* out) {
+  memset(out, 0, sizeof *out);
+  memcpy(out->final_transformation, guess, sizeof(float) * 16);
+  ndt_cells cells;
+  ndt_build_cells(target, n, (double)cfg->resolution, &cells);
+  ndt_problem P;
+  memset(&P, 0, sizeof P);
+  P.input = input; P.m = m; P.cells = &cells; P.resolution = (double)cfg->resolution;
+  {                                                          /* init(): Eq. 6.8 [Magnusson 2009] */
+    const double c1 = 10 * (1 - cfg->outlier_ratio), c2 = cfg->outlier_ratio / pow(P.resolution, 3), d3 = -log(c2);
+    P.d1 = -log(c1 + c2) - d3;
+    P.d2 = -2 * log((-log(c1 * exp(-0.5) + c2) - d3) / P.d1);
+  }
+  float T[16];
+  memcpy(T, guess, sizeof T);
+  double p[6];
+  {
+    float R[3][3], e[3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i][j] = guess[j * 4 + i];
+    ndt_euler_xyz(R, e);
+    for (int i = 0; i < 3; ++i) { p[i] = (double)guess[12 + i]; p[3 + i] = (double)e[i]; }
+  }
+  double g[6], H[36];
+  double score = cells.n > 0 ? ndt_derivatives(&P, T, p, g, H, 1) : 0.0;
+  int converged = 0, iterations = 0;
+  while (!converged && cells.n > 0) {
+    double mg[6], delta[6];
+    for (int i = 0; i < 6; ++i) mg[i] = -g[i];
+    ndt_solve6(H, mg, delta);
+    double dn = vnorm6(delta);
+    if (dn == 0 || dn != dn) { converged = dn == 0; break; }
+    for (int i = 0; i < 6; ++i) delta[i] /= dn;
+    dn = ndt_step_length(&P, p, delta, dn, cfg->step_size, cfg->transformation_epsilon / 2, &score, g, H, T);
+    for (int i = 0; i < 6; ++i) { delta[i] *= dn; p[i] += delta[i]; }
+    float Tstep[16];
+    ndt_convert_transform(delta, Tstep);                     /* transformation_ of this iteration */
+    const double translation_sqr = (double)Tstep[12] * Tstep[12] + (double)Tstep[13] * Tstep[13] + (double)Tstep[14] * Tstep[14];
+    iterations++;
+    /* transformation_rotation_epsilon_ is 0 (never set by slam3d): the 1.12 test reduces to this */
+    if (iterations >= cfg->maximum_iterations ||
+        (cfg->transformation_epsilon > 0 && translation_sqr <= cfg->transformation_epsilon))
+      converged = 1;
+  }
+  memcpy(out->final_transformation, T, sizeof T);
+  out->converged = converged;
+  out->iterations = iterations;
+  out->evaluations_total = P.evaluations;
+  out->correspondences = cells.n;
+  out->fitness = s3o_fitness_score(input, m, target, n, T, cfg->max_correspondence_distance);   /* PCS.cpp:107 */
+  ndt_cells_free(&cells);
+  return 0;
+}
+
 /* ------------------------------------------------------------------ align (A2) */
 
 int s3o_align(const float* source, int n_source, int stride_source, const float* target, int n_target,
@@ -1210,7 +1642,9 @@ int s3o_align(const float* source, int n_source, int stride_source, const float*
       break;
     case S3D_ALG_NDT:
     case S3D_ALG_NDT_OMP:
-      status = S3D_STATUS_UNSUPPORTED_ALGORITHM; goto done;
+      /* doNDT (PCS.cpp:84-117): same source/target swap */
+      rc = s3o_ndt(ft, nt, fs, ns, guess_f, cfg, &r);
+      break;
     default:
       status = S3D_STATUS_UNKNOWN_ALGORITHM; goto done;
   }

@@ -75,6 +75,12 @@ int s3o_icp_point_to_plane(const float* pcl_source, int m, const float* pcl_targ
                            const float guess[16], const s3d_reg_params* cfg, int force_iterations,
                            s3o_icp_result* out);
 
+/* doNDT (PCS.cpp:84-117) -> pcl::NormalDistributionsTransform: Newton steps with More-Thuente line search on
+ * the NDT score of the voxelised target (resolution, step_size, outlier_ratio of cfg).  `correspondences`
+ * returns the number of NDT cells, `evaluations_total` the derivative passes. */
+int s3o_ndt(const float* pcl_source, int m, const float* pcl_target, int n, const float guess[16],
+            const s3d_reg_params* cfg, s3o_icp_result* out);
+
 /* GICP objective (mean Mahalanobis residual) of a candidate final transformation F */
 double s3o_gicp_cost(const float* pcl_source, int m, const float* pcl_target, int n, const float F[16],
                      const s3d_reg_params* cfg, int* n_corr);

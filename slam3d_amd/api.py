@@ -78,7 +78,7 @@ def lib_path():
 
 def build(force=False, verbose=False):
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("s3d_api.hip", "s3d_kernels.h", "s3d_core.h")]
+    srcs = [os.path.join(_CSRC, f) for f in ("s3d_api.hip", "s3d_kernels.h", "s3d_core.h", "s3d_ndt.h")]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("slam3d_hip.h", "slam3d_registration_types.h")]
     stale = force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
     if stale:

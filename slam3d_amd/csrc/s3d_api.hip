@@ -17,6 +17,7 @@
 
 #include "../../include/slam3d_hip.h"
 #include "s3d_kernels.h"
+#include "s3d_ndt.h"
 
 using namespace s3d;
 
@@ -505,7 +506,7 @@ struct Batch {
 int check_algorithm(const s3d_reg_params* p) {
   switch (p->registration_algorithm) {  // PointCloudSensor.cpp:139-165
     case S3D_ALG_ICP: case S3D_ALG_GICP: case S3D_ALG_GICP_OMP: return S3D_STATUS_OK;
-    case S3D_ALG_NDT: case S3D_ALG_NDT_OMP: return S3D_STATUS_UNSUPPORTED_ALGORITHM;
+    case S3D_ALG_NDT: case S3D_ALG_NDT_OMP: return S3D_STATUS_OK;   // host-driven, see align_ndt()
     default: return S3D_STATUS_UNKNOWN_ALGORITHM;
   }
 }
@@ -689,6 +690,110 @@ void download_packed(s3d_context* ctx, const s3d_cloud* c, float* xyz, int strid
   }
 }
 
+bool is_ndt(const s3d_reg_params* p) {
+  return p->registration_algorithm == S3D_ALG_NDT || p->registration_algorithm == S3D_ALG_NDT_OMP;
+}
+
+float host_ord2f(unsigned int u) {
+  const unsigned int v = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+  float f;
+  std::memcpy(&f, &v, sizeof f);
+  return f;
+}
+
+// doNDT (PointCloudSensor.cpp:84-117) for the single pair of `b` (voxel filter and grid already staged and
+// downloaded).  The voxel statistics and every derivative pass run on the device; the Newton / More-Thuente
+// loop around them is host code (s3d_ndt.h) and costs one small D2H copy per pass.  NDT_OMP is served by the
+// same code (pclomp differs in its neighbourhood search, not in the objective).
+int align_ndt(Batch& b, const s3d_reg_params* params, const double guess[16], double result[16], s3d_align_info* info) {
+  s3d_context* ctx = b.ctx;
+  hipStream_t st = ctx->stream;
+  PairDev& P = b.h_pairs[0];
+  const SlotDev Ss = b.h_slots[P.slot_s], St = b.h_slots[P.slot_t];
+  for (int i = 0; i < 16; ++i) result[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  if (info) { info->n_source_filtered = Ss.n; info->n_target_filtered = St.n; }
+  if (St.n < 100 || Ss.n < 100) return S3D_STATUS_TOO_FEW_POINTS;                 // :134-135
+  if (!(params->resolution > 0.f)) return S3D_STATUS_INVALID_ARGUMENT;
+  // voxel layout of the NDT target = the slam3d SOURCE cloud after the density filter (:101-102 swap)
+  float mn[3], mx[3];
+  for (int a = 0; a < 3; ++a) { mn[a] = host_ord2f(Ss.bb[a]); mx[a] = host_ord2f(Ss.bb[3 + a]); }
+  const VoxelParams vp = voxel_params_from_bbox(mn, mx, params->resolution);
+  const long long table_cells = (long long)vp.div_b[0] * vp.div_b[1] * vp.div_b[2];
+  if (vp.passthrough || table_cells > (1ll << 27)) return S3D_STATUS_INVALID_ARGUMENT;
+  struct Scratch {   // released on every exit path
+    int* table = nullptr; double* cells = nullptr; int* counter = nullptr; double* partials = nullptr; double* out = nullptr;
+    ~Scratch() { (void)hipFree(table); (void)hipFree(cells); (void)hipFree(counter); (void)hipFree(partials); (void)hipFree(out); }
+  } S;
+  const int max_cells = Ss.n / 6 + 1;
+  const int nblocks = std::max(1, std::min(512, cdiv(St.n, kBlock)));
+  HIPCHK(hipMalloc((void**)&S.table, sizeof(int) * (size_t)table_cells));
+  HIPCHK(hipMalloc((void**)&S.cells, sizeof(double) * kNdtCellDoubles * (size_t)max_cells));
+  HIPCHK(hipMalloc((void**)&S.counter, sizeof(int)));
+  HIPCHK(hipMalloc((void**)&S.partials, sizeof(double) * NDT_NACC * (size_t)nblocks));
+  HIPCHK(hipMalloc((void**)&S.out, sizeof(double) * NDT_NACC));
+  HIPCHK(hipMemsetAsync(S.table, 0xFF, sizeof(int) * (size_t)table_cells, st));
+  HIPCHK(hipMemsetAsync(S.counter, 0, sizeof(int), st));
+  const float4* src_pts = b.filt() + Ss.off;
+  k_ndt_keys<<<cdiv(Ss.n, kBlock), kBlock, 0, st>>>(src_pts, Ss.n, vp, b.kA() + Ss.off, b.vA() + Ss.off);
+  k_ndt_select_slot<<<cdiv(b.C(), 64), 64, 0, st>>>(b.d_slots(), b.C(), P.slot_s, Ss.n);
+  b.sort(4);   // result back in A
+  k_ndt_cells<<<cdiv(Ss.n, kBlock), kBlock, 0, st>>>(src_pts, b.kA() + Ss.off, b.vA() + Ss.off, Ss.n, S.table, S.cells,
+                                                     S.counter);
+  int n_cells = 0;
+  HIPCHK(hipMemcpyAsync(&n_cells, S.counter, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  double d1, d2;
+  ndt::gauss_constants(params->outlier_ratio, (double)params->resolution, &d1, &d2);
+  const float r2 = params->resolution * params->resolution;
+  const float4* in_pts = b.filt() + St.off;
+  ndt::EvalFn eval = [&](const float T[16], const double p[6], bool want_h, ndt::Eval& o) {
+    Mat4f Tm;
+    std::memcpy(Tm.m, T, sizeof Tm.m);
+    NdtAngles ang;
+    ndt::angle_derivatives(p, ang.dR, ang.d2R);
+    s3d_ndt_derivatives_kernel<<<nblocks, kBlock, 0, st>>>(in_pts, St.n, Tm, ang, vp, S.table, S.cells, r2, d1, d2,
+                                                           want_h ? 1 : 0, S.partials);
+    k_ndt_reduce<<<1, 64, 0, st>>>(S.partials, nblocks, S.out);
+    double h[NDT_NACC];
+    HIPCHK(hipMemcpyAsync(h, S.out, sizeof h, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    o.score = h[0];
+    for (int i = 0; i < 6; ++i) o.g[i] = h[1 + i];
+    int k = 7;
+    for (int i = 0; i < 6; ++i)
+      for (int j = i; j < 6; ++j, ++k) o.H[i * 6 + j] = o.H[j * 6 + i] = want_h ? h[k] : 0.0;
+  };
+  float guess_f[16];
+  for (int i = 0; i < 16; ++i) guess_f[i] = (float)guess[i];                    // :104 guess.matrix().cast<float>()
+  ndt::Result R;
+  if (n_cells > 0) {
+    R = ndt::run(eval, guess_f, params->step_size, params->transformation_epsilon, params->maximum_iterations);
+  } else {
+    std::memcpy(R.T, guess_f, sizeof R.T);
+    R.converged = 0; R.iterations = 0; R.evaluations = 0;
+  }
+  // getFitnessScore(max_correspondence_distance) (:107): the K8 path on the final transformation
+  Mat4f Tf;
+  std::memcpy(Tf.m, R.T, sizeof Tf.m);
+  HIPCHK(hipMemcpyAsync(&b.d_pairs()[0].final_T, &Tf, sizeof Tf, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(ctx->corr_d2.p, 0xFF, 4 * std::max<size_t>(b.total_corr, 4), st));
+  HIPCHK(hipMemsetAsync(ctx->corr_lb.p, 0, 4 * std::max<size_t>(b.total_corr, 4), st));
+  b.launch_nn(1, (float)(std::sqrt(std::max(b.rp.fit_range, 0.0)) * 1.0001));
+  double* part = (double*)ctx->partials.p;
+  s3d_fitness_partial_kernel<<<dim3(b.accum_blocks, 1), kBlock, 0, st>>>(b.d_pairs(), b.d_slots(), (float*)ctx->corr_d2.p,
+                                                                         part, b.rp);
+  k_fitness_final<<<1, 64, 0, st>>>(b.d_pairs(), part, b.accum_blocks, 1);
+  b.download();
+  PairDev& Pd = b.h_pairs[0];
+  Pd.converged = R.converged;
+  Pd.iterations = R.iterations;
+  Pd.correspondences = n_cells;
+  Pd.evals_total = R.evaluations;
+  Pd.inner_total = 0;
+  Pd.final_T = Tf;
+  return b.finish_pair(0, params, guess, result, info);
+}
+
 // align() of two device-resident clouds (PointCloudSensor.cpp:119-174)
 int align_dev(s3d_context* ctx, s3d_cloud* ps, s3d_cloud* pt, const double guess[16], const s3d_reg_params* params,
               const s3d_exec_options* opts, double result[16], s3d_align_info* info) {
@@ -708,6 +813,14 @@ int align_dev(s3d_context* ctx, s3d_cloud* ps, s3d_cloud* pt, const double guess
     b.download();
     status = (b.h_slots[0].n < 100 || b.h_slots[b.h_pairs[0].slot_t].n < 100) ? S3D_STATUS_TOO_FEW_POINTS : alg;
     if (info) { info->n_source_filtered = b.h_slots[0].n; info->n_target_filtered = b.h_slots[b.h_pairs[0].slot_t].n; }
+  } else if (is_ndt(params)) {
+    b.set_params(params, opts);
+    b.add_pairs(1, &ps, &pt, guess);
+    b.allocate();
+    b.stage_voxel();
+    b.stage_grid();
+    b.download();
+    status = align_ndt(b, params, guess, result, info);
   } else {
     b.set_params(params, opts);
     b.add_pairs(1, &ps, &pt, guess);
@@ -869,6 +982,22 @@ int s3d_align_batch(s3d_context* ctx, int n_pairs, s3d_cloud* const* sources, s3
   }
   try {
     ScopedDevice sd(ctx);
+    if (is_ndt(params)) {   // NDT is driven from the host, pair by pair (align_ndt)
+      for (int p = 0; p < n_pairs; ++p) {
+        double result[16];
+        s3d_align_info info{};
+        const int st = align_dev(ctx, sources[p], targets[p], guesses + (size_t)p * 16, params, opts, result, &info);
+        s3d_edge_record& r = records[p];
+        for (int c = 0; c < 4; ++c)
+          for (int rr = 0; rr < 3; ++rr) r.transform[c * 3 + rr] = result[c * 4 + rr];
+        r.fitness = info.fitness;
+        r.iterations = info.iterations;
+        r.correspondences = info.correspondences;
+        r.status = st;
+        if (infos) infos[p] = info;
+      }
+      return S3D_STATUS_OK;
+    }
     Batch b;
     b.ctx = ctx;
     b.set_params(params, opts);

@@ -801,6 +801,36 @@ S3D_HD void sym3_smallest_eigvec(double a00, double a01, double a02, double a11,
   n[2] = m == 0 ? V[2][0] : (m == 1 ? V[2][1] : V[2][2]);
 }
 
+// full decomposition by the same cyclic Jacobi: eigenvalues descending, eigenvectors in the columns of V
+// (row-major 3x3).  Used for the NDT voxel covariances (pcl::VoxelGridCovariance runs a SelfAdjointEigenSolver).
+S3D_HD void sym3_eig_desc(double a00, double a01, double a02, double a11, double a12, double a22, double ev[3],
+                          double Vout[9]) {
+  double a[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
+  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+    const double diag = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+    if (off <= 1e-300 || off <= 1e-34 * diag) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (a[p][q] == 0.0) continue;
+        const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < 3; ++k) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - sn * akq; a[k][q] = sn * akp + c * akq; }
+        for (int k = 0; k < 3; ++k) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - sn * aqk; a[q][k] = sn * apk + c * aqk; }
+        for (int k = 0; k < 3; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
+      }
+  }
+  int o0 = 0, o1 = 1, o2 = 2;
+  const double d[3] = {a[0][0], a[1][1], a[2][2]};
+  if (d[o1] > d[o0]) { const int t = o0; o0 = o1; o1 = t; }
+  if (d[o2] > d[o0]) { const int t = o0; o0 = o2; o2 = t; }
+  if (d[o2] > d[o1]) { const int t = o1; o1 = o2; o2 = t; }
+  ev[0] = d[o0]; ev[1] = d[o1]; ev[2] = d[o2];
+  for (int r = 0; r < 3; ++r) { Vout[r * 3] = V[r][o0]; Vout[r * 3 + 1] = V[r][o1]; Vout[r * 3 + 2] = V[r][o2]; }
+}
+
 // Closed-form variant for the common, well-conditioned case (a surface patch: lambda_min well separated):
 // eigenvalues by the trigonometric solution of the characteristic cubic, eigenvector = the largest cross
 // product of two rows of (A - lambda_min I).  ~4x fewer operations than the Jacobi sweeps and no loop.

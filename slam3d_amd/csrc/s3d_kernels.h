@@ -1224,4 +1224,186 @@ __global__ void __launch_bounds__(kBlock) k_flags_compact(const SlotDev* __restr
   if (keep) out[pos] = filt[s.off + i];
 }
 
+// ------------------------------------------------------------------ K9: NDT
+// doNDT (PointCloudSensor.cpp:84-117) -> pcl::NormalDistributionsTransform.  The data-parallel parts run here:
+// the voxel statistics of the target (pcl::VoxelGridCovariance: >= 6 points per voxel of edge `resolution`,
+// unbiased covariance, eigenvalues raised to 1 % of the largest, inverse) and the score / gradient / Hessian pass
+// over the input points (ndt.hpp computeDerivatives + updateDerivatives).  The Newton step and the More-Thuente
+// line search around them are scalar and run on the host (s3d_ndt.h), one derivative pass per trial step.
+constexpr int NDT_NACC = 28;          // score, gradient (6), upper triangle of the Hessian (21)
+constexpr int kNdtCellDoubles = 10;   // mean (3), inverse covariance xx xy xz yy yz zz (6), pad
+
+struct NdtAngles {                    // R = Rx Ry Rz: first and second derivatives by the three angles (3x3 each)
+  double dR[3][9];
+  double d2R[6][9];                   // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+};
+
+__global__ void k_ndt_select_slot(SlotDev* slots, int nslots, int slot, int n) {   // the segmented sort then sorts this slot only
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nslots) slots[i].n_sort = i == slot ? n : 0;
+}
+
+__global__ void __launch_bounds__(kBlock) k_ndt_keys(const float4* __restrict__ pts, int n, VoxelParams vp,
+                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  keys[i] = voxel_key(vp, p.x, p.y, p.z);
+  vals[i] = (uint32_t)i;
+}
+
+// one thread per sorted element; the head of a run of >= 6 equal keys builds the cell.  Sums run in ascending
+// point index (the stable sort keeps that order), in double, as VoxelGridCovariance does.
+__global__ void __launch_bounds__(kBlock) k_ndt_cells(const float4* __restrict__ pts, const uint32_t* __restrict__ keys,
+                                                       const uint32_t* __restrict__ vals, int n, int* __restrict__ table,
+                                                       double* __restrict__ cells, int* __restrict__ counter) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t key = keys[i];
+  if (i > 0 && keys[i - 1] == key) return;
+  double s[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
+  int j = i;
+  for (; j < n && keys[j] == key; ++j) {
+    const float4 p = pts[vals[j]];
+    const double x = p.x, y = p.y, z = p.z;
+    s[0] += x; s[1] += y; s[2] += z;
+    c[0] += x * x; c[1] += x * y; c[2] += x * z; c[3] += y * y; c[4] += y * z; c[5] += z * z;
+  }
+  const int np = j - i;
+  if (np < 6) return;
+  const double inv_n = 1.0 / (double)np, inv_n1 = 1.0 / ((double)np - 1.0);
+  const double m0 = s[0] * inv_n, m1 = s[1] * inv_n, m2 = s[2] * inv_n;
+  double a00 = (c[0] - s[0] * m0) * inv_n1, a01 = (c[1] - s[0] * m1) * inv_n1, a02 = (c[2] - s[0] * m2) * inv_n1;
+  double a11 = (c[3] - s[1] * m1) * inv_n1, a12 = (c[4] - s[1] * m2) * inv_n1, a22 = (c[5] - s[2] * m2) * inv_n1;
+  double ev[3], V[9];
+  sym3_eig_desc(a00, a01, a02, a11, a12, a22, ev, V);
+  if (ev[2] < -1e-12 || ev[1] < -1e-12 || !(ev[0] > 0.0)) return;
+  const double floor_ev = 0.01 * ev[0];
+  if (ev[2] < floor_ev) {
+    ev[2] = floor_ev;
+    if (ev[1] < floor_ev) ev[1] = floor_ev;
+    double r[9];
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) r[a * 3 + b] = V[a * 3] * ev[0] * V[b * 3] + V[a * 3 + 1] * ev[1] * V[b * 3 + 1] + V[a * 3 + 2] * ev[2] * V[b * 3 + 2];
+    a00 = r[0]; a01 = r[1]; a02 = r[2]; a11 = r[4]; a12 = r[5]; a22 = r[8];
+  }
+  // symmetric cofactor inverse
+  const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+  const double det = a00 * c00 + a01 * c01 + a02 * c02;
+  const double id = 1.0 / det;
+  const double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;
+  const double i11 = (a00 * a22 - a02 * a02) * id, i12 = (a01 * a02 - a00 * a12) * id, i22 = (a00 * a11 - a01 * a01) * id;
+  if (!(isfinite(i00) && isfinite(i01) && isfinite(i02) && isfinite(i11) && isfinite(i12) && isfinite(i22))) return;
+  const int id_cell = atomicAdd(counter, 1);   // (cell ids are arbitrary: look-ups go through the dense table)
+  double* o = cells + (size_t)id_cell * kNdtCellDoubles;
+  o[0] = m0; o[1] = m1; o[2] = m2;
+  o[3] = i00; o[4] = i01; o[5] = i02; o[6] = i11; o[7] = i12; o[8] = i22; o[9] = 0.0;
+  table[key] = id_cell;
+}
+
+// score, gradient and Hessian of the NDT objective at the transform T (parameters enter through the angle
+// derivatives): every input point against the cells whose centroid lies within `resolution` of its image —
+// the kd-tree radius query of PCL, answered here by the 27 voxels around the point in the dense table.
+__global__ void __launch_bounds__(kBlock) s3d_ndt_derivatives_kernel(const float4* __restrict__ input, int m, Mat4f T,
+                                                                      NdtAngles ang, VoxelParams vp,
+                                                                      const int* __restrict__ table,
+                                                                      const double* __restrict__ cells, float r2,
+                                                                      double d1, double d2, int want_hessian,
+                                                                      double* __restrict__ partials) {
+  double acc[NDT_NACC];
+#pragma unroll
+  for (int c = 0; c < NDT_NACC; ++c) acc[c] = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < m; i += gridDim.x * kBlock) {
+    const float4 pf = input[i];
+    const F3 xt = xf_pcl(T, pf.x, pf.y, pf.z);
+    const int c0 = (int)(floorf(xt.x * vp.inv_leaf) - (float)vp.min_b[0]);
+    const int c1 = (int)(floorf(xt.y * vp.inv_leaf) - (float)vp.min_b[1]);
+    const int c2 = (int)(floorf(xt.z * vp.inv_leaf) - (float)vp.min_b[2]);
+    const double x[3] = {pf.x, pf.y, pf.z};
+    double J[3][3];                       // columns 3..5 of point_gradient_
+    double Hx[6][3];                      // d2R[kl] x
+    bool have = false;
+    for (int dz = -1; dz <= 1; ++dz)
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int v0 = c0 + dx, v1 = c1 + dy, v2 = c2 + dz;
+          if (v0 < 0 || v1 < 0 || v2 < 0 || v0 >= vp.div_b[0] || v1 >= vp.div_b[1] || v2 >= vp.div_b[2]) continue;
+          const int cid = table[v0 + v1 * vp.div_b[0] + v2 * vp.div_b[0] * vp.div_b[1]];
+          if (cid < 0) continue;
+          const double* __restrict__ cell = cells + (size_t)cid * kNdtCellDoubles;
+          const double mu0 = cell[0], mu1 = cell[1], mu2 = cell[2];
+          // radius test on the float centroid, float arithmetic, strict (FLANN radius search)
+          if (!(dist2(xt.x, xt.y, xt.z, (float)mu0, (float)mu1, (float)mu2) < r2)) continue;
+          if (!have) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+              for (int a = 0; a < 3; ++a)
+                J[a][k] = ang.dR[k][a * 3] * x[0] + ang.dR[k][a * 3 + 1] * x[1] + ang.dR[k][a * 3 + 2] * x[2];
+            if (want_hessian) {
+#pragma unroll
+              for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                  Hx[k][a] = ang.d2R[k][a * 3] * x[0] + ang.d2R[k][a * 3 + 1] * x[1] + ang.d2R[k][a * 3 + 2] * x[2];
+            }
+            have = true;
+          }
+          const double q0 = (double)xt.x - mu0, q1 = (double)xt.y - mu1, q2 = (double)xt.z - mu2;
+          const double C00 = cell[3], C01 = cell[4], C02 = cell[5], C11 = cell[6], C12 = cell[7], C22 = cell[8];
+          const double Cx0 = C00 * q0 + C01 * q1 + C02 * q2, Cx1 = C01 * q0 + C11 * q1 + C12 * q2,
+                       Cx2 = C02 * q0 + C12 * q1 + C22 * q2;
+          double e = exp(-d2 * (q0 * Cx0 + q1 * Cx1 + q2 * Cx2) / 2);
+          const double score_inc = -d1 * e;
+          e = d2 * e;
+          if (e > 1 || e < 0 || e != e) continue;
+          acc[0] += score_inc;
+          e *= d1;
+          // C J for the six parameter columns (the first three columns of J are the unit vectors)
+          double CJ[6][3], xCJ[6];
+          CJ[0][0] = C00; CJ[0][1] = C01; CJ[0][2] = C02;
+          CJ[1][0] = C01; CJ[1][1] = C11; CJ[1][2] = C12;
+          CJ[2][0] = C02; CJ[2][1] = C12; CJ[2][2] = C22;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            CJ[3 + k][0] = C00 * J[0][k] + C01 * J[1][k] + C02 * J[2][k];
+            CJ[3 + k][1] = C01 * J[0][k] + C11 * J[1][k] + C12 * J[2][k];
+            CJ[3 + k][2] = C02 * J[0][k] + C12 * J[1][k] + C22 * J[2][k];
+          }
+#pragma unroll
+          for (int col = 0; col < 6; ++col) {
+            xCJ[col] = q0 * CJ[col][0] + q1 * CJ[col][1] + q2 * CJ[col][2];
+            acc[1 + col] += xCJ[col] * e;
+          }
+          if (!want_hessian) continue;
+          int o = 7;
+#pragma unroll
+          for (int ii = 0; ii < 6; ++ii)
+#pragma unroll
+            for (int jj = ii; jj < 6; ++jj) {
+              double hx = 0.0;
+              if (ii >= 3) {   // (jj >= ii >= 3)
+                const int a = ii - 3, b = jj - 3;
+                const int kl = a == 0 ? b : (a == 1 ? 2 + b : 5);
+                hx = Cx0 * Hx[kl][0] + Cx1 * Hx[kl][1] + Cx2 * Hx[kl][2];
+              }
+              // J_jj . (C J_ii)
+              double jcj;
+              if (jj < 3) jcj = CJ[ii][jj];
+              else jcj = J[0][jj - 3] * CJ[ii][0] + J[1][jj - 3] * CJ[ii][1] + J[2][jj - 3] * CJ[ii][2];
+              acc[o++] += e * (-d2 * xCJ[ii] * xCJ[jj] + hx + jcj);
+            }
+        }
+  }
+  block_reduce_store<NDT_NACC>(acc, partials + (size_t)blockIdx.x * NDT_NACC);
+}
+
+__global__ void k_ndt_reduce(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
+  const int c = threadIdx.x;
+  if (c >= NDT_NACC) return;
+  double v = 0.0;
+  for (int b = 0; b < nblocks; ++b) v += partials[(size_t)b * NDT_NACC + c];
+  out[c] = v;
+}
+
 }  // namespace s3d

@@ -153,8 +153,6 @@ def test_align_gates(oracle_mod, fixture_clouds):
     few = fixture_clouds[0][:20]                                    # test.ply has 20 vertices
     st, _, _ = o.align(few, fixture_clouds[1])
     assert st == o.STATUS_TOO_FEW_POINTS                            # PointCloudSensor.cpp:134-135
-    st, _, _ = o.align(fixture_clouds[0], fixture_clouds[1], params=o.default_params(registration_algorithm=o.ALG_NDT))
-    assert st == o.STATUS_UNSUPPORTED_ALGORITHM
     st, _, _ = o.align(fixture_clouds[0], fixture_clouds[1], params=o.default_params(registration_algorithm=9))
     assert st == o.STATUS_UNKNOWN_ALGORITHM                         # :163-164
     st, _, info = o.align(fixture_clouds[0], fixture_clouds[1], params=o.default_params(max_fitness_score=0.01))
@@ -195,3 +193,24 @@ def test_synthetic_known_answer(oracle_mod):
         st, T, info = oracle_mod.align(src, tgt, np.eye(4), p)
         dt, dr = transform_delta(T_true, T)
         assert st == 0 and dt < 5e-3 and dr < 1e-3      # independent resample + 1 cm noise: mm-level truth
+
+
+def test_ndt_oracle_converges_next_to_gicp(oracle_mod, fixture_clouds):
+    """doNDT restatement (PointCloudSensor.cpp:84-117, pcl::NormalDistributionsTransform): on the reference's
+    fixture scans it must land within millimetres of the (independent) GICP result, reduce the NDT objective, and
+    stop by the translation-epsilon rule well before the iteration cap."""
+    o = oracle_mod
+    o.set_eval_precision(2)
+    for a, b in ((0, 1), (2, 3)):
+        st_g, T_g, _ = o.align(fixture_clouds[a], fixture_clouds[b], np.eye(4), o.default_params())
+        st_n, T_n, info = o.align(fixture_clouds[a], fixture_clouds[b], np.eye(4),
+                                  o.default_params(registration_algorithm=o.ALG_NDT))
+        assert st_g == st_n == 0
+        dt, dr = transform_delta(T_g, T_n)
+        assert dt < 5e-3 and dr < 2e-3
+        assert info["converged"] == 1 and 3 <= info["iterations"] < 35 and info["correspondences"] > 500
+    o.set_eval_precision(0)
+    # a coarser NDT grid still converges; a wrong guess far outside max_translation is rejected by the align() gate
+    st, T, info = o.align(fixture_clouds[0], fixture_clouds[1], np.eye(4),
+                          o.default_params(registration_algorithm=o.ALG_NDT, resolution=2.0))
+    assert st == 0 and abs(T[0, 3] - 0.68) < 0.05

@@ -1,0 +1,15 @@
+import sys, time, numpy as np
+sys.path.insert(0,'.')
+import slam3d_amd as s3d, oracle
+from tests.conftest import transform_delta
+G='tests/golden'
+clouds=[np.load(f'{G}/cloud{i}.npz')['xyzi'].astype(np.float32) for i in range(1,5)]
+ctx=s3d.Context(0)
+for a,b,g in ((0,1,None),(1,2,None),(2,3,None),(0,3,2.0)):
+    guess=np.eye(4)
+    if g: guess[0,3]=g
+    po=oracle.default_params(registration_algorithm=oracle.ALG_NDT)
+    so,To,io=oracle.align(clouds[a],clouds[b],guess,po)
+    pg=s3d.default_params(registration_algorithm=s3d.ALG_NDT)
+    t=time.time(); sg,Tg,ig=ctx.align(clouds[a],clouds[b],guess,pg); dt=time.time()-t
+    print('pair',a,b,'status',so,sg,'iters',io['iterations'],ig['iterations'],'cells',io['correspondences'],ig['correspondences'],'fit %.6f %.6f'%(io['fitness'],ig['fitness']),'delta',transform_delta(To,Tg),'gpu %.1f ms evals %d'%(dt*1e3, ig['evaluations']))
