@@ -181,6 +181,17 @@ def test_ndt_matches_oracle(gpu_ctx, oracle_mod, fixture_clouds, pair, gx):
         assert abs(io["fitness"] - ig["fitness"]) <= 1e-9 * max(1.0, io["fitness"])
 
 
+def test_ndt_golden(gpu_ctx, fixture_clouds):
+    import slam3d_amd as s3d
+    for case in json.load(open(os.path.join(GOLDEN, "ndt_golden.json"))):
+        g = np.eye(4)
+        g[0, 3] = case["guess_x"]
+        p = s3d.default_params(registration_algorithm=s3d.ALG_NDT, **case["params"])
+        st, T, info = gpu_ctx.align(fixture_clouds[case["source"] - 1], fixture_clouds[case["target"] - 1], g, p)
+        dt, dr = transform_delta(np.array(case["T"]), T)
+        assert st == case["status"] and dt < TOL_T and dr < TOL_R and info["iterations"] == case["info"]["iterations"]
+
+
 def test_ndt_batch_and_omp_enumerator(gpu_ctx, fixture_clouds):
     import slam3d_amd as s3d
     dev = [gpu_ctx.upload(c) for c in fixture_clouds]

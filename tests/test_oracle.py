@@ -214,3 +214,14 @@ def test_ndt_oracle_converges_next_to_gicp(oracle_mod, fixture_clouds):
     st, T, info = o.align(fixture_clouds[0], fixture_clouds[1], np.eye(4),
                           o.default_params(registration_algorithm=o.ALG_NDT, resolution=2.0))
     assert st == 0 and abs(T[0, 3] - 0.68) < 0.05
+
+
+def test_ndt_golden_replay(oracle_mod, fixture_clouds):
+    """tests/golden/ndt_golden.json (tests/golden/make_ndt_golden.py) replayed bit for bit."""
+    for case in json.load(open(os.path.join(GOLDEN, "ndt_golden.json"))):
+        g = np.eye(4)
+        g[0, 3] = case["guess_x"]
+        p = oracle_mod.default_params(registration_algorithm=oracle_mod.ALG_NDT, **case["params"])
+        st, T, info = oracle_mod.align(fixture_clouds[case["source"] - 1], fixture_clouds[case["target"] - 1], g, p)
+        assert st == case["status"] and np.array_equal(T, np.array(case["T"]))
+        assert info["iterations"] == case["info"]["iterations"] and info["fitness"] == case["info"]["fitness"]
