@@ -192,6 +192,26 @@ def test_ndt_golden(gpu_ctx, fixture_clouds):
         assert st == case["status"] and dt < TOL_T and dr < TOL_R and info["iterations"] == case["info"]["iterations"]
 
 
+def test_ndt_edge_cases(gpu_ctx, oracle_mod, fixture_clouds):
+    import slam3d_amd as s3d
+    rng = np.random.default_rng(3)
+    sparse = rng.uniform(-100, 100, (400, 3)).astype(np.float32)          # no voxel reaches 6 points: no NDT cell
+    po = oracle_mod.default_params(registration_algorithm=oracle_mod.ALG_NDT)
+    pg = s3d.default_params(registration_algorithm=s3d.ALG_NDT)
+    so, _, io = oracle_mod.align(sparse, sparse + 0.1, np.eye(4), po)
+    sg, _, ig = gpu_ctx.align(sparse, sparse + 0.1, np.eye(4), pg)
+    assert so == sg == 2 and io["correspondences"] == ig["correspondences"] == 0     # NOT_CONVERGED -> NoMatch (:108-111)
+    sg, _, _ = gpu_ctx.align(fixture_clouds[0][:20], fixture_clouds[1], np.eye(4), pg)
+    assert sg == 1                                                                    # 100-point gate first (:134)
+    sg, _, _ = gpu_ctx.align(fixture_clouds[0], fixture_clouds[1], np.eye(4),
+                             s3d.default_params(registration_algorithm=s3d.ALG_NDT, resolution=0.0))
+    assert sg == 7
+    # the distance-from-guess gate of align() applies to NDT results too (:167-172)
+    so, _, _ = oracle_mod.align(fixture_clouds[0], fixture_clouds[3], np.eye(4), po)
+    sg, _, _ = gpu_ctx.align(fixture_clouds[0], fixture_clouds[3], np.eye(4), pg)
+    assert so == sg
+
+
 def test_ndt_batch_and_omp_enumerator(gpu_ctx, fixture_clouds):
     import slam3d_amd as s3d
     dev = [gpu_ctx.upload(c) for c in fixture_clouds]
