@@ -13,3 +13,12 @@ for a,b,g in ((0,1,None),(1,2,None),(2,3,None),(0,3,2.0)):
     pg=s3d.default_params(registration_algorithm=s3d.ALG_NDT)
     t=time.time(); sg,Tg,ig=ctx.align(clouds[a],clouds[b],guess,pg); dt=time.time()-t
     print('pair',a,b,'status',so,sg,'iters',io['iterations'],ig['iterations'],'cells',io['correspondences'],ig['correspondences'],'fit %.6f %.6f'%(io['fitness'],ig['fitness']),'delta',transform_delta(To,Tg),'gpu %.1f ms evals %d'%(dt*1e3, ig['evaluations']))
+# synthetic 100k-point pair (bench generator), NDT defaults
+a, b, Ttrue = s3d.make_pair(100000, 0)
+da, db = ctx.upload(a), ctx.upload(b)
+pg = s3d.default_params(registration_algorithm=s3d.ALG_NDT, point_cloud_density=0.02)
+ctx.align_clouds(da, db, np.eye(4), pg)
+t = time.time()
+for _ in range(5): sg, Tg, ig = ctx.align_clouds(da, db, np.eye(4), pg)
+dt = (time.time() - t) / 5
+print('synthetic 100k NDT: status', sg, 'iters', ig['iterations'], 'evals', ig['evaluations'], 'cells', ig['correspondences'], '%.2f ms per registration' % (dt * 1e3), 'err vs truth', transform_delta(Ttrue, Tg))
