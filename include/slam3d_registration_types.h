@@ -24,7 +24,7 @@ enum s3d_registration_algorithm {
   S3D_ALG_GICP     = 1, /* reference default: pcl::GeneralizedIterativeClosestPoint */
   S3D_ALG_GICP_OMP = 2, /* reference: pclomp variant, same arithmetic as GICP */
   S3D_ALG_NDT      = 3, /* doNDT (:84-117): voxel statistics + derivative passes on the device, Newton /
-                           More-Thuente on the host; one pair at a time */
+                           More-Thuente state machines on the host, batches advance in lock-step rounds */
   S3D_ALG_NDT_OMP  = 4
 };
 

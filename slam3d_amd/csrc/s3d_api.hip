@@ -6,11 +6,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <chrono>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -701,97 +703,161 @@ float host_ord2f(unsigned int u) {
   return f;
 }
 
-// doNDT (PointCloudSensor.cpp:84-117) for the single pair of `b` (voxel filter and grid already staged and
-// downloaded).  The voxel statistics and every derivative pass run on the device; the Newton / More-Thuente
-// loop around them is host code (s3d_ndt.h) and costs one small D2H copy per pass.  NDT_OMP is served by the
+constexpr int kNdtBlocks = 64;   // blocks per derivative pass and pair (fixed: the sum order must not depend on the batch)
+
+// doNDT (PointCloudSensor.cpp:84-117) for every pair of `b` (voxel filter and grid already staged and
+// downloaded).  The voxel statistics and every derivative pass run on the device — one launch per ROUND over
+// all pairs that still iterate — and the Newton / More-Thuente state machines (s3d_ndt.h, one per pair) run on
+// the host between the rounds (one 224-byte result per pair and round comes back).  NDT_OMP is served by the
 // same code (pclomp differs in its neighbourhood search, not in the objective).
-int align_ndt(Batch& b, const s3d_reg_params* params, const double guess[16], double result[16], s3d_align_info* info) {
+// statuses / results / infos: one per pair.
+void align_ndt_pairs(Batch& b, const s3d_reg_params* params, const double* guesses, std::vector<int>& statuses,
+                     std::vector<std::array<double, 16>>& results, std::vector<s3d_align_info>& infos) {
   s3d_context* ctx = b.ctx;
   hipStream_t st = ctx->stream;
-  PairDev& P = b.h_pairs[0];
-  const SlotDev Ss = b.h_slots[P.slot_s], St = b.h_slots[P.slot_t];
-  for (int i = 0; i < 16; ++i) result[i] = (i % 5 == 0) ? 1.0 : 0.0;
-  if (info) { info->n_source_filtered = Ss.n; info->n_target_filtered = St.n; }
-  if (St.n < 100 || Ss.n < 100) return S3D_STATUS_TOO_FEW_POINTS;                 // :134-135
-  if (!(params->resolution > 0.f)) return S3D_STATUS_INVALID_ARGUMENT;
-  // voxel layout of the NDT target = the slam3d SOURCE cloud after the density filter (:101-102 swap)
-  float mn[3], mx[3];
-  for (int a = 0; a < 3; ++a) { mn[a] = host_ord2f(Ss.bb[a]); mx[a] = host_ord2f(Ss.bb[3 + a]); }
-  const VoxelParams vp = voxel_params_from_bbox(mn, mx, params->resolution);
-  const long long table_cells = (long long)vp.div_b[0] * vp.div_b[1] * vp.div_b[2];
-  if (vp.passthrough || table_cells > (1ll << 27)) return S3D_STATUS_INVALID_ARGUMENT;
+  const int NP = b.P();
+  statuses.assign(NP, S3D_STATUS_OK);
+  results.assign(NP, std::array<double, 16>{});
+  infos.assign(NP, s3d_align_info{});
   struct Scratch {   // released on every exit path
-    int* table = nullptr; double* cells = nullptr; int* counter = nullptr; double* partials = nullptr; double* out = nullptr;
-    ~Scratch() { (void)hipFree(table); (void)hipFree(cells); (void)hipFree(counter); (void)hipFree(partials); (void)hipFree(out); }
+    std::vector<void*> ptrs;
+    void* get(size_t bytes) { void* p = nullptr; HIPCHK(hipMalloc(&p, std::max<size_t>(bytes, 16))); ptrs.push_back(p); return p; }
+    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
   } S;
-  const int max_cells = Ss.n / 6 + 1;
-  const int nblocks = std::max(1, std::min(512, cdiv(St.n, kBlock)));
-  HIPCHK(hipMalloc((void**)&S.table, sizeof(int) * (size_t)table_cells));
-  HIPCHK(hipMalloc((void**)&S.cells, sizeof(double) * kNdtCellDoubles * (size_t)max_cells));
-  HIPCHK(hipMalloc((void**)&S.counter, sizeof(int)));
-  HIPCHK(hipMalloc((void**)&S.partials, sizeof(double) * NDT_NACC * (size_t)nblocks));
-  HIPCHK(hipMalloc((void**)&S.out, sizeof(double) * NDT_NACC));
-  HIPCHK(hipMemsetAsync(S.table, 0xFF, sizeof(int) * (size_t)table_cells, st));
-  HIPCHK(hipMemsetAsync(S.counter, 0, sizeof(int), st));
-  const float4* src_pts = b.filt() + Ss.off;
-  k_ndt_keys<<<cdiv(Ss.n, kBlock), kBlock, 0, st>>>(src_pts, Ss.n, vp, b.kA() + Ss.off, b.vA() + Ss.off);
-  k_ndt_select_slot<<<cdiv(b.C(), 64), 64, 0, st>>>(b.d_slots(), b.C(), P.slot_s, Ss.n);
-  b.sort(4);   // result back in A
-  k_ndt_cells<<<cdiv(Ss.n, kBlock), kBlock, 0, st>>>(src_pts, b.kA() + Ss.off, b.vA() + Ss.off, Ss.n, S.table, S.cells,
-                                                     S.counter);
-  int n_cells = 0;
-  HIPCHK(hipMemcpyAsync(&n_cells, S.counter, sizeof(int), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  // ---- gates that precede the registration, voxel layouts of the distinct target clouds (= slam3d sources)
+  std::vector<NdtGrid> grids;
+  std::map<int, int> grid_of_slot;
+  std::vector<int> pair_grid(NP, -1);
+  for (int p = 0; p < NP; ++p) {
+    const PairDev& P = b.h_pairs[p];
+    const SlotDev& Ss = b.h_slots[P.slot_s];
+    const SlotDev& St = b.h_slots[P.slot_t];
+    for (int i = 0; i < 16; ++i) results[p][i] = (i % 5 == 0) ? 1.0 : 0.0;
+    infos[p].n_source_filtered = Ss.n; infos[p].n_target_filtered = St.n;
+    if (St.n < 100 || Ss.n < 100) { statuses[p] = S3D_STATUS_TOO_FEW_POINTS; continue; }     // :134-135
+    if (!(params->resolution > 0.f)) { statuses[p] = S3D_STATUS_INVALID_ARGUMENT; continue; }
+    auto it = grid_of_slot.find(P.slot_s);
+    if (it == grid_of_slot.end()) {
+      float mn[3], mx[3];
+      for (int a = 0; a < 3; ++a) { mn[a] = host_ord2f(Ss.bb[a]); mx[a] = host_ord2f(Ss.bb[3 + a]); }
+      NdtGrid G;
+      std::memset(&G, 0, sizeof G);
+      G.slot = P.slot_s; G.n = Ss.n;
+      G.vp = voxel_params_from_bbox(mn, mx, params->resolution);
+      const long long cells = (long long)G.vp.div_b[0] * G.vp.div_b[1] * G.vp.div_b[2];
+      if (G.vp.passthrough || cells > (1ll << 27)) { statuses[p] = S3D_STATUS_INVALID_ARGUMENT; continue; }
+      G.table = (int*)S.get(sizeof(int) * (size_t)cells);
+      G.cells = (double*)S.get(sizeof(double) * kNdtCellDoubles * (size_t)(Ss.n / 6 + 1));
+      G.counter = (int*)S.get(sizeof(int));
+      HIPCHK(hipMemsetAsync(G.table, 0xFF, sizeof(int) * (size_t)cells, st));
+      HIPCHK(hipMemsetAsync(G.counter, 0, sizeof(int), st));
+      it = grid_of_slot.emplace(P.slot_s, (int)grids.size()).first;
+      grids.push_back(G);
+    }
+    pair_grid[p] = it->second;
+  }
+  const int NG = (int)grids.size();
+  std::vector<int> n_cells(std::max(NG, 1), 0);
+  NdtGrid* d_grids = nullptr;
+  if (NG > 0) {
+    d_grids = (NdtGrid*)S.get(sizeof(NdtGrid) * NG);
+    HIPCHK(hipMemcpyAsync(d_grids, grids.data(), sizeof(NdtGrid) * NG, hipMemcpyHostToDevice, st));
+    int max_n = 1;
+    for (const NdtGrid& G : grids) max_n = std::max(max_n, G.n);
+    k_ndt_keys<<<dim3(cdiv(max_n, kBlock), NG), kBlock, 0, st>>>(b.d_slots(), d_grids, b.filt(), b.kA(), b.vA());
+    k_ndt_select_slots<<<cdiv(b.C(), 64), 64, 0, st>>>(b.d_slots(), b.C(), d_grids, NG);
+    b.sort(4);   // result back in A
+    k_ndt_cells<<<dim3(cdiv(max_n, kBlock), NG), kBlock, 0, st>>>(b.d_slots(), d_grids, b.filt(), b.kA(), b.vA());
+    for (int g = 0; g < NG; ++g)
+      HIPCHK(hipMemcpyAsync(&n_cells[g], grids[g].counter, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  // ---- the optimisers, advanced in lock step: one derivative launch per round over the pairs still iterating
   double d1, d2;
   ndt::gauss_constants(params->outlier_ratio, (double)params->resolution, &d1, &d2);
   const float r2 = params->resolution * params->resolution;
-  const float4* in_pts = b.filt() + St.off;
-  ndt::EvalFn eval = [&](const float T[16], const double p[6], bool want_h, ndt::Eval& o) {
-    Mat4f Tm;
-    std::memcpy(Tm.m, T, sizeof Tm.m);
-    NdtAngles ang;
-    ndt::angle_derivatives(p, ang.dR, ang.d2R);
-    s3d_ndt_derivatives_kernel<<<nblocks, kBlock, 0, st>>>(in_pts, St.n, Tm, ang, vp, S.table, S.cells, r2, d1, d2,
-                                                           want_h ? 1 : 0, S.partials);
-    k_ndt_reduce<<<1, 64, 0, st>>>(S.partials, nblocks, S.out);
-    double h[NDT_NACC];
-    HIPCHK(hipMemcpyAsync(h, S.out, sizeof h, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    o.score = h[0];
-    for (int i = 0; i < 6; ++i) o.g[i] = h[1 + i];
-    int k = 7;
-    for (int i = 0; i < 6; ++i)
-      for (int j = i; j < 6; ++j, ++k) o.H[i * 6 + j] = o.H[j * 6 + i] = want_h ? h[k] : 0.0;
-  };
-  float guess_f[16];
-  for (int i = 0; i < 16; ++i) guess_f[i] = (float)guess[i];                    // :104 guess.matrix().cast<float>()
-  ndt::Result R;
-  if (n_cells > 0) {
-    R = ndt::run(eval, guess_f, params->step_size, params->transformation_epsilon, params->maximum_iterations);
-  } else {
-    std::memcpy(R.T, guess_f, sizeof R.T);
-    R.converged = 0; R.iterations = 0; R.evaluations = 0;
+  std::vector<std::unique_ptr<ndt::Solver>> solver(NP);
+  std::vector<ndt::Result> res(NP);
+  for (int p = 0; p < NP; ++p) {
+    float guess_f[16];
+    for (int i = 0; i < 16; ++i) guess_f[i] = (float)guesses[(size_t)p * 16 + i];   // :104 guess.matrix().cast<float>()
+    std::memcpy(res[p].T, guess_f, sizeof guess_f);
+    res[p].converged = 0; res[p].iterations = 0; res[p].evaluations = 0;
+    if (statuses[p] == S3D_STATUS_OK && n_cells[pair_grid[p]] > 0)
+      solver[p].reset(new ndt::Solver(guess_f, params->step_size, params->transformation_epsilon,
+                                      params->maximum_iterations));
   }
-  // getFitnessScore(max_correspondence_distance) (:107): the K8 path on the final transformation
-  Mat4f Tf;
-  std::memcpy(Tf.m, R.T, sizeof Tf.m);
-  HIPCHK(hipMemcpyAsync(&b.d_pairs()[0].final_T, &Tf, sizeof Tf, hipMemcpyHostToDevice, st));
+  NdtJob* d_jobs = (NdtJob*)S.get(sizeof(NdtJob) * std::max(NP, 1));
+  double* d_part = (double*)S.get(sizeof(double) * NDT_NACC * kNdtBlocks * (size_t)std::max(NP, 1));
+  double* d_out = (double*)S.get(sizeof(double) * NDT_NACC * (size_t)std::max(NP, 1));
+  std::vector<NdtJob> jobs;
+  std::vector<int> job_pair;
+  std::vector<double> h_out;
+  for (;;) {
+    jobs.clear(); job_pair.clear();
+    for (int p = 0; p < NP; ++p) {
+      if (!solver[p] || !solver[p]->pending()) continue;
+      NdtJob J;
+      std::memset(&J, 0, sizeof J);
+      J.slot_in = b.h_pairs[p].slot_t;
+      J.m = b.h_slots[J.slot_in].n;
+      J.grid = pair_grid[p];
+      J.want_hessian = solver[p]->request_hessian() ? 1 : 0;
+      std::memcpy(J.T.m, solver[p]->request_T(), sizeof J.T.m);
+      ndt::angle_derivatives(solver[p]->request_p(), J.ang.dR, J.ang.d2R);
+      jobs.push_back(J);
+      job_pair.push_back(p);
+    }
+    const int NJ = (int)jobs.size();
+    if (NJ == 0) break;
+    HIPCHK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(NdtJob) * NJ, hipMemcpyHostToDevice, st));
+    s3d_ndt_derivatives_kernel<<<dim3(kNdtBlocks, NJ), kBlock, 0, st>>>(b.d_slots(), d_grids, d_jobs, b.filt(), r2, d1, d2,
+                                                                        d_part);
+    k_ndt_reduce<<<NJ, 64, 0, st>>>(d_part, kNdtBlocks, d_out);
+    h_out.resize((size_t)NJ * NDT_NACC);
+    HIPCHK(hipMemcpyAsync(h_out.data(), d_out, sizeof(double) * NDT_NACC * (size_t)NJ, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int j = 0; j < NJ; ++j) {
+      const double* h = h_out.data() + (size_t)j * NDT_NACC;
+      ndt::Eval e;
+      e.score = h[0];
+      for (int i = 0; i < 6; ++i) e.g[i] = h[1 + i];
+      int k = 7;
+      for (int i = 0; i < 6; ++i)
+        for (int jj = i; jj < 6; ++jj, ++k) e.H[i * 6 + jj] = e.H[jj * 6 + i] = jobs[j].want_hessian ? h[k] : 0.0;
+      solver[job_pair[j]]->feed(e);
+    }
+  }
+  for (int p = 0; p < NP; ++p)
+    if (solver[p]) res[p] = solver[p]->result();
+  // ---- getFitnessScore(max_correspondence_distance) (:107): the K8 path on the final transformations
+  for (int p = 0; p < NP; ++p) {
+    Mat4f Tf;
+    std::memcpy(Tf.m, res[p].T, sizeof Tf.m);
+    b.h_pairs[p].final_T = Tf;
+    HIPCHK(hipMemcpyAsync(&b.d_pairs()[p].final_T, &b.h_pairs[p].final_T, sizeof(Mat4f), hipMemcpyHostToDevice, st));
+  }
   HIPCHK(hipMemsetAsync(ctx->corr_d2.p, 0xFF, 4 * std::max<size_t>(b.total_corr, 4), st));
   HIPCHK(hipMemsetAsync(ctx->corr_lb.p, 0, 4 * std::max<size_t>(b.total_corr, 4), st));
   b.launch_nn(1, (float)(std::sqrt(std::max(b.rp.fit_range, 0.0)) * 1.0001));
   double* part = (double*)ctx->partials.p;
-  s3d_fitness_partial_kernel<<<dim3(b.accum_blocks, 1), kBlock, 0, st>>>(b.d_pairs(), b.d_slots(), (float*)ctx->corr_d2.p,
-                                                                         part, b.rp);
-  k_fitness_final<<<1, 64, 0, st>>>(b.d_pairs(), part, b.accum_blocks, 1);
+  s3d_fitness_partial_kernel<<<dim3(b.accum_blocks, NP), kBlock, 0, st>>>(b.d_pairs(), b.d_slots(), (float*)ctx->corr_d2.p,
+                                                                          part, b.rp);
+  k_fitness_final<<<cdiv(NP, 64), 64, 0, st>>>(b.d_pairs(), part, b.accum_blocks, NP);
+  std::vector<Mat4f> finals(NP);
+  for (int p = 0; p < NP; ++p) finals[p] = b.h_pairs[p].final_T;
   b.download();
-  PairDev& Pd = b.h_pairs[0];
-  Pd.converged = R.converged;
-  Pd.iterations = R.iterations;
-  Pd.correspondences = n_cells;
-  Pd.evals_total = R.evaluations;
-  Pd.inner_total = 0;
-  Pd.final_T = Tf;
-  return b.finish_pair(0, params, guess, result, info);
+  for (int p = 0; p < NP; ++p) {
+    if (statuses[p] != S3D_STATUS_OK) continue;
+    PairDev& Pd = b.h_pairs[p];
+    Pd.converged = res[p].converged;
+    Pd.iterations = res[p].iterations;
+    Pd.correspondences = n_cells[pair_grid[p]];
+    Pd.evals_total = res[p].evaluations;
+    Pd.inner_total = 0;
+    Pd.final_T = finals[p];
+    statuses[p] = b.finish_pair(p, params, guesses + (size_t)p * 16, results[p].data(), &infos[p]);
+  }
 }
 
 // align() of two device-resident clouds (PointCloudSensor.cpp:119-174)
@@ -820,7 +886,13 @@ int align_dev(s3d_context* ctx, s3d_cloud* ps, s3d_cloud* pt, const double guess
     b.stage_voxel();
     b.stage_grid();
     b.download();
-    status = align_ndt(b, params, guess, result, info);
+    std::vector<int> sts;
+    std::vector<std::array<double, 16>> rs;
+    std::vector<s3d_align_info> is;
+    align_ndt_pairs(b, params, guess, sts, rs, is);
+    status = sts[0];
+    std::memcpy(result, rs[0].data(), sizeof(double) * 16);
+    if (info) *info = is[0];
   } else {
     b.set_params(params, opts);
     b.add_pairs(1, &ps, &pt, guess);
@@ -982,19 +1054,28 @@ int s3d_align_batch(s3d_context* ctx, int n_pairs, s3d_cloud* const* sources, s3
   }
   try {
     ScopedDevice sd(ctx);
-    if (is_ndt(params)) {   // NDT is driven from the host, pair by pair (align_ndt)
+    if (is_ndt(params)) {   // NDT: device passes for all pairs per round, host state machines in between
+      Batch b;
+      b.ctx = ctx;
+      b.set_params(params, opts);
+      b.add_pairs(n_pairs, sources, targets, guesses);
+      b.allocate();
+      b.stage_voxel();
+      b.stage_grid();
+      b.download();
+      std::vector<int> sts;
+      std::vector<std::array<double, 16>> rs;
+      std::vector<s3d_align_info> is;
+      align_ndt_pairs(b, params, guesses, sts, rs, is);
       for (int p = 0; p < n_pairs; ++p) {
-        double result[16];
-        s3d_align_info info{};
-        const int st = align_dev(ctx, sources[p], targets[p], guesses + (size_t)p * 16, params, opts, result, &info);
         s3d_edge_record& r = records[p];
         for (int c = 0; c < 4; ++c)
-          for (int rr = 0; rr < 3; ++rr) r.transform[c * 3 + rr] = result[c * 4 + rr];
-        r.fitness = info.fitness;
-        r.iterations = info.iterations;
-        r.correspondences = info.correspondences;
-        r.status = st;
-        if (infos) infos[p] = info;
+          for (int rr = 0; rr < 3; ++rr) r.transform[c * 3 + rr] = rs[p][c * 4 + rr];
+        r.fitness = is[p].fitness;
+        r.iterations = is[p].iterations;
+        r.correspondences = is[p].correspondences;
+        r.status = sts[p];
+        if (infos) infos[p] = is[p];
       }
       return S3D_STATUS_OK;
     }

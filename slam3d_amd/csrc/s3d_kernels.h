@@ -1238,27 +1238,59 @@ struct NdtAngles {                    // R = Rx Ry Rz: first and second derivati
   double d2R[6][9];                   // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
 };
 
-__global__ void k_ndt_select_slot(SlotDev* slots, int nslots, int slot, int n) {   // the segmented sort then sorts this slot only
+struct NdtGrid {                      // the voxelised target of one cloud (slot)
+  int slot, n;                        // slot of the batch, its filtered point count
+  VoxelParams vp;                     // voxel layout at `resolution`
+  int* table;                         // dense voxel index -> cell id (-1: no cell)
+  double* cells;                      // kNdtCellDoubles per cell
+  int* counter;                       // number of cells
+};
+
+struct NdtJob {                       // one derivative pass of one pair
+  int slot_in, m;                     // the input cloud (slot) and its point count
+  int grid;                           // index of the target's NdtGrid
+  int want_hessian;
+  Mat4f T;
+  NdtAngles ang;
+};
+
+// the segmented sort then sorts exactly the clouds that get an NDT grid
+__global__ void k_ndt_select_slots(SlotDev* slots, int nslots, const NdtGrid* __restrict__ grids, int ngrids) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nslots) slots[i].n_sort = i == slot ? n : 0;
+  if (i >= nslots) return;
+  int n = 0;
+  for (int g = 0; g < ngrids; ++g) n = grids[g].slot == i ? grids[g].n : n;
+  slots[i].n_sort = n;
 }
 
-__global__ void __launch_bounds__(kBlock) k_ndt_keys(const float4* __restrict__ pts, int n, VoxelParams vp,
-                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+__global__ void __launch_bounds__(kBlock) k_ndt_keys(const SlotDev* __restrict__ slots, const NdtGrid* __restrict__ grids,
+                                                      const float4* __restrict__ filt, uint32_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ vals) {
+  const NdtGrid& G = grids[blockIdx.y];
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = pts[i];
-  keys[i] = voxel_key(vp, p.x, p.y, p.z);
-  vals[i] = (uint32_t)i;
+  if (i >= G.n) return;
+  const int off = slots[G.slot].off;
+  const float4 p = filt[off + i];
+  keys[off + i] = voxel_key(G.vp, p.x, p.y, p.z);
+  vals[off + i] = (uint32_t)i;
 }
 
 // one thread per sorted element; the head of a run of >= 6 equal keys builds the cell.  Sums run in ascending
 // point index (the stable sort keeps that order), in double, as VoxelGridCovariance does.
-__global__ void __launch_bounds__(kBlock) k_ndt_cells(const float4* __restrict__ pts, const uint32_t* __restrict__ keys,
-                                                       const uint32_t* __restrict__ vals, int n, int* __restrict__ table,
-                                                       double* __restrict__ cells, int* __restrict__ counter) {
+__global__ void __launch_bounds__(kBlock) k_ndt_cells(const SlotDev* __restrict__ slots, const NdtGrid* __restrict__ grids,
+                                                       const float4* __restrict__ filt, const uint32_t* __restrict__ keys_all,
+                                                       const uint32_t* __restrict__ vals_all) {
+  const NdtGrid& G = grids[blockIdx.y];
+  const int n = G.n;
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
+  const int off = slots[G.slot].off;
+  const float4* __restrict__ pts = filt + off;
+  const uint32_t* __restrict__ keys = keys_all + off;
+  const uint32_t* __restrict__ vals = vals_all + off;
+  int* __restrict__ table = G.table;
+  double* __restrict__ cells = G.cells;
+  int* __restrict__ counter = G.counter;
   const uint32_t key = keys[i];
   if (i > 0 && keys[i - 1] == key) return;
   double s[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
@@ -1304,12 +1336,22 @@ __global__ void __launch_bounds__(kBlock) k_ndt_cells(const float4* __restrict__
 // score, gradient and Hessian of the NDT objective at the transform T (parameters enter through the angle
 // derivatives): every input point against the cells whose centroid lies within `resolution` of its image —
 // the kd-tree radius query of PCL, answered here by the 27 voxels around the point in the dense table.
-__global__ void __launch_bounds__(kBlock) s3d_ndt_derivatives_kernel(const float4* __restrict__ input, int m, Mat4f T,
-                                                                      NdtAngles ang, VoxelParams vp,
-                                                                      const int* __restrict__ table,
-                                                                      const double* __restrict__ cells, float r2,
-                                                                      double d1, double d2, int want_hessian,
+__global__ void __launch_bounds__(kBlock) s3d_ndt_derivatives_kernel(const SlotDev* __restrict__ slots,
+                                                                      const NdtGrid* __restrict__ grids,
+                                                                      const NdtJob* __restrict__ jobs,
+                                                                      const float4* __restrict__ filt, float r2,
+                                                                      double d1, double d2,
                                                                       double* __restrict__ partials) {
+  const NdtJob& Jb = jobs[blockIdx.y];
+  const NdtGrid& G = grids[Jb.grid];
+  const float4* __restrict__ input = filt + slots[Jb.slot_in].off;
+  const int m = Jb.m;
+  const Mat4f T = Jb.T;
+  const NdtAngles& ang = Jb.ang;
+  const VoxelParams vp = G.vp;
+  const int* __restrict__ table = G.table;
+  const double* __restrict__ cells = G.cells;
+  const int want_hessian = Jb.want_hessian;
   double acc[NDT_NACC];
 #pragma unroll
   for (int c = 0; c < NDT_NACC; ++c) acc[c] = 0.0;
@@ -1395,15 +1437,16 @@ __global__ void __launch_bounds__(kBlock) s3d_ndt_derivatives_kernel(const float
             }
         }
   }
-  block_reduce_store<NDT_NACC>(acc, partials + (size_t)blockIdx.x * NDT_NACC);
+  block_reduce_store<NDT_NACC>(acc, partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NDT_NACC);
 }
 
+// fixed-order sum of the block partials of every job
 __global__ void k_ndt_reduce(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
   const int c = threadIdx.x;
   if (c >= NDT_NACC) return;
   double v = 0.0;
-  for (int b = 0; b < nblocks; ++b) v += partials[(size_t)b * NDT_NACC + c];
-  out[c] = v;
+  for (int b = 0; b < nblocks; ++b) v += partials[((size_t)blockIdx.x * nblocks + b) * NDT_NACC + c];
+  out[(size_t)blockIdx.x * NDT_NACC + c] = v;
 }
 
 }  // namespace s3d

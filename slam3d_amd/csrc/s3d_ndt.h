@@ -169,95 +169,160 @@ inline bool update_interval(double& a_l, double& f_l, double& g_l, double& a_u, 
   return true;
 }
 
-// computeStepLengthMT: on return `ev` / `T` describe the accepted trial point
-inline double step_length(const EvalFn& eval, const double x[6], double dir[6], double step_init, double step_max,
-                          double step_min, Eval& ev, float T[16]) {
-  const double phi_0 = -ev.score;
-  double d_phi_0 = -dot6(ev.g, dir);
-  if (d_phi_0 >= 0) {
-    if (d_phi_0 == 0) return 0;
-    d_phi_0 = -d_phi_0;
-    for (int i = 0; i < 6; ++i) dir[i] = -dir[i];
-  }
-  const int max_step_iterations = 10;
-  int step_iterations = 0;
-  const double mu = 1.e-4, nu = 0.9;
-  double a_l = 0, a_u = 0, f_l = 0, g_l = d_phi_0 - mu * d_phi_0, f_u = 0, g_u = g_l;
-  bool interval_converged = (step_max - step_min) < 0, open_interval = true;
-  double a_t = std::fmax(std::fmin(step_init, step_max), step_min);
-  double x_t[6];
-  for (int i = 0; i < 6; ++i) x_t[i] = x[i] + dir[i] * a_t;
-  convert_transform(x_t, T);
-  eval(T, x_t, true, ev);
-  double phi_t = -ev.score, d_phi_t = -dot6(ev.g, dir);
-  double psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t, d_psi_t = d_phi_t - mu * d_phi_0;
-  while (!interval_converged && step_iterations < max_step_iterations && !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
-    a_t = open_interval ? trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t)
-                        : trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
-    a_t = std::fmax(std::fmin(a_t, step_max), step_min);
-    for (int i = 0; i < 6; ++i) x_t[i] = x[i] + dir[i] * a_t;
-    convert_transform(x_t, T);
-    Eval trial;
-    eval(T, x_t, false, trial);
-    ev.score = trial.score;
-    std::memcpy(ev.g, trial.g, sizeof ev.g);
-    phi_t = -ev.score;
-    d_phi_t = -dot6(ev.g, dir);
-    psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t;
-    d_psi_t = d_phi_t - mu * d_phi_0;
-    if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
-      open_interval = false;
-      f_l += phi_0 - mu * d_phi_0 * a_l;
-      g_l += mu * d_phi_0;
-      f_u += phi_0 - mu * d_phi_0 * a_u;
-      g_u += mu * d_phi_0;
-    }
-    interval_converged = open_interval ? update_interval(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t)
-                                       : update_interval(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
-    ++step_iterations;
-  }
-  if (step_iterations) {   // computeHessian at the accepted point
-    Eval at;
-    eval(T, x_t, true, at);
-    std::memcpy(ev.H, at.H, sizeof ev.H);
-  }
-  return a_t;
-}
-
 struct Result { float T[16]; int converged, iterations, evaluations; };
 
-// computeTransformation.  rotation epsilon is never set by slam3d (0): the PCL 1.12 stopping test reduces to the
-// iteration cap or the squared translation of the step <= transformation_epsilon.
-inline Result run(const EvalFn& eval_in, const float guess[16], double step_size, double transformation_epsilon,
-                  int maximum_iterations) {
-  Result R;
-  std::memcpy(R.T, guess, sizeof R.T);
-  R.converged = 0; R.iterations = 0; R.evaluations = 0;
-  EvalFn eval = [&](const float T[16], const double p[6], bool h, Eval& o) { ++R.evaluations; eval_in(T, p, h, o); };
-  double p[6];
-  {
+// computeTransformation + computeStepLengthMT as a resumable state machine: it advances until it needs a
+// derivative pass (request()), is fed the result (feed()) and continues.  One instance per scan pair; the batched
+// entry point advances many of them in lock step so that every round is ONE kernel launch over all pairs.
+// The rotation epsilon is never set by slam3d (0): the PCL 1.12 stopping test reduces to the iteration cap or the
+// squared translation of the step <= transformation_epsilon.
+class Solver {
+ public:
+  Solver(const float guess[16], double step_size, double transformation_epsilon, int maximum_iterations)
+      : step_max_(step_size), step_min_(transformation_epsilon / 2), eps_(transformation_epsilon),
+        max_iter_(maximum_iterations) {
+    std::memcpy(res_.T, guess, sizeof res_.T);
+    res_.converged = 0; res_.iterations = 0; res_.evaluations = 0;
     float e[3];
     euler_xyz(guess, e);
-    for (int i = 0; i < 3; ++i) { p[i] = (double)guess[12 + i]; p[3 + i] = (double)e[i]; }
+    for (int i = 0; i < 3; ++i) { p_[i] = (double)guess[12 + i]; p_[3 + i] = (double)e[i]; }
+    std::memcpy(req_T_, guess, sizeof req_T_);
+    std::memcpy(req_p_, p_, sizeof req_p_);
+    req_h_ = true;
+    phase_ = INIT;
   }
-  Eval ev;
-  eval(R.T, p, true, ev);
-  while (!R.converged) {
-    double mg[6], delta[6];
-    for (int i = 0; i < 6; ++i) mg[i] = -ev.g[i];
-    solve6(ev.H, mg, delta);
-    double dn = norm6(delta);
-    if (dn == 0 || dn != dn) { R.converged = dn == 0; break; }
-    for (int i = 0; i < 6; ++i) delta[i] /= dn;
-    dn = step_length(eval, p, delta, dn, step_size, transformation_epsilon / 2, ev, R.T);
-    for (int i = 0; i < 6; ++i) { delta[i] *= dn; p[i] += delta[i]; }
+  bool pending() const { return phase_ != DONE; }
+  const float* request_T() const { return req_T_; }
+  const double* request_p() const { return req_p_; }
+  bool request_hessian() const { return req_h_; }
+  const Result& result() const { return res_; }
+
+  void feed(const Eval& e) {
+    ++res_.evaluations;
+    switch (phase_) {
+      case INIT:
+        ev_ = e;
+        newton();
+        break;
+      case LS_FIRST:
+        ev_ = e;
+        std::memcpy(res_.T, req_T_, sizeof res_.T);
+        ls_measure();
+        ls_check();
+        break;
+      case LS_LOOP:
+        ev_.score = e.score;
+        std::memcpy(ev_.g, e.g, sizeof ev_.g);
+        std::memcpy(res_.T, req_T_, sizeof res_.T);
+        ls_measure();
+        if (open_ && (psi_t_ <= 0 && d_psi_t_ >= 0)) {
+          open_ = false;
+          f_l_ += phi_0_ - mu_ * d_phi_0_ * a_l_;
+          g_l_ += mu_ * d_phi_0_;
+          f_u_ += phi_0_ - mu_ * d_phi_0_ * a_u_;
+          g_u_ += mu_ * d_phi_0_;
+        }
+        conv_ = open_ ? update_interval(a_l_, f_l_, g_l_, a_u_, f_u_, g_u_, a_t_, psi_t_, d_psi_t_)
+                      : update_interval(a_l_, f_l_, g_l_, a_u_, f_u_, g_u_, a_t_, phi_t_, d_phi_t_);
+        ++step_iterations_;
+        ls_check();
+        break;
+      case LS_HESS:
+        std::memcpy(ev_.H, e.H, sizeof ev_.H);
+        after_line_search();
+        break;
+      case DONE:
+        break;
+    }
+  }
+
+ private:
+  enum Phase { INIT, LS_FIRST, LS_LOOP, LS_HESS, DONE };
+
+  void newton() {   // Newton direction, then the first trial of computeStepLengthMT
+    double mg[6];
+    for (int i = 0; i < 6; ++i) mg[i] = -ev_.g[i];
+    solve6(ev_.H, mg, dir_);
+    const double dn = norm6(dir_);
+    if (dn == 0 || dn != dn) { res_.converged = dn == 0; phase_ = DONE; return; }
+    for (int i = 0; i < 6; ++i) dir_[i] /= dn;
+    phi_0_ = -ev_.score;
+    d_phi_0_ = -dot6(ev_.g, dir_);
+    if (d_phi_0_ >= 0) {
+      if (d_phi_0_ == 0) { a_t_ = 0; after_line_search(); return; }
+      d_phi_0_ = -d_phi_0_;
+      for (int i = 0; i < 6; ++i) dir_[i] = -dir_[i];
+    }
+    step_iterations_ = 0;
+    a_l_ = 0; a_u_ = 0; f_l_ = 0; g_l_ = d_phi_0_ - mu_ * d_phi_0_; f_u_ = 0; g_u_ = g_l_;
+    conv_ = (step_max_ - step_min_) < 0;
+    open_ = true;
+    a_t_ = std::fmax(std::fmin(dn, step_max_), step_min_);
+    ask(true, LS_FIRST);
+  }
+  void ask(bool hessian, Phase next) {
+    for (int i = 0; i < 6; ++i) req_p_[i] = p_[i] + dir_[i] * a_t_;
+    convert_transform(req_p_, req_T_);
+    req_h_ = hessian;
+    phase_ = next;
+  }
+  void ls_measure() {
+    phi_t_ = -ev_.score;
+    d_phi_t_ = -dot6(ev_.g, dir_);
+    psi_t_ = phi_t_ - phi_0_ - mu_ * d_phi_0_ * a_t_;
+    d_psi_t_ = d_phi_t_ - mu_ * d_phi_0_;
+  }
+  void ls_check() {
+    if (!conv_ && step_iterations_ < 10 && !(psi_t_ <= 0 && d_phi_t_ <= -nu_ * d_phi_0_)) {
+      a_t_ = open_ ? trial_value(a_l_, f_l_, g_l_, a_u_, f_u_, g_u_, a_t_, psi_t_, d_psi_t_)
+                   : trial_value(a_l_, f_l_, g_l_, a_u_, f_u_, g_u_, a_t_, phi_t_, d_phi_t_);
+      a_t_ = std::fmax(std::fmin(a_t_, step_max_), step_min_);
+      ask(false, LS_LOOP);
+    } else if (step_iterations_) {
+      req_h_ = true;          // computeHessian at the accepted point (same T / p as the last trial)
+      phase_ = LS_HESS;
+    } else {
+      after_line_search();
+    }
+  }
+  void after_line_search() {
+    double delta[6];
+    for (int i = 0; i < 6; ++i) { delta[i] = dir_[i] * a_t_; p_[i] += delta[i]; }
     float Tstep[16];
     convert_transform(delta, Tstep);
     const double tsq = (double)Tstep[12] * Tstep[12] + (double)Tstep[13] * Tstep[13] + (double)Tstep[14] * Tstep[14];
-    ++R.iterations;
-    if (R.iterations >= maximum_iterations || (transformation_epsilon > 0 && tsq <= transformation_epsilon)) R.converged = 1;
+    ++res_.iterations;
+    if (res_.iterations >= max_iter_ || (eps_ > 0 && tsq <= eps_)) { res_.converged = 1; phase_ = DONE; return; }
+    newton();
   }
-  return R;
+
+  static constexpr double mu_ = 1.e-4, nu_ = 0.9;
+  double step_max_, step_min_, eps_;
+  int max_iter_;
+  Result res_;
+  Phase phase_;
+  Eval ev_;
+  double p_[6], dir_[6];
+  float req_T_[16];
+  double req_p_[6];
+  bool req_h_;
+  // line-search state
+  double phi_0_ = 0, d_phi_0_ = 0, a_t_ = 0, a_l_ = 0, a_u_ = 0, f_l_ = 0, g_l_ = 0, f_u_ = 0, g_u_ = 0;
+  double phi_t_ = 0, d_phi_t_ = 0, psi_t_ = 0, d_psi_t_ = 0;
+  bool conv_ = false, open_ = true;
+  int step_iterations_ = 0;
+};
+
+// the same thing driven by a callback (one pair)
+inline Result run(const EvalFn& eval, const float guess[16], double step_size, double transformation_epsilon,
+                  int maximum_iterations) {
+  Solver s(guess, step_size, transformation_epsilon, maximum_iterations);
+  while (s.pending()) {
+    Eval e;
+    eval(s.request_T(), s.request_p(), s.request_hessian(), e);
+    s.feed(e);
+  }
+  return s.result();
 }
 
 }  // namespace ndt

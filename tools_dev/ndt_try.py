@@ -22,3 +22,11 @@ t = time.time()
 for _ in range(5): sg, Tg, ig = ctx.align_clouds(da, db, np.eye(4), pg)
 dt = (time.time() - t) / 5
 print('synthetic 100k NDT: status', sg, 'iters', ig['iterations'], 'evals', ig['evaluations'], 'cells', ig['correspondences'], '%.2f ms per registration' % (dt * 1e3), 'err vs truth', transform_delta(Ttrue, Tg))
+# batch of 64 synthetic pairs
+from multiprocessing.pool import ThreadPool
+with ThreadPool(16) as pool: pairs = pool.map(lambda i: s3d.make_pair(100000, i), range(64))
+sa = [ctx.upload(x[0]) for x in pairs]; sb = [ctx.upload(x[1]) for x in pairs]
+ctx.align_batch(sa, sb, None, pg)
+t = time.time(); rec = ctx.align_batch(sa, sb, None, pg); dt = time.time() - t
+errs = [transform_delta(pairs[i][2], s3d.api.record_transform(rec[i]))[0] for i in range(64)]
+print('batch of 64 NDT: %.1f ms (%.2f ms per pair), ok %d, median err %.2e m' % (dt * 1e3, dt * 1e3 / 64, int((rec[:, 15] == 0).sum()), np.median(errs)))
