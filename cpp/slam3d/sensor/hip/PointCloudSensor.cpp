@@ -191,7 +191,7 @@ Transform PointCloudSensor::align(const PointCloudMeasurement::Ptr& source, cons
   Transform result;
   s3d_align_info info;
   const int st = s3d_align_clouds(mContext, s->cloud, t->cloud, guess.data(),
-                                  reinterpret_cast<const s3d_reg_params*>(&config), nullptr, result.data(), &info);
+                                  static_cast<const s3d_reg_params*>(&config), nullptr, result.data(), &info);
   switch (st) {
     case S3D_STATUS_OK: return result;
     case S3D_STATUS_TOO_FEW_POINTS:   // PointCloudSensor.cpp:135

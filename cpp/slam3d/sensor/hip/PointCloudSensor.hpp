@@ -21,8 +21,7 @@
 
 namespace slam3d {
 
-static_assert(sizeof(RegistrationParameters) == sizeof(s3d_reg_params), "RegistrationParameters must match s3d_reg_params");
-static_assert(sizeof(RegistrationAlgorithm) == sizeof(int), "enum must be int-sized");
+static_assert(sizeof(RegistrationParameters) == sizeof(s3d_reg_params), "RegistrationParameters is the C ABI struct");
 
 // pcl::PointXYZ: 16 bytes (x, y, z, padding)
 struct PointType { float x, y, z, data_w; };

@@ -1,28 +1,19 @@
-// Field-for-field mirror of slam3d/sensor/pcl/RegistrationParameters.hpp:30-97 (same enum, same
-// member names, order, types and in-class defaults), so application code that assigns members keeps
-// compiling; layout-compatible with the C ABI's s3d_reg_params (static_assert in PointCloudSensor.hpp).
+// slam3d::RegistrationParameters for the MI355X build.  The reference declares the fifteen tuning members one by
+// one (slam3d/sensor/pcl/RegistrationParameters.hpp:30-97); here the type IS the C ABI's s3d_reg_params
+// (include/slam3d_registration_types.h — same member names, order and types, which is what application code that
+// assigns `config.maximum_iterations = ...` relies on) with the reference's defaults filled in by the library.
 #pragma once
+
+#include "../../../../include/slam3d_hip.h"
 
 namespace slam3d {
 
-enum RegistrationAlgorithm { ICP, GICP, GICP_OMP, NDT, NDT_OMP };
+// same enumerators and values as the reference; the C struct stores the value as an int
+enum RegistrationAlgorithm { ICP = S3D_ALG_ICP, GICP = S3D_ALG_GICP, GICP_OMP = S3D_ALG_GICP_OMP, NDT = S3D_ALG_NDT,
+                             NDT_OMP = S3D_ALG_NDT_OMP };
 
-struct RegistrationParameters {
-  RegistrationAlgorithm registration_algorithm = GICP;
-  double point_cloud_density = 0.2;
-  double max_fitness_score = 2.0;
-  double max_translation = 1.0;
-  double max_rotation = 1.0;
-  double euclidean_fitness_epsilon = 1.0;
-  double transformation_epsilon = 1e-5;
-  double max_correspondence_distance = 2.5;
-  int maximum_iterations = 50;
-  double rotation_epsilon = 2e-3;
-  int correspondence_randomness = 20;
-  int maximum_optimizer_iterations = 20;
-  float resolution = 1.0;
-  double step_size = 0.05;
-  double outlier_ratio = 0.35;
+struct RegistrationParameters : s3d_reg_params {
+  RegistrationParameters() { s3d_default_params(this); }   // RegistrationParameters.hpp:36-97 defaults
 };
 
 }  // namespace slam3d
