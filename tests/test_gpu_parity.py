@@ -486,3 +486,42 @@ def test_million_point_pair(gpu_ctx, oracle_mod):
     assert st == 0 and info["iterations"] == 50 and info["n_target_filtered"] > 900_000
     assert dt < 2e-3 and dr < 3e-4, (dt, dr)
     assert np.array_equal(T, T2) and info == info2
+
+
+def test_bench_contract_line(tmp_path):
+    """bench.py prints ONE JSON line with the driver's contract keys plus `roofline` and `cpu_baseline` (tiny config)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "4", "--points", "20000",
+                                   "--steps", "1", "--warmup", "1", "--cpu-pairs", "1", "--cpu-threads", "2"],
+                                  stderr=subprocess.DEVNULL, cwd=ROOT).decode().strip().splitlines()
+    line = json.loads(out[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 1 and line["value"] > 0 and line["vs_baseline"] is None
+    assert "workload" in line["config"] and "model" not in line["config"]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["avg_launch_ms"] > 0
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert line["accuracy"]["status_ok"] == 4
+
+
+def test_ndt_batch_mixed_inputs(gpu_ctx, fixture_clouds):
+    """one cloud shared by several pairs, a pair below the 100-point gate and a sparse (cell-less) target in ONE batch"""
+    import slam3d_amd as s3d
+    rng = np.random.default_rng(4)
+    dev = [gpu_ctx.upload(c) for c in fixture_clouds]
+    tiny = gpu_ctx.upload(fixture_clouds[0][:50])
+    sparse = gpu_ctx.upload(rng.uniform(-100, 100, (400, 3)).astype(np.float32))
+    p = s3d.default_params(registration_algorithm=s3d.ALG_NDT)
+    src = [dev[0], dev[0], tiny, sparse, dev[1]]
+    tgt = [dev[1], dev[1], dev[1], sparse, dev[2]]
+    rec = gpu_ctx.align_batch(src, tgt, None, p)
+    assert rec[:, 15].astype(int).tolist() == [0, 0, 1, 2, 0]
+    assert np.array_equal(rec[0], rec[1])
+    st, T, _ = gpu_ctx.align(fixture_clouds[1], fixture_clouds[2], np.eye(4), p)
+    assert st == 0 and np.array_equal(s3d.api.record_transform(rec[4]), T)
