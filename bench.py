@@ -71,11 +71,20 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29513")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # S3D_BENCH_BACKEND=gloo: self-test of the multi-rank logic on a box with fewer GPUs than ranks (ranks share
+        # devices modulo the device count, collectives run on CPU tensors); the driver's runs use nccl (= RCCL)
+        backend = os.environ.get("S3D_BENCH_BACKEND", "nccl")
+        if backend == "gloo":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank)
+    coll_dev = torch.device("cpu") if (dist is not None and dist.get_backend() == "gloo") else dev
 
     # ---- synthetic input (SURVEY.md §8d generator), distinct pairs per rank
     t0 = time.time()
@@ -99,8 +108,8 @@ def main():
     def step():
         rec = ctx.align_batch(src, tgt, guesses, params, opts)
         if dist is not None:
-            local = torch.from_numpy(rec).to(dev)
-            out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=local.dtype, device=dev)
+            local = torch.from_numpy(rec).to(coll_dev)
+            out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=local.dtype, device=coll_dev)
             dist.all_gather_into_tensor(out, local)  # RCCL over xGMI: 128 B per edge
             return out
         return rec
@@ -122,7 +131,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -525,3 +525,20 @@ def test_ndt_batch_mixed_inputs(gpu_ctx, fixture_clouds):
     assert np.array_equal(rec[0], rec[1])
     st, T, _ = gpu_ctx.align(fixture_clouds[1], fixture_clouds[2], np.eye(4), p)
     assert st == 0 and np.array_equal(s3d.api.record_transform(rec[4]), T)
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """The multi-rank path of bench.py (pair sharding, all-gather of the edge records, max-over-ranks timing) with
+    two ranks on this one GPU: S3D_BENCH_BACKEND=gloo maps ranks to devices modulo the device count."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, S3D_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                   "--master-addr", "127.0.0.1", "--master-port", "29521", os.path.join(ROOT, "bench.py"),
+                                   "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "4", "--points", "20000",
+                                   "--no-cpu"], stderr=subprocess.DEVNULL, cwd=ROOT, env=env, timeout=600)
+    line = json.loads(out.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["pairs_per_gpu"] == 4
+    assert line["accuracy"]["status_ok"] == 8          # the gathered records of both ranks
+    assert line["value"] > 0 and line["cpu_baseline"] is None
