@@ -1,0 +1,41 @@
+"""dev tool: turn gpurun_out/final{,_prof} (see profiles/README.md for the commands) into the files under profiles/."""
+import collections, csv, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R, F, D = (os.path.join(ROOT, p) for p in ("gpurun_out/final_prof", "gpurun_out/final", "profiles/r1"))
+out = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    rows = list(csv.DictReader(open(f"{R}/{c}/p_counter_collection.csv")))
+    agg = collections.defaultdict(list)
+    for r in rows:
+        if r["Counter_Name"] == c:
+            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    summ = sorted(((k, sum(v) / len(v), len(v)) for k, v in agg.items()), key=lambda x: -x[1] * x[2])
+    with open(f"{D}/rocprofv3_pmc_{c}_summary.csv", "w") as f:
+        f.write("Kernel_Name,mean_%s_KB_per_launch,launches\n" % c)
+        for k, m, n in summ:
+            f.write('"%s",%.1f,%d\n' % (k, m, n))
+    out[c] = [x for x in summ if "nn_search_kernel<0>" in x[0]][0][1]
+hbm = int(2 * out["FETCH_SIZE"] * 1024 + out["WRITE_SIZE"] * 1024)
+json.dump({"kernel": "s3d_nn_search_kernel<0>", "fetch_size_kb_per_launch": round(out["FETCH_SIZE"], 1),
+           "write_size_kb_per_launch": round(out["WRITE_SIZE"], 1), "hbm_bytes_per_launch": hbm,
+           "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is",
+           "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --no-cpu --steps 2 --warmup 1",
+           "workload": "256 pairs x 100k points, 20 iterations (bench default)"},
+          open(os.path.join(ROOT, "profiles/nn_traffic.json"), "w"), indent=1)
+for f in os.listdir(F):
+    shutil.copy(f"{F}/{f}", f"{D}/{f}")
+shutil.copy(f"{R}/stats/b_kernel_stats.csv", f"{D}/rocprofv3_kernel_stats_bench_default.csv")
+shutil.copy(f"{R}/bench_under_rocprof.json", f"{D}/bench_under_rocprof.json")
+shutil.copy(f"{R}/map/m_kernel_stats.csv", f"{D}/rocprofv3_kernel_stats_bench_map.csv")
+d = json.load(open(f"{D}/bench_default.json"))
+print("default", d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["avg_launch_ms"], d["roofline"]["achieved"],
+      d["cpu_baseline"]["value"], d["cpu_baseline_parallel"]["value"], d["single_pair"], d["stage_ms"], d["nn_launch_ms"][:6])
+d = json.load(open(f"{D}/bench_under_rocprof.json")); print("rocprof", d["value"], d["roofline"]["avg_launch_ms"])
+rows = list(csv.DictReader(open(f"{D}/rocprofv3_kernel_stats_bench_default.csv")))
+for r in rows[:8]:
+    print(r["Name"][:60], r["Calls"], round(float(r["AverageNs"]) / 1e6, 4), r["Percentage"])
+print("p2p", json.load(open(f"{D}/bench_p2p.json"))["value"])
+d = json.load(open(f"{D}/bench_1M_50it.json")); print("1M", d["value"], d["ms_per_step"], d["roofline"]["frac"], d["nn_launch_ms"][:6])
+d = json.load(open(f"{D}/bench_map.json")); print("map", d["value"], d["ms_per_step"], d["cpu_baseline"]["value"])
+d = json.load(open(f"{D}/bench_map_640.json")); print("map640", d["value"], d["ms_per_step"])
+print("traffic", hbm)
