@@ -192,9 +192,13 @@ S3D_HD int grid_radius_count(const GridParams& g, const uint32_t* __restrict__ c
     for (int y = y0; y <= y1; ++y) {
       const int row = g.dim[0] * (y + g.dim[1] * z);
       const int b = (int)cell_start[row + x0], e = (int)cell_start[row + x1 + 1];
-      for (int j = b; j < e; ++j) {
-        const F4T p = pts[j];
-        if (dist2(qx, qy, qz, p.x, p.y, p.z) <= r2f && ++count >= need) return count;
+      for (int j = b; j < e; j += 4) {      // four loads in flight per step
+        F4T pp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pp[u] = pts[j + u < e ? j + u : e - 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j + u < e && dist2(qx, qy, qz, pp[u].x, pp[u].y, pp[u].z) <= r2f && ++count >= need) return count;
       }
     }
   return count;
@@ -313,11 +317,14 @@ S3D_HD void nn1_scan_rows(NNResult& best, const GridParams& g, const uint32_t* _
     if (rs[r] < re[r]) nn1_consider(best, first[r], rs[r], qx, qy, qz);
 #pragma unroll
   for (int r = 0; r < NR * NR; ++r) {
-    for (uint32_t k = rs[r] + 1; k < re[r]; k += 2) {
-      const F4T pa = pts[k];
-      const F4T pb = pts[k + 1 < re[r] ? k + 1 : k];
-      nn1_consider(best, pa, k, qx, qy, qz);
-      if (k + 1 < re[r]) nn1_consider(best, pb, k + 1, qx, qy, qz);
+    for (uint32_t k = rs[r] + 1; k < re[r]; k += 8) {      // eight loads in flight per step
+      const uint32_t e = re[r], last = e - 1;
+      F4T pp[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pp[u] = pts[k + u < e ? k + u : last];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k + u < e) nn1_consider(best, pp[u], k + u, qx, qy, qz);
     }
   }
 }
@@ -408,7 +415,15 @@ S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ c
             const int rowbase = g.dim[0] * (cy + g.dim[1] * cz);
             const uint32_t s = cell_start[rowbase + xa], e = cell_start[rowbase + xb + 1];
             S3D_COUNT(0, 1); S3D_COUNT(1, s == e); S3D_COUNT(2, (long long)(e - s));
-            for (uint32_t k = s; k < e; ++k) nn1_consider(best, pts[k], k, qx, qy, qz);
+            for (uint32_t k = s; k < e; k += 8) {      // eight loads in flight per step (a row holds ~13 points here)
+              const uint32_t last = e - 1;
+              F4T pp[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) pp[u] = pts[k + u < e ? k + u : last];
+#pragma unroll
+              for (int u = 0; u < 8; ++u)
+                if (k + u < e) nn1_consider(best, pp[u], k + u, qx, qy, qz);
+            }
             lim2 = limit2();
           }
         }
@@ -700,10 +715,18 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
             else { sa = imax(xa, ix + 2); sb = xb; }                  // right of them
             if (sa > sb) continue;
             const uint32_t s = cell_start[rowbase + sa], e = cell_start[rowbase + sb + 1];
-            for (uint32_t kk = s; kk < e; ++kk) {
-              const F4T p = pts[kk];
-              const float d2 = dist2(qx, qy, qz, p.x, p.y, p.z);
-              S3D_KNN_INSERT(p, d2)
+            for (uint32_t kk = s; kk < e; kk += 4) {      // four loads in flight per step
+              const uint32_t last = e - 1;
+              F4T pp[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) pp[u] = pts[kk + u < e ? kk + u : last];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                if (kk + u < e) {
+                  const float d2 = dist2(qx, qy, qz, pp[u].x, pp[u].y, pp[u].z);
+                  S3D_KNN_INSERT(pp[u], d2)
+                }
+              }
             }
           }
           lim2 = fminf(lim2, knn_key_d2(worst));
