@@ -1,0 +1,61 @@
+"""Randomized GPU-vs-oracle sweep of the bit-exact stages on odd inputs (volumes, planes with far outliers, a
+line, duplicated points, the bench scene): voxel grid, exact 1-NN with near / far / outside-the-grid queries,
+radius outlier removal, and point-to-plane align() — tools_dev/fuzz.py runs the same loop for thousands of cases."""
+import numpy as np
+import pytest
+
+from conftest import transform_delta
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(rng, kind, n):
+    import slam3d_amd as s3d
+    if kind == 0:
+        return rng.uniform(-20, 20, (n, 3)).astype(np.float32)
+    if kind == 1:
+        p = rng.uniform(-30, 30, (n, 3)).astype(np.float32)
+        p[: n // 2, 2] = rng.normal(0, 0.02, n // 2)
+        p[n // 2: 3 * n // 4, 0] = 5 + rng.normal(0, 0.02, 3 * n // 4 - n // 2)
+        p[-5:] *= 40
+        return p
+    if kind == 2:
+        return (rng.normal(0, 1, (n, 3)) * [30, 0.05, 0.05]).astype(np.float32)
+    if kind == 3:
+        return np.repeat(rng.uniform(-5, 5, (max(n // 8, 1), 3)).astype(np.float32), 8, 0)
+    return s3d.make_scene_cloud(n, int(rng.integers(1 << 30))).astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_inputs_match_oracle(gpu_ctx, oracle_mod, seed):
+    import slam3d_amd as s3d
+    rng = np.random.default_rng(seed)
+    for case in range(20):
+        kind = int(rng.integers(5))
+        n = int(rng.integers(200, 40000))
+        c = _cloud(rng, kind, n)
+        leaf = float(rng.choice([0.05, 0.2, 0.5, 1.0, 3.0]))
+        v_o = oracle_mod.voxel_downsample(c, leaf)[0]
+        v_g = gpu_ctx.voxel_downsample(c, leaf)
+        assert v_o.shape == v_g.shape and np.array_equal(v_o, v_g), (case, kind, n, leaf)
+        q = (c[rng.integers(0, len(c), 2000)] + rng.normal(0, rng.choice([0.01, 0.3, 3.0]), (2000, 3))).astype(np.float32)
+        q[:20] *= 50
+        md = float(rng.choice([0.5, 2.5, 10.0]))
+        io, do = oracle_mod.nn_search(v_o, q)
+        ig, dg = gpu_ctx.nn_search(v_o, q, md)
+        m = do < md * md
+        assert np.array_equal(ig[m], io[m]) and np.array_equal(dg[m], do[m]), (case, kind, n, leaf, md)
+        r = float(rng.choice([0.1, 0.3, 1.0]))
+        k = int(rng.choice([1, 3, 10]))
+        assert np.array_equal(oracle_mod.remove_outliers(v_o, r, k), gpu_ctx.remove_outliers(v_o, r, k)), (case, kind, r, k)
+        if len(v_o) >= 200 and kind in (1, 4):
+            b = (v_o + rng.uniform(-0.3, 0.3, 3)).astype(np.float32)
+            po = oracle_mod.default_params(registration_algorithm=oracle_mod.ALG_ICP, point_cloud_density=0.0,
+                                           maximum_iterations=15)
+            pg = s3d.default_params(registration_algorithm=s3d.ALG_ICP, point_cloud_density=0.0, maximum_iterations=15)
+            so, To, _ = oracle_mod.align(b, v_o, np.eye(4), po)
+            sg, Tg, _ = gpu_ctx.align(b, v_o, np.eye(4), pg)
+            assert so == sg
+            if so == 0:
+                dt, dr = transform_delta(To, Tg)
+                assert dt < 1e-4 and dr < 1e-4, (case, kind, dt, dr)
