@@ -916,8 +916,12 @@ S3D_HD void moments_normal(const Moments& m, int k, double n[3]) {
   const double mx = m.mean[0] / kd, my = m.mean[1] / kd, mz = m.mean[2] / kd;
   const double c00 = m.c00 / kd - mx * mx, c10 = m.c10 / kd - my * mx, c11 = m.c11 / kd - my * my;
   const double c20 = m.c20 / kd - mz * mx, c21 = m.c21 / kd - mz * my, c22 = m.c22 / kd - mz * mz;
+#if defined(S3D_EIG_JACOBI_ONLY)
+  sym3_smallest_eigvec(c00, c10, c20, c11, c21, c22, n);
+#else
   if (!sym3_smallest_eigvec_direct(c00, c10, c20, c11, c21, c22, n))
     sym3_smallest_eigvec(c00, c10, c20, c11, c21, c22, n);
+#endif
 }
 
 // ------------------------------------------------------------------ GICP quadratic form (K6/K7)
