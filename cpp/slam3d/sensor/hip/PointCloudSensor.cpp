@@ -6,6 +6,9 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
 #include <iostream>
 
 namespace slam3d {
@@ -182,6 +185,153 @@ PointCloud::Ptr PointCloudSensor::buildMap(const VertexObjectList& vertices) con
   DeviceCloud guard(map);
   mLogger->message(INFO, "Generated Pointcloud from " + std::to_string(vertices.size()) + " scans.");
   return download(map);
+}
+
+void PointCloudSensor::fillGroundPlane(PointCloud::Ptr cloud, ScalarType radius) {
+  // PointCloudSensor.cpp:364-368 (RANSAC plane, threshold 0.01) and :370-387 (the ring points) in one call
+  const int n = (int)cloud->size();
+  const float* xyz = n > 0 ? &cloud->points[0].x : nullptr;
+  int n_ring = 0;
+  // at most (radius / res + 1) rings of (2 pi radius / res + 2) points
+  const double rings = radius / mMapResolution + 2, per_ring = 2 * 3.14159265358979323846 * radius / mMapResolution + 3;
+  std::vector<float> ring((size_t)(rings * per_ring) * 3 + 3);
+  const int st = s3d_fill_ground_plane(mContext, xyz, n, 4, radius, mMapResolution, ring.data(), (int)(ring.size() / 3),
+                                       &n_ring, nullptr);
+  if (st == S3D_STATUS_TOO_FEW_POINTS) {   // the reference reads the coefficients of a failed fit (undefined)
+    mLogger->message(ERROR, "Could not fit a ground plane.");
+    return;
+  }
+  if (st != S3D_STATUS_OK) throw std::runtime_error(std::string("HIP back-end error: ") + s3d_last_error(mContext));
+  for (int i = 0; i < n_ring; ++i) cloud->push_back(PointType{ring[3 * i], ring[3 * i + 1], ring[3 * i + 2], 1.f});
+}
+
+namespace {
+
+// PLY scalar types (name, aliases) -> size; value read as double
+int plyTypeSize(const std::string& t) {
+  if (t == "char" || t == "int8" || t == "uchar" || t == "uint8") return 1;
+  if (t == "short" || t == "int16" || t == "ushort" || t == "uint16") return 2;
+  if (t == "int" || t == "int32" || t == "uint" || t == "uint32" || t == "float" || t == "float32") return 4;
+  if (t == "double" || t == "float64") return 8;
+  return 0;
+}
+
+double plyDecode(const std::string& t, const unsigned char* b, bool swap) {
+  unsigned char tmp[8];
+  const int sz = plyTypeSize(t);
+  for (int i = 0; i < sz; ++i) tmp[i] = b[swap ? sz - 1 - i : i];
+  if (t == "char" || t == "int8") { int8_t v; std::memcpy(&v, tmp, 1); return v; }
+  if (t == "uchar" || t == "uint8") { uint8_t v; std::memcpy(&v, tmp, 1); return v; }
+  if (t == "short" || t == "int16") { int16_t v; std::memcpy(&v, tmp, 2); return v; }
+  if (t == "ushort" || t == "uint16") { uint16_t v; std::memcpy(&v, tmp, 2); return v; }
+  if (t == "int" || t == "int32") { int32_t v; std::memcpy(&v, tmp, 4); return v; }
+  if (t == "uint" || t == "uint32") { uint32_t v; std::memcpy(&v, tmp, 4); return v; }
+  if (t == "float" || t == "float32") { float v; std::memcpy(&v, tmp, 4); return v; }
+  double v; std::memcpy(&v, tmp, 8); return v;
+}
+
+struct PlyProperty { std::string name, type, count_type; bool list = false; };
+struct PlyElement { std::string name; size_t count = 0; std::vector<PlyProperty> props; };
+
+}  // namespace
+
+int PointCloudSensor::readPLY(const std::string& path, PointCloud& cloud, Transform& sensor_pose) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return -1;
+  std::string line;
+  if (!std::getline(f, line) || line.compare(0, 3, "ply") != 0) return -1;
+  int format = -1;   // 0 ascii, 1 binary little endian, 2 binary big endian
+  std::vector<PlyElement> elements;
+  bool header_done = false;
+  while (std::getline(f, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    std::istringstream ls(line);
+    std::string word;
+    ls >> word;
+    if (word == "format") {
+      std::string fmt_name;
+      ls >> fmt_name;
+      format = fmt_name == "ascii" ? 0 : fmt_name == "binary_little_endian" ? 1 : fmt_name == "binary_big_endian" ? 2 : -1;
+    } else if (word == "element") {
+      PlyElement e;
+      ls >> e.name >> e.count;
+      elements.push_back(e);
+    } else if (word == "property" && !elements.empty()) {
+      PlyProperty p;
+      ls >> p.type;
+      if (p.type == "list") { p.list = true; ls >> p.count_type >> p.type; }
+      ls >> p.name;
+      if (!plyTypeSize(p.type) || (p.list && !plyTypeSize(p.count_type))) return -1;
+      elements.back().props.push_back(p);
+    } else if (word == "end_header") {
+      header_done = true;
+      break;
+    }
+  }
+  if (!header_done || format < 0) return -1;
+  uint16_t probe = 1;
+  const bool host_little = *reinterpret_cast<unsigned char*>(&probe) == 1;
+  const bool swap = (format == 1 && !host_little) || (format == 2 && host_little);
+  auto next = [&](const std::string& type, double& v) -> bool {   // one scalar of the body
+    if (format == 0) return bool(f >> v);
+    unsigned char b[8];
+    if (!f.read(reinterpret_cast<char*>(b), plyTypeSize(type))) return false;
+    v = plyDecode(type, b, swap);
+    return true;
+  };
+  cloud.points.clear();
+  float origin[3] = {0, 0, 0};
+  float R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};   // rows = the camera's x / y / z axis (PLYReader's orientation_)
+  for (const PlyElement& e : elements) {
+    for (size_t i = 0; i < e.count; ++i) {
+      PointType p{0.f, 0.f, 0.f, 1.f};
+      for (const PlyProperty& pr : e.props) {
+        double v = 0;
+        if (pr.list) {
+          double cnt = 0;
+          if (!next(pr.count_type, cnt)) return -1;
+          for (int k = 0; k < (int)cnt; ++k)
+            if (!next(pr.type, v)) return -1;
+          continue;
+        }
+        if (!next(pr.type, v)) return -1;
+        if (e.name == "vertex") {
+          if (pr.name == "x") p.x = (float)v; else if (pr.name == "y") p.y = (float)v; else if (pr.name == "z") p.z = (float)v;
+        } else if (e.name == "camera") {
+          static const char* axes[3] = {"x_axis", "y_axis", "z_axis"};
+          if (pr.name == "view_px") origin[0] = (float)v;
+          else if (pr.name == "view_py") origin[1] = (float)v;
+          else if (pr.name == "view_pz") origin[2] = (float)v;
+          else
+            for (int a = 0; a < 3; ++a)
+              for (int c = 0; c < 3; ++c)
+                if (pr.name == std::string(axes[a]) + "xyz"[c]) R[a][c] = (float)v;
+        }
+      }
+      if (e.name == "vertex") cloud.points.push_back(p);
+    }
+  }
+  cloud.width = (uint32_t)cloud.points.size();
+  cloud.height = 1;
+  cloud.is_dense = true;
+  sensor_pose = Transform::Identity();   // :396-397: rotation = sensor_orientation_, translation = sensor_origin_
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) sensor_pose(r, c) = R[r][c];
+    sensor_pose(r, 3) = origin[r];
+  }
+  return 0;
+}
+
+void PointCloudSensor::loadPLY(const std::string& path, const std::string& robot) {
+  PointCloud::Ptr pcl_cloud(new PointCloud());
+  Transform pc_tr;
+  if (readPLY(path, *pcl_cloud, pc_tr) == 0) {   // PointCloudSensor.cpp:394
+    mInitialMap.reset(new PointCloudMeasurement(pcl_cloud, robot, mName, pc_tr));
+    if (mStorage) mStorage->add(mInitialMap);   // reference: graph vertex + identity PoseConstraint (:401-405)
+    mLogger->message(INFO, "Successfully loaded initial map.");
+  } else {
+    mLogger->message(ERROR, "Could not load initial map.");
+  }
 }
 
 Transform PointCloudSensor::align(const PointCloudMeasurement::Ptr& source, const PointCloudMeasurement::Ptr& target,

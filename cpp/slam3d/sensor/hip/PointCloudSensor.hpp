@@ -112,6 +112,17 @@ class PointCloudSensor : public ScanSensor {
   PointCloud::Ptr getAccumulatedCloud(const VertexObjectList& vertices) const;
   Measurement::Ptr createCombinedMeasurement(const VertexObjectList& vertices, Transform pose) const;
   PointCloud::Ptr buildMap(const VertexObjectList& vertices) const;
+  // reference PointCloudSensor.hpp:227: fit the ground plane (RANSAC, scored on the device) and append rings of
+  // points on it out to `radius` at the map resolution
+  void fillGroundPlane(PointCloud::Ptr cloud, ScalarType radius);
+  // reference PointCloudSensor.hpp:234: read a PLY file as the initial map.  The reference adds it to the pose
+  // graph as vertex 0 with an identity PoseConstraint (PointCloudSensor.cpp:401-405); the mirror has no Mapper /
+  // Graph: the measurement goes to the MeasurementStorage (if set) and is returned by getInitialMap().
+  void loadPLY(const std::string& path, const std::string& robot);
+  PointCloudMeasurement::Ptr getInitialMap() const { return mInitialMap; }
+  // what pcl::PLYReader::read gives loadPLY: the vertex x/y/z and the sensor pose of the `camera` element.
+  // Returns 0 on success (like PLYReader::read), -1 otherwise.
+  static int readPLY(const std::string& path, PointCloud& cloud, Transform& sensor_pose);
 
   // the same align() the reference keeps file-local (PointCloudSensor.cpp:119-174), exposed for tests
   Transform align(const PointCloudMeasurement::Ptr& source, const PointCloudMeasurement::Ptr& target,
@@ -133,6 +144,7 @@ class PointCloudSensor : public ScanSensor {
               std::vector<s3d_cloud*>& clouds, std::vector<double>& poses) const;
   PointCloud::Ptr download(s3d_cloud* c) const;
   MeasurementStorage* mStorage = nullptr;
+  PointCloudMeasurement::Ptr mInitialMap;
   s3d_context* mContext;   // one HIP device + stream; calls are serialised inside the library,
                            // so createConstraint may be entered from the link thread (ScanSensor.cpp:210)
 };

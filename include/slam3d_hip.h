@@ -164,6 +164,26 @@ int  s3d_build_map(s3d_context* ctx, int n_clouds, s3d_cloud* const* clouds, con
                    double outlier_radius, unsigned outlier_neighbors, double map_resolution, s3d_cloud** out_map);
 int  s3d_last_map_profile(const s3d_context* ctx, s3d_map_profile* out);
 
+/* ---- B4  PointCloudSensor::fillGroundPlane (:362-388).  s3d_fit_plane is the
+ *          pcl::RandomSampleConsensus<pcl::SampleConsensusModelPlane>::computeModel call of :364-368 (the model's
+ *          fixed seed, so the result is deterministic as in the reference); the inlier counting of every
+ *          hypothesis runs on the device.  s3d_fill_ground_plane runs it with the reference's settings
+ *          (threshold 0.01, PCL defaults 1000 iterations / probability 0.99) and returns the ring points of
+ *          :370-387 (packed xyz): *n_out is their number, the first min(*n_out, out_capacity) are written -
+ *          call with out_capacity 0 to size the buffer.  The caller appends them to its cloud (cloud->push_back).
+ *          No plane (fewer than 3 points, every sample collinear): S3D_STATUS_TOO_FEW_POINTS, found = 0. */
+typedef struct s3d_plane_fit {
+  float coefficients[4];    /* a, b, c, d of a x + b y + c z + d = 0, (a,b,c) normalised */
+  int   found;
+  int   n_inliers;          /* points within the threshold of the returned plane */
+  int   iterations;         /* RANSAC iterations the sequential algorithm ran */
+  int   hypotheses_scored;  /* planes actually scored on the device (>= iterations: batches of 32) */
+} s3d_plane_fit;
+int  s3d_fit_plane(s3d_context* ctx, const float* xyz, int n, int stride, double threshold, int max_iterations,
+                   double probability, s3d_plane_fit* out);
+int  s3d_fill_ground_plane(s3d_context* ctx, const float* xyz, int n, int stride, double radius, double map_resolution,
+                           float* out_xyz, int out_capacity, int* n_out, s3d_plane_fit* fit /* may be NULL */);
+
 /* ---- measurement hook (bench.py roofline): time `reps` launches of the NN-search kernel
  *          as a FIRST correspondence pass (transformation_ = I, no radius hints, no re-validation
  *          of earlier correspondences — the most expensive pass of a registration) with HIP events

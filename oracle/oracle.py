@@ -101,6 +101,12 @@ def lib():
         L.s3o_remove_outliers.argtypes = [fp, C.c_int, C.c_int, C.c_double, C.c_uint, fp]
         L.s3o_build_map.restype = C.c_int
         L.s3o_build_map.argtypes = [fpp, ip, ip, C.c_int, dp, C.c_double, C.c_uint, C.c_double, fp]
+        L.s3o_fit_plane_ransac.restype = C.c_int
+        L.s3o_fit_plane_ransac.argtypes = [fp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, fp, ip, ip]
+        L.s3o_fill_ground_points.restype = C.c_int
+        L.s3o_fill_ground_points.argtypes = [fp, C.c_double, C.c_double, fp, C.c_int]
+        L.s3o_mt19937_outputs.restype = None
+        L.s3o_mt19937_outputs.argtypes = [C.c_uint, C.c_int, C.POINTER(C.c_uint)]
         L.s3o_sym_eig3.argtypes = [dp, dp, dp]
         L.s3o_rotation_angle.restype = C.c_double
         L.s3o_rotation_angle.argtypes = [dp]
@@ -296,6 +302,36 @@ def build_map(clouds, poses, outlier_radius=0.2, outlier_neighbors=3, map_resolu
     n = lib().s3o_build_map(ptrs, _iptr(sizes), _iptr(strides), len(arrs), _dptr(P), float(outlier_radius),
                             int(outlier_neighbors), float(map_resolution), _fptr(out))
     return out[:n].copy()
+
+
+def fit_plane_ransac(xyz, threshold=0.01, max_iterations=1000, probability=0.99):
+    """pcl::RandomSampleConsensus over SampleConsensusModelPlane as fillGroundPlane (:364-368) runs it.
+    Returns (found, coeffs[4] float32, n_inliers, iterations)."""
+    a, n, stride = _cloud(xyz)
+    co = np.zeros(4, np.float32)
+    ni, it = np.zeros(1, np.int32), np.zeros(1, np.int32)
+    ok = lib().s3o_fit_plane_ransac(_fptr(a), n, stride, float(threshold), int(max_iterations), float(probability),
+                                    _fptr(co), _iptr(ni), _iptr(it))
+    return bool(ok), co, int(ni[0]), int(it[0])
+
+
+def mt19937_outputs(seed, n):
+    out = np.zeros(n, np.uint32)
+    lib().s3o_mt19937_outputs(int(seed), int(n), out.ctypes.data_as(C.POINTER(C.c_uint)))
+    return out
+
+
+def fill_ground_plane(xyz, radius, map_resolution=0.1, threshold=0.01):
+    """fillGroundPlane (:362-388): the cloud with the ring points on the RANSAC plane appended."""
+    a, n, stride = _cloud(xyz)
+    ok, co, _, _ = fit_plane_ransac(xyz, threshold)
+    base = np.ascontiguousarray(a[:, :3])
+    if not ok:
+        return base
+    m = lib().s3o_fill_ground_points(_fptr(co), float(radius), float(map_resolution), _fptr(np.empty(3, np.float32)), 0)
+    out = np.empty((max(m, 1), 3), np.float32)
+    lib().s3o_fill_ground_points(_fptr(co), float(radius), float(map_resolution), _fptr(out), m)
+    return np.vstack([base, out[:m]])
 
 
 def set_eval_precision(mode):

@@ -14,6 +14,7 @@
 #include <float.h>
 #include <limits.h>
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
@@ -1790,4 +1791,141 @@ int s3o_build_map(const float* const* clouds, const int* sizes, const int* strid
   const int r = s3o_voxel_downsample(kept, m, 3, map_resolution, out, NULL);
   free(accu); free(kept);
   return r;
+}
+
+/* ---- fillGroundPlane (PCS.cpp:362-388): pcl::RandomSampleConsensus over pcl::SampleConsensusModelPlane ----
+ * Restated from PCL 1.12 (sample_consensus/ransac.hpp computeModel, sac_model.h getSamples/drawIndexSample,
+ * sac_model_plane.hpp isSampleGood / computeModelCoefficients / countWithinDistance):
+ *  - the model is constructed with random = false: boost::mt19937 seeded 12345, rnd() = uniform_int(0, INT_MAX)
+ *    of it = engine() / 2 (boost's bucket division for a 2^31 range over a 2^32 engine);
+ *  - drawIndexSample: partial Fisher-Yates on a persistent index permutation, swap(perm[i], perm[i + rnd() % (N-i)]);
+ *  - a sample is bad when the component-wise ratios (p1-p0)/(p2-p0) are all equal (collinear), <= 1000 redraws;
+ *  - plane = normalised (p1-p0) x (p2-p0), d = -n.p0; Eigen packet order for the 4-float sums;
+ *  - an inlier has |(a x + b y) + (c z + d)| < (float)threshold (the SSE form of countWithinDistance; the
+ *    scalar tail of PCL's loop sums in Eigen's order instead - a last-ulp ambiguity this restatement ignores);
+ *  - k = log(1 - 0.99) / log(1 - w^3) after every improvement, stop at iterations >= k or > 1000.
+ * Returns 1 and the best model, 0 when no model could be drawn (fewer than 3 points / all samples collinear). */
+typedef struct { uint32_t mt[624]; int idx; } s3o_mt19937;
+static void s3o_mt_seed(s3o_mt19937* g, uint32_t seed) {
+  g->mt[0] = seed;
+  for (int i = 1; i < 624; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+  g->idx = 624;
+}
+static uint32_t s3o_mt_next(s3o_mt19937* g) {
+  if (g->idx >= 624) {
+    for (int i = 0; i < 624; ++i) {
+      const uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+      g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    g->idx = 0;
+  }
+  uint32_t y = g->mt[g->idx++];
+  y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+  return y;
+}
+static int s3o_plane_from_sample(const float* xyz, int stride, const int* s, float mc[4]) {
+  const float* p0 = xyz + (size_t)s[0] * stride;
+  const float* p1 = xyz + (size_t)s[1] * stride;
+  const float* p2 = xyz + (size_t)s[2] * stride;
+  float a[3], b[3], r[3];
+  for (int i = 0; i < 3; ++i) { a[i] = p1[i] - p0[i]; b[i] = p2[i] - p0[i]; r[i] = a[i] / b[i]; }
+  if (r[0] == r[1] && r[2] == r[1]) return 0;
+  mc[0] = a[1] * b[2] - a[2] * b[1];
+  mc[1] = a[2] * b[0] - a[0] * b[2];
+  mc[2] = a[0] * b[1] - a[1] * b[0];
+  const float z = (mc[0] * mc[0] + mc[2] * mc[2]) + (mc[1] * mc[1] + 0.0f);
+  if (z > 0.f) { const float nrm = sqrtf(z); mc[0] /= nrm; mc[1] /= nrm; mc[2] /= nrm; }
+  mc[3] = -1.0f * ((mc[0] * p0[0] + mc[2] * p0[2]) + (mc[1] * p0[1] + 0.0f));
+  return 1;
+}
+int s3o_fit_plane_ransac(const float* xyz, int n, int stride, double threshold, int max_iterations, double probability,
+                         float coeffs[4], int* n_inliers, int* iterations) {
+  if (n_inliers) *n_inliers = 0;
+  if (iterations) *iterations = 0;
+  if (n < 3) return 0;
+  s3o_mt19937 g;
+  s3o_mt_seed(&g, 12345u);
+  int* perm = (int*)malloc(sizeof(int) * (size_t)n);
+  for (int i = 0; i < n; ++i) perm[i] = i;
+  const float thr = (float)threshold;
+  const double log_probability = log(1.0 - probability), one_over_indices = 1.0 / (double)n;
+  int iters = 0, best = -2147483647, found = 0, skipped = 0;
+  const int max_skip = max_iterations * 10;
+  double k = 1.0;
+  while ((double)iters < k && skipped < max_skip) {
+    int s[3], good = 0;
+    for (int check = 0; check < 1000 && !good; ++check) {
+      for (int i = 0; i < 3; ++i) {
+        const int j = i + (int)((s3o_mt_next(&g) >> 1) % (uint32_t)(n - i));
+        const int tmp = perm[i]; perm[i] = perm[j]; perm[j] = tmp;
+      }
+      s[0] = perm[0]; s[1] = perm[1]; s[2] = perm[2];
+      float r[3];
+      const float* p0 = xyz + (size_t)s[0] * stride;
+      const float* p1 = xyz + (size_t)s[1] * stride;
+      const float* p2 = xyz + (size_t)s[2] * stride;
+      for (int i = 0; i < 3; ++i) r[i] = (p1[i] - p0[i]) / (p2[i] - p0[i]);
+      good = (r[0] != r[1]) || (r[2] != r[1]);
+    }
+    if (!good) break;
+    float mc[4];
+    if (!s3o_plane_from_sample(xyz, stride, s, mc)) { ++skipped; continue; }
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+      const float* p = xyz + (size_t)i * stride;
+      const float v = (mc[0] * p[0] + mc[1] * p[1]) + (mc[2] * p[2] + mc[3]);
+      if (fabsf(v) < thr) ++cnt;
+    }
+    if (cnt > best) {
+      best = cnt; found = 1;
+      memcpy(coeffs, mc, sizeof(float) * 4);
+      const double w = (double)best * one_over_indices;
+      double p_no_outliers = 1.0 - pow(w, 3.0);
+      if (p_no_outliers < 2.220446049250313e-16) p_no_outliers = 2.220446049250313e-16;
+      if (p_no_outliers > 1.0 - 2.220446049250313e-16) p_no_outliers = 1.0 - 2.220446049250313e-16;
+      k = log_probability / log(p_no_outliers);
+    }
+    ++iters;
+    if (iters > max_iterations) break;
+  }
+  free(perm);
+  if (n_inliers) *n_inliers = found ? best : 0;
+  if (iterations) *iterations = iters;
+  return found;
+}
+
+/* The points fillGroundPlane appends (PCS.cpp:370-387): for r = res, 2 res, ... <= radius the projection of
+ * (r,0,0) onto the plane, rotated about the plane normal (through the origin) in steps of res/radius.
+ * Eigen::Hyperplane(normal, d).projection(p) = p - (n.p + d) n;  AngleAxis(angle, n).toRotationMatrix() (Rodrigues,
+ * Eigen's evaluation order).  coeffs: the float RANSAC model.  out: capacity from s3o_fill_ground_count. */
+int s3o_fill_ground_points(const float coeffs[4], double radius, double map_resolution, float* out, int cap) {
+  const double n[3] = {(double)coeffs[0], (double)coeffs[1], (double)coeffs[2]}, d = (double)coeffs[3];
+  const double angle_inc = map_resolution / radius;
+  int m = 0;
+  if (!(map_resolution > 0)) return 0;
+  for (double r = map_resolution; r <= radius; r += map_resolution) {
+    const double sd = (n[0] * r + n[1] * 0.0 + n[2] * 0.0) + d;
+    const double sp[3] = {r - sd * n[0], 0.0 - sd * n[1], 0.0 - sd * n[2]};
+    for (double angle = 0; angle < 2 * 3.14159265358979323846; angle += angle_inc) {
+      const double s = sin(angle), c = cos(angle);
+      const double sa[3] = {s * n[0], s * n[1], s * n[2]};
+      const double ca[3] = {(1.0 - c) * n[0], (1.0 - c) * n[1], (1.0 - c) * n[2]};
+      double R[3][3], tmp;
+      tmp = ca[0] * n[1]; R[0][1] = tmp - sa[2]; R[1][0] = tmp + sa[2];
+      tmp = ca[0] * n[2]; R[0][2] = tmp + sa[1]; R[2][0] = tmp - sa[1];
+      tmp = ca[1] * n[2]; R[1][2] = tmp - sa[0]; R[2][1] = tmp + sa[0];
+      for (int i = 0; i < 3; ++i) R[i][i] = ca[i] * n[i] + c;
+      if (m < cap)
+        for (int i = 0; i < 3; ++i) out[(size_t)m * 3 + i] = (float)(R[i][0] * sp[0] + R[i][1] * sp[1] + R[i][2] * sp[2]);
+      ++m;
+    }
+  }
+  return m;
+}
+
+/* test hook: the first n outputs of the mt19937 above (checked against numpy's legacy RandomState in tests) */
+void s3o_mt19937_outputs(unsigned seed, int n, unsigned* out) {
+  s3o_mt19937 g;
+  s3o_mt_seed(&g, (uint32_t)seed);
+  for (int i = 0; i < n; ++i) out[i] = s3o_mt_next(&g);
 }

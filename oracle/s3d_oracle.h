@@ -120,6 +120,13 @@ int  s3o_remove_outliers(const float* xyz, int n, int stride, double radius, uns
 int  s3o_build_map(const float* const* clouds, const int* sizes, const int* strides, int n_clouds, const double* poses,
                    double outlier_radius, unsigned outlier_neighbors, double map_resolution, float* out);
 
+/* ---- fillGroundPlane (:362-388): pcl::RandomSampleConsensus<SampleConsensusModelPlane> (threshold 0.01 there,
+ * PCL defaults max_iterations 1000, probability 0.99) and the ring points appended afterwards */
+int  s3o_fit_plane_ransac(const float* xyz, int n, int stride, double threshold, int max_iterations, double probability,
+                          float coeffs[4], int* n_inliers, int* iterations);
+int  s3o_fill_ground_points(const float coeffs[4], double radius, double map_resolution, float* out, int cap);
+void s3o_mt19937_outputs(unsigned seed, int n, unsigned* out);   /* test hook for the sampler's generator */
+
 /* ---- variants / diagnostics (process-global; defaults = PCL-literal behaviour)
  * eval_precision 0: the BFGS functor transforms points with a float 4x4 in float, as PCL does
  *                   (f(x) is then piecewise constant at the 1e-7 level: "float staircase");

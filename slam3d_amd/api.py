@@ -72,6 +72,17 @@ class MapProfile(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class PlaneFit(C.Structure):
+    """s3d_plane_fit (include/slam3d_hip.h)."""
+    _fields_ = [("coefficients", C.c_float * 4), ("found", C.c_int), ("n_inliers", C.c_int),
+                ("iterations", C.c_int), ("hypotheses_scored", C.c_int)]
+
+    def asdict(self):
+        return {"coefficients": np.array(list(self.coefficients), np.float32), "found": bool(self.found),
+                "n_inliers": self.n_inliers, "iterations": self.iterations,
+                "hypotheses_scored": self.hypotheses_scored}
+
+
 def lib_path():
     return _LIB
 
@@ -130,6 +141,9 @@ def load_library():
         "s3d_voxel_downsample_cloud": (C.c_int, [vp, vp, C.c_double, C.POINTER(vp)]),
         "s3d_build_map": (C.c_int, [vp, C.c_int, C.POINTER(vp), dp, C.c_double, C.c_uint, C.c_double, C.POINTER(vp)]),
         "s3d_last_map_profile": (C.c_int, [vp, C.POINTER(MapProfile)]),
+        "s3d_fit_plane": (C.c_int, [vp, fp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.POINTER(PlaneFit)]),
+        "s3d_fill_ground_plane": (C.c_int, [vp, fp, C.c_int, C.c_int, C.c_double, C.c_double, fp, C.c_int, ip,
+                                            C.POINTER(PlaneFit)]),
         "s3d_profile_nn_kernel": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, pp, C.c_int, dp,
                                             C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     }
@@ -414,6 +428,32 @@ class Context:
         if st:
             raise ValueError(STATUS_NAMES[st])
         return out[:m.value].copy()
+
+    def fit_plane(self, xyz, threshold=0.01, max_iterations=1000, probability=0.99):
+        """The RANSAC plane fit of fillGroundPlane (:364-368); returns PlaneFit.asdict()."""
+        a, n, stride = _cloud(xyz)
+        f = PlaneFit()
+        st = self._check(self._L.s3d_fit_plane(self._h, _fp(a), n, stride, float(threshold), int(max_iterations),
+                                               float(probability), C.byref(f)))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
+        return f.asdict()
+
+    def fill_ground_plane(self, xyz, radius, map_resolution=0.1):
+        """fillGroundPlane (:362-388): the cloud with the ring points on its RANSAC ground plane appended."""
+        a, n, stride = _cloud(xyz)
+        m = C.c_int(0)
+        f = PlaneFit()
+        # upper bound of the ring points: (radius / res + 1) rings of (2 pi radius / res + 2) points
+        res = float(map_resolution)
+        cap = int((radius / res + 2) * (2 * np.pi * radius / res + 3)) if res > 0 else 0
+        out = np.empty((max(cap, 1), 3), np.float32)
+        st = self._check(self._L.s3d_fill_ground_plane(self._h, _fp(a), n, stride, float(radius), res, _fp(out), cap,
+                                                       C.byref(m), C.byref(f)))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
+        assert m.value <= cap
+        return np.vstack([np.ascontiguousarray(a[:, :3]), out[:m.value]])
 
     def voxel_downsample_cloud(self, cloud, leaf):
         h = C.c_void_p()

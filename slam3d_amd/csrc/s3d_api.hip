@@ -12,6 +12,7 @@
 #include <cstring>
 #include <chrono>
 #include <map>
+#include <random>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -1389,6 +1390,185 @@ int s3d_remove_outliers(s3d_context* ctx, const float* xyz, int n, int stride, d
     free_cloud(&kept);
     return fail(ctx, e);
   }
+  return S3D_STATUS_OK;
+}
+
+// ---- B4: fillGroundPlane (PointCloudSensor.cpp:362-388) ------------------------------------------------
+// pcl::RandomSampleConsensus<SampleConsensusModelPlane>::computeModel with the model's fixed seed.  The sample
+// stream (boost::mt19937(12345), partial Fisher-Yates, collinearity re-draws) and the stopping rule are scalar
+// and stay on the host; scoring - the pass over all points per hypothesis, which is all of the time - runs on
+// the device for kPlaneBatch hypotheses per pass.  The hypotheses of a batch are then replayed in order, so
+// the result is the one the sequential loop reaches (hypotheses scored beyond its stopping point are ignored).
+namespace {
+
+struct PlaneSampler {
+  std::mt19937 eng{12345u};
+  std::vector<int> perm;
+  const float* xyz; int stride;
+  PlaneSampler(const float* x, int n, int st) : perm((size_t)n), xyz(x), stride(st) {
+    for (int i = 0; i < n; ++i) perm[(size_t)i] = i;
+  }
+  const float* pt(int i) const { return xyz + (size_t)i * stride; }
+  // sac_model.h getSamples: <= 1000 draws until isSampleGood
+  bool draw(int s[3]) {
+    const uint32_t n = (uint32_t)perm.size();
+    for (int check = 0; check < 1000; ++check) {
+      for (uint32_t i = 0; i < 3; ++i) std::swap(perm[i], perm[i + ((uint32_t)eng() >> 1) % (n - i)]);
+      for (int i = 0; i < 3; ++i) s[i] = perm[(size_t)i];
+      const float *p0 = pt(s[0]), *p1 = pt(s[1]), *p2 = pt(s[2]);
+      float r[3];
+      for (int i = 0; i < 3; ++i) r[i] = (p1[i] - p0[i]) / (p2[i] - p0[i]);
+      if (r[0] != r[1] || r[2] != r[1]) return true;
+    }
+    return false;
+  }
+  // sac_model_plane.hpp computeModelCoefficients (Eigen's packet order for the two 4-float sums)
+  bool model(const int s[3], float mc[4]) const {
+    const float *p0 = pt(s[0]), *p1 = pt(s[1]), *p2 = pt(s[2]);
+    float a[3], b[3], r[3];
+    for (int i = 0; i < 3; ++i) { a[i] = p1[i] - p0[i]; b[i] = p2[i] - p0[i]; r[i] = a[i] / b[i]; }
+    if (r[0] == r[1] && r[2] == r[1]) return false;
+    mc[0] = a[1] * b[2] - a[2] * b[1];
+    mc[1] = a[2] * b[0] - a[0] * b[2];
+    mc[2] = a[0] * b[1] - a[1] * b[0];
+    const float z = (mc[0] * mc[0] + mc[2] * mc[2]) + (mc[1] * mc[1] + 0.0f);
+    if (z > 0.f) { const float nrm = std::sqrt(z); mc[0] /= nrm; mc[1] /= nrm; mc[2] /= nrm; }
+    mc[3] = -1.0f * ((mc[0] * p0[0] + mc[2] * p0[2]) + (mc[1] * p0[1] + 0.0f));
+    return true;
+  }
+};
+
+void fit_plane_dev(s3d_context* ctx, const float* xyz, int n, int stride, double threshold, int max_iterations,
+                   double probability, s3d_plane_fit* out) {
+  std::memset(out, 0, sizeof *out);
+  if (n < 3) return;
+  s3d_cloud in;
+  int* d_counts = nullptr;
+  try {
+    upload_cloud(ctx, xyz, n, stride, &in);
+    HIPCHK(hipMalloc((void**)&d_counts, sizeof(int) * kPlaneBatch));
+    PlaneSampler sampler(xyz, n, stride);
+    const float thr = (float)threshold;
+    const double log_probability = std::log(1.0 - probability), one_over_indices = 1.0 / (double)n;
+    const int max_skip = max_iterations * 10;
+    const int blocks = std::max(1, std::min(cdiv(n, kBlock), 2048));
+    int iters = 0, best = -0x7FFFFFFF, skipped = 0;
+    double k = 1.0;
+    bool done = false;
+    while (!done) {
+      // the next events of the sequential loop: a hypothesis to score, a degenerate sample (skip), or no sample
+      struct Event { int kind; int h; };   // 0 hypothesis h of the batch, 1 skipped, 2 no sample could be drawn
+      std::vector<Event> events;
+      PlaneBatch B;
+      int nh = 0, batch_skips = 0;
+      while (nh < kPlaneBatch && skipped + batch_skips < max_skip) {
+        int s[3];
+        if (!sampler.draw(s)) { events.push_back({2, 0}); break; }
+        float mc[4];
+        if (!sampler.model(s, mc)) { events.push_back({1, 0}); ++batch_skips; continue; }
+        B.pl[nh] = make_float4(mc[0], mc[1], mc[2], mc[3]);
+        events.push_back({0, nh});
+        ++nh;
+      }
+      for (int h = nh; h < kPlaneBatch; ++h) B.pl[h] = make_float4(0.f, 0.f, 0.f, 3.0e38f);
+      int counts[kPlaneBatch] = {};
+      if (nh > 0) {
+        HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int) * kPlaneBatch, ctx->stream));
+        s3d_plane_count_kernel<<<blocks, kBlock, 0, ctx->stream>>>(in.d, n, B, thr, d_counts);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(counts, d_counts, sizeof counts, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        out->hypotheses_scored += nh;
+      }
+      if (events.empty()) break;   // max_skip reached
+      for (const Event& e : events) {
+        if (!((double)iters < k && skipped < max_skip)) { done = true; break; }
+        if (e.kind == 2) { done = true; break; }
+        if (e.kind == 1) { ++skipped; continue; }
+        const int cnt = counts[e.h];
+        if (cnt > best) {
+          best = cnt;
+          out->found = 1;
+          out->coefficients[0] = B.pl[e.h].x; out->coefficients[1] = B.pl[e.h].y;
+          out->coefficients[2] = B.pl[e.h].z; out->coefficients[3] = B.pl[e.h].w;
+          const double w = (double)best * one_over_indices;
+          double p_no = 1.0 - std::pow(w, 3.0);
+          p_no = std::max(std::numeric_limits<double>::epsilon(), p_no);
+          p_no = std::min(1.0 - std::numeric_limits<double>::epsilon(), p_no);
+          k = log_probability / std::log(p_no);
+        }
+        ++iters;
+        if (iters > max_iterations) { done = true; break; }
+      }
+      if (!((double)iters < k && skipped < max_skip)) done = true;
+    }
+    out->n_inliers = out->found ? best : 0;
+    out->iterations = iters;
+    (void)hipFree(d_counts);
+    free_cloud(&in);
+  } catch (...) {
+    if (d_counts) (void)hipFree(d_counts);
+    free_cloud(&in);
+    throw;
+  }
+}
+
+// the ring points of PointCloudSensor.cpp:370-387 (Eigen::Hyperplane::projection, AngleAxis::toRotationMatrix)
+int fill_ground_points(const float coeffs[4], double radius, double map_resolution, float* out, int cap) {
+  const double n[3] = {(double)coeffs[0], (double)coeffs[1], (double)coeffs[2]}, d = (double)coeffs[3];
+  if (!(map_resolution > 0)) return 0;
+  const double angle_inc = map_resolution / radius;
+  const double two_pi = 2 * 3.14159265358979323846;
+  int m = 0;
+  for (double r = map_resolution; r <= radius; r += map_resolution) {
+    const double sd = (n[0] * r + n[1] * 0.0 + n[2] * 0.0) + d;
+    const double sp[3] = {r - sd * n[0], 0.0 - sd * n[1], 0.0 - sd * n[2]};
+    for (double angle = 0; angle < two_pi; angle += angle_inc) {
+      const double sn = std::sin(angle), c = std::cos(angle);
+      const double sa[3] = {sn * n[0], sn * n[1], sn * n[2]};
+      const double ca[3] = {(1.0 - c) * n[0], (1.0 - c) * n[1], (1.0 - c) * n[2]};
+      double R[3][3], t;
+      t = ca[0] * n[1]; R[0][1] = t - sa[2]; R[1][0] = t + sa[2];
+      t = ca[0] * n[2]; R[0][2] = t + sa[1]; R[2][0] = t - sa[1];
+      t = ca[1] * n[2]; R[1][2] = t - sa[0]; R[2][1] = t + sa[0];
+      for (int i = 0; i < 3; ++i) R[i][i] = ca[i] * n[i] + c;
+      if (m < cap)
+        for (int i = 0; i < 3; ++i) out[(size_t)m * 3 + i] = (float)(R[i][0] * sp[0] + R[i][1] * sp[1] + R[i][2] * sp[2]);
+      if (m == 0x7FFFFFFF) return m;
+      ++m;
+    }
+  }
+  return m;
+}
+
+}  // namespace
+
+int s3d_fit_plane(s3d_context* ctx, const float* xyz, int n, int stride, double threshold, int max_iterations,
+                  double probability, s3d_plane_fit* out) {
+  if (!ctx || !out || n < 0 || stride < 3 || (n > 0 && !xyz) || !(threshold >= 0) || max_iterations < 0 ||
+      !(probability > 0 && probability < 1))
+    return S3D_STATUS_INVALID_ARGUMENT;
+  try {
+    ScopedDevice sd(ctx);
+    fit_plane_dev(ctx, xyz, n, stride, threshold, max_iterations, probability, out);
+  } catch (const HipError& e) {
+    return fail(ctx, e);
+  }
+  return S3D_STATUS_OK;
+}
+
+int s3d_fill_ground_plane(s3d_context* ctx, const float* xyz, int n, int stride, double radius, double map_resolution,
+                          float* out_xyz, int out_capacity, int* n_out, s3d_plane_fit* fit) {
+  if (!ctx || !n_out || out_capacity < 0 || (out_capacity > 0 && !out_xyz) || !(radius > 0))
+    return S3D_STATUS_INVALID_ARGUMENT;
+  *n_out = 0;
+  s3d_plane_fit f;
+  // PointCloudSensor.cpp:366: setDistanceThreshold(.01); PCL defaults: 1000 iterations, probability 0.99
+  const int st = s3d_fit_plane(ctx, xyz, n, stride, 0.01, 1000, 0.99, &f);
+  if (fit) *fit = f;
+  if (st != S3D_STATUS_OK) return st;
+  if (!f.found) return S3D_STATUS_TOO_FEW_POINTS;
+  *n_out = fill_ground_points(f.coefficients, radius, map_resolution, out_xyz, out_capacity);
   return S3D_STATUS_OK;
 }
 

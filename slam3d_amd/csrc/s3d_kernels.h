@@ -1225,6 +1225,37 @@ __global__ void __launch_bounds__(kBlock) k_flags_compact(const SlotDev* __restr
   if (keep) out[pos] = filt[s.off + i];
 }
 
+// ------------------------------------------------------------------ B4: plane RANSAC scoring (fillGroundPlane)
+// fillGroundPlane (PointCloudSensor.cpp:362-388) fits the ground with pcl::RandomSampleConsensus over
+// SampleConsensusModelPlane; all of its time is countWithinDistance - one pass over the whole map per hypothesis.
+// The hypotheses do not depend on each other's scores (the sample stream is fixed by the seed), so kPlaneBatch of
+// them are scored by ONE pass over the points: each point is read once and tested against every plane of the
+// batch (the planes arrive as kernel arguments = scalar registers), the counts are reduced per wave and added
+// with one atomic per wave and plane.  Inlier test = PCL's: |(a x + b y) + (c z + d)| < (float)threshold.
+constexpr int kPlaneBatch = 32;
+struct PlaneBatch { float4 pl[kPlaneBatch]; };
+
+__global__ void __launch_bounds__(kBlock) s3d_plane_count_kernel(const float4* __restrict__ pts, int n, PlaneBatch B,
+                                                                  float thr, int* __restrict__ counts) {
+  int c[kPlaneBatch];
+#pragma unroll
+  for (int h = 0; h < kPlaneBatch; ++h) c[h] = 0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 p = pts[i];
+#pragma unroll
+    for (int h = 0; h < kPlaneBatch; ++h) {
+      const float v = (B.pl[h].x * p.x + B.pl[h].y * p.y) + (B.pl[h].z * p.z + B.pl[h].w);
+      c[h] += fabsf(v) < thr ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < kPlaneBatch; ++h) {
+    int v = c[h];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    if (lane_id() == 0 && v) atomicAdd(&counts[h], v);
+  }
+}
+
 // ------------------------------------------------------------------ K9: NDT
 // doNDT (PointCloudSensor.cpp:84-117) -> pcl::NormalDistributionsTransform.  The data-parallel parts run here:
 // the voxel statistics of the target (pcl::VoxelGridCovariance: >= 6 points per voxel of edge `resolution`,
