@@ -44,7 +44,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--algorithm", default="gicp", choices=["gicp", "icp"])
     ap.add_argument("--density", type=float, default=0.02)
-    ap.add_argument("--cpu-pairs", type=int, default=3, help="pairs timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-pairs", type=int, default=10,
+                    help="pairs timed one after another on the CPU oracle (rank 0, N=1): ~12 s at the default size")
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="also time this many pairs on as many oracle threads at once (cpu_baseline_parallel; 0/1 = off)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -223,7 +224,7 @@ def main():
             cpu = {"value": round(1.0 / float(np.median(times)), 4), "unit": "registrations/s", "cores": 1,
                    "kind": "port",
                    "sample": "%d of the %d pairs of this workload, oracle/s3d_oracle.c align() (kd-tree + "
-                             "PCL-structured %s), median of %d runs, %.1f s total" %
+                             "PCL-structured %s), median over the %d pairs, %.1f s total" %
                              (len(times), args.pairs, args.algorithm.upper(), len(times), sum(times)),
                    "host_cpus": os.cpu_count()}
         line = {
