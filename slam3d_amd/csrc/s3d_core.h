@@ -14,9 +14,11 @@
 // must evaluate exactly as the oracle's; fma() is used explicitly elsewhere.
 #pragma once
 
-// candidate loads issued per step of the nearest-neighbour row scans (8: the measured optimum, 92 VGPRs)
+// candidate loads issued per step of the nearest-neighbour row scans.  Measured together with the kernel's
+// register cap (S3D_NN_WAVES, s3d_kernels.h): 6 loads under a 72-VGPR cap (7 waves per SIMD) beat 8 loads at the
+// compiler's free choice of 92 VGPRs (5 waves) by 8 % on the default batch; 8 waves (64 VGPRs) spill.
 #ifndef S3D_NN_BATCH
-#define S3D_NN_BATCH 8
+#define S3D_NN_BATCH 6
 #endif
 #ifndef S3D_KNN_PREFETCH
 #define S3D_KNN_PREFETCH 1

@@ -893,8 +893,11 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
 // 3.39 -> 3.49, 2.77 -> 2.17, 1.06 -> 0.94, then 0.25 -> 0.29 ms once nearly every query re-validates (five block
 // barriers on a streaming kernel): the host asks for it in passes 3 to 5 only.  A global worklist (atomics, second
 // kernel) loses the spatial order of the queries and was 2x slower.  Same results either way, bit for bit.
+#ifndef S3D_NN_WAVES
+#define S3D_NN_WAVES 7     // waves per SIMD the register allocation is capped for (see S3D_NN_BATCH, s3d_core.h)
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(kBlock) s3d_nn_search_kernel(const PairDev* __restrict__ pairs,
+__global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_search_kernel(const PairDev* __restrict__ pairs,
                                                                 const SlotDev* __restrict__ slots, NNArrays A,
                                                                 float max_d, int chunks_per_pair, int npairs, int dbg,
                                                                 int* __restrict__ prof_counts, int compact) {
