@@ -124,6 +124,7 @@ struct s3d_context {
   // array in separate hipMallocs left some processes with 3x slower streaming kernels on this pool
   // (fragmented page mappings); one large arena gets the driver's largest fragments.
   DevBuf arena;
+  DevBuf staging;   // raw host floats of an upload with stride != 4 (grown on demand)
   void carve(std::initializer_list<std::pair<DevBuf*, size_t>> reqs) {
     const size_t gran = (size_t)2 << 20;
     size_t total = 0;
@@ -145,6 +146,7 @@ struct s3d_context {
   }
   void release_all() {
     if (arena.p) { (void)hipFree(arena.p); arena.p = nullptr; arena.cap = 0; }
+    if (staging.p) { (void)hipFree(staging.p); staging.p = nullptr; staging.cap = 0; }
   }
 };
 
@@ -521,13 +523,26 @@ int upload_cloud(s3d_context* ctx, const float* xyz, int n, int stride, s3d_clou
     if (stride == 4) {
       HIPCHK(hipMemcpyAsync(c->d, xyz, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
       HIPCHK(hipStreamSynchronize(ctx->stream));
-    } else {
+    } else if (stride > 6) {   // wide records: pack on the host rather than ship the unused fields
       std::vector<float4> tmp((size_t)n);
       for (int i = 0; i < n; ++i) {
         const float* p = xyz + (size_t)i * stride;
         tmp[i] = make_float4(p[0], p[1], p[2], 1.f);
       }
       HIPCHK(hipMemcpyAsync(c->d, tmp.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    } else {
+      // raw floats to a staging buffer of the context, float4 expansion on the device
+      const size_t bytes = sizeof(float) * ((size_t)(n - 1) * stride + 3);
+      if (ctx->staging.cap < bytes) {
+        if (ctx->staging.p) HIPCHK(hipFree(ctx->staging.p));
+        ctx->staging.p = nullptr; ctx->staging.cap = 0;
+        HIPCHK(hipMalloc(&ctx->staging.p, bytes + bytes / 4));
+        ctx->staging.cap = bytes + bytes / 4;
+      }
+      HIPCHK(hipMemcpyAsync(ctx->staging.p, xyz, bytes, hipMemcpyHostToDevice, ctx->stream));
+      k_expand_points<<<cdiv(n, kBlock), kBlock, 0, ctx->stream>>>((const float*)ctx->staging.p, n, stride, c->d);
+      HIPCHK(hipGetLastError());
       HIPCHK(hipStreamSynchronize(ctx->stream));
     }
   }

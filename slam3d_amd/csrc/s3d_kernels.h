@@ -1169,6 +1169,16 @@ __global__ void k_fitness_final(PairDev* pairs, const double* __restrict__ parti
   pairs[p].fit_count = (int)c;
 }
 
+// host hand-over of a cloud with a stride other than 4 floats: the raw floats are copied as they are and
+// expanded to the float4 layout on the device (no host-side conversion pass, 25 % fewer PCIe bytes for packed xyz)
+__global__ void __launch_bounds__(kBlock) k_expand_points(const float* __restrict__ raw, int n, int stride,
+                                                          float4* __restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float* p = raw + (size_t)i * stride;
+  out[i] = make_float4(p[0], p[1], p[2], 1.f);
+}
+
 // ------------------------------------------------------------------ B1: patch accumulation
 // PointCloudSensor::getAccumulatedCloud / createCombinedMeasurement (PointCloudSensor.cpp:235-266): every
 // cloud of the patch through its own pose, appended in vertex order; with `frame` the float result goes

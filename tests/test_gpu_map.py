@@ -310,3 +310,19 @@ def test_pose_graph_loop_closure_sweep(gpu_ctx):
             assert dt < 0.25 and dr < 0.05
     errs = np.array(errs)
     assert len(errs) >= 2 and errs[:, 0].mean() < errs[:, 1].mean()   # the links correct the drifted graph estimate
+
+
+def test_upload_any_stride(gpu_ctx):
+    """s3d_cloud_upload takes records of >= 3 floats: packed xyz, PCL's 16-byte points, wider records (x, y, z first)."""
+    import ctypes as C
+    import slam3d_amd.api as api
+    rng = np.random.default_rng(5)
+    for stride in (3, 4, 5, 6, 8, 11):
+        for n in (1, 255, 4097):
+            rec = rng.normal(size=(n, stride)).astype(np.float32)
+            h = C.c_void_p()
+            st = gpu_ctx._L.s3d_cloud_upload(gpu_ctx._h, rec.ctypes.data_as(C.POINTER(C.c_float)), n, stride, C.byref(h))
+            assert st == 0
+            cloud = api.Cloud(gpu_ctx, h, n)
+            assert np.array_equal(cloud.download(), rec[:, :3])
+            cloud.release()
