@@ -252,7 +252,7 @@ struct Batch {
     nb_head = std::max(1, cdiv(max_n, kBlock));
     // blocks per pair in the accumulate kernels: enough blocks to fill the chip for small batches, few
     // (long per-thread loops, one 76-value tree reduction per block) for large ones
-    accum_blocks = std::min(kAccumBlocks, std::max(1, cdiv(max_n_t, kBlock * 8)));
+    accum_blocks = std::min(kAccumBlocks, std::max(1, cdiv(max_n_t, kBlock * 4)));
     accum_blocks = std::min(accum_blocks, std::max(4, cdiv(1024, std::max(1, P()))));
     const size_t np = std::max<size_t>(total_pts, 4);
     const size_t nc = std::max<size_t>(total_corr, 4);

@@ -22,7 +22,7 @@ constexpr int kBlock = 256;        // 4 waves
 constexpr int kWave = 64;
 constexpr int kSortTile = 4096;    // elements per block and pass in the radix sort (16 per thread: digit runs of a
                                    // tile are then ~64 B long; 1024 -> 4096 took 1.3 ms off the 256-pair step)
-constexpr int kAccumBlocks = 32;   // max blocks per pair in the accumulate kernels
+constexpr int kAccumBlocks = 64;   // max blocks per pair in the accumulate kernels
 constexpr uint32_t kInvalidKey = 0xFFFFFFFFu;
 
 // ------------------------------------------------------------------ device-side records
