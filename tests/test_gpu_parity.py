@@ -542,3 +542,33 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["pairs_per_gpu"] == 4
     assert line["accuracy"]["status_ok"] == 8          # the gathered records of both ranks
     assert line["value"] > 0 and line["cpu_baseline"] is None
+
+
+def test_concurrent_callers(gpu_ctx, fixture_clouds):
+    """createConstraint is entered from two threads in the reference (the application's addMeasurement and the
+    detached link thread, ScanSensor.cpp:209-210; PointCloudSensor.cpp:58/:90 keep all state in locals).  Here calls
+    on ONE context are serialised inside the library and calls on two contexts run side by side: both give the
+    results of the same calls made one after the other, bit for bit."""
+    import threading
+    import slam3d_amd as s3d
+    p = s3d.default_params(maximum_iterations=10)
+    jobs = [(fixture_clouds[i], fixture_clouds[i + 1]) for i in range(3)] * 2
+    want = [gpu_ctx.align(a, b, np.eye(4), p) for a, b in jobs]
+    other = s3d.Context(0)
+    try:
+        for ctxs in ([gpu_ctx, gpu_ctx], [gpu_ctx, other]):
+            got = [None] * len(jobs)
+
+            def work(k, ctx):
+                for j in range(k, len(jobs), 2):
+                    got[j] = ctx.align(jobs[j][0], jobs[j][1], np.eye(4), p)
+
+            th = [threading.Thread(target=work, args=(k, ctxs[k])) for k in range(2)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            for (st, T, info), (st2, T2, info2) in zip(want, got):
+                assert st == st2 and np.array_equal(T, T2) and info == info2
+    finally:
+        other.close()
