@@ -182,7 +182,7 @@ struct Batch {
   uint32_t* vB() { return (uint32_t*)ctx->valsB.p; }
   float4* filt() { return (float4*)ctx->filt.p; }
   float4* sorted() { return (float4*)ctx->sorted.p; }
-  float4* normals() { return (float4*)ctx->normals.p; }
+  CorrVec* normals() { return (CorrVec*)ctx->normals.p; }
   uint32_t* cells() { return (uint32_t*)ctx->cell_start.p; }
   int C() const { return (int)h_slots.size(); }
   int P() const { return (int)h_pairs.size(); }
@@ -362,7 +362,7 @@ struct Batch {
     NNArrays A;
     A.sorted = sorted(); A.cell_start = cells(); A.normals = normals();
     A.corr_idx = (int*)ctx->corr_idx.p; A.corr_d2 = (float*)ctx->corr_d2.p; A.corr_lb = (float*)ctx->corr_lb.p;
-    A.corr_q = (float4*)ctx->corr_q.p; A.corr_n = (float4*)ctx->corr_n.p;
+    A.corr_q = (CorrVec*)ctx->corr_q.p; A.corr_n = (CorrVec*)ctx->corr_n.p;
     int* pc = (prof_slot >= 0 && prof_slot < 64) ? (int*)ctx->n_active.p + 16 + 2 * prof_slot : nullptr;
     const int cmp = (compact && mode == 0 && !(dbg_nn & 65536)) ? 1 : 0;
     if (mode == 0)
@@ -398,11 +398,11 @@ struct Batch {
       if (prof) HIPCHK(hipEventRecord(ctx->nn_ev[2 * it + 1], st));
       if (rp.algorithm)
         s3d_gicp_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
-            d_pairs(), d_slots(), sorted(), normals(), (float*)ctx->corr_d2.p, (float4*)ctx->corr_q.p,
-            (float4*)ctx->corr_n.p, part, rp);
+            d_pairs(), d_slots(), sorted(), normals(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p,
+            (CorrVec*)ctx->corr_n.p, part, rp);
       else
         s3d_p2plane_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
-            d_pairs(), d_slots(), sorted(), (float*)ctx->corr_d2.p, (float4*)ctx->corr_q.p, (float4*)ctx->corr_n.p,
+            d_pairs(), d_slots(), sorted(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p, (CorrVec*)ctx->corr_n.p,
             part, rp);
       s3d_icp_control_kernel<<<P(), 128, 0, st>>>(d_pairs(), part, accum_blocks, rp, d_active);
       ctx->prof.nn_launches = it + 1;

@@ -93,6 +93,19 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // exclusive prefix over the 256 threads of a block of a 0/1 flag; returns also the block total
+// unit normals, and the matched point + normal that travel with each correspondence, are stored as xyz only
+// (12-byte records, dwordx3 accesses): K6 and the re-validating NN passes stream them
+#ifndef S3D_CORR_PACKED
+#define S3D_CORR_PACKED 1
+#endif
+#if S3D_CORR_PACKED
+struct CorrVec { float x, y, z; };
+__device__ __forceinline__ CorrVec corr_vec(const float4& v) { CorrVec c; c.x = v.x; c.y = v.y; c.z = v.z; return c; }
+#else
+typedef float4 CorrVec;
+__device__ __forceinline__ CorrVec corr_vec(const float4& v) { return v; }
+#endif
+
 // sum of n block partials (src[b * stride]) in ascending b: the loads are issued eight at a time, the additions
 // keep their order (a plain loop waits out one L2 round trip per partial: 32 of them cost the single-pair
 // controller ~20 us per outer iteration)
@@ -558,7 +571,7 @@ __global__ void __launch_bounds__(kBlock) k_grid_finalize(const SlotDev* __restr
 // generic fallback (k > 32): top-k in LDS columns
 __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ slots, const float4* __restrict__ filt,
                                                      const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start,
-                                                     float4* __restrict__ normals, int k) {
+                                                     CorrVec* __restrict__ normals, int k) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* d2s = reinterpret_cast<float*>(smem);               // [k][kBlock]
   int* idxs = reinterpret_cast<int*>(smem) + k * kBlock;      // [k][kBlock]
@@ -577,7 +590,7 @@ __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ 
   }
   double n[3];
   moments_normal(m, k, n);
-  normals[s.off + i] = make_float4((float)n[0], (float)n[1], (float)n[2], 0.f);  // CELL-SORTED order
+  normals[s.off + i] = corr_vec(make_float4((float)n[0], (float)n[1], (float)n[2], 0.f));  // CELL-SORTED order
 }
 
 // k <= KMAX: the k best live in registers as sorted packed keys (s3d_core.h grid_knn_sorted).
@@ -623,7 +636,7 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_WAVES) s3d_knn_moments_kernel(
 
 __global__ void __launch_bounds__(kBlock) s3d_normals_from_moments_kernel(const SlotDev* __restrict__ slots,
                                                                            const double* __restrict__ moments,
-                                                                           float4* __restrict__ normals, int k) {
+                                                                           CorrVec* __restrict__ normals, int k) {
   const SlotDev& s = slots[blockIdx.y];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= s.n) return;
@@ -633,7 +646,7 @@ __global__ void __launch_bounds__(kBlock) s3d_normals_from_moments_kernel(const 
   m.c00 = o[3]; m.c10 = o[4]; m.c11 = o[5]; m.c20 = o[6]; m.c21 = o[7]; m.c22 = o[8];
   double n[3];
   moments_normal(m, k, n);
-  normals[s.off + i] = make_float4((float)n[0], (float)n[1], (float)n[2], 0.f);  // CELL-SORTED order
+  normals[s.off + i] = corr_vec(make_float4((float)n[0], (float)n[1], (float)n[2], 0.f));  // CELL-SORTED order
 }
 
 // ------------------------------------------------------------------ pair state
@@ -789,12 +802,12 @@ __device__ __forceinline__ NNResult wave_nn1_coop(const GridParams& g, const uin
 struct NNArrays {
   const float4* __restrict__ sorted;
   const uint32_t* __restrict__ cell_start;
-  const float4* __restrict__ normals;
+  const CorrVec* __restrict__ normals;
   int* __restrict__ corr_idx;
   float* __restrict__ corr_d2;
   float* __restrict__ corr_lb;
-  float4* __restrict__ corr_q;
-  float4* __restrict__ corr_n;
+  CorrVec* __restrict__ corr_q;
+  CorrVec* __restrict__ corr_n;
 };
 
 template <int MODE, int PHASE>
@@ -818,7 +831,7 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
     move = sqrtf(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
     if (PHASE != 2) {                                    // (a PHASE 2 query has failed this test already)
       if (prev < 1.0e30f) {
-        const float4 ps = A.corr_q[ci];                  // the neighbour itself travels with the correspondence
+        const CorrVec ps = A.corr_q[ci];                  // the neighbour itself travels with the correspondence
         const float d2n = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z);
         if (nn_still_nearest(sqrtf(d2n), move, lb)) {
           A.corr_d2[ci] = d2n;                           // same point, its exact new distance
@@ -895,7 +908,7 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   if (r.pos >= 0) {
     // a copy of the matched point and of its normal is kept with the correspondence: the re-validation
     // above and the accumulate kernel then stream them instead of gathering by index
-    A.corr_q[ci] = A.sorted[Ss.off + r.pos];
+    A.corr_q[ci] = corr_vec(A.sorted[Ss.off + r.pos]);
     A.corr_n[ci] = A.normals[Ss.off + r.pos];
   }
 }
@@ -966,11 +979,12 @@ __global__ void __launch_bounds__(kBlock) k_export_corr(const PairDev* __restric
   out_d2[P.corr_off + orig] = corr_d2[P.corr_off + i];
 }
 __global__ void __launch_bounds__(kBlock) k_export_normals(const SlotDev* __restrict__ slots, const float4* __restrict__ sorted,
-                                                            const float4* __restrict__ normals, float4* __restrict__ out) {
+                                                            const CorrVec* __restrict__ normals, float4* __restrict__ out) {
   const SlotDev& s = slots[blockIdx.y];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= s.n) return;
-  out[s.off + __float_as_int(sorted[s.off + i].w)] = normals[s.off + i];
+  const CorrVec nv = normals[s.off + i];
+  out[s.off + __float_as_int(sorted[s.off + i].w)] = make_float4(nv.x, nv.y, nv.z, 0.f);
 }
 
 // ------------------------------------------------------------------ K6: per-correspondence terms + reduction
@@ -997,10 +1011,10 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
 __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairDev* __restrict__ pairs,
                                                                       const SlotDev* __restrict__ slots,
                                                                       const float4* __restrict__ sorted,
-                                                                      const float4* __restrict__ normals,
+                                                                      const CorrVec* __restrict__ normals,
                                                                       const float* __restrict__ corr_d2,
-                                                                      const float4* __restrict__ corr_q,
-                                                                      const float4* __restrict__ corr_n,
+                                                                      const CorrVec* __restrict__ corr_q,
+                                                                      const CorrVec* __restrict__ corr_n,
                                                                       double* __restrict__ partials, RunParams rp) {
   const PairDev& P = pairs[blockIdx.y];
   if (!P.active) return;
@@ -1030,7 +1044,8 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
   const int stride = gridDim.x * kBlock;
   int i = blockIdx.x * kBlock + threadIdx.x;
   float d2 = 3.0e38f;
-  float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), qf = p0, na = p0, nb = p0;
+  float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  CorrVec qf = corr_vec(p0), na = qf, nb = qf;
   if (i < M) {
     d2 = corr_d2[P.corr_off + i];          // 3e38 when the query has no neighbour at all
     p0 = sorted[St.off + i]; qf = corr_q[P.corr_off + i];
@@ -1040,8 +1055,8 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
     const int in = i + stride;
     const int j = in < M ? in : i;         // (the last step re-reads its own element: no branch around the loads)
     const float d2n = corr_d2[P.corr_off + j];
-    const float4 p0n = sorted[St.off + j], qfn = corr_q[P.corr_off + j];
-    const float4 nan_ = normals[St.off + j], nbn = corr_n[P.corr_off + j];
+    const float4 p0n = sorted[St.off + j];
+    const CorrVec nan_ = normals[St.off + j], qfn = corr_q[P.corr_off + j], nbn = corr_n[P.corr_off + j];
     if ((double)d2 < rp.dist_threshold) {
       const F3 pf = xf_pcl(P.guess, p0.x, p0.y, p0.z);
       // xyz + normal, both float4: the float-rounded unit normals are used as stored (measured effect on
@@ -1066,8 +1081,8 @@ __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const Pa
                                                                          const SlotDev* __restrict__ slots,
                                                                          const float4* __restrict__ sorted,
                                                                          const float* __restrict__ corr_d2,
-                                                                         const float4* __restrict__ corr_q,
-                                                                         const float4* __restrict__ corr_n,
+                                                                         const CorrVec* __restrict__ corr_q,
+                                                                         const CorrVec* __restrict__ corr_n,
                                                                          double* __restrict__ partials, RunParams rp) {
   const PairDev& P = pairs[blockIdx.y];
   if (!P.active) return;
@@ -1082,8 +1097,8 @@ __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const Pa
     const float4 p0 = sorted[St.off + i];
     const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
     const F3 pq = xf_eigen(P.T, pg.x, pg.y, pg.z);
-    const float4 qf = corr_q[P.corr_off + i];
-    const float4 nf = corr_n[P.corr_off + i];
+    const CorrVec qf = corr_q[P.corr_off + i];
+    const CorrVec nf = corr_n[P.corr_off + i];
     const double pd[3] = {pq.x, pq.y, pq.z};
     const double qd[3] = {qf.x, qf.y, qf.z};
     const double nd[3] = {nf.x, nf.y, nf.z};
