@@ -114,7 +114,7 @@ struct s3d_context {
   s3d_profile prof{};
   s3d_map_profile map_prof{};
   // workspace (grown on demand, reused across calls)
-  DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, normals, moments, cell_start, counts, digit_tot, blockcnt,
+  DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, sorted3, normals, moments, cell_start, counts, digit_tot, blockcnt,
       corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active;
   int* h_active = nullptr;  // pinned
   hipEvent_t ev[8] = {};
@@ -182,6 +182,8 @@ struct Batch {
   uint32_t* vB() { return (uint32_t*)ctx->valsB.p; }
   float4* filt() { return (float4*)ctx->filt.p; }
   float4* sorted() { return (float4*)ctx->sorted.p; }
+  CorrVec* sorted3() { return has_sorted3 ? (CorrVec*)ctx->sorted3.p : nullptr; }
+  bool has_sorted3 = false;
   CorrVec* normals() { return (CorrVec*)ctx->normals.p; }
   uint32_t* cells() { return (uint32_t*)ctx->cell_start.p; }
   int C() const { return (int)h_slots.size(); }
@@ -257,10 +259,11 @@ struct Batch {
     const size_t np = std::max<size_t>(total_pts, 4);
     const size_t nc = std::max<size_t>(total_corr, 4);
     const size_t npi = icp_buffers ? np : 4;
+    has_sorted3 = icp_buffers;
     ctx->carve({{&ctx->slots, sizeof(SlotDev) * std::max(1, C())},
                 {&ctx->pairs, sizeof(PairDev) * std::max(1, P())},
                 {&ctx->keysA, 4 * np}, {&ctx->keysB, 4 * np}, {&ctx->valsA, 4 * np}, {&ctx->valsB, 4 * np},
-                {&ctx->filt, 16 * np}, {&ctx->sorted, 16 * np}, {&ctx->normals, 16 * npi}, {&ctx->moments, 80 * npi},
+                {&ctx->filt, 16 * np}, {&ctx->sorted, 16 * np}, {&ctx->sorted3, 12 * npi}, {&ctx->normals, 16 * npi}, {&ctx->moments, 80 * npi},
                 {&ctx->cell_start, 4 * std::max<size_t>(total_cells, 4)},
                 {&ctx->counts, 4 * (size_t)std::max(1, C()) * 256 * nb_sort},
                 {&ctx->digit_tot, 4 * (size_t)std::max(1, C()) * 256},
@@ -323,7 +326,7 @@ struct Batch {
     const bool wide = max_cell_cap > (1ll << 24);
     sort(wide ? 4 : 3);  // cell ids < 2^24 unless a map job raised the cap
     k_grid_finalize<<<dim3(cdiv(max_n + 1, kBlock), C()), kBlock, 0, st>>>(d_slots(), filt(), wide ? kA() : kB(),
-                                                                           wide ? vA() : vB(), sorted(), cells());
+                                                                           wide ? vA() : vB(), sorted(), sorted3(), cells());
   }
 
   // K4
@@ -360,7 +363,7 @@ struct Batch {
     const int pairs8 = P() >= 8 ? cdiv(P(), 8) * 8 : P();
     dim3 grid((unsigned)(pairs8 * chunks));
     NNArrays A;
-    A.sorted = sorted(); A.cell_start = cells(); A.normals = normals();
+    A.sorted = sorted(); A.sorted3 = sorted3(); A.cell_start = cells(); A.normals = normals();
     A.corr_idx = (int*)ctx->corr_idx.p; A.corr_d2 = (float*)ctx->corr_d2.p; A.corr_lb = (float*)ctx->corr_lb.p;
     A.corr_q = (CorrVec*)ctx->corr_q.p; A.corr_n = (CorrVec*)ctx->corr_n.p;
     int* pc = (prof_slot >= 0 && prof_slot < 64) ? (int*)ctx->n_active.p + 16 + 2 * prof_slot : nullptr;
@@ -398,11 +401,11 @@ struct Batch {
       if (prof) HIPCHK(hipEventRecord(ctx->nn_ev[2 * it + 1], st));
       if (rp.algorithm)
         s3d_gicp_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
-            d_pairs(), d_slots(), sorted(), normals(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p,
+            d_pairs(), d_slots(), sorted3(), normals(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p,
             (CorrVec*)ctx->corr_n.p, part, rp);
       else
         s3d_p2plane_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
-            d_pairs(), d_slots(), sorted(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p, (CorrVec*)ctx->corr_n.p,
+            d_pairs(), d_slots(), sorted3(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p, (CorrVec*)ctx->corr_n.p,
             part, rp);
       s3d_icp_control_kernel<<<P(), 128, 0, st>>>(d_pairs(), part, accum_blocks, rp, d_active);
       ctx->prof.nn_launches = it + 1;

@@ -534,7 +534,10 @@ __global__ void __launch_bounds__(kBlock) k_cell_keys(const SlotDev* __restrict_
 // sorted position i owns the cells (key[i-1], key[i]]; position n owns the tail up to ncells.
 __global__ void __launch_bounds__(kBlock) k_grid_finalize(const SlotDev* __restrict__ slots, const float4* __restrict__ filt,
                                                            const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                           float4* __restrict__ sorted, uint32_t* __restrict__ cell_start) {
+                                                           float4* __restrict__ sorted, CorrVec* __restrict__ sorted3,
+                                                           uint32_t* __restrict__ cell_start) {
+  // sorted: xyz + original index (the search reads it); sorted3 (registration only, may be null): the same points as
+  // 12-byte xyz records for the kernels that stream a cloud in cell order (queries of K5, K6)
   const SlotDev& s = slots[blockIdx.y];
   const int n = s.n;
   const int base = blockIdx.x * kBlock;
@@ -550,6 +553,7 @@ __global__ void __launch_bounds__(kBlock) k_grid_finalize(const SlotDev* __restr
       const uint32_t src = vals[s.off + i];
       const float4 p = filt[s.off + src];
       sorted[s.off + i] = make_float4(p.x, p.y, p.z, __uint_as_float(src));
+      if (sorted3) sorted3[s.off + i] = corr_vec(p);
     }
   }
   const int gap = hi - lo + 1;
@@ -801,6 +805,7 @@ __device__ __forceinline__ NNResult wave_nn1_coop(const GridParams& g, const uin
 // block in between).
 struct NNArrays {
   const float4* __restrict__ sorted;
+  const CorrVec* __restrict__ sorted3;   // the same points, xyz only (the query side streams these)
   const uint32_t* __restrict__ cell_start;
   const CorrVec* __restrict__ normals;
   int* __restrict__ corr_idx;
@@ -816,7 +821,7 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
                                          int* __restrict__ prof_counts, int* out_class = nullptr) {
   const int ci = P.corr_off + (need ? i : 0);
   // queries are taken in the CELL-SORTED order of their own cloud (spatially coherent waves)
-  const float4 p0 = A.sorted[St.off + (need ? i : 0)];
+  const CorrVec p0 = A.sorted3[St.off + (need ? i : 0)];
   const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
   F3 q;
   if (MODE == 0) q = xf_eigen(P.T, pg.x, pg.y, pg.z);
@@ -1010,7 +1015,7 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
 // GICP: Mahalanobis matrix + 73-term quadratic form (s3d_core.h "GICP quadratic form")
 __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairDev* __restrict__ pairs,
                                                                       const SlotDev* __restrict__ slots,
-                                                                      const float4* __restrict__ sorted,
+                                                                      const CorrVec* __restrict__ sorted,
                                                                       const CorrVec* __restrict__ normals,
                                                                       const float* __restrict__ corr_d2,
                                                                       const CorrVec* __restrict__ corr_q,
@@ -1044,8 +1049,7 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
   const int stride = gridDim.x * kBlock;
   int i = blockIdx.x * kBlock + threadIdx.x;
   float d2 = 3.0e38f;
-  float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f);
-  CorrVec qf = corr_vec(p0), na = qf, nb = qf;
+  CorrVec p0 = corr_vec(make_float4(0.f, 0.f, 0.f, 0.f)), qf = p0, na = p0, nb = p0;
   if (i < M) {
     d2 = corr_d2[P.corr_off + i];          // 3e38 when the query has no neighbour at all
     p0 = sorted[St.off + i]; qf = corr_q[P.corr_off + i];
@@ -1055,8 +1059,7 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
     const int in = i + stride;
     const int j = in < M ? in : i;         // (the last step re-reads its own element: no branch around the loads)
     const float d2n = corr_d2[P.corr_off + j];
-    const float4 p0n = sorted[St.off + j];
-    const CorrVec nan_ = normals[St.off + j], qfn = corr_q[P.corr_off + j], nbn = corr_n[P.corr_off + j];
+    const CorrVec p0n = sorted[St.off + j], nan_ = normals[St.off + j], qfn = corr_q[P.corr_off + j], nbn = corr_n[P.corr_off + j];
     if ((double)d2 < rp.dist_threshold) {
       const F3 pf = xf_pcl(P.guess, p0.x, p0.y, p0.z);
       // xyz + normal, both float4: the float-rounded unit normals are used as stored (measured effect on
@@ -1079,7 +1082,7 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
 // point-to-plane: J^T J (21) + J^T r (6) + r^2 + count
 __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const PairDev* __restrict__ pairs,
                                                                          const SlotDev* __restrict__ slots,
-                                                                         const float4* __restrict__ sorted,
+                                                                         const CorrVec* __restrict__ sorted,
                                                                          const float* __restrict__ corr_d2,
                                                                          const CorrVec* __restrict__ corr_q,
                                                                          const CorrVec* __restrict__ corr_n,
@@ -1094,7 +1097,7 @@ __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const Pa
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < M; i += gridDim.x * kBlock) {
     const float d2 = corr_d2[P.corr_off + i];
     if (!((double)d2 < rp.dist_threshold)) continue;
-    const float4 p0 = sorted[St.off + i];
+    const CorrVec p0 = sorted[St.off + i];
     const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
     const F3 pq = xf_eigen(P.T, pg.x, pg.y, pg.z);
     const CorrVec qf = corr_q[P.corr_off + i];
