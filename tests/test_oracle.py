@@ -270,3 +270,27 @@ def test_gicp_objective_vs_independent_numpy_and_scipy(oracle_mod, fixture_cloud
     res = minimize(f, np.zeros(6), method="BFGS", options={"gtol": 1e-10})
     assert (f(np.zeros(6)) - res.fun) < 1e-3 * res.fun
     assert np.abs(res.x[:3]).max() < 5e-3 and np.abs(res.x[3:]).max() < 1e-4
+
+
+def test_point_to_plane_result_is_stationary_for_independent_normal_equations(oracle_mod, fixture_clouds):
+    """The point-to-plane oracle's result against an independent statement: with correspondences from cKDTree and the
+    target normals, the numpy least-squares step of the linearised point-to-plane residuals at the returned
+    transform is (numerically) zero - the iteration has converged to the minimiser of its own objective."""
+    from scipy.spatial import cKDTree
+    c1, c2 = fixture_clouds[0], fixture_clouds[1]
+    p = oracle_mod.default_params(point_cloud_density=0.5, registration_algorithm=oracle_mod.ALG_ICP)
+    st, T, info = oracle_mod.align(c1, c2, np.eye(4), p)
+    assert st == 0
+    S = oracle_mod.voxel_downsample(c1, 0.5)[0]
+    Q = oracle_mod.voxel_downsample(c2, 0.5)[0]
+    _, NS = oracle_mod.gicp_covariances(S, 20, 1e-3)
+    F = T.astype(np.float32)
+    q = (Q.astype(np.float32) @ F[:3, :3].T + F[:3, 3]).astype(np.float32).astype(np.float64)
+    d, j = cKDTree(S.astype(np.float64)).query(q)
+    m = d ** 2 < p.max_correspondence_distance ** 2
+    assert int(m.sum()) == info["correspondences"]
+    n, s, qq = NS[j[m]], S[j[m]].astype(np.float64), q[m]
+    r = np.einsum("na,na->n", qq - s, n)
+    J = np.hstack([n, np.cross(qq, n)])          # d r / d (translation, small rotation)
+    x = np.linalg.lstsq(J, -r, rcond=None)[0]
+    assert np.abs(x[:3]).max() < 1e-5 and np.abs(x[3:]).max() < 1e-6
