@@ -294,3 +294,58 @@ def test_point_to_plane_result_is_stationary_for_independent_normal_equations(or
     J = np.hstack([n, np.cross(qq, n)])          # d r / d (translation, small rotation)
     x = np.linalg.lstsq(J, -r, rcond=None)[0]
     assert np.abs(x[:3]).max() < 1e-5 and np.abs(x[3:]).max() < 1e-6
+
+
+def test_ndt_result_maximises_independent_ndt_score(oracle_mod, fixture_clouds):
+    """The NDT oracle against an independent numpy statement of pcl::NormalDistributionsTransform's score: voxel
+    Gaussians of the target (>= 6 points per voxel of edge `resolution`, unbiased covariance, eigenvalues raised to
+    1 % of the largest), score = sum over points and over the cells whose mean lies within `resolution` of
+    -d1 exp(-d2/2 (x-mu)^T Sigma^-1 (x-mu)).  Same number of cells; the oracle's result scores far above the
+    initial guess and every +-1 cm / +-5 mrad step away from it lowers the score."""
+    from scipy.spatial import cKDTree
+    c1, c2 = fixture_clouds[0], fixture_clouds[1]
+    p = oracle_mod.default_params(registration_algorithm=oracle_mod.ALG_NDT)
+    st, T, info = oracle_mod.align(c1, c2, np.eye(4), p)
+    assert st == 0
+    res, orat = p.resolution, p.outlier_ratio
+    S = oracle_mod.voxel_downsample(c1, p.point_cloud_density)[0].astype(np.float64)
+    Q = oracle_mod.voxel_downsample(c2, p.point_cloud_density)[0].astype(np.float64)
+    _, inv, cnt = np.unique(np.floor(S / res).astype(np.int64), axis=0, return_inverse=True, return_counts=True)
+    inv = inv.reshape(-1)
+    mus, icovs = [], []
+    for c in np.nonzero(cnt >= 6)[0]:
+        P = S[inv == c]
+        Cv = np.cov(P.T)
+        w, V = np.linalg.eigh(Cv)
+        if w[0] < 0.01 * w[2]:
+            Cv = V @ np.diag(np.maximum(w, 0.01 * w[2])) @ V.T
+        mus.append(P.mean(0))
+        icovs.append(np.linalg.inv(Cv))
+    mus, icovs = np.array(mus), np.array(icovs)
+    assert len(mus) == info["correspondences"]            # the oracle reports its cell count there
+    g1, g2 = 10 * (1 - orat), orat / res ** 3
+    d3 = -np.log(g2)
+    d1 = -np.log(g1 + g2) - d3
+    d2 = -2 * np.log((-np.log(g1 * np.exp(-0.5) + g2) - d3) / d1)
+    tree = cKDTree(mus)
+
+    def score(A):
+        X = Q @ A[:3, :3].T + A[:3, 3]
+        nb = tree.query_ball_point(X, res)
+        ii = np.repeat(np.arange(len(X)), [len(b) for b in nb])
+        jj = np.concatenate([np.array(b, dtype=int) for b in nb])
+        dd = X[ii] - mus[jj]
+        return float((-d1 * np.exp(-d2 / 2 * np.einsum("na,nab,nb->n", dd, icovs[jj], dd))).sum())
+
+    s0 = score(T)
+    assert s0 > 1.4 * score(np.eye(4))
+    for k in range(6):
+        for sign in (1.0, -1.0):
+            D = np.eye(4)
+            if k < 3:
+                D[k, 3] = sign * 1e-2
+            else:
+                a, b = [(1, 2), (0, 2), (0, 1)][k - 3]
+                c, s = np.cos(5e-3), np.sin(sign * 5e-3)
+                D[a, a], D[b, b], D[a, b], D[b, a] = c, c, -s, s
+            assert score(D @ T) < s0, (k, sign)
