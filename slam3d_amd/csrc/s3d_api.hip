@@ -263,7 +263,7 @@ struct Batch {
     ctx->carve({{&ctx->slots, sizeof(SlotDev) * std::max(1, C())},
                 {&ctx->pairs, sizeof(PairDev) * std::max(1, P())},
                 {&ctx->keysA, 4 * np}, {&ctx->keysB, 4 * np}, {&ctx->valsA, 4 * np}, {&ctx->valsB, 4 * np},
-                {&ctx->filt, 16 * np}, {&ctx->sorted, 16 * np}, {&ctx->sorted3, 12 * npi}, {&ctx->normals, 16 * npi}, {&ctx->moments, 80 * npi},
+                {&ctx->filt, 16 * np}, {&ctx->sorted, 16 * np}, {&ctx->sorted3, 12 * npi}, {&ctx->normals, 12 * npi}, {&ctx->moments, 72 * npi},
                 {&ctx->cell_start, 4 * std::max<size_t>(total_cells, 4)},
                 {&ctx->counts, 4 * (size_t)std::max(1, C()) * 256 * nb_sort},
                 {&ctx->digit_tot, 4 * (size_t)std::max(1, C()) * 256},
@@ -339,19 +339,20 @@ struct Batch {
       return;
     }
     double* mom = (double*)ctx->moments.p;
+    const size_t mom_plane = std::max<size_t>(total_pts, 4);   // nine planes, one double per point each
     const int slots8 = C() >= 8 ? cdiv(C(), 8) * 8 : C();
     dim3 grid((unsigned)(slots8 * nb_head));
     if (k <= 8)
-      s3d_knn_moments_kernel<8><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, k, nb_head, C());
+      s3d_knn_moments_kernel<8><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, C());
     else if (k <= 16)
-      s3d_knn_moments_kernel<16><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, k, nb_head, C());
+      s3d_knn_moments_kernel<16><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, C());
     else if (k == 20)   // the reference default (correspondence_randomness = 20): list length known at compile time
-      s3d_knn_moments_kernel<20, true><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, k, nb_head, C());
+      s3d_knn_moments_kernel<20, true><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, C());
     else if (k < 20)
-      s3d_knn_moments_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, k, nb_head, C());
+      s3d_knn_moments_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, C());
     else
-      s3d_knn_moments_kernel<32><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, k, nb_head, C());
-    s3d_normals_from_moments_kernel<<<dim3(nb_head, C()), kBlock, 0, st>>>(d_slots(), mom, normals(), k);
+      s3d_knn_moments_kernel<32><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, C());
+    s3d_normals_from_moments_kernel<<<dim3(nb_head, C()), kBlock, 0, st>>>(d_slots(), mom, mom_plane, normals(), k);
   }
 
   int dbg_nn = getenv("S3D_DBG_NN") ? atoi(getenv("S3D_DBG_NN")) : 0;

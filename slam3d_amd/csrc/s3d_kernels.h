@@ -611,7 +611,7 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_WAVES) s3d_knn_moments_kernel(
                                                                   const float4* __restrict__ filt,
                                                                   const float4* __restrict__ sorted,
                                                                   const uint32_t* __restrict__ cell_start,
-                                                                  double* __restrict__ moments, int k,
+                                                                  double* __restrict__ moments, size_t plane, int k,
                                                                   int chunks_per_slot, int nslots) {
   int si, chunk;
   nn_block_map(chunks_per_slot, nslots, &si, &chunk);
@@ -632,22 +632,24 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_WAVES) s3d_knn_moments_kernel(
       moments_add(m, p.x, p.y, p.z);
     }
   }
-  // SoA, 9 planes of total_pts doubles would need the batch size; keep AoS rows of 9 (+pad to 10 = 80 B)
-  double* o = moments + (size_t)(s.off + i) * 10;
-  o[0] = m.mean[0]; o[1] = m.mean[1]; o[2] = m.mean[2];
-  o[3] = m.c00; o[4] = m.c10; o[5] = m.c11; o[6] = m.c20; o[7] = m.c21; o[8] = m.c22;
+  // nine planes of `plane` doubles (the batch's point count): every store of a wave is one contiguous 512 bytes
+  double* o = moments + (size_t)(s.off + i);
+  o[0] = m.mean[0]; o[plane] = m.mean[1]; o[2 * plane] = m.mean[2];
+  o[3 * plane] = m.c00; o[4 * plane] = m.c10; o[5 * plane] = m.c11;
+  o[6 * plane] = m.c20; o[7 * plane] = m.c21; o[8 * plane] = m.c22;
 }
 
 __global__ void __launch_bounds__(kBlock) s3d_normals_from_moments_kernel(const SlotDev* __restrict__ slots,
-                                                                           const double* __restrict__ moments,
+                                                                           const double* __restrict__ moments, size_t plane,
                                                                            CorrVec* __restrict__ normals, int k) {
   const SlotDev& s = slots[blockIdx.y];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= s.n) return;
-  const double* o = moments + (size_t)(s.off + i) * 10;
+  const double* o = moments + (size_t)(s.off + i);
   Moments m;
-  m.mean[0] = o[0]; m.mean[1] = o[1]; m.mean[2] = o[2];
-  m.c00 = o[3]; m.c10 = o[4]; m.c11 = o[5]; m.c20 = o[6]; m.c21 = o[7]; m.c22 = o[8];
+  m.mean[0] = o[0]; m.mean[1] = o[plane]; m.mean[2] = o[2 * plane];
+  m.c00 = o[3 * plane]; m.c10 = o[4 * plane]; m.c11 = o[5 * plane];
+  m.c20 = o[6 * plane]; m.c21 = o[7 * plane]; m.c22 = o[8 * plane];
   double n[3];
   moments_normal(m, k, n);
   normals[s.off + i] = corr_vec(make_float4((float)n[0], (float)n[1], (float)n[2], 0.f));  // CELL-SORTED order
