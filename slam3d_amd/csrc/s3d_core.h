@@ -20,6 +20,9 @@
 #ifndef S3D_NN_BATCH
 #define S3D_NN_BATCH 6
 #endif
+#ifndef S3D_KNN_TWOPHASE
+#define S3D_KNN_TWOPHASE 1
+#endif
 #ifndef S3D_KNN_PREFETCH
 #define S3D_KNN_PREFETCH 1
 #endif
@@ -632,6 +635,52 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
       const uint32_t a = cell_start[rowbase + (ok ? xa : 0)], b = cell_start[rowbase + (ok ? xb + 1 : 0)];
       rs[r] = a; re[r] = ok ? b : a;
     }
+#if S3D_KNN_TWOPHASE
+    // Flattened loops over the candidates of several rows: with a loop per row the wave would run max-over-lanes
+    // steps for every row (and pay the insertion chain on each); flattened it runs max-over-lanes of the TOTAL.
+    // Two of them: the point's own row + the four face rows, then the four corner rows - the select chain that
+    // maps a flat index to its row is then 4 or 3 compare/select pairs long instead of 8 (it is a quarter of the
+    // loop's instructions), and a corner row whose slab lies beyond the k-th distance reached so far is dropped.
+#define S3D_KNN_PHASE(R0_, NR_)                                                                                  \
+    {                                                                                                            \
+      uint32_t cum[NR_ + 1];                                                                                     \
+      cum[0] = 0;                                                                                                \
+      _Pragma("unroll") for (int r = 0; r < NR_; ++r) cum[r + 1] = cum[r] + (re[R0_ + r] - rs[R0_ + r]);         \
+      const uint32_t total = cum[NR_];                                                                           \
+      auto flatpos = [&](uint32_t t) {                                                                           \
+        uint32_t b_ = rs[R0_];                                                                                   \
+        _Pragma("unroll") for (int r = 1; r < NR_; ++r) b_ = t >= cum[r] ? rs[R0_ + r] - cum[r] : b_;            \
+        return t + b_;                                                                                           \
+      };                                                                                                         \
+      F4T na = pts[0], nb = pts[0];                                                                              \
+      if (total > 0) { na = pts[flatpos(0u)]; nb = pts[flatpos(total > 1 ? 1u : 0u)]; }                          \
+      for (uint32_t t = 0; t < total; t += 2) {                                                                  \
+        const F4T pa = na, pb = nb;                                                                              \
+        const bool two = t + 1 < total;                                                                          \
+        if (t + 2 < total) {                                                                                     \
+          na = pts[flatpos(t + 2)];                                                                              \
+          nb = pts[flatpos(t + 3 < total ? t + 3 : t + 2)];                                                      \
+        }                                                                                                        \
+        const float da = dist2(qx, qy, qz, pa.x, pa.y, pa.z);                                                    \
+        const float db = dist2(qx, qy, qz, pb.x, pb.y, pb.z);                                                    \
+        S3D_KNN_INSERT(pa, da)                                                                                   \
+        if (two) S3D_KNN_INSERT(pb, db)                                                                          \
+      }                                                                                                          \
+    }
+    S3D_KNN_PHASE(0, 5)
+    if (worst != kInf) {   // the list is full: corner rows out of reach of the k-th distance hold nothing
+      const float lim2 = knn_key_d2(worst), eps = 2.0e-3f * g.h;
+      const float ylo = g.origin[1] + (float)iy * g.h, zlo = g.origin[2] + (float)iz * g.h;
+      const float dym = fmaxf(qy - ylo - eps, 0.f), dyp = fmaxf(ylo + g.h - qy - eps, 0.f);   // to the rows at y-1 / y+1
+      const float dzm = fmaxf(qz - zlo - eps, 0.f), dzp = fmaxf(zlo + g.h - qz - eps, 0.f);
+      if (dym * dym + dzm * dzm > lim2) re[5] = rs[5];
+      if (dyp * dyp + dzm * dzm > lim2) re[6] = rs[6];
+      if (dym * dym + dzp * dzp > lim2) re[7] = rs[7];
+      if (dyp * dyp + dzp * dzp > lim2) re[8] = rs[8];
+    }
+    S3D_KNN_PHASE(5, 4)
+#undef S3D_KNN_PHASE
+#else
     // ONE flattened loop over the candidates of all nine rows: with a loop per row the wave would run
     // max-over-lanes steps for every row (and pay the insertion chain on each); flattened it runs
     // max-over-lanes of the TOTAL.  cum[r] = candidates before row r, off[r] maps a flat index into it.
@@ -679,6 +728,7 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
       if (two) S3D_KNN_INSERT(pb, db)
     }
 #undef S3D_KNN_FLATPOS
+#endif
     const float bound = (1.0f + face) * g.h;
     if (worst != kInf && knn_key_d2(worst) <= bound * bound) {
 #pragma unroll

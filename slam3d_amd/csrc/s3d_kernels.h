@@ -604,7 +604,7 @@ __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ 
 // Jacobi iteration's registers out of the latency-bound search doubles its occupancy.
 // Slot -> XCD affinity as in nn_block_map: blocks of one cloud share one L2.
 #ifndef S3D_KNN_WAVES
-#define S3D_KNN_WAVES 5
+#define S3D_KNN_WAVES 4
 #endif
 template <int KMAX, bool FULL = false>
 __global__ void __launch_bounds__(kBlock, S3D_KNN_WAVES) s3d_knn_moments_kernel(const SlotDev* __restrict__ slots,
