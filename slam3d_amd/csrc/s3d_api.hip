@@ -115,7 +115,7 @@ struct s3d_context {
   s3d_map_profile map_prof{};
   // workspace (grown on demand, reused across calls)
   DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, sorted3, normals, moments, cell_start, counts, digit_tot, blockcnt,
-      corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active;
+      corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active, knn_list;
   int* h_active = nullptr;  // pinned
   hipEvent_t ev[8] = {};
   std::vector<hipEvent_t> nn_ev;
@@ -168,6 +168,7 @@ struct Batch {
   s3d_exec_options opts{};
   std::vector<const s3d_cloud*> slot_clouds;
   std::vector<SlotDev> h_slots;
+  std::vector<int> knn_slots;   // slots that get the k-NN pre-pass (stage_normals)
   std::vector<PairDev> h_pairs;
   int max_n = 0, max_n_t = 0, nb_sort = 0, nb_head = 0, accum_blocks = 1;
   long long cell_cap_max = 1ll << 24;  // 24-bit cell ids sort in 3 radix passes; map jobs raise it (4 passes)
@@ -271,9 +272,17 @@ struct Batch {
                 {&ctx->corr_idx, 4 * nc}, {&ctx->corr_d2, 4 * nc}, {&ctx->corr_lb, 4 * nc},
                 {&ctx->corr_q, 16 * nc}, {&ctx->corr_n, 16 * nc},
                 {&ctx->partials, 8 * (size_t)std::max(1, P()) * kAccumBlocks * GQ_NACC},
-                {&ctx->n_active, 64 + 2 * 64 * sizeof(int)}});
+                {&ctx->n_active, 64 + 2 * 64 * sizeof(int)},
+                {&ctx->knn_list, sizeof(int) * (size_t)std::max(1, C())}});
     if (!ctx->h_active) HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
     hipStream_t st = ctx->stream;
+    // which clouds need the k-NN pre-pass: GICP uses the covariances of both clouds of a pair, point-to-plane only
+    // the normals of the searched one (PCL target = slam3d source); a batch without pairs is s3d_knn_normals
+    for (SlotDev& sl : h_slots) sl.want_normals = h_pairs.empty() ? 1 : 0;
+    for (const PairDev& pr : h_pairs) {
+      h_slots[pr.slot_s].want_normals = 1;
+      if (rp.algorithm != 0) h_slots[pr.slot_t].want_normals = 1;
+    }
     if (C()) HIPCHK(hipMemcpyAsync(ctx->slots.p, h_slots.data(), sizeof(SlotDev) * C(), hipMemcpyHostToDevice, st));
     if (P()) HIPCHK(hipMemcpyAsync(ctx->pairs.p, h_pairs.data(), sizeof(PairDev) * P(), hipMemcpyHostToDevice, st));
   }
@@ -340,19 +349,27 @@ struct Batch {
     }
     double* mom = (double*)ctx->moments.p;
     const size_t mom_plane = std::max<size_t>(total_pts, 4);   // nine planes, one double per point each
-    const int slots8 = C() >= 8 ? cdiv(C(), 8) * 8 : C();
+    std::vector<int>& list = knn_slots;   // (a member: the asynchronous copy below reads it)
+    list.clear();
+    for (int c = 0; c < C(); ++c)
+      if (h_slots[(size_t)c].want_normals) list.push_back(c);
+    const int NL = (int)list.size();
+    if (NL == 0) return;
+    int* d_list = (int*)ctx->knn_list.p;
+    HIPCHK(hipMemcpyAsync(d_list, list.data(), sizeof(int) * (size_t)NL, hipMemcpyHostToDevice, st));
+    const int slots8 = NL >= 8 ? cdiv(NL, 8) * 8 : NL;
     dim3 grid((unsigned)(slots8 * nb_head));
     if (k <= 8)
-      s3d_knn_moments_kernel<8><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, C());
+      s3d_knn_moments_kernel<8><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL);
     else if (k <= 16)
-      s3d_knn_moments_kernel<16><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, C());
+      s3d_knn_moments_kernel<16><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL);
     else if (k == 20)   // the reference default (correspondence_randomness = 20): list length known at compile time
-      s3d_knn_moments_kernel<20, true><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, C());
+      s3d_knn_moments_kernel<20, true><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL);
     else if (k < 20)
-      s3d_knn_moments_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, C());
+      s3d_knn_moments_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL);
     else
-      s3d_knn_moments_kernel<32><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, C());
-    s3d_normals_from_moments_kernel<<<dim3(nb_head, C()), kBlock, 0, st>>>(d_slots(), mom, mom_plane, normals(), k);
+      s3d_knn_moments_kernel<32><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL);
+    s3d_normals_from_moments_kernel<<<dim3(nb_head, NL), kBlock, 0, st>>>(d_slots(), mom, mom_plane, normals(), k, d_list);
   }
 
   int dbg_nn = getenv("S3D_DBG_NN") ? atoi(getenv("S3D_DBG_NN")) : 0;

@@ -36,6 +36,7 @@ struct SlotDev {          // one cloud of the batch
   // device-computed
   int   n;                // points after the voxel filter
   int   n_sort;           // element count of the sort in flight
+  int   want_normals;     // K4 runs on this cloud (point-to-plane: only the searched side of a pair needs normals)
   unsigned int bb[6];     // bbox as order-preserving uint (min xyz, max xyz), atomics
   VoxelParams vp;
   GridParams  g;
@@ -581,7 +582,7 @@ __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ 
   int* idxs = reinterpret_cast<int*>(smem) + k * kBlock;      // [k][kBlock]
   const SlotDev& s = slots[blockIdx.y];
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= s.n) return;
+  if (i >= s.n || !s.want_normals) return;
   const float4* __restrict__ P = filt + s.off;
   const float4 q = sorted[s.off + i];
   const int cnt = grid_knn(s.g, cell_start + s.cell_off, sorted + s.off, q.x, q.y, q.z, k, d2s + threadIdx.x,
@@ -612,11 +613,14 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_WAVES) s3d_knn_moments_kernel(
                                                                   const float4* __restrict__ sorted,
                                                                   const uint32_t* __restrict__ cell_start,
                                                                   double* __restrict__ moments, size_t plane, int k,
-                                                                  int chunks_per_slot, int nslots) {
-  int si, chunk;
-  nn_block_map(chunks_per_slot, nslots, &si, &chunk);
-  if (si >= nslots) return;
-  const SlotDev& s = slots[si];
+                                                                  int chunks_per_slot, const int* __restrict__ slot_list,
+                                                                  int nslots) {
+  // slot_list: the clouds that need normals (all of them for GICP, the searched side of each pair for
+  // point-to-plane), so that the block -> XCD map spreads exactly those over the chip
+  int li, chunk;
+  nn_block_map(chunks_per_slot, nslots, &li, &chunk);
+  if (li >= nslots) return;
+  const SlotDev& s = slots[slot_list[li]];
   const int i = chunk * kBlock + threadIdx.x;
   if (i >= s.n) return;
   const float4* __restrict__ P = filt + s.off;
@@ -641,8 +645,9 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_WAVES) s3d_knn_moments_kernel(
 
 __global__ void __launch_bounds__(kBlock) s3d_normals_from_moments_kernel(const SlotDev* __restrict__ slots,
                                                                            const double* __restrict__ moments, size_t plane,
-                                                                           CorrVec* __restrict__ normals, int k) {
-  const SlotDev& s = slots[blockIdx.y];
+                                                                           CorrVec* __restrict__ normals, int k,
+                                                                           const int* __restrict__ slot_list) {
+  const SlotDev& s = slots[slot_list[blockIdx.y]];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= s.n) return;
   const double* o = moments + (size_t)(s.off + i);
