@@ -195,6 +195,19 @@ def main():
             nn0 = ctx.profile_nn_kernel(src, tgt, guesses, params, reps=args.nn_reps)
             single = {"latency_ms": round(single_ms, 3), "registrations_per_s": round(1e3 / single_ms, 2),
                       "first_iteration_nn_launch_ms_full_batch": round(nn0["avg_ms"], 4)}
+            # the same batch through the other algorithm of the path (GICP <-> point-to-plane), for the reader
+            other = s3d.ALG_ICP if alg == s3d.ALG_GICP else s3d.ALG_GICP
+            op2 = s3d.default_params(registration_algorithm=other, point_cloud_density=args.density,
+                                     maximum_iterations=args.iters, max_correspondence_distance=2.5,
+                                     correspondence_randomness=20)
+            ctx.align_batch(src, tgt, guesses, op2, opts)
+            t2 = time.perf_counter()
+            for _ in range(3):
+                ctx.align_batch(src, tgt, guesses, op2, opts)
+            ms2 = (time.perf_counter() - t2) / 3 * 1e3
+            single["other_algorithm"] = {"algorithm": "icp (point-to-plane)" if other == s3d.ALG_ICP else "gicp",
+                                         "ms_per_step": round(ms2, 3),
+                                         "registrations_per_s": round(args.pairs / ms2 * 1e3, 2)}
         # ---- CPU baseline: the oracle (a port of the reference path), one thread, same inputs/iterations
         cpu = None
         cpu_par = None
