@@ -494,7 +494,7 @@ def test_bench_contract_line(tmp_path):
     import sys
     from conftest import ROOT
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "4", "--points", "20000",
-                                   "--steps", "1", "--warmup", "1", "--cpu-pairs", "1", "--cpu-threads", "2"],
+                                   "--steps", "1", "--warmup", "1", "--cpu-pairs", "1", "--cpu-threads", "2", "--extras"],
                                   stderr=subprocess.DEVNULL, cwd=ROOT).decode().strip().splitlines()
     line = json.loads(out[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -508,6 +508,8 @@ def test_bench_contract_line(tmp_path):
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     assert line["accuracy"]["status_ok"] == 4
+    sp = line["single_pair"]                       # --extras: configs[1] latency and the other algorithm of the path
+    assert sp["latency_ms"] > 0 and sp["other_algorithm"]["registrations_per_s"] > 0
 
 
 def test_ndt_batch_mixed_inputs(gpu_ctx, fixture_clouds):
