@@ -375,15 +375,19 @@ struct Batch {
   int dbg_nn = getenv("S3D_DBG_NN") ? atoi(getenv("S3D_DBG_NN")) : 0;
   // prof_slot >= 0: count searched / unseeded queries of this launch into the profile counters.
   // compact: the block-compacting mode of the kernel (see s3d_nn_search_kernel).
+  NNArrays nn_arrays() {
+    NNArrays A;
+    A.sorted = sorted(); A.sorted3 = sorted3(); A.cell_start = cells(); A.normals = normals();
+    A.corr_idx = (int*)ctx->corr_idx.p; A.corr_d2 = (float*)ctx->corr_d2.p; A.corr_lb = (float*)ctx->corr_lb.p;
+    A.corr_q = (CorrVec*)ctx->corr_q.p; A.corr_n = (CorrVec*)ctx->corr_n.p;
+    return A;
+  }
   void launch_nn(int mode, float max_d, int prof_slot = -1, bool compact = false) {
     hipStream_t st = ctx->stream;
     const int chunks = cdiv(std::max(max_n_t, 1), kBlock);
     const int pairs8 = P() >= 8 ? cdiv(P(), 8) * 8 : P();
     dim3 grid((unsigned)(pairs8 * chunks));
-    NNArrays A;
-    A.sorted = sorted(); A.sorted3 = sorted3(); A.cell_start = cells(); A.normals = normals();
-    A.corr_idx = (int*)ctx->corr_idx.p; A.corr_d2 = (float*)ctx->corr_d2.p; A.corr_lb = (float*)ctx->corr_lb.p;
-    A.corr_q = (CorrVec*)ctx->corr_q.p; A.corr_n = (CorrVec*)ctx->corr_n.p;
+    NNArrays A = nn_arrays();
     int* pc = (prof_slot >= 0 && prof_slot < 64) ? (int*)ctx->n_active.p + 16 + 2 * prof_slot : nullptr;
     const int cmp = (compact && mode == 0 && !(dbg_nn & 65536)) ? 1 : 0;
     if (mode == 0)
@@ -1690,7 +1694,18 @@ int s3d_profile_nn_kernel(s3d_context* ctx, int n_pairs, s3d_cloud* const* sourc
       HIPCHK(hipMemsetAsync(ctx->corr_d2.p, 0xFF, 4 * std::max<size_t>(b.total_corr, 4), ctx->stream));
       HIPCHK(hipMemsetAsync(ctx->corr_lb.p, 0, 4 * std::max<size_t>(b.total_corr, 4), ctx->stream));
       HIPCHK(hipEventRecord(e0, ctx->stream));
-      b.launch_nn(0, max_d);
+      static const int probe = getenv("S3D_DBG_FIRSTPASS") ? atoi(getenv("S3D_DBG_FIRSTPASS")) : 0;
+      if (probe) {   // measurement aid: the lean first-pass kernels (s3d_kernels.h)
+        NNArrays A = b.nn_arrays();
+        const int chunks = cdiv(b.max_n_t, kBlock);
+        const int p8 = n_pairs >= 8 ? cdiv(n_pairs, 8) * 8 : n_pairs;
+        if (probe == 2)
+          s3d_nn_first_pass_probe_kernel<true><<<(unsigned)(p8 * chunks), kBlock, 0, ctx->stream>>>(b.d_pairs(), b.d_slots(), A, max_d, chunks, n_pairs);
+        else
+          s3d_nn_first_pass_probe_kernel<false><<<(unsigned)(p8 * chunks), kBlock, 0, ctx->stream>>>(b.d_pairs(), b.d_slots(), A, max_d, chunks, n_pairs);
+      } else {
+        b.launch_nn(0, max_d);
+      }
       HIPCHK(hipEventRecord(e1, ctx->stream));
       HIPCHK(hipEventSynchronize(e1));
       float ms = 0;

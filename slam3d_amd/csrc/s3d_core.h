@@ -349,7 +349,7 @@ constexpr float kNNRevalSlack = 0.25f;   // in cells
 // best, so that the examined radius exceeds the neighbour's distance and the NEXT pass can re-validate the
 // correspondence without a search (nn_still_nearest).  Without it every such query walks its whole ball again in
 // every ICP iteration: on the reference's fixture scans those 2 % of the queries were 75 % of the step time.
-template <typename F4T>
+template <typename F4T, bool ROWITER = false>
 S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ cell_start,
                              const F4T* __restrict__ pts, float qx, float qy, float qz, float max_d, float d_hint,
                              int seed_pos = -1, bool seed_trusted = false) {
@@ -399,6 +399,59 @@ S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ c
         float lim2 = limit2();
         // (layers / rows are visited centre-out, alternating sides: once BOTH sides have produced a slab beyond
         // the limit, every later one is beyond it too and the loop ends)
+        if constexpr (ROWITER) {
+        // (probe form, tools_dev/firstpass_probe.py: every lane on its OWN next row; not used by the product kernels)
+        int zfar = 0, yfar = 0, oz = 0, oy = 0, cz = 0;
+        float dz2 = 0.f;
+        bool layer_open = false;
+        auto advance = [&](uint32_t& s, uint32_t& e) -> bool {
+          for (;;) {
+            if (!layer_open) {
+              if (!(oz <= 2 * (z1 - z0) + 1 && zfar != 3)) return false;
+              cz = cz0 + ((oz & 1) ? -((oz + 1) >> 1) : (oz >> 1));
+              const int sz = (oz & 1) ? 1 : 2;
+              ++oz;
+              if (cz < z0 || cz > z1) { zfar |= sz; continue; }
+              const float zlo = g.origin[2] + (float)cz * g.h, zhi = zlo + g.h;
+              const float dz = fmaxf(fmaxf(zlo - qz, qz - zhi) - eps, 0.f);
+              if (dz * dz > lim2) { zfar |= sz; continue; }
+              dz2 = dz * dz; oy = 0; yfar = 0; layer_open = true;
+            }
+            if (!(oy <= 2 * (y1 - y0) + 1 && yfar != 3)) { layer_open = false; continue; }
+            const int cy = cy0 + ((oy & 1) ? -((oy + 1) >> 1) : (oy >> 1));
+            const int sy = (oy & 1) ? 1 : 2;
+            ++oy;
+            if (cy < y0 || cy > y1) { yfar |= sy; continue; }
+            const float ylo = g.origin[1] + (float)cy * g.h, yhi = ylo + g.h;
+            const float dy = fmaxf(fmaxf(ylo - qy, qy - yhi) - eps, 0.f);
+            const float rowd2 = dy * dy + dz2;
+            if (rowd2 > lim2) { yfar |= sy; continue; }
+            int xa = x0, xb = x1;
+            if (best.idx >= 0) {
+              const float rx = sqrtf(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
+              xa = imax(x0, grid_coord(g, 0, qx - rx));
+              xb = imin(x1, grid_coord(g, 0, qx + rx));
+              if (xa > xb) continue;
+            }
+            const int rowbase = g.dim[0] * (cy + g.dim[1] * cz);
+            s = cell_start[rowbase + xa]; e = cell_start[rowbase + xb + 1];
+            return true;
+          }
+        };
+        uint32_t s = 0, e = 0;
+        while (advance(s, e)) {
+          for (uint32_t k = s; k < e; k += S3D_NN_BATCH) {
+            const uint32_t last = e - 1;
+            F4T pp[S3D_NN_BATCH];
+#pragma unroll
+            for (int u = 0; u < S3D_NN_BATCH; ++u) pp[u] = pts[k + u < e ? k + u : last];
+#pragma unroll
+            for (int u = 0; u < S3D_NN_BATCH; ++u)
+              if (k + u < e) nn1_consider(best, pp[u], k + u, qx, qy, qz);
+          }
+          lim2 = limit2();
+        }
+        } else {
         int zfar = 0;
         for (int oz = 0; oz <= 2 * (z1 - z0) + 1 && zfar != 3; ++oz) {
           const int cz = cz0 + ((oz & 1) ? -((oz + 1) >> 1) : (oz >> 1));
@@ -435,6 +488,7 @@ S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ c
             }
             lim2 = limit2();
           }
+        }
         }
       }
     }

@@ -925,6 +925,32 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   }
 }
 
+// Measurement aid (s3d_profile_nn_kernel with S3D_DBG_FIRSTPASS = 1 / 2, tools_dev/firstpass_probe.py): a lean FIRST
+// pass - transform, unseeded search with the first radius, result - without the re-validation, the cooperative
+// search and the compaction of the product kernel, in the lock-step (ROWITER = false) and per-lane (true) loop forms.
+template <bool ROWITER>
+__global__ void __launch_bounds__(kBlock) s3d_nn_first_pass_probe_kernel(const PairDev* __restrict__ pairs,
+                                                                          const SlotDev* __restrict__ slots, NNArrays A,
+                                                                          float max_d, int chunks_per_pair, int npairs) {
+  int pair, chunk;
+  nn_block_map(chunks_per_pair, npairs, &pair, &chunk);
+  if (pair >= npairs) return;
+  const PairDev& P = pairs[pair];
+  const SlotDev& St = slots[P.slot_t];
+  const SlotDev& Ss = slots[P.slot_s];
+  const int i = chunk * kBlock + threadIdx.x;
+  if (i >= St.n) return;
+  const CorrVec p0 = A.sorted3[St.off + i];
+  const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
+  const F3 q = xf_eigen(P.T, pg.x, pg.y, pg.z);
+  const NNResult r = grid_nn1_box<float4, ROWITER>(Ss.g, A.cell_start + Ss.cell_off, A.sorted + Ss.off, q.x, q.y, q.z,
+                                                   max_d, 3.0f * Ss.g.h, -1, false);
+  const int ci = P.corr_off + i;
+  A.corr_idx[ci] = r.pos;
+  A.corr_d2[ci] = r.d2;
+  A.corr_lb[ci] = nn_lower_bound_others(r);
+}
+
 // One thread per query of the pair.  compact = 0: every lane re-validates and, if it must, searches its own query.
 // compact = 1, block-level compaction: the 256 queries of a block are re-validated and classified, the ones that
 // still need a search are packed to the front of the block — near-seeded first, wide ones after them — and
