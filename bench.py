@@ -34,6 +34,23 @@ def _gen_pair(args):
     return syn.make_pair(n, idx)
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _self_launch(n):
+    """Run this script on n ranks (one per GPU) under torch.distributed.run, as the driver does for N > 1."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,11 +68,18 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--nn-reps", type=int, default=20)
     ap.add_argument("--cells-per-point", type=int, default=0, help="search-grid budget (0 = library default)")
+    ap.add_argument("--no-single", action="store_true",
+                    help="skip the single-pair latency (BASELINE.json configs[1]) that is otherwise measured after the "
+                         "timed region: with it off every s3d_nn_search_kernel<0> launch of the run belongs to the "
+                         "batch workload (rocprofv3 average == roofline.avg_launch_ms, the profiles/ cross-check)")
     ap.add_argument("--extras", action="store_true",
-                    help="also time a single pair (configs[1]) and the first-iteration NN launch; off by default so "
-                         "that every s3d_nn_search_kernel<0> launch of the run is the timed workload (rocprof average "
-                         "== roofline.avg_launch_ms)")
+                    help="also time the first-iteration NN launch and the other algorithm of the path")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves.  Fresh child processes (torch.distributed.run),
+        # started BEFORE this process has touched the GPU; this process only relays their output and exit code.
+        sys.exit(_self_launch(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -67,25 +91,32 @@ def main():
     import slam3d_amd as s3d
 
     dist = None
+    shared_devices = False
     # S3D_BENCH_FORCE_DIST=1: take the RCCL path with a single rank too (smoke test of the collective on a 1-GPU box)
     if world > 1 or os.environ.get("S3D_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29513")
-        # S3D_BENCH_BACKEND=gloo: self-test of the multi-rank logic on a box with fewer GPUs than ranks (ranks share
-        # devices modulo the device count, collectives run on CPU tensors); the driver's runs use nccl (= RCCL)
-        backend = os.environ.get("S3D_BENCH_BACKEND", "nccl")
+        # The driver's runs use nccl (= RCCL over xGMI), one rank per GPU.  On a box with FEWER GPUs than ranks RCCL
+        # cannot form the communicator (one rank per device): the ranks then share devices modulo the device count and
+        # the all-gather runs over gloo on host tensors - a self-test of the multi-rank logic, flagged in the output
+        # line ("collective", "ranks_share_devices"), never a scaling measurement.  S3D_BENCH_BACKEND forces either.
+        ndev = max(torch.cuda.device_count(), 1)          # (counting devices does not initialise the GPU)
+        backend = os.environ.get("S3D_BENCH_BACKEND") or ("nccl" if ndev >= world else "gloo")
         if backend == "gloo":
-            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            shared_devices = ndev < world
+            local_rank = local_rank % ndev
             torch.cuda.set_device(local_rank)
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
+        local_rank = 0
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank)
-    coll_dev = torch.device("cpu") if (dist is not None and dist.get_backend() == "gloo") else dev
+    coll_backend = dist.get_backend() if dist is not None else None
+    coll_dev = torch.device("cpu") if coll_backend == "gloo" else dev
 
     # ---- synthetic input (SURVEY.md §8d generator), distinct pairs per rank
     t0 = time.time()
@@ -101,7 +132,9 @@ def main():
     params = s3d.default_params(registration_algorithm=alg, point_cloud_density=args.density,
                                 maximum_iterations=args.iters, max_correspondence_distance=2.5,
                                 correspondence_randomness=20)
-    opts = s3d.ExecOptions(force_iterations=1, check_interval=0, grid_cells_per_point=args.cells_per_point, profile=0)
+    # cache_prepass=0: every step repeats the whole path (voxel filter, grid, k-NN pre-pass) like the reference
+    opts = s3d.ExecOptions(force_iterations=1, check_interval=0, grid_cells_per_point=args.cells_per_point, profile=0,
+                           cache_prepass=0)
     src = [ctx.upload(p[0]) for p in pairs]
     tgt = [ctx.upload(p[1]) for p in pairs]
     guesses = np.tile(np.eye(4), (args.pairs, 1, 1))
@@ -182,19 +215,49 @@ def main():
                                    "steady_avg_launch_ms": round(steady, 4),
                                    "steady_achieved_gbs": round(alg_bytes / (steady * 1e-3) / 1e9, 1),
                                    "steady_frac": round(alg_bytes / (steady * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        # ---- optional extras: single pair latency (BASELINE.json configs[1]), first-iteration NN launch
+        # ---- BASELINE.json configs[1]: one pair through the same entry point (latency of the reference's actual
+        # call pattern, ScanSensor.cpp:113 - one createConstraint per new scan)
         single = None
-        if args.extras:
+        if not args.no_single:
             one_s, one_t = [src[0]], [tgt[0]]
             ctx.align_batch(one_s, one_t, guesses[:1], params, opts)
+            reps = 10
             t1 = time.perf_counter()
-            reps = 5
             for _ in range(reps):
                 ctx.align_batch(one_s, one_t, guesses[:1], params, opts)
             single_ms = (time.perf_counter() - t1) / reps * 1e3
+            single = {"workload": "single %dk-pt synthetic scan pair, %d outer iterations, 1 GPU" %
+                                  (args.points // 1000, args.iters),
+                      "latency_ms": round(single_ms, 3), "registrations_per_s": round(1e3 / single_ms, 2)}
+        # ---- secondary: the mapper's call pattern (ScanSensor.cpp:113, :179-201) - every NEW scan is linked to 8
+        # scans that were registered before.  With the cross-call pre-pass cache (s3d_exec_options.cache_prepass, not
+        # in the reference, never used by the timed region above) the 8 old scans pay the voxel filter / grid / k-NN
+        # pre-pass once, when they were new.
+        mapper = None
+        if not args.no_single and args.pairs >= 16:
+            nb = 8
+            res = {}
+            for label, cache in (("cache_off", 0), ("cache_on", 1)):
+                ctx.cache_control(clear=True)
+                o = s3d.ExecOptions(force_iterations=1, check_interval=0, grid_cells_per_point=args.cells_per_point,
+                                    profile=0, cache_prepass=cache)
+                # the synthetic sources all sample the same scene at the identity pose: any of them is a valid neighbour
+                ctx.align_batch(src[:nb], [tgt[0]] * nb, guesses[:nb], params, o)          # warm-up (fills the cache)
+                n_new = min(args.pairs - 1, 20)
+                t1 = time.perf_counter()
+                for j in range(1, n_new + 1):
+                    ctx.align_batch(src[:nb], [tgt[j]] * nb, guesses[:nb], params, o)
+                res[label] = (time.perf_counter() - t1) / n_new * 1e3
+            ctx.cache_control(clear=True)
+            mapper = {"workload": "each new %dk-pt scan registered against %d earlier scans (one batch call per new "
+                                  "scan), %d outer iterations" % (args.points // 1000, nb, args.iters),
+                      "ms_per_new_scan_cache_off": round(res["cache_off"], 3),
+                      "ms_per_new_scan_cache_on": round(res["cache_on"], 3),
+                      "links_per_s_cache_on": round(nb / res["cache_on"] * 1e3, 1)}
+        if args.extras:
+            single = single or {}
             nn0 = ctx.profile_nn_kernel(src, tgt, guesses, params, reps=args.nn_reps)
-            single = {"latency_ms": round(single_ms, 3), "registrations_per_s": round(1e3 / single_ms, 2),
-                      "first_iteration_nn_launch_ms_full_batch": round(nn0["avg_ms"], 4)}
+            single["first_iteration_nn_launch_ms_full_batch"] = round(nn0["avg_ms"], 4)
             # the same batch through the other algorithm of the path (GICP <-> point-to-plane), for the reader
             other = s3d.ALG_ICP if alg == s3d.ALG_GICP else s3d.ALG_GICP
             op2 = s3d.default_params(registration_algorithm=other, point_cloud_density=args.density,
@@ -247,17 +310,22 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 points / f64 accumulators", "data": "synthetic",
             "config": {"workload": "batch of %d independent %dk-pt synthetic scan pairs per GPU, %d outer "
                                    "iterations (early exit disabled), %s, voxel leaf %.2f m, "
-                                   "max_correspondence_distance 2.5 m, k=20" %
+                                   "max_correspondence_distance 2.5 m, k=20, no cross-call caching (every step runs voxel filter, grid and "
+                                   "k-NN pre-pass of all clouds again)" %
                                    (args.pairs, args.points // 1000, args.iters,
                                     "GICP (reference default)" if alg == s3d.ALG_GICP else "point-to-plane ICP",
                                     args.density),
                        "pairs_per_gpu": args.pairs, "points": args.points, "iterations": args.iters,
                        "algorithm": args.algorithm, "parallelism": "pair-sharded x%d" % world,
-                       "collective": "all_gather of 128-B edge records (RCCL)" if world > 1 else "none"},
+                       "collective": ("none" if dist is None else
+                                      "all_gather of 128-B edge records (%s)" %
+                                      ("RCCL over xGMI" if coll_backend == "nccl" else "gloo on host tensors")),
+                       "ranks_share_devices": shared_devices},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "cpu_baseline_parallel": cpu_par,
             "single_pair": single,
+            "mapper_pattern": mapper,
             "step_ms": step_ms,
             "stage_ms": {k: round(v, 3) for k, v in prof.items() if k.endswith("_ms") and k != "nn_launch_ms"},
             "nn_launch_ms": prof["nn_launch_ms"],

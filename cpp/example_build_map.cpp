@@ -7,7 +7,7 @@
 #include <cstring>
 #include <fstream>
 
-#include "slam3d/sensor/hip/PointCloudSensor.hpp"
+#include "slam3d/sensor/pcl/PointCloudSensor.hpp"
 
 using namespace slam3d;
 
@@ -15,7 +15,7 @@ static PointCloud::Ptr load_bin(const char* path) {
   PointCloud::Ptr c(new PointCloud);
   std::ifstream f(path, std::ios::binary);
   float v[4];
-  while (f.read(reinterpret_cast<char*>(v), sizeof v)) c->push_back(PointType{v[0], v[1], v[2], 1.f});
+  while (f.read(reinterpret_cast<char*>(v), sizeof v)) c->push_back(makePoint(v[0], v[1], v[2]));
   return c;
 }
 
@@ -55,11 +55,11 @@ int main(int argc, char** argv) {
       sensor.setRegistrationParameters(fine, false);
       sensor.setRegistrationParameters(coarse, true);
       Transform guess = vertices[0].correctedPose.inverse() * vertices[2].correctedPose;      // Graph::getTransform
-      std::printf("PATCH %zu %zu\n", std::dynamic_pointer_cast<PointCloudMeasurement>(pa)->getPointCloud()->size(),
-                  std::dynamic_pointer_cast<PointCloudMeasurement>(pb)->getPointCloud()->size());
+      std::printf("PATCH %zu %zu\n", ptr::dynamic_pointer_cast<PointCloudMeasurement>(pa)->getPointCloud()->size(),
+                  ptr::dynamic_pointer_cast<PointCloudMeasurement>(pb)->getPointCloud()->size());
       try {
         Constraint::Ptr c = sensor.createConstraint(pa, pb, guess, true);
-        SE3Constraint::Ptr se3 = std::dynamic_pointer_cast<SE3Constraint>(c);
+        SE3Constraint::Ptr se3 = ptr::dynamic_pointer_cast<SE3Constraint>(c);
         std::printf("OK %s\n", se3->getTypeName());
         for (int r = 0; r < 4; ++r)
           std::printf("%.12g %.12g %.12g %.12g\n", se3->getRelativePose()(r, 0), se3->getRelativePose()(r, 1),

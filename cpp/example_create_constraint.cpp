@@ -5,7 +5,7 @@
 #include <cstring>
 #include <fstream>
 
-#include "slam3d/sensor/hip/PointCloudSensor.hpp"
+#include "slam3d/sensor/pcl/PointCloudSensor.hpp"
 
 using namespace slam3d;
 
@@ -13,7 +13,7 @@ static PointCloud::Ptr load_bin(const char* path) {
   PointCloud::Ptr c(new PointCloud);
   std::ifstream f(path, std::ios::binary);
   float v[4];
-  while (f.read(reinterpret_cast<char*>(v), sizeof v)) c->push_back(PointType{v[0], v[1], v[2], 1.f});
+  while (f.read(reinterpret_cast<char*>(v), sizeof v)) c->push_back(makePoint(v[0], v[1], v[2]));
   return c;
 }
 
@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
     Measurement::Ptr m1(new PointCloudMeasurement(load_bin(argv[1]), "robot", sensor.getName(), Transform::Identity()));
     Measurement::Ptr m2(new PointCloudMeasurement(load_bin(argv[2]), "robot", sensor.getName(), Transform::Identity()));
     Constraint::Ptr c = sensor.createConstraint(m1, m2, Transform::Identity(), loop);
-    SE3Constraint::Ptr se3 = std::dynamic_pointer_cast<SE3Constraint>(c);
+    SE3Constraint::Ptr se3 = ptr::dynamic_pointer_cast<SE3Constraint>(c);
     std::printf("OK %s\n", se3->getTypeName());
     for (int r = 0; r < 4; ++r)
       std::printf("%.12g %.12g %.12g %.12g\n", se3->getRelativePose()(r, 0), se3->getRelativePose()(r, 1),

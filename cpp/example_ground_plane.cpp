@@ -6,7 +6,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "slam3d/sensor/hip/PointCloudSensor.hpp"
+#include "slam3d/sensor/pcl/PointCloudSensor.hpp"
 
 using namespace slam3d;
 
@@ -18,7 +18,7 @@ int main(int argc, char** argv) {
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) return 2;
   float p[4];
-  while (std::fread(p, sizeof(float), 4, f) == 4) cloud->push_back(PointType{p[0], p[1], p[2], 1.f});
+  while (std::fread(p, sizeof(float), 4, f) == 4) cloud->push_back(makePoint(p[0], p[1], p[2]));
   std::fclose(f);
   const size_t before = cloud->size();
   sensor.fillGroundPlane(cloud, std::atof(argv[2]));

@@ -1,11 +1,13 @@
 // slam3d/core/Types.hpp (MI355X build) — the boundary value types of the registration path.
 //
 // Mirrors the names and members the hot path and its callers use from the reference's
-// slam3d/core/Types.hpp:46-187 and slam3d/core/Sensor.hpp:44-72.  The reference builds these on
-// Eigen + Boost, which are not available in this build environment; this header is a
-// dependency-free stand-in with the same spelling so that code written against the reference
-// (createConstraint callers, tests) reads the same.  On a machine that has the real slam3d core,
-// use the real headers and the binding shown in INTEGRATION.md instead.
+// slam3d/core/Types.hpp:46-187 and slam3d/core/Sensor.hpp:44-72, so that code written against the reference
+// (createConstraint callers, tests) reads the same.  The reference builds these on Eigen and Boost
+// (Types.hpp:30-39): where those headers are installed they are used - Transform, Position and Covariance<N>
+// are then the reference's own Eigen typedefs (Types.hpp:49-54) and the smart pointers are boost::shared_ptr
+// (Types.hpp:30) - and only where they are missing (this build environment has neither) the dependency-free
+// stand-ins below take their place, with the same spelling.  -DS3D_MIRROR_NO_EIGEN / -DS3D_MIRROR_NO_BOOST force
+// the stand-ins.  On a machine that has the whole slam3d core, use its headers and the binding of INTEGRATION.md.
 #pragma once
 
 #include <cmath>
@@ -17,11 +19,40 @@
 #include <string>
 #include <vector>
 
+#if defined(__has_include)
+#if __has_include(<Eigen/Geometry>) && !defined(S3D_MIRROR_NO_EIGEN)
+#define S3D_MIRROR_HAVE_EIGEN 1
+#endif
+#if __has_include(<boost/shared_ptr.hpp>) && __has_include(<boost/make_shared.hpp>) && !defined(S3D_MIRROR_NO_BOOST)
+#define S3D_MIRROR_HAVE_BOOST 1
+#endif
+#endif
+
+#if defined(S3D_MIRROR_HAVE_BOOST)
+#include <boost/make_shared.hpp>
+#include <boost/pointer_cast.hpp>
+#include <boost/shared_ptr.hpp>
+namespace slam3d { namespace ptr { using boost::shared_ptr; using boost::make_shared; using boost::dynamic_pointer_cast; } }
+#else
+namespace slam3d { namespace ptr { using std::shared_ptr; using std::make_shared; using std::dynamic_pointer_cast; } }
+#endif
+
+#if defined(S3D_MIRROR_HAVE_EIGEN)
+#include <Eigen/Geometry>
+#endif
+
 namespace slam3d {
 
 typedef unsigned IdType;
 typedef double ScalarType;
 
+#if defined(S3D_MIRROR_HAVE_EIGEN)
+// slam3d/core/Types.hpp:49-54, verbatim semantics: the mirror's code only uses operator(), data(), inverse(),
+// operator*, Identity() and translation(), which Eigen provides with the same meaning (column-major 4x4 double)
+typedef Eigen::Matrix<ScalarType, 3, 1> Position;
+typedef Eigen::Transform<ScalarType, 3, Eigen::Isometry> Transform;
+template <unsigned N> using Covariance = Eigen::Matrix<ScalarType, N, N>;
+#else
 struct Position {  // Eigen::Matrix<double,3,1>
   double v[3] = {0, 0, 0};
   double& operator[](int i) { return v[i]; }
@@ -70,13 +101,15 @@ struct Covariance {  // Eigen::Matrix<double,N,N>, row/col symmetric use only
   double operator()(unsigned r, unsigned c) const { return v[r * N + c]; }
 };
 
+#endif  // S3D_MIRROR_HAVE_EIGEN
+
 // Types.hpp:108-135
 typedef std::string Uuid;  // reference: boost::uuids::uuid (random); here a process-unique string
-Uuid generateUuid();        // defined in sensor/hip/PointCloudSensor.cpp
+Uuid generateUuid();        // defined in sensor/pcl/PointCloudSensor.cpp
 
 class Measurement {
  public:
-  typedef std::shared_ptr<Measurement> Ptr;  // reference: boost::shared_ptr
+  typedef ptr::shared_ptr<Measurement> Ptr;  // boost::shared_ptr where Boost is installed (Types.hpp:30)
   Measurement(const std::string& r, const std::string& s, const Transform& p)
       : mRobotName(r), mSensorName(s), mSensorPose(p), mInverseSensorPose(p.inverse()), mUniqueId(generateUuid()) {}
   virtual ~Measurement() {}
@@ -125,7 +158,7 @@ enum ConstraintType { TENTATIVE, SE3, GRAVITY, POSITION, ORIENTATION, POSE };
 // Types.hpp:137-187
 class Constraint {
  public:
-  typedef std::shared_ptr<Constraint> Ptr;
+  typedef ptr::shared_ptr<Constraint> Ptr;
   explicit Constraint(const std::string& s) : mSensorName(s) {}
   virtual ~Constraint() {}
   virtual ConstraintType getType() = 0;
@@ -137,7 +170,7 @@ class Constraint {
 
 class SE3Constraint : public Constraint {
  public:
-  typedef std::shared_ptr<SE3Constraint> Ptr;
+  typedef ptr::shared_ptr<SE3Constraint> Ptr;
   SE3Constraint(const std::string& s, const Transform& t, const Covariance<6>& i) : Constraint(s), mRelativePose(t), mInformation(i) {}
   ConstraintType getType() override { return SE3; }
   const char* getTypeName() override { return "SE(3)"; }

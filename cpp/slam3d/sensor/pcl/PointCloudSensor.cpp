@@ -50,9 +50,10 @@ PointCloudSensor::PointCloudSensor(const std::string& n, Logger* l, int device) 
   mMapOutlierNeighbors = 3;
   if (s3d_context_create(device, nullptr, &mContext) != S3D_STATUS_OK)
     throw std::runtime_error("slam3d (MI355X build): no usable HIP device, and there is no CPU fallback");
+  mContextHolder = std::make_shared<ContextHolder>(mContext);
 }
 
-PointCloudSensor::~PointCloudSensor() { s3d_context_destroy(mContext); }
+PointCloudSensor::~PointCloudSensor() {}   // the context goes with mContextHolder
 
 PointCloud::Ptr PointCloudSensor::downsample(PointCloud::Ptr in, double leaf_size) {
   PointCloud::Ptr out(new PointCloud);
@@ -63,7 +64,7 @@ PointCloud::Ptr PointCloudSensor::downsample(PointCloud::Ptr in, double leaf_siz
                                         leaf_size, packed.data(), &n_out);
     if (st != S3D_STATUS_OK) throw std::runtime_error("s3d_voxel_downsample failed");
     out->points.resize(n_out);
-    for (int i = 0; i < n_out; ++i) out->points[i] = PointType{packed[3 * i], packed[3 * i + 1], packed[3 * i + 2], 1.f};
+    for (int i = 0; i < n_out; ++i) out->points[i] = makePoint(packed[3 * i], packed[3 * i + 1], packed[3 * i + 2]);
     out->width = (uint32_t)n_out;
     out->height = 1;
     out->is_dense = true;
@@ -96,7 +97,7 @@ std::shared_ptr<DeviceCloud> PointCloudSensor::deviceCloudOf(const PointCloudMea
   s3d_cloud* h = nullptr;
   if (s3d_cloud_upload(mContext, c->size() ? &c->points[0].x : dummy, (int)c->size(), 4, &h) != S3D_STATUS_OK)
     throw std::runtime_error(std::string("HIP back-end error: ") + s3d_last_error(mContext));
-  d = std::make_shared<DeviceCloud>(h);
+  d = std::make_shared<DeviceCloud>(mContextHolder, h);
   m->setDeviceCloud(d);
   return d;
 }
@@ -122,7 +123,7 @@ PointCloud::Ptr PointCloudSensor::removeOutliers(PointCloud::Ptr in, double radi
     throw std::runtime_error(std::string("HIP back-end error: ") + s3d_last_error(mContext));
   PointCloud::Ptr out(new PointCloud);
   out->points.resize(n_out);
-  for (int i = 0; i < n_out; ++i) out->points[i] = PointType{packed[3 * i], packed[3 * i + 1], packed[3 * i + 2], 1.f};
+  for (int i = 0; i < n_out; ++i) out->points[i] = makePoint(packed[3 * i], packed[3 * i + 1], packed[3 * i + 2]);
   out->width = (uint32_t)n_out;
   return out;
 }
@@ -132,7 +133,7 @@ void PointCloudSensor::gather(const VertexObjectList& vertices, std::vector<std:
   if (!mStorage) throw std::runtime_error("PointCloudSensor: no MeasurementStorage set (setMeasurementStorage)");
   for (const VertexObject& v : vertices) {
     Measurement::Ptr m = mStorage->get(v.measurementUuid);   // reference: mMapper->getGraph()->getMeasurement(uuid)
-    PointCloudMeasurement::Ptr pcl = std::dynamic_pointer_cast<PointCloudMeasurement>(m);
+    PointCloudMeasurement::Ptr pcl = ptr::dynamic_pointer_cast<PointCloudMeasurement>(m);
     if (!pcl) {   // PointCloudSensor.cpp:243-247
       mLogger->message(ERROR, "Measurement in getAccumulatedCloud() is not a point cloud!");
       throw BadMeasurementType();
@@ -152,7 +153,7 @@ PointCloud::Ptr PointCloudSensor::getAccumulatedCloud(const VertexObjectList& ve
   s3d_cloud* accu = nullptr;
   if (s3d_cloud_accumulate(mContext, (int)clouds.size(), clouds.data(), poses.data(), nullptr, &accu) != S3D_STATUS_OK)
     throw std::runtime_error(std::string("HIP back-end error: ") + s3d_last_error(mContext));
-  DeviceCloud guard(accu);
+  DeviceCloud guard(mContextHolder, accu);
   return download(accu);
 }
 
@@ -165,7 +166,7 @@ Measurement::Ptr PointCloudSensor::createCombinedMeasurement(const VertexObjectL
   if (s3d_cloud_accumulate(mContext, (int)clouds.size(), clouds.data(), poses.data(), pose.data(), &shifted) !=
       S3D_STATUS_OK)
     throw std::runtime_error(std::string("HIP back-end error: ") + s3d_last_error(mContext));
-  std::shared_ptr<DeviceCloud> dev = std::make_shared<DeviceCloud>(shifted);
+  std::shared_ptr<DeviceCloud> dev = std::make_shared<DeviceCloud>(mContextHolder, shifted);
   PointCloud::Ptr cloud = download(shifted);
   mLogger->message(DEBUG, "Patch pointcloud has " + std::to_string(cloud->size()) + " points.");
   PointCloudMeasurement::Ptr m(new PointCloudMeasurement(cloud, "AccumulatedPointcloud", mName, Transform::Identity()));
@@ -182,7 +183,7 @@ PointCloud::Ptr PointCloudSensor::buildMap(const VertexObjectList& vertices) con
   if (s3d_build_map(mContext, (int)clouds.size(), clouds.data(), poses.data(), mMapOutlierRadius, mMapOutlierNeighbors,
                     mMapResolution, &map) != S3D_STATUS_OK)
     throw std::runtime_error(std::string("HIP back-end error: ") + s3d_last_error(mContext));
-  DeviceCloud guard(map);
+  DeviceCloud guard(mContextHolder, map);
   mLogger->message(INFO, "Generated Pointcloud from " + std::to_string(vertices.size()) + " scans.");
   return download(map);
 }
@@ -193,7 +194,7 @@ void PointCloudSensor::fillGroundPlane(PointCloud::Ptr cloud, ScalarType radius)
   const float* xyz = n > 0 ? &cloud->points[0].x : nullptr;
   int n_ring = 0;
   // at most (radius / res + 1) rings of (2 pi radius / res + 2) points
-  const double rings = radius / mMapResolution + 2, per_ring = 2 * 3.14159265358979323846 * radius / mMapResolution + 3;
+  const double rings = radius / mMapResolution + 2, per_ring = 2 * 3.141592654 * radius / mMapResolution + 3;   // the reference's PI (:48)
   std::vector<float> ring((size_t)(rings * per_ring) * 3 + 3);
   const int st = s3d_fill_ground_plane(mContext, xyz, n, 4, radius, mMapResolution, ring.data(), (int)(ring.size() / 3),
                                        &n_ring, nullptr);
@@ -202,7 +203,7 @@ void PointCloudSensor::fillGroundPlane(PointCloud::Ptr cloud, ScalarType radius)
     return;
   }
   if (st != S3D_STATUS_OK) throw std::runtime_error(std::string("HIP back-end error: ") + s3d_last_error(mContext));
-  for (int i = 0; i < n_ring; ++i) cloud->push_back(PointType{ring[3 * i], ring[3 * i + 1], ring[3 * i + 2], 1.f});
+  for (int i = 0; i < n_ring; ++i) cloud->push_back(makePoint(ring[3 * i], ring[3 * i + 1], ring[3 * i + 2]));
 }
 
 namespace {
@@ -340,8 +341,11 @@ Transform PointCloudSensor::align(const PointCloudMeasurement::Ptr& source, cons
   std::shared_ptr<DeviceCloud> s = deviceCloudOf(source), t = deviceCloudOf(target);
   Transform result;
   s3d_align_info info;
+  s3d_exec_options opts;
+  std::memset(&opts, 0, sizeof opts);
+  opts.cache_prepass = mPrepassCache ? 1 : 0;
   const int st = s3d_align_clouds(mContext, s->cloud, t->cloud, guess.data(),
-                                  static_cast<const s3d_reg_params*>(&config), nullptr, result.data(), &info);
+                                  static_cast<const s3d_reg_params*>(&config), &opts, result.data(), &info);
   switch (st) {
     case S3D_STATUS_OK: return result;
     case S3D_STATUS_TOO_FEW_POINTS:   // PointCloudSensor.cpp:135
@@ -358,6 +362,12 @@ Transform PointCloudSensor::align(const PointCloudMeasurement::Ptr& source, cons
       throw std::runtime_error("Registration algorithm not available in this build.");
     case S3D_STATUS_UNKNOWN_ALGORITHM:  // :164
       throw std::runtime_error("Unknown registration algorithm specified.");
+    case S3D_STATUS_INVALID_ARGUMENT:
+      // PCL accepts these and fails later ("Number of points in cloud is less than k", an empty NDT grid); the
+      // back-end refuses them up front: correspondence_randomness outside 1..64 or above the filtered cloud size,
+      // NDT resolution <= 0
+      throw std::runtime_error("Registration parameters not supported by the MI355X back-end (correspondence_randomness "
+                               "must be 1..64 and at most the filtered cloud size; NDT resolution must be positive).");
     default:
       throw std::runtime_error(std::string("HIP back-end error: ") + s3d_last_error(mContext));
   }
@@ -367,8 +377,8 @@ Constraint::Ptr PointCloudSensor::createConstraint(const Measurement::Ptr& sourc
                                                    const Transform& odometry, bool loop) {
   // PointCloudSensor.cpp:274
   Transform guess = source->getInverseSensorPose() * odometry * target->getSensorPose();
-  PointCloudMeasurement::Ptr sourceCloud = std::dynamic_pointer_cast<PointCloudMeasurement>(source);
-  PointCloudMeasurement::Ptr targetCloud = std::dynamic_pointer_cast<PointCloudMeasurement>(target);
+  PointCloudMeasurement::Ptr sourceCloud = ptr::dynamic_pointer_cast<PointCloudMeasurement>(source);
+  PointCloudMeasurement::Ptr targetCloud = ptr::dynamic_pointer_cast<PointCloudMeasurement>(target);
   if (!sourceCloud || !targetCloud) {  // :279-283
     mLogger->message(ERROR, "Measurement given to createConstraint() is not a PointCloud!");
     throw BadMeasurementType();

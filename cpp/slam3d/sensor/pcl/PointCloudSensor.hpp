@@ -1,14 +1,17 @@
-// slam3d::PointCloudSensor on the MI355X back-end.
+// slam3d::PointCloudSensor on the MI355X back-end — include path, class names, method names, argument meaning and
+// exceptions of the reference's slam3d/sensor/pcl/PointCloudSensor.hpp:43-243:
+//   createConstraint (PointCloudSensor.cpp:269-299), createCombinedMeasurement (:258-266), getAccumulatedCloud
+//   (:235-256), buildMap (:301-318), removeOutliers (:211-226), fillGroundPlane (:362-388), loadPLY (:390-417),
+//   setRegistrationParameters (:320-340), downsample (:190-201), downsampleScan (:203-209), transform (:228-233) and
+//   the scalar setters.
+// The arithmetic runs in libslam3d_hip.so through the C ABI (include/slam3d_hip.h); this header only does what the
+// reference's own lines around PCL do: casts, exceptions, logging.  Not mirrored: the ScanSensor front-end policy
+// (addMeasurement, link, linkToNeighbors) and the Mapper / Graph of slam3d core it talks to (out of
+// scope; the candidate rules are restated in slam3d_amd/posegraph.py); the measurements of a patch therefore come
+// from a MeasurementStorage handed in directly instead of mMapper->getGraph().
 //
-// Same class names, method names, argument meaning and exceptions as the reference's
-// slam3d/sensor/pcl/PointCloudSensor.hpp:43-243 for the registration path:
-//   createConstraint (PointCloudSensor.cpp:269-299), setRegistrationParameters (:320-340),
-//   downsample (:190-201), downsampleScan (:203-209), transform (:228-233), the scalar setters.
-// The arithmetic runs in libslam3d_hip.so through the C ABI (include/slam3d_hip.h); this header
-// only does what the reference's own 120 lines around PCL do: casts, exceptions, logging.
-// Out of scope here (SURVEY.md §8f "next"): getAccumulatedCloud / createCombinedMeasurement /
-// buildMap / removeOutliers / fillGroundPlane / loadPLY and the ScanSensor front-end policy, which
-// need the Mapper/Graph of slam3d core.
+// pcl::PointXYZ / pcl::PointCloud are used where PCL's headers are installed (PointCloudSensor.hpp:43-44); this
+// build environment has no PCL, and the stand-ins below carry the members the path touches.
 #pragma once
 
 #include <cstdint>
@@ -23,8 +26,24 @@ namespace slam3d {
 
 static_assert(sizeof(RegistrationParameters) == sizeof(s3d_reg_params), "RegistrationParameters is the C ABI struct");
 
+#if defined(__has_include)
+#if __has_include(<pcl/point_cloud.h>) && __has_include(<pcl/point_types.h>) && !defined(S3D_MIRROR_NO_PCL)
+#define S3D_MIRROR_HAVE_PCL 1
+#endif
+#endif
+
+#if defined(S3D_MIRROR_HAVE_PCL)
+}  // namespace slam3d
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+namespace slam3d {
+typedef pcl::PointXYZ PointType;                 // PointCloudSensor.hpp:43
+typedef pcl::PointCloud<PointType> PointCloud;   // PointCloudSensor.hpp:44
+inline PointType makePoint(float x, float y, float z) { return PointType(x, y, z); }
+#else
 // pcl::PointXYZ: 16 bytes (x, y, z, padding)
 struct PointType { float x, y, z, data_w; };
+inline PointType makePoint(float x, float y, float z) { return PointType{x, y, z, 1.f}; }
 struct PointCloudHeader { uint64_t stamp = 0; uint32_t seq = 0; std::string frame_id; };
 
 // the members of pcl::PointCloud<pcl::PointXYZ> the path touches
@@ -40,22 +59,32 @@ class PointCloud {
   void push_back(const PointType& p) { points.push_back(p); width = (uint32_t)points.size(); }
   PointCloud& operator+=(const PointCloud& o) { points.insert(points.end(), o.points.begin(), o.points.end()); width = (uint32_t)points.size(); return *this; }
 };
+#endif  // S3D_MIRROR_HAVE_PCL
 
 // PointCloudSensor.hpp:50-100
 // The HBM copy of a measurement's cloud.  Not in the reference: it is what lets a scan be uploaded once and
 // then registered against every neighbour (ScanSensor::linkToNeighbors), and a loop-closure patch go from
 // createCombinedMeasurement into createConstraint without visiting the host.
+struct ContextHolder {   // the sensor's s3d_context; device clouds refer to it weakly (a measurement may outlive its sensor)
+  explicit ContextHolder(s3d_context* c) : ctx(c) {}
+  ~ContextHolder() { s3d_context_destroy(ctx); }
+  ContextHolder(const ContextHolder&) = delete;
+  ContextHolder& operator=(const ContextHolder&) = delete;
+  s3d_context* ctx;
+};
 struct DeviceCloud {
-  explicit DeviceCloud(s3d_cloud* c) : cloud(c) {}
-  ~DeviceCloud() { s3d_cloud_release(nullptr, cloud); }
+  DeviceCloud(const std::shared_ptr<ContextHolder>& owner, s3d_cloud* c) : context(owner), cloud(c) {}
+  // released through its context while that is alive: the context then also drops the cloud's cached pre-pass products
+  ~DeviceCloud() { std::shared_ptr<ContextHolder> h = context.lock(); s3d_cloud_release(h ? h->ctx : nullptr, cloud); }
   DeviceCloud(const DeviceCloud&) = delete;
   DeviceCloud& operator=(const DeviceCloud&) = delete;
+  std::weak_ptr<ContextHolder> context;
   s3d_cloud* cloud;
 };
 
 class PointCloudMeasurement : public Measurement {
  public:
-  typedef std::shared_ptr<PointCloudMeasurement> Ptr;
+  typedef ptr::shared_ptr<PointCloudMeasurement> Ptr;   // boost::shared_ptr where Boost is installed
   PointCloudMeasurement(const PointCloud::Ptr& cloud, const std::string& r, const std::string& s, const Transform& p)
       : Measurement(r, s, p), mPointCloud(cloud) {}
   const PointCloud::Ptr getPointCloud() const { return mPointCloud; }
@@ -85,6 +114,8 @@ class Sensor {
 class ScanSensor : public Sensor {
  public:
   ScanSensor(const std::string& n, Logger* l) : Sensor(n, l) {}
+  // ScanSensor.hpp:105 — builds the patch a loop-closure link is registered against (ScanSensor.cpp:269)
+  virtual Measurement::Ptr createCombinedMeasurement(const VertexObjectList& vertices, Transform pose) const = 0;
   // ScanSensor.hpp:122-125 — THE plugin hook of the hot path
   virtual Constraint::Ptr createConstraint(const Measurement::Ptr& source, const Measurement::Ptr& target,
                                            const Transform& odometry, bool loop) = 0;
@@ -108,9 +139,14 @@ class PointCloudSensor : public ScanSensor {
   // ---- patches and maps (reference: PointCloudSensor.hpp:127, :200-216).  The reference reaches the
   // measurements through mMapper->getGraph(); the mirror has no Mapper/Graph, the storage is handed in directly.
   void setMeasurementStorage(MeasurementStorage* s) { mStorage = s; }
+  // Not in the reference (PointCloudSensor.cpp:127-131 re-filters both clouds in every align()): keep the voxel
+  // filter / search grid / k-NN normals of every measurement's device cloud in HBM between createConstraint calls
+  // (s3d_exec_options.cache_prepass).  On by default: a mapper links every scan to several others
+  // (ScanSensor.cpp:113, :179-201); the results are bit-identical either way.
+  void setPrepassCache(bool on) { mPrepassCache = on; }
   PointCloud::Ptr removeOutliers(PointCloud::Ptr source, double radius, unsigned min_neighbors) const;
   PointCloud::Ptr getAccumulatedCloud(const VertexObjectList& vertices) const;
-  Measurement::Ptr createCombinedMeasurement(const VertexObjectList& vertices, Transform pose) const;
+  Measurement::Ptr createCombinedMeasurement(const VertexObjectList& vertices, Transform pose) const override;
   PointCloud::Ptr buildMap(const VertexObjectList& vertices) const;
   // reference PointCloudSensor.hpp:227: fit the ground plane (RANSAC, scored on the device) and append rings of
   // points on it out to `radius` at the map resolution
@@ -144,8 +180,10 @@ class PointCloudSensor : public ScanSensor {
               std::vector<s3d_cloud*>& clouds, std::vector<double>& poses) const;
   PointCloud::Ptr download(s3d_cloud* c) const;
   MeasurementStorage* mStorage = nullptr;
+  bool mPrepassCache = true;
   PointCloudMeasurement::Ptr mInitialMap;
-  s3d_context* mContext;   // one HIP device + stream; calls are serialised inside the library,
+  std::shared_ptr<ContextHolder> mContextHolder;
+  s3d_context* mContext;   // == mContextHolder->ctx: one HIP device + stream; calls are serialised inside the library,
                            // so createConstraint may be entered from the link thread (ScanSensor.cpp:210)
 };
 

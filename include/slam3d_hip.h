@@ -8,7 +8,7 @@
  * host pointers are borrowed for the duration of the call, results are returned
  * by value into caller buffers, no device pointer crosses the ABI except through
  * the explicit s3d_cloud handle.  The C++ mirror of the reference classes that
- * sits on top of this ABI is cpp/slam3d/sensor/hip/PointCloudSensor.hpp; the
+ * sits on top of this ABI is cpp/slam3d/sensor/pcl/PointCloudSensor.hpp; the
  * binding stub is shown in INTEGRATION.md.
  *
  * There is no CPU fallback: every call fails with S3D_STATUS_BACKEND_ERROR when
@@ -34,10 +34,18 @@ typedef struct s3d_cloud   s3d_cloud;   /* a device-resident point cloud (immuta
 /* knobs that are not part of slam3d::RegistrationParameters */
 typedef struct s3d_exec_options {
   int force_iterations;     /* != 0: run exactly maximum_iterations outer iterations (bench mode, no early exit) */
-  int check_interval;       /* host polls "all pairs converged" every N outer iterations (0 = default 2)          */
+  int check_interval;       /* host polls "all pairs converged" every N outer iterations (0 = default 4)          */
   int grid_cells_per_point; /* search-grid budget, cells per input point (0 = default 2)                         */
   int profile;              /* != 0: record per-stage HIP-event timings, read with s3d_last_profile();
                                >= 2: also count the searched queries per NN launch (slows the first passes)      */
+  int cache_prepass;        /* 0 (default): like the reference, every call voxel-filters, grids and runs the k-NN
+                               pre-pass of both clouds again (PointCloudSensor.cpp:127-131, "no caching").
+                               1: keep those per-cloud products in HBM, keyed by (s3d_cloud, point_cloud_density,
+                               grid budget, correspondence_randomness), and reuse them in later calls on the same
+                               context - the mapper pattern (ScanSensor.cpp:113 links every new scan to the previous
+                               one, :179-201 to its neighbours) then pays the pre-pass once per scan.  Results are
+                               bit-identical either way.  Entries die with s3d_cloud_release(ctx, cloud); see
+                               s3d_context_cache_control.  A cloud must not be modified while it is cached.       */
 } s3d_exec_options;
 
 typedef struct s3d_align_info {   /* diagnostics of one align() */
@@ -65,6 +73,11 @@ const char* s3d_last_error(const s3d_context* ctx);
 /* fills "name|gcnArch|CUs|HBM bytes"; returns S3D_STATUS_BACKEND_ERROR without a device */
 int  s3d_backend_info(int device, char* buf, int len);
 int  s3d_last_profile(const s3d_context* ctx, s3d_profile* out);
+/* the cross-call pre-pass cache of a context (s3d_exec_options.cache_prepass): limit_bytes > 0 sets the HBM budget
+ * (default 16 GiB, least-recently-used entries are dropped first), clear != 0 drops every entry.  stats (may be
+ * NULL): entries, bytes, hits, misses (per cloud and call, since the context was created). */
+typedef struct s3d_cache_stats { long long entries, bytes, hits, misses; } s3d_cache_stats;
+int  s3d_context_cache_control(s3d_context* ctx, long long limit_bytes, int clear, s3d_cache_stats* stats);
 void s3d_default_params(s3d_reg_params* p);          /* RegistrationParameters.hpp:36-97 defaults */
 
 /* ---- device-resident clouds ----------------------------------------------------- */
@@ -183,6 +196,40 @@ int  s3d_fit_plane(s3d_context* ctx, const float* xyz, int n, int stride, double
                    double probability, s3d_plane_fit* out);
 int  s3d_fill_ground_plane(s3d_context* ctx, const float* xyz, int n, int stride, double radius, double map_resolution,
                            float* out_xyz, int out_capacity, int* n_out, s3d_plane_fit* fit /* may be NULL */);
+
+/* ==== C1  loop-closure sweep sharded over the GPUs of one node ==========================
+ * Replaces the serial candidate loop of ScanSensor::linkToNeighbors (slam3d/core/ScanSensor.cpp:170-202, also
+ * run from the detached link thread, :209-210), which calls createConstraint once per candidate on the CPU.
+ * One process, one rank (s3d_context + host thread) per device: the pair list is cut into contiguous blocks
+ * (s3d_sweep_shard_range), every rank uploads the clouds its block references on first use (they stay resident
+ * for later sweeps) and runs one s3d_align_batch; then ONE all-gather of the 128-byte s3d_edge_record's
+ * (RCCL ncclAllGather over xGMI, communicators from ncclCommInitAll) leaves every edge in every GPU's HBM in
+ * pair order, and `records` is read back from rank 0's gathered buffer.  A pair's record does not depend on the
+ * block it lands in: the result equals s3d_align_batch on one context bit for bit.
+ *
+ * devices: the HIP device of every rank (NULL: devices 0 .. n_devices-1; n_devices 0: every visible device).
+ * RCCL admits one rank per device; a list that names a device twice (several contexts on one GPU) gathers
+ * with device-to-device copies instead - s3d_sweep_collective() returns "rccl" or "copy".  More than one
+ * distinct device without a usable librccl: S3D_STATUS_BACKEND_ERROR. */
+typedef struct s3d_sweep       s3d_sweep;
+typedef struct s3d_sweep_cloud s3d_sweep_cloud;   /* a host cloud + its lazily created per-rank device copies */
+int  s3d_sweep_create(int n_devices, const int* devices, s3d_sweep** out);
+void s3d_sweep_destroy(s3d_sweep* sw);
+int  s3d_sweep_ranks(const s3d_sweep* sw);
+const char* s3d_sweep_collective(const s3d_sweep* sw);
+const char* s3d_sweep_last_error(const s3d_sweep* sw);
+s3d_context* s3d_sweep_context(s3d_sweep* sw, int rank);          /* borrowed; owned by the sweep */
+/* the host data is copied: xyz need not outlive the call */
+int  s3d_sweep_cloud_create(s3d_sweep* sw, const float* xyz, int n, int stride, s3d_sweep_cloud** out);
+void s3d_sweep_cloud_release(s3d_sweep* sw, s3d_sweep_cloud* c);
+/* block [lo, hi) of `rank`: ceil(n_pairs / n_ranks) pairs per rank, the last ranks may be short or empty */
+void s3d_sweep_shard_range(int n_pairs, int n_ranks, int rank, int* lo, int* hi);
+/* same contract as s3d_align_batch; records: n_pairs, pair order */
+int  s3d_align_batch_multi(s3d_sweep* sw, int n_pairs, s3d_sweep_cloud* const* sources,
+                           s3d_sweep_cloud* const* targets, const double* guesses, const s3d_reg_params* params,
+                           const s3d_exec_options* opts, s3d_edge_record* records);
+/* the records of the last sweep as rank `rank` holds them in HBM after the all-gather (n_pairs, pair order) */
+int  s3d_sweep_gathered_records(s3d_sweep* sw, int rank, int n_pairs, s3d_edge_record* records);
 
 /* ---- measurement hook (bench.py roofline): time `reps` launches of the NN-search kernel
  *          as a FIRST correspondence pass (transformation_ = I, no radius hints, no re-validation

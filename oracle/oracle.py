@@ -339,7 +339,9 @@ def set_eval_precision(mode):
     lib().s3o_set_eval_precision(int(mode))
 
 
-def set_debug_perturbation(rel):
+def set_debug_perturbation(rel, seed=1):
+    """Conditioning probe: relative noise of this size on the Mahalanobis matrices (deterministic in `seed`)."""
+    lib().s3o_set_debug_perturbation_seed(C.c_ulonglong(int(seed)))
     lib().s3o_set_debug_perturbation(C.c_double(float(rel)))
 
 

@@ -608,9 +608,21 @@ static void gicp_fdf(gicp_functor* F, const double x[6], double* f_out, double g
 /* diagnostics / variants (all default to the PCL-literal behaviour) */
 static int    g_eval_double = 0; /* see s3d_oracle.h: 0 PCL-literal, 1 double arithmetic, 2 double matrix */
 static double g_perturb = 0.0;   /* relative noise injected into the Mahalanobis matrices */
+static unsigned long long g_perturb_seed = 1;
 static int    g_trace = 0;
 void s3o_set_eval_precision(int mode) { g_eval_double = mode; }
 void s3o_set_debug_perturbation(double rel) { g_perturb = rel; }
+void s3o_set_debug_perturbation_seed(unsigned long long seed) { g_perturb_seed = seed; }
+/* the conditioning probe's noise: a pure function of (seed, outer iteration, correspondence, matrix entry), so that the
+ * experiment is reproducible and independent of the thread / call order (splitmix64 finaliser -> [0, 1)) */
+static double perturb_unit(unsigned long long seed, int iter, int i, int entry) {
+  unsigned long long z = seed * 0x9E3779B97F4A7C15ull + ((unsigned long long)(unsigned)iter << 40) +
+                         ((unsigned long long)(unsigned)i << 4) + (unsigned long long)entry;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
 void s3o_set_trace(int on) { g_trace = on; }
 
 /* ---- PCL registration/bfgs.h (a port of GSL vector_bfgs2 + Fletcher line search) */
@@ -973,7 +985,7 @@ int s3o_gicp(const float* input, int m, const float* target, int n, const float 
         if (g_perturb != 0.0) /* conditioning probe, see s3o_set_debug_perturbation */
           for (int a = 0; a < 3; ++a)
             for (int b = a; b < 3; ++b) {
-              double r = 1.0 + g_perturb * ((double)rand() / RAND_MAX - 0.5);
+              double r = 1.0 + g_perturb * (perturb_unit(g_perturb_seed, nr_iterations, i, a * 3 + b) - 0.5);
               inv[a][b] *= r; inv[b][a] = inv[a][b];
             }
         memcpy(mahal + (size_t)i * 9, inv, sizeof inv);
@@ -1906,7 +1918,7 @@ int s3o_fill_ground_points(const float coeffs[4], double radius, double map_reso
   for (double r = map_resolution; r <= radius; r += map_resolution) {
     const double sd = (n[0] * r + n[1] * 0.0 + n[2] * 0.0) + d;
     const double sp[3] = {r - sd * n[0], 0.0 - sd * n[1], 0.0 - sd * n[2]};
-    for (double angle = 0; angle < 2 * 3.14159265358979323846; angle += angle_inc) {
+    for (double angle = 0; angle < 2 * 3.141592654 /* #define PI 3.141592654, PointCloudSensor.cpp:48, :376 */; angle += angle_inc) {
       const double s = sin(angle), c = cos(angle);
       const double sa[3] = {s * n[0], s * n[1], s * n[2]};
       const double ca[3] = {(1.0 - c) * n[0], (1.0 - c) * n[1], (1.0 - c) * n[2]};

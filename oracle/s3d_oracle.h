@@ -137,6 +137,7 @@ void s3o_mt19937_outputs(unsigned seed, int n, unsigned* out);   /* test hook fo
  *                   tests/test_conditioning.py to measure how well-defined the reference result is. */
 void s3o_set_eval_precision(int mode);
 void s3o_set_debug_perturbation(double rel);
+void s3o_set_debug_perturbation_seed(unsigned long long seed);   /* the noise is a pure function of (seed, iteration, correspondence, entry) */
 void s3o_set_trace(int on);
 
 /* small helpers exposed for tests */

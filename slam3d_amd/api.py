@@ -32,7 +32,11 @@ class RegParams(C.Structure):
 
 class ExecOptions(C.Structure):
     _fields_ = [("force_iterations", C.c_int), ("check_interval", C.c_int), ("grid_cells_per_point", C.c_int),
-                ("profile", C.c_int)]
+                ("profile", C.c_int), ("cache_prepass", C.c_int)]
+
+
+class CacheStats(C.Structure):
+    _fields_ = [("entries", C.c_longlong), ("bytes", C.c_longlong), ("hits", C.c_longlong), ("misses", C.c_longlong)]
 
 
 class AlignInfo(C.Structure):
@@ -89,7 +93,7 @@ def lib_path():
 
 def build(force=False, verbose=False):
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("s3d_api.hip", "s3d_kernels.h", "s3d_core.h", "s3d_ndt.h")]
+    srcs = [os.path.join(_CSRC, f) for f in ("s3d_api.hip", "s3d_kernels.h", "s3d_core.h", "s3d_ndt.h", "s3d_sweep.h")]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("slam3d_hip.h", "slam3d_registration_types.h")]
     stale = force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
     if stale:
@@ -118,6 +122,7 @@ def load_library():
         "s3d_last_error": (C.c_char_p, [vp]),
         "s3d_backend_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
         "s3d_last_profile": (C.c_int, [vp, C.POINTER(Profile)]),
+        "s3d_context_cache_control": (C.c_int, [vp, C.c_longlong, C.c_int, C.POINTER(CacheStats)]),
         "s3d_default_params": (None, [pp]),
         "s3d_cloud_upload": (C.c_int, [vp, fp, C.c_int, C.c_int, C.POINTER(vp)]),
         "s3d_cloud_wrap_device": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp)]),
@@ -146,6 +151,18 @@ def load_library():
                                             C.POINTER(PlaneFit)]),
         "s3d_profile_nn_kernel": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, pp, C.c_int, dp,
                                             C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+        "s3d_sweep_create": (C.c_int, [C.c_int, ip, C.POINTER(vp)]),
+        "s3d_sweep_destroy": (None, [vp]),
+        "s3d_sweep_ranks": (C.c_int, [vp]),
+        "s3d_sweep_collective": (C.c_char_p, [vp]),
+        "s3d_sweep_last_error": (C.c_char_p, [vp]),
+        "s3d_sweep_context": (vp, [vp, C.c_int]),
+        "s3d_sweep_cloud_create": (C.c_int, [vp, fp, C.c_int, C.c_int, C.POINTER(vp)]),
+        "s3d_sweep_cloud_release": (None, [vp, vp]),
+        "s3d_sweep_shard_range": (None, [C.c_int, C.c_int, C.c_int, ip, ip]),
+        "s3d_align_batch_multi": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, pp, op,
+                                            C.POINTER(EdgeRecord)]),
+        "s3d_sweep_gathered_records": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(EdgeRecord)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)  # AttributeError if the symbol is not exported
@@ -446,7 +463,7 @@ class Context:
         f = PlaneFit()
         # upper bound of the ring points: (radius / res + 1) rings of (2 pi radius / res + 2) points
         res = float(map_resolution)
-        cap = int((radius / res + 2) * (2 * np.pi * radius / res + 3)) if res > 0 else 0
+        cap = int((radius / res + 2) * (2 * 3.141592654 * radius / res + 3)) if res > 0 else 0
         out = np.empty((max(cap, 1), 3), np.float32)
         st = self._check(self._L.s3d_fill_ground_plane(self._h, _fp(a), n, stride, float(radius), res, _fp(out), cap,
                                                        C.byref(m), C.byref(f)))
@@ -477,6 +494,12 @@ class Context:
         self._L.s3d_last_map_profile(self._h, C.byref(p))
         return p.asdict()
 
+    def cache_control(self, limit_bytes=0, clear=False):
+        """s3d_context_cache_control: set the budget / clear; returns the stats dict."""
+        st = CacheStats()
+        self._check(self._L.s3d_context_cache_control(self._h, int(limit_bytes), int(bool(clear)), C.byref(st)))
+        return {k: getattr(st, k) for k, _ in CacheStats._fields_}
+
     def last_profile(self):
         p = Profile()
         self._L.s3d_last_profile(self._h, C.byref(p))
@@ -488,3 +511,77 @@ def record_transform(rec):
     T = np.eye(4)
     T[:3, :4] = np.asarray(rec[:12]).reshape(4, 3).T
     return T
+
+
+class Sweep:
+    """s3d_sweep: one rank (context + host thread) per device, pair list sharded in contiguous blocks, one
+    all-gather of the edge records (include/slam3d_hip.h, C1)."""
+
+    def __init__(self, devices=None):
+        self._L = load_library()
+        h = C.c_void_p()
+        if devices is None:
+            st = self._L.s3d_sweep_create(0, None, C.byref(h))
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            st = self._L.s3d_sweep_create(len(devices), arr, C.byref(h))
+        if st != 0 or not h:
+            raise BackendError("s3d_sweep_create failed (status %d): no usable HIP devices / RCCL (no CPU fallback)" % st)
+        self._h = h
+        self.ranks = int(self._L.s3d_sweep_ranks(h))
+        self.collective = self._L.s3d_sweep_collective(h).decode()
+        self._clouds = []
+
+    def upload(self, xyz):
+        a, n, stride = _cloud(xyz)
+        h = C.c_void_p()
+        st = self._L.s3d_sweep_cloud_create(self._h, _fp(a), n, stride, C.byref(h))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
+        self._clouds.append(h)
+        return h
+
+    def align_batch(self, sources, targets, guesses=None, params=None, opts=None):
+        n = len(sources)
+        assert len(targets) == n
+        params = params or default_params()
+        if guesses is None:
+            guesses = np.tile(np.eye(4), (n, 1, 1))
+        g = np.ascontiguousarray(np.asarray(guesses, np.float64).transpose(0, 2, 1).reshape(max(n, 0), 16))
+        rec = np.zeros((max(n, 1), EDGE_RECORD_DOUBLES), np.float64)
+        sa, ta = (C.c_void_p * max(n, 1))(), (C.c_void_p * max(n, 1))()
+        for i in range(n):
+            sa[i], ta[i] = sources[i], targets[i]
+        st = self._L.s3d_align_batch_multi(self._h, n, sa, ta, _dp(g), C.byref(params), C.byref(opts) if opts else None,
+                                           rec.ctypes.data_as(C.POINTER(EdgeRecord)))
+        if st == 8:
+            raise BackendError(self._L.s3d_sweep_last_error(self._h).decode())
+        if st not in (0, 5, 6):
+            raise ValueError(STATUS_NAMES[st])
+        return rec[:n]
+
+    def gathered(self, rank, n_pairs):
+        rec = np.zeros((max(n_pairs, 1), EDGE_RECORD_DOUBLES), np.float64)
+        st = self._L.s3d_sweep_gathered_records(self._h, rank, n_pairs, rec.ctypes.data_as(C.POINTER(EdgeRecord)))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
+        return rec[:n_pairs]
+
+    def shard_range(self, n_pairs, rank):
+        lo, hi = C.c_int(), C.c_int()
+        self._L.s3d_sweep_shard_range(n_pairs, self.ranks, rank, C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for c in self._clouds:
+                self._L.s3d_sweep_cloud_release(self._h, c)
+            self._clouds = []
+            self._L.s3d_sweep_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -16,6 +17,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/slam3d_hip.h"
@@ -30,6 +32,7 @@ struct s3d_cloud {
   float4* d = nullptr;
   int n = 0;
   bool owned = false;
+  unsigned long long uid = 0;   // never reused: the key of the pre-pass cache (an address could be recycled)
 };
 
 namespace {
@@ -105,7 +108,44 @@ double rotation_angle(const double m[16]) {  // Eigen::AngleAxisd(R).angle() via
 
 }  // namespace
 
+namespace {
+std::atomic<unsigned long long> g_cloud_uid{1};
+
+// One cloud's pre-pass products (cross-call cache, s3d_exec_options.cache_prepass): the voxel-filtered points, the
+// cell-sorted copies, the cell table, the normals (if a GICP / point-to-plane call computed them) and the
+// device-computed part of its SlotDev.  ONE device allocation per entry.
+struct CacheKey {
+  unsigned long long uid; uint32_t leaf_bits, h0_bits; int cell_cap;
+  bool operator<(const CacheKey& o) const {
+    return std::tie(uid, leaf_bits, h0_bits, cell_cap) < std::tie(o.uid, o.leaf_bits, o.h0_bits, o.cell_cap);
+  }
+};
+struct CacheEntry {
+  char* block = nullptr;
+  size_t bytes = 0;
+  size_t o_filt = 0, o_sorted = 0, o_sorted3 = 0, o_normals = 0, o_cells = 0, o_slot = 0;
+  int cap_pts = 0, cap_cells = 0;
+  int k_normals = 0;              // correspondence_randomness the cached normals were computed with (0: none)
+  bool has_sorted3 = false;
+  unsigned long long last_use = 0;
+  s3d::SlotDev snap;              // host copy of the slot record; its device-computed part (n, bbox, vp, g) is reused
+};
+}  // namespace
+
 struct s3d_context {
+  std::map<CacheKey, CacheEntry> cache;
+  size_t cache_bytes = 0, cache_limit = (size_t)16 << 30;
+  unsigned long long cache_clock = 0;
+  long long cache_hits = 0, cache_misses = 0;
+  void cache_drop(std::map<CacheKey, CacheEntry>::iterator it) {
+    if (it->second.block) (void)hipFree(it->second.block);
+    cache_bytes -= it->second.bytes;
+    cache.erase(it);
+  }
+  void cache_clear() { while (!cache.empty()) cache_drop(cache.begin()); }
+  void cache_forget_cloud(unsigned long long uid) {
+    for (auto it = cache.lower_bound(CacheKey{uid, 0, 0, 0}); it != cache.end() && it->first.uid == uid;) cache_drop(it++);
+  }
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -145,6 +185,7 @@ struct s3d_context {
     }
   }
   void release_all() {
+    cache_clear();
     if (arena.p) { (void)hipFree(arena.p); arena.p = nullptr; arena.cap = 0; }
     if (staging.p) { (void)hipFree(staging.p); staging.p = nullptr; staging.cap = 0; }
   }
@@ -171,6 +212,12 @@ struct Batch {
   std::vector<int> knn_slots;   // slots that get the k-NN pre-pass (stage_normals)
   std::vector<PairDev> h_pairs;
   int max_n = 0, max_n_t = 0, nb_sort = 0, nb_head = 0, accum_blocks = 1;
+  // cross-call pre-pass cache (s3d_exec_options.cache_prepass): the slots are ordered so that [0, Cu) are the clouds
+  // this call has to filter / grid itself and [Cu, C()) are restored from the context's cache
+  bool use_cache = false;
+  int Cu = 0;
+  std::vector<CacheEntry*> slot_entry;   // per slot: the cache entry it is restored from (nullptr: computed here)
+  std::vector<char> slot_has_normals;    // per slot: its normals came with the entry
   long long cell_cap_max = 1ll << 24;  // 24-bit cell ids sort in 3 radix passes; map jobs raise it (4 passes)
   long long max_cell_cap = 0;
   size_t total_pts = 0, total_cells = 0, total_corr = 0;
@@ -248,15 +295,140 @@ struct Batch {
   }
 
   // icp_buffers = false: voxel filter / search grid only (map building), no normals or correspondences
+  CacheKey cache_key(int slot) const {
+    CacheKey k;
+    k.uid = slot_clouds[(size_t)slot]->uid;
+    std::memcpy(&k.leaf_bits, &rp.leaf, 4);
+    std::memcpy(&k.h0_bits, &rp.h0, 4);
+    k.cell_cap = h_slots[(size_t)slot].cell_cap;
+    return k;
+  }
+
+  // cached clouds to the back of the slot list (the staging kernels then cover the first Cu slots only)
+  void order_slots_for_cache() {
+    const int n = C();
+    Cu = n;
+    slot_entry.assign((size_t)n, nullptr);
+    slot_has_normals.assign((size_t)n, 0);
+    if (!use_cache || n == 0) return;
+    ++ctx->cache_clock;
+    std::vector<CacheEntry*> ent((size_t)n, nullptr);
+    int hits = 0;
+    for (int i = 0; i < n; ++i) {
+      auto it = ctx->cache.find(cache_key(i));
+      if (it != ctx->cache.end()) { ent[i] = &it->second; it->second.last_use = ctx->cache_clock; ++hits; }
+    }
+    ctx->cache_hits += hits; ctx->cache_misses += n - hits;
+    if (hits == 0) return;
+    std::vector<int> order, remap((size_t)n);
+    for (int i = 0; i < n; ++i) if (!ent[i]) order.push_back(i);
+    Cu = (int)order.size();
+    for (int i = 0; i < n; ++i) if (ent[i]) order.push_back(i);
+    std::vector<SlotDev> hs((size_t)n);
+    std::vector<const s3d_cloud*> sc((size_t)n);
+    total_pts = 0; total_cells = 0;
+    for (int j = 0; j < n; ++j) {
+      const int i = order[(size_t)j];
+      remap[(size_t)i] = j;
+      hs[j] = h_slots[(size_t)i];
+      sc[j] = slot_clouds[(size_t)i];
+      slot_entry[j] = ent[i];
+      hs[j].off = (int)total_pts;
+      total_pts += (size_t)((hs[j].n_raw + 3) & ~3);
+      hs[j].cell_off = (int)total_cells;
+      total_cells += (size_t)hs[j].cell_cap + 1;
+    }
+    h_slots.swap(hs);
+    slot_clouds.swap(sc);
+    for (PairDev& pr : h_pairs) { pr.slot_s = remap[(size_t)pr.slot_s]; pr.slot_t = remap[(size_t)pr.slot_t]; }
+  }
+
+  // restore the cached clouds into this batch's arrays (after allocate() has carved them)
+  void restore_from_cache() {
+    hipStream_t st = ctx->stream;
+    for (int j = Cu; j < C(); ++j) {
+      const CacheEntry& e = *slot_entry[(size_t)j];
+      const SlotDev& sl = h_slots[(size_t)j];
+      const size_t n = (size_t)sl.n;
+      if (n) {
+        HIPCHK(hipMemcpyAsync(filt() + sl.off, e.block + e.o_filt, 16 * n, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(sorted() + sl.off, e.block + e.o_sorted, 16 * n, hipMemcpyDeviceToDevice, st));
+        if (has_sorted3) HIPCHK(hipMemcpyAsync(sorted3() + sl.off, e.block + e.o_sorted3, sizeof(CorrVec) * n, hipMemcpyDeviceToDevice, st));
+        if (slot_has_normals[(size_t)j])
+          HIPCHK(hipMemcpyAsync(normals() + sl.off, e.block + e.o_normals, sizeof(CorrVec) * n, hipMemcpyDeviceToDevice, st));
+      }
+      HIPCHK(hipMemcpyAsync(cells() + sl.cell_off, e.block + e.o_cells, 4 * ((size_t)sl.g.ncells + 1), hipMemcpyDeviceToDevice, st));
+    }
+  }
+
+  // after download(): keep the products of the clouds this call computed (and normals a cached cloud lacked)
+  void store_to_cache(bool have_normals) {
+    if (!use_cache) return;
+    hipStream_t st = ctx->stream;
+    const int k = (have_normals && rp.k >= 1 && rp.k <= 64) ? rp.k : 0;
+    for (int j = 0; j < C(); ++j) {
+      const SlotDev& sl = h_slots[(size_t)j];
+      const size_t n = (size_t)sl.n;
+      const bool normals_now = k != 0 && sl.want_normals;      // K4 ran on this slot in this call
+      if (j >= Cu) {   // restored from the cache: at most the normals are new
+        CacheEntry& e = *slot_entry[(size_t)j];
+        if (normals_now && n) {
+          HIPCHK(hipMemcpyAsync(e.block + e.o_normals, normals() + sl.off, sizeof(CorrVec) * n, hipMemcpyDeviceToDevice, st));
+          e.k_normals = k;
+        }
+        continue;
+      }
+      CacheEntry e;
+      const size_t cells_n = (size_t)sl.g.ncells + 1;
+      auto place = [&](size_t bytes) { const size_t o = e.bytes; e.bytes += (bytes + 255) & ~(size_t)255; return o; };
+      e.o_filt = place(16 * n); e.o_sorted = place(16 * n); e.o_sorted3 = place(sizeof(CorrVec) * n);
+      e.o_normals = place(sizeof(CorrVec) * n); e.o_cells = place(4 * cells_n);
+      e.bytes = std::max<size_t>(e.bytes, 256);
+      // make room: least-recently-used entries that this call does not use
+      while (ctx->cache_bytes + e.bytes > ctx->cache_limit) {
+        auto victim = ctx->cache.end();
+        for (auto it = ctx->cache.begin(); it != ctx->cache.end(); ++it)
+          if (it->second.last_use < ctx->cache_clock && (victim == ctx->cache.end() || it->second.last_use < victim->second.last_use))
+            victim = it;
+        if (victim == ctx->cache.end()) break;
+        HIPCHK(hipStreamSynchronize(st));
+        ctx->cache_drop(victim);
+      }
+      if (ctx->cache_bytes + e.bytes > ctx->cache_limit) continue;   // does not fit: stay uncached
+      HIPCHK(hipMalloc((void**)&e.block, e.bytes));
+      if (n) {
+        HIPCHK(hipMemcpyAsync(e.block + e.o_filt, filt() + sl.off, 16 * n, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(e.block + e.o_sorted, sorted() + sl.off, 16 * n, hipMemcpyDeviceToDevice, st));
+        if (has_sorted3) HIPCHK(hipMemcpyAsync(e.block + e.o_sorted3, sorted3() + sl.off, sizeof(CorrVec) * n, hipMemcpyDeviceToDevice, st));
+        if (normals_now) HIPCHK(hipMemcpyAsync(e.block + e.o_normals, normals() + sl.off, sizeof(CorrVec) * n, hipMemcpyDeviceToDevice, st));
+      }
+      HIPCHK(hipMemcpyAsync(e.block + e.o_cells, cells() + sl.cell_off, 4 * cells_n, hipMemcpyDeviceToDevice, st));
+      e.k_normals = normals_now ? k : 0;
+      e.snap = sl;
+      e.has_sorted3 = has_sorted3;
+      e.last_use = ctx->cache_clock;
+      ctx->cache_bytes += e.bytes;
+      ctx->cache[cache_key(j)] = e;
+    }
+    HIPCHK(hipStreamSynchronize(st));   // the arena may be re-carved by the next call on another stream order
+  }
+
   void allocate(bool icp_buffers = true) {
+    order_slots_for_cache();
     if (total_pts > (size_t)0x7FFFFFF0 || total_cells > (size_t)0x7FFFFFF0 || total_corr > (size_t)0x7FFFFFF0)
       throw HipError{hipErrorInvalidValue, "batch too large for 32-bit offsets", __LINE__};
     nb_sort = std::max(1, cdiv(max_n, kSortTile));
     nb_head = std::max(1, cdiv(max_n, kBlock));
-    // blocks per pair in the accumulate kernels: enough blocks to fill the chip for small batches, few
-    // (long per-thread loops, one 76-value tree reduction per block) for large ones
-    accum_blocks = std::min(kAccumBlocks, std::max(1, cdiv(max_n_t, kBlock * 4)));
-    accum_blocks = std::min(accum_blocks, std::max(4, cdiv(1024, std::max(1, P()))));
+    // REAL blocks per pair in the accumulate kernels: enough to fill the chip for small batches, few long-running
+    // ones for large batches.  Speed only: the sums are defined over kAccumVB virtual blocks per pair whatever
+    // this number is (a divisor of kAccumVB), so a pair's result does not depend on the batch it is part of.
+    accum_blocks = kAccumVB;
+    while (accum_blocks > 4 && (long long)accum_blocks * std::max(1, P()) > 1024) accum_blocks >>= 1;
+    while (accum_blocks > 1 && accum_blocks * kBlock * 2 > std::max(max_n_t, 1)) accum_blocks >>= 1;
+    if (const char* e = getenv("S3D_ACCUM_BLOCKS")) {   // A/B and the invariance test: any divisor of kAccumVB
+      const int v = atoi(e);
+      if (v >= 1 && v <= kAccumVB && kAccumVB % v == 0) accum_blocks = v;
+    }
     const size_t np = std::max<size_t>(total_pts, 4);
     const size_t nc = std::max<size_t>(total_corr, 4);
     const size_t npi = icp_buffers ? np : 4;
@@ -271,7 +443,7 @@ struct Batch {
                 {&ctx->blockcnt, 4 * (size_t)std::max(1, C()) * nb_head},
                 {&ctx->corr_idx, 4 * nc}, {&ctx->corr_d2, 4 * nc}, {&ctx->corr_lb, 4 * nc},
                 {&ctx->corr_q, 16 * nc}, {&ctx->corr_n, 16 * nc},
-                {&ctx->partials, 8 * (size_t)std::max(1, P()) * kAccumBlocks * GQ_NACC},
+                {&ctx->partials, 8 * (size_t)std::max(1, P()) * kAccumVB * GQ_NACC},
                 {&ctx->n_active, 64 + 2 * 64 * sizeof(int)},
                 {&ctx->knn_list, sizeof(int) * (size_t)std::max(1, C())}});
     if (!ctx->h_active) HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
@@ -283,59 +455,74 @@ struct Batch {
       h_slots[pr.slot_s].want_normals = 1;
       if (rp.algorithm != 0) h_slots[pr.slot_t].want_normals = 1;
     }
+    for (int j = Cu; j < C(); ++j) {   // cached clouds: the device-computed part of the slot record, normals if they match
+      const CacheEntry& e = *slot_entry[(size_t)j];
+      SlotDev& sl = h_slots[(size_t)j];
+      sl.n = e.snap.n; sl.n_sort = 0;
+      std::memcpy(sl.bb, e.snap.bb, sizeof sl.bb);
+      sl.vp = e.snap.vp; sl.g = e.snap.g;
+      if (sl.want_normals && icp_buffers && e.k_normals != 0 && e.k_normals == rp.k && (e.has_sorted3 || !icp_buffers)) {
+        slot_has_normals[(size_t)j] = 1;
+        sl.want_normals = 0;
+      }
+    }
     if (C()) HIPCHK(hipMemcpyAsync(ctx->slots.p, h_slots.data(), sizeof(SlotDev) * C(), hipMemcpyHostToDevice, st));
     if (P()) HIPCHK(hipMemcpyAsync(ctx->pairs.p, h_pairs.data(), sizeof(PairDev) * P(), hipMemcpyHostToDevice, st));
+    restore_from_cache();
   }
 
   // segmented LSD radix sort of (keys, vals) of every slot; `passes` 8-bit digits.
   // input in A; result in A for even `passes`, in B for odd.
-  void sort(int passes) {
+  void sort(int passes, int nslots) {
     hipStream_t st = ctx->stream;
+    if (nslots <= 0) return;
     uint32_t *ki = kA(), *vi = vA(), *ko = kB(), *vo = vB();
     uint32_t* cnt = (uint32_t*)ctx->counts.p;
     uint32_t* dtot = (uint32_t*)ctx->digit_tot.p;
     for (int p = 0; p < passes; ++p) {
       const int shift = 8 * p;
-      k_sort_hist<<<dim3(nb_sort, C()), kBlock, 0, st>>>(d_slots(), ki, cnt, shift, nb_sort);
-      k_sort_scan_rows<<<dim3(256 / (kBlock / kWave), C()), kBlock, 0, st>>>(d_slots(), cnt, dtot, nb_sort);
-      k_sort_scan_digits<<<C(), kBlock, 0, st>>>(dtot);
-      k_sort_scatter<<<dim3(nb_sort, C()), kBlock, 0, st>>>(d_slots(), ki, vi, ko, vo, cnt, dtot, shift, nb_sort);
+      k_sort_hist<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(d_slots(), ki, cnt, shift, nb_sort);
+      k_sort_scan_rows<<<dim3(256 / (kBlock / kWave), nslots), kBlock, 0, st>>>(d_slots(), cnt, dtot, nb_sort);
+      k_sort_scan_digits<<<nslots, kBlock, 0, st>>>(dtot);
+      k_sort_scatter<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(d_slots(), ki, vi, ko, vo, cnt, dtot, shift, nb_sort);
       std::swap(ki, ko);
       std::swap(vi, vo);
     }
   }
 
-  // K1 + K2: pcl::VoxelGrid of every slot (or a plain copy when leaf <= 0)
+  // K1 + K2: pcl::VoxelGrid of every slot that is not restored from the cache (or a plain copy when leaf <= 0)
   void stage_voxel() {
     hipStream_t st = ctx->stream;
-    if (C() == 0) return;
+    const int NS = Cu;
+    if (NS == 0) return;
     if (rp.leaf > 0.f) {
-      k_slot_reset_bbox<<<C(), 64, 0, st>>>(d_slots());
-      k_bbox<0><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), C()), kBlock, 0, st>>>(d_slots(), filt());
-      k_voxel_params<<<cdiv(C(), 64), 64, 0, st>>>(d_slots(), rp, C());
-      k_voxel_keys<<<dim3(nb_head, C()), kBlock, 0, st>>>(d_slots(), kA(), vA());
-      sort(4);
+      k_slot_reset_bbox<<<NS, 64, 0, st>>>(d_slots());
+      k_bbox<0><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), NS), kBlock, 0, st>>>(d_slots(), filt());
+      k_voxel_params<<<cdiv(NS, 64), 64, 0, st>>>(d_slots(), rp, NS);
+      k_voxel_keys<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), kA(), vA());
+      sort(4, NS);
       uint32_t* bc = (uint32_t*)ctx->blockcnt.p;
-      k_heads_count<<<dim3(nb_head, C()), kBlock, 0, st>>>(d_slots(), kA(), bc, nb_head);
-      k_heads_scan<<<C(), kBlock, 0, st>>>(d_slots(), bc, nb_head);
-      k_centroids<<<dim3(nb_head, C()), kBlock, 0, st>>>(d_slots(), kA(), vA(), bc, filt(), nb_head);
+      k_heads_count<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), kA(), bc, nb_head);
+      k_heads_scan<<<NS, kBlock, 0, st>>>(d_slots(), bc, nb_head);
+      k_centroids<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), kA(), vA(), bc, filt(), nb_head);
     } else {
-      k_copy_raw<<<dim3(nb_head, C()), kBlock, 0, st>>>(d_slots(), filt());
+      k_copy_raw<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), filt());
     }
   }
 
-  // K3: dense search grid + cell-sorted copy of every slot
+  // K3: dense search grid + cell-sorted copy of every slot that is not restored from the cache
   void stage_grid() {
     hipStream_t st = ctx->stream;
-    if (C() == 0) return;
-    k_slot_reset_bbox<<<C(), 64, 0, st>>>(d_slots());
-    k_bbox<1><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), C()), kBlock, 0, st>>>(d_slots(), filt());
-    k_grid_params<<<cdiv(C(), 64), 64, 0, st>>>(d_slots(), rp, C());
-    k_cell_keys<<<dim3(nb_head, C()), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA());
+    const int NS = Cu;
+    if (NS == 0) return;
+    k_slot_reset_bbox<<<NS, 64, 0, st>>>(d_slots());
+    k_bbox<1><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), NS), kBlock, 0, st>>>(d_slots(), filt());
+    k_grid_params<<<cdiv(NS, 64), 64, 0, st>>>(d_slots(), rp, NS);
+    k_cell_keys<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA());
     const bool wide = max_cell_cap > (1ll << 24);
-    sort(wide ? 4 : 3);  // cell ids < 2^24 unless a map job raised the cap
-    k_grid_finalize<<<dim3(cdiv(max_n + 1, kBlock), C()), kBlock, 0, st>>>(d_slots(), filt(), wide ? kA() : kB(),
-                                                                           wide ? vA() : vB(), sorted(), sorted3(), cells());
+    sort(wide ? 4 : 3, NS);  // cell ids < 2^24 unless a map job raised the cap
+    k_grid_finalize<<<dim3(cdiv(max_n + 1, kBlock), NS), kBlock, 0, st>>>(d_slots(), filt(), wide ? kA() : kB(),
+                                                                          wide ? vA() : vB(), sorted(), sorted3(), cells());
   }
 
   // K4
@@ -429,7 +616,7 @@ struct Batch {
         s3d_p2plane_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
             d_pairs(), d_slots(), sorted3(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p, (CorrVec*)ctx->corr_n.p,
             part, rp);
-      s3d_icp_control_kernel<<<P(), 128, 0, st>>>(d_pairs(), part, accum_blocks, rp, d_active);
+      s3d_icp_control_kernel<<<P(), kCtrlThreads, 0, st>>>(d_pairs(), part, rp, d_active);
       ctx->prof.nn_launches = it + 1;
       if (!rp.force_iterations && (it + 1) % opts.check_interval == 0 && it + 1 < rp.max_iterations) {
         HIPCHK(hipMemcpyAsync(ctx->h_active, d_active, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -448,7 +635,7 @@ struct Batch {
     double* part = (double*)ctx->partials.p;
     s3d_fitness_partial_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(d_pairs(), d_slots(), (float*)ctx->corr_d2.p,
                                                                            part, rp);
-    k_fitness_final<<<cdiv(P(), 64), 64, 0, st>>>(d_pairs(), part, accum_blocks, P());
+    k_fitness_final<<<cdiv(P(), 64), 64, 0, st>>>(d_pairs(), part, P());
   }
 
   void download() {
@@ -480,6 +667,7 @@ struct Batch {
     stage_fitness();
     mark(5);
     download();
+    store_to_cache(true);
     if (prof) {
       float ms = 0;
       auto el = [&](int a, int b) { HIPCHK(hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b])); return (double)ms; };
@@ -542,7 +730,7 @@ int check_algorithm(const s3d_reg_params* p) {
 }
 
 int upload_cloud(s3d_context* ctx, const float* xyz, int n, int stride, s3d_cloud* c) {
-  c->n = n; c->owned = true; c->d = nullptr;
+  c->n = n; c->owned = true; c->d = nullptr; c->uid = g_cloud_uid++;
   HIPCHK(hipMalloc((void**)&c->d, sizeof(float4) * (size_t)std::max(n, 1)));
   if (n > 0) {
     if (stride == 4) {
@@ -581,7 +769,7 @@ void free_cloud(s3d_cloud* c) {
 // ---- device-resident helpers shared by the map / patch entry points --------------------------------
 
 void alloc_cloud(s3d_cloud* c, int n) {
-  c->n = n; c->owned = true; c->d = nullptr;
+  c->n = n; c->owned = true; c->d = nullptr; c->uid = g_cloud_uid++;
   HIPCHK(hipMalloc((void**)&c->d, sizeof(float4) * (size_t)std::max(n, 1)));
 }
 
@@ -807,7 +995,7 @@ void align_ndt_pairs(Batch& b, const s3d_reg_params* params, const double* guess
     for (const NdtGrid& G : grids) max_n = std::max(max_n, G.n);
     k_ndt_keys<<<dim3(cdiv(max_n, kBlock), NG), kBlock, 0, st>>>(b.d_slots(), d_grids, b.filt(), b.kA(), b.vA());
     k_ndt_select_slots<<<cdiv(b.C(), 64), 64, 0, st>>>(b.d_slots(), b.C(), d_grids, NG);
-    b.sort(4);   // result back in A
+    b.sort(4, b.C());   // result back in A
     k_ndt_cells<<<dim3(cdiv(max_n, kBlock), NG), kBlock, 0, st>>>(b.d_slots(), d_grids, b.filt(), b.kA(), b.vA());
     for (int g = 0; g < NG; ++g)
       HIPCHK(hipMemcpyAsync(&n_cells[g], grids[g].counter, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -884,7 +1072,7 @@ void align_ndt_pairs(Batch& b, const s3d_reg_params* params, const double* guess
   double* part = (double*)ctx->partials.p;
   s3d_fitness_partial_kernel<<<dim3(b.accum_blocks, NP), kBlock, 0, st>>>(b.d_pairs(), b.d_slots(), (float*)ctx->corr_d2.p,
                                                                           part, b.rp);
-  k_fitness_final<<<cdiv(NP, 64), 64, 0, st>>>(b.d_pairs(), part, b.accum_blocks, NP);
+  k_fitness_final<<<cdiv(NP, 64), 64, 0, st>>>(b.d_pairs(), part, NP);
   std::vector<Mat4f> finals(NP);
   for (int p = 0; p < NP; ++p) finals[p] = b.h_pairs[p].final_T;
   b.download();
@@ -902,11 +1090,14 @@ void align_ndt_pairs(Batch& b, const s3d_reg_params* params, const double* guess
 }
 
 // align() of two device-resident clouds (PointCloudSensor.cpp:119-174)
+// persistent: the clouds are caller-held handles (the pre-pass cache may keep their products); false for the
+// host-buffer entry points, whose device copies die with the call
 int align_dev(s3d_context* ctx, s3d_cloud* ps, s3d_cloud* pt, const double guess[16], const s3d_reg_params* params,
-              const s3d_exec_options* opts, double result[16], s3d_align_info* info) {
+              const s3d_exec_options* opts, double result[16], s3d_align_info* info, bool persistent) {
   const int alg = check_algorithm(params);
   Batch b;
   b.ctx = ctx;
+  b.use_cache = persistent && opts && opts->cache_prepass != 0 && alg == S3D_STATUS_OK;
   int status;
   if (alg != S3D_STATUS_OK) {
     // the reference downsamples and applies the 100-point gate before it dispatches (:127-135)
@@ -927,6 +1118,7 @@ int align_dev(s3d_context* ctx, s3d_cloud* ps, s3d_cloud* pt, const double guess
     b.stage_voxel();
     b.stage_grid();
     b.download();
+    b.store_to_cache(false);
     std::vector<int> sts;
     std::vector<std::array<double, 16>> rs;
     std::vector<s3d_align_info> is;
@@ -955,6 +1147,12 @@ struct ScopedDevice {
 // ------------------------------------------------------------------ C ABI
 
 extern "C" {
+
+static int create_constraint_impl(s3d_context* ctx, s3d_cloud* source, const double source_sensor_pose[16],
+                                  s3d_cloud* target, const double target_sensor_pose[16], const double odometry[16],
+                                  int loop, const s3d_reg_params* fine, const s3d_reg_params* coarse,
+                                  double covariance_scale, const s3d_exec_options* opts, double relative_pose[16],
+                                  double information[36], s3d_align_info* info, bool persistent);
 
 void s3d_default_params(s3d_reg_params* p) {
   p->registration_algorithm = S3D_ALG_GICP;
@@ -1039,6 +1237,29 @@ int s3d_last_profile(const s3d_context* ctx, s3d_profile* out) {
   return S3D_STATUS_OK;
 }
 
+int s3d_context_cache_control(s3d_context* ctx, long long limit_bytes, int clear, s3d_cache_stats* stats) {
+  if (!ctx) return S3D_STATUS_INVALID_ARGUMENT;
+  try {
+    ScopedDevice sd(ctx);
+    if (ctx->stream) HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (limit_bytes > 0) ctx->cache_limit = (size_t)limit_bytes;
+    if (clear) ctx->cache_clear();
+    while (ctx->cache_bytes > ctx->cache_limit && !ctx->cache.empty()) {   // a lowered budget: oldest first
+      auto victim = ctx->cache.begin();
+      for (auto it = ctx->cache.begin(); it != ctx->cache.end(); ++it)
+        if (it->second.last_use < victim->second.last_use) victim = it;
+      ctx->cache_drop(victim);
+    }
+  } catch (const HipError& e) {
+    return fail(ctx, e);
+  }
+  if (stats) {
+    stats->entries = (long long)ctx->cache.size(); stats->bytes = (long long)ctx->cache_bytes;
+    stats->hits = ctx->cache_hits; stats->misses = ctx->cache_misses;
+  }
+  return S3D_STATUS_OK;
+}
+
 int s3d_cloud_upload(s3d_context* ctx, const float* xyz, int n, int stride, s3d_cloud** out) {
   if (!ctx || !out || n < 0 || stride < 3 || (n > 0 && !xyz)) return S3D_STATUS_INVALID_ARGUMENT;
   s3d_cloud* c = new s3d_cloud();
@@ -1060,6 +1281,7 @@ int s3d_cloud_wrap_device(s3d_context* ctx, const void* device_float4, int n, s3
   c->d = (float4*)device_float4;
   c->n = n;
   c->owned = false;
+  c->uid = g_cloud_uid++;
   *out = c;
   return S3D_STATUS_OK;
 }
@@ -1072,6 +1294,7 @@ void s3d_cloud_release(s3d_context* ctx, s3d_cloud* c) {
     std::lock_guard<std::mutex> lock(ctx->mtx);
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->cache_forget_cloud(c->uid);   // eviction: the cached pre-pass products die with the cloud
     free_cloud(c);
   } else {
     free_cloud(c);
@@ -1098,12 +1321,14 @@ int s3d_align_batch(s3d_context* ctx, int n_pairs, s3d_cloud* const* sources, s3
     if (is_ndt(params)) {   // NDT: device passes for all pairs per round, host state machines in between
       Batch b;
       b.ctx = ctx;
+      b.use_cache = opts && opts->cache_prepass != 0;
       b.set_params(params, opts);
       b.add_pairs(n_pairs, sources, targets, guesses);
       b.allocate();
       b.stage_voxel();
       b.stage_grid();
       b.download();
+      b.store_to_cache(false);
       std::vector<int> sts;
       std::vector<std::array<double, 16>> rs;
       std::vector<s3d_align_info> is;
@@ -1122,6 +1347,7 @@ int s3d_align_batch(s3d_context* ctx, int n_pairs, s3d_cloud* const* sources, s3
     }
     Batch b;
     b.ctx = ctx;
+    b.use_cache = opts && opts->cache_prepass != 0;
     b.set_params(params, opts);
     b.add_pairs(n_pairs, sources, targets, guesses);
     b.allocate();
@@ -1158,7 +1384,7 @@ int s3d_align(s3d_context* ctx, const float* source_xyz, int n_source, int strid
     ScopedDevice sd(ctx);
     upload_cloud(ctx, source_xyz, n_source, stride_source, &cs);
     upload_cloud(ctx, target_xyz, n_target, stride_target, &ct);
-    status = align_dev(ctx, &cs, &ct, guess, params, opts, result, info);
+    status = align_dev(ctx, &cs, &ct, guess, params, opts, result, info, false);
     free_cloud(&cs);
     free_cloud(&ct);
   } catch (const HipError& e) {
@@ -1188,8 +1414,8 @@ int s3d_create_constraint(s3d_context* ctx, const float* source_xyz, int n_sourc
     free_cloud(&ct);
     return fail(ctx, e);
   }
-  const int st = s3d_create_constraint_clouds(ctx, &cs, source_sensor_pose, &ct, target_sensor_pose, odometry, loop, fine,
-                                              coarse, covariance_scale, opts, relative_pose, information, info);
+  const int st = create_constraint_impl(ctx, &cs, source_sensor_pose, &ct, target_sensor_pose, odometry, loop, fine,
+                                        coarse, covariance_scale, opts, relative_pose, information, info, false);
   {
     std::lock_guard<std::mutex> lock(ctx->mtx);
     (void)hipSetDevice(ctx->device);
@@ -1354,7 +1580,7 @@ int s3d_align_clouds(s3d_context* ctx, s3d_cloud* source, s3d_cloud* target, con
   if (info) std::memset(info, 0, sizeof *info);
   try {
     ScopedDevice sd(ctx);
-    return align_dev(ctx, source, target, guess, params, opts, result, info);
+    return align_dev(ctx, source, target, guess, params, opts, result, info, true);
   } catch (const HipError& e) {
     return fail(ctx, e);
   }
@@ -1365,6 +1591,15 @@ int s3d_create_constraint_clouds(s3d_context* ctx, s3d_cloud* source, const doub
                                  int loop, const s3d_reg_params* fine, const s3d_reg_params* coarse,
                                  double covariance_scale, const s3d_exec_options* opts, double relative_pose[16],
                                  double information[36], s3d_align_info* info) {
+  return create_constraint_impl(ctx, source, source_sensor_pose, target, target_sensor_pose, odometry, loop, fine, coarse,
+                                covariance_scale, opts, relative_pose, information, info, true);
+}
+
+static int create_constraint_impl(s3d_context* ctx, s3d_cloud* source, const double source_sensor_pose[16],
+                                  s3d_cloud* target, const double target_sensor_pose[16], const double odometry[16],
+                                  int loop, const s3d_reg_params* fine, const s3d_reg_params* coarse,
+                                  double covariance_scale, const s3d_exec_options* opts, double relative_pose[16],
+                                  double information[36], s3d_align_info* info, bool persistent) {
   if (!ctx || !source || !target || !source_sensor_pose || !target_sensor_pose || !odometry || !fine ||
       (loop && !coarse) || !relative_pose || !information)
     return S3D_STATUS_INVALID_ARGUMENT;
@@ -1379,11 +1614,11 @@ int s3d_create_constraint_clouds(s3d_context* ctx, s3d_cloud* source, const doub
     int st;
     double result[16];
     if (loop) {                                // :286-289
-      st = align_dev(ctx, source, target, guess, coarse, opts, result, info);
+      st = align_dev(ctx, source, target, guess, coarse, opts, result, info, persistent);
       if (st != S3D_STATUS_OK) return st;
       std::memcpy(guess, result, sizeof guess);
     }
-    st = align_dev(ctx, source, target, guess, fine, opts, result, info);   // :292
+    st = align_dev(ctx, source, target, guess, fine, opts, result, info, persistent);   // :292
     if (st != S3D_STATUS_OK) return st;
     mat4d_mul(source_sensor_pose, result, tmp);   // :295
     mat4d_mul(tmp, tinv, relative_pose);
@@ -1558,7 +1793,7 @@ int fill_ground_points(const float coeffs[4], double radius, double map_resoluti
   const double n[3] = {(double)coeffs[0], (double)coeffs[1], (double)coeffs[2]}, d = (double)coeffs[3];
   if (!(map_resolution > 0)) return 0;
   const double angle_inc = map_resolution / radius;
-  const double two_pi = 2 * 3.14159265358979323846;
+  const double two_pi = 2 * 3.141592654;   // the reference's own macro: #define PI 3.141592654 (PointCloudSensor.cpp:48, :376)
   int m = 0;
   for (double r = map_resolution; r <= radius; r += map_resolution) {
     const double sd = (n[0] * r + n[1] * 0.0 + n[2] * 0.0) + d;
@@ -1727,3 +1962,5 @@ int s3d_profile_nn_kernel(s3d_context* ctx, int n_pairs, s3d_cloud* const* sourc
 }
 
 }  // extern "C"
+
+#include "s3d_sweep.h"

@@ -22,7 +22,8 @@ constexpr int kBlock = 256;        // 4 waves
 constexpr int kWave = 64;
 constexpr int kSortTile = 4096;    // elements per block and pass in the radix sort (16 per thread: digit runs of a
                                    // tile are then ~64 B long; 1024 -> 4096 took 1.3 ms off the 256-pair step)
-constexpr int kAccumBlocks = 64;   // max blocks per pair in the accumulate kernels
+constexpr int kAccumVB = 64;       // VIRTUAL blocks per pair in the accumulate / fitness kernels: the unit of the
+                                   // fixed summation tree (block_reduce_store_fixed); a launch runs them on 1..64 real blocks
 constexpr uint32_t kInvalidKey = 0xFFFFFFFFu;
 
 // ------------------------------------------------------------------ device-side records
@@ -33,10 +34,10 @@ struct SlotDev {          // one cloud of the batch
   int   off;              // offset of this slot in the per-point work arrays (capacity n_raw)
   int   cell_off;         // offset of this slot's cell_start[] (capacity cell_cap + 1)
   int   cell_cap;
-  // device-computed
+  int   want_normals;     // K4 runs on this cloud (point-to-plane: only the searched side of a pair needs normals)
+  // device-computed (from `n` to the end: what the cross-call pre-pass cache keeps and restores, s3d_api.hip)
   int   n;                // points after the voxel filter
   int   n_sort;           // element count of the sort in flight
-  int   want_normals;     // K4 runs on this cloud (point-to-plane: only the searched side of a pair needs normals)
   unsigned int bb[6];     // bbox as order-preserving uint (min xyz, max xyz), atomics
   VoxelParams vp;
   GridParams  g;
@@ -1027,6 +1028,74 @@ __global__ void __launch_bounds__(kBlock) k_export_normals(const SlotDev* __rest
 
 // ------------------------------------------------------------------ K6: per-correspondence terms + reduction
 
+// ---- fixed summation tree of the accumulate kernels --------------------------------------------------------
+// A pair's sums are defined over kAccumVB VIRTUAL blocks of 256 virtual threads: virtual thread t of virtual block
+// v folds the elements (v + 64 j) * 256 + t, j = 0, 1, ... in ascending j; the 256 per-thread sums of a virtual
+// block are combined by the butterfly below (64 lanes) and then over its four waves in ascending order; the
+// controller adds the kAccumVB block sums in 8 groups of 8 (ascending inside a group, then the groups in ascending
+// order: s3d_icp_control_kernel, k_fitness_final).  HOW MANY real blocks execute the virtual blocks (64 for
+// a single pair, 4 for a 256-pair batch: few long-running blocks are faster there) is a launch parameter that
+// cannot change a bit of the result: a pair registers to the same edge alone, in any batch and in any shard of a
+// multi-GPU sweep.
+//
+// Wave reduction as a butterfly that HALVES the value set at every level: partners l and l ^ MASK split the N
+// live values - the lane with the bit clear keeps the low half and sends the high half, its partner the other
+// way round - so the six levels move N/2 + N/4 + ... ~ N values per lane instead of 6 N (76 accumulators: 77
+// exchanges instead of 456; a real block of a large batch reduces 16 virtual blocks per launch).  Lane l ends up
+// holding the wave totals of at most kSlots of the N values (wrs_index).
+template <int N, int MASK>
+__device__ __forceinline__ void wrs_level(double* v, int lane) {
+  constexpr int H = (N + 1) / 2;
+  const bool hi = (lane & MASK) != 0;
+#pragma unroll
+  for (int k = 0; k < H; ++k) {
+    const double lo_v = v[k];
+    const double hi_v = (H + k < N) ? v[H + k] : 0.0;
+    const double send = hi ? lo_v : hi_v;
+    const double keep = hi ? hi_v : lo_v;
+    v[k] = keep + __shfl_xor(send, MASK, kWave);
+  }
+}
+// index (among the N inputs of the level with mask MASK) of the value whose wave total lane `lane` holds in
+// slot `slot` after the last level; -1: that slot holds nothing
+template <int N, int MASK>
+__device__ __forceinline__ int wrs_index(int lane, int slot) {
+  constexpr int H = (N + 1) / 2;
+  int idx;
+  if constexpr (MASK == 1) idx = slot;
+  else idx = wrs_index<H, MASK / 2>(lane, slot);
+  if (idx < 0 || idx >= H) return -1;
+  idx = (lane & MASK) ? H + idx : idx;
+  return idx < N ? idx : -1;
+}
+constexpr int wrs_half(int n, int levels) { return levels == 0 ? n : wrs_half((n + 1) / 2, levels - 1); }
+
+template <int NACC>
+__device__ __forceinline__ void block_reduce_store_fixed(double (&acc)[NACC], double* __restrict__ out) {
+  __shared__ double red[kBlock / kWave][NACC];
+  const int lane = lane_id(), w = wave_id();
+  wrs_level<NACC, 32>(acc, lane);
+  wrs_level<wrs_half(NACC, 1), 16>(acc, lane);
+  wrs_level<wrs_half(NACC, 2), 8>(acc, lane);
+  wrs_level<wrs_half(NACC, 3), 4>(acc, lane);
+  wrs_level<wrs_half(NACC, 4), 2>(acc, lane);
+  wrs_level<wrs_half(NACC, 5), 1>(acc, lane);
+  constexpr int kSlots = wrs_half(NACC, 6);
+#pragma unroll
+  for (int sl = 0; sl < kSlots; ++sl) {
+    const int idx = wrs_index<NACC, 32>(lane, sl);
+    if (idx >= 0) red[w][idx] = acc[sl];
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double v = red[0][threadIdx.x];
+#pragma unroll
+    for (int ww = 1; ww < kBlock / kWave; ++ww) v += red[ww][threadIdx.x];
+    out[threadIdx.x] = v;
+  }
+  __syncthreads();   // `red` is reused by the next virtual block of this real block
+}
+
 template <int NACC>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* __restrict__ out) {
   __shared__ double red[kBlock / kWave][NACC];
@@ -1072,44 +1141,59 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
   for (int c = 0; c < 6; ++c) S[c] = wave_uniform(S[c]);
 #pragma unroll
   for (int c = 0; c < 12; ++c) Th0[c] = wave_uniform(Th0[c]);
-  double acc[GQ_NACC];
-#pragma unroll
-  for (int c = 0; c < GQ_NACC; ++c) acc[c] = 0.0;
   const int M = St.n;
-  // software-pipelined stream: the five loads of element i + stride are in flight while element i is folded
-  // into the 73 accumulators (the loads of ONE element per lane and wave do not cover the HBM
-  // latency-bandwidth product)
-  const int stride = gridDim.x * kBlock;
-  int i = blockIdx.x * kBlock + threadIdx.x;
+  // The virtual blocks v = blockIdx.x, blockIdx.x + gridDim.x, ... of this pair (see block_reduce_store_fixed), one
+  // after the other, as ONE software-pipelined stream: the five loads of the next element - the first element of
+  // the next virtual block included - are in flight while the current one is folded into the 73 accumulators (the
+  // loads of one element per lane and wave do not cover the HBM latency-bandwidth product).  Every virtual block
+  // takes `per` steps; steps past the end of the cloud are masked.
+  const int per = (M + kAccumVB * kBlock - 1) / (kAccumVB * kBlock);
+  double* __restrict__ out = partials + (size_t)blockIdx.y * kAccumVB * GQ_NACC;
+  int v = blockIdx.x;
+  for (; v < kAccumVB && v * kBlock >= M; v += gridDim.x)    // (virtual blocks past the end of a small cloud)
+    if (threadIdx.x < GQ_NACC) out[(size_t)v * GQ_NACC + threadIdx.x] = 0.0;
+  if (v >= kAccumVB) return;
+  int i = v * kBlock + threadIdx.x;
   float d2 = 3.0e38f;
   CorrVec p0 = corr_vec(make_float4(0.f, 0.f, 0.f, 0.f)), qf = p0, na = p0, nb = p0;
-  if (i < M) {
-    d2 = corr_d2[P.corr_off + i];          // 3e38 when the query has no neighbour at all
-    p0 = sorted[St.off + i]; qf = corr_q[P.corr_off + i];
-    na = normals[St.off + i]; nb = corr_n[P.corr_off + i];
+  {
+    const int j = i < M ? i : M - 1;
+    d2 = corr_d2[P.corr_off + j];          // 3e38 when the query has no neighbour at all
+    p0 = sorted[St.off + j]; qf = corr_q[P.corr_off + j];
+    na = normals[St.off + j]; nb = corr_n[P.corr_off + j];
   }
-  while (i < M) {
-    const int in = i + stride;
-    const int j = in < M ? in : i;         // (the last step re-reads its own element: no branch around the loads)
-    const float d2n = corr_d2[P.corr_off + j];
-    const CorrVec p0n = sorted[St.off + j], nan_ = normals[St.off + j], qfn = corr_q[P.corr_off + j], nbn = corr_n[P.corr_off + j];
-    if ((double)d2 < rp.dist_threshold) {
-      const F3 pf = xf_pcl(P.guess, p0.x, p0.y, p0.z);
-      // xyz + normal, both float4: the float-rounded unit normals are used as stored (measured effect on
-      // the GICP result vs double normals: <= 2e-6 m)
-      const double n1[3] = {na.x, na.y, na.z}, n2[3] = {nb.x, nb.y, nb.z};
-      double n1r[3], Mm[6];
+  while (v < kAccumVB) {
+    double acc[GQ_NACC];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) n1r[a] = R[a * 3] * n1[0] + R[a * 3 + 1] * n1[1] + R[a * 3 + 2] * n1[2];
-      gicp_mahalanobis(S, n1r, n2, rp.gicp_epsilon, Mm);
-      const double pd[3] = {pf.x, pf.y, pf.z};
-      const double qd[3] = {qf.x, qf.y, qf.z};
-      gq_accumulate(acc, pd, qd, Mm, Th0);
+    for (int c = 0; c < GQ_NACC; ++c) acc[c] = 0.0;
+    int vn = v + gridDim.x;                // next virtual block with any element
+    if (vn * kBlock >= M) vn = kAccumVB;
+    for (int step = 0; step < per; ++step) {
+      const int in = step + 1 < per ? i + kAccumVB * kBlock : vn * kBlock + (int)threadIdx.x;
+      const int j = in < M ? in : M - 1;   // (masked steps re-read the last element: no branch around the loads)
+      const float d2n = corr_d2[P.corr_off + j];
+      const CorrVec p0n = sorted[St.off + j], nan_ = normals[St.off + j], qfn = corr_q[P.corr_off + j], nbn = corr_n[P.corr_off + j];
+      if (i < M && (double)d2 < rp.dist_threshold) {
+        const F3 pf = xf_pcl(P.guess, p0.x, p0.y, p0.z);
+        // the float-rounded unit normals are used as stored (measured effect on the GICP result vs double
+        // normals: <= 2e-6 m)
+        const double n1[3] = {na.x, na.y, na.z}, n2[3] = {nb.x, nb.y, nb.z};
+        double n1r[3], Mm[6];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) n1r[a] = R[a * 3] * n1[0] + R[a * 3 + 1] * n1[1] + R[a * 3 + 2] * n1[2];
+        gicp_mahalanobis(S, n1r, n2, rp.gicp_epsilon, Mm);
+        const double pd[3] = {pf.x, pf.y, pf.z};
+        const double qd[3] = {qf.x, qf.y, qf.z};
+        gq_accumulate(acc, pd, qd, Mm, Th0);
+      }
+      d2 = d2n; p0 = p0n; qf = qfn; na = nan_; nb = nbn;
+      i = in;
     }
-    d2 = d2n; p0 = p0n; qf = qfn; na = nan_; nb = nbn;
-    i = in;
+    block_reduce_store_fixed<GQ_NACC>(acc, out + (size_t)v * GQ_NACC);
+    for (int u = v + gridDim.x; u < kAccumVB && u < vn; u += gridDim.x)   // empty virtual blocks in between: none
+      if (threadIdx.x < GQ_NACC) out[(size_t)u * GQ_NACC + threadIdx.x] = 0.0;
+    v = vn;
   }
-  block_reduce_store<GQ_NACC>(acc, partials + ((size_t)blockIdx.y * kAccumBlocks + blockIdx.x) * GQ_NACC);
 }
 
 // point-to-plane: J^T J (21) + J^T r (6) + r^2 + count
@@ -1123,39 +1207,66 @@ __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const Pa
   const PairDev& P = pairs[blockIdx.y];
   if (!P.active) return;
   const SlotDev& St = slots[P.slot_t];
-  double acc[PP_NACC];
-#pragma unroll
-  for (int c = 0; c < PP_NACC; ++c) acc[c] = 0.0;
   const int M = St.n;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < M; i += gridDim.x * kBlock) {
-    const float d2 = corr_d2[P.corr_off + i];
-    if (!((double)d2 < rp.dist_threshold)) continue;
-    const CorrVec p0 = sorted[St.off + i];
-    const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
-    const F3 pq = xf_eigen(P.T, pg.x, pg.y, pg.z);
-    const CorrVec qf = corr_q[P.corr_off + i];
-    const CorrVec nf = corr_n[P.corr_off + i];
-    const double pd[3] = {pq.x, pq.y, pq.z};
-    const double qd[3] = {qf.x, qf.y, qf.z};
-    const double nd[3] = {nf.x, nf.y, nf.z};
-    pp_accumulate(acc, pd, qd, nd);
+  const int per = (M + kAccumVB * kBlock - 1) / (kAccumVB * kBlock);
+  double* __restrict__ out = partials + (size_t)blockIdx.y * kAccumVB * GQ_NACC;
+  // virtual blocks of the fixed summation tree (block_reduce_store_fixed), gridDim.x of them at a time
+  for (int v = blockIdx.x; v < kAccumVB; v += gridDim.x) {
+    if (v * kBlock >= M) {
+      if (threadIdx.x < PP_NACC) out[(size_t)v * GQ_NACC + threadIdx.x] = 0.0;
+      continue;
+    }
+    double acc[PP_NACC];
+#pragma unroll
+    for (int c = 0; c < PP_NACC; ++c) acc[c] = 0.0;
+    int i = v * kBlock + threadIdx.x;
+    for (int step = 0; step < per; ++step, i += kAccumVB * kBlock) {
+      if (i >= M) break;
+      const float d2 = corr_d2[P.corr_off + i];
+      if (!((double)d2 < rp.dist_threshold)) continue;
+      const CorrVec p0 = sorted[St.off + i];
+      const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
+      const F3 pq = xf_eigen(P.T, pg.x, pg.y, pg.z);
+      const CorrVec qf = corr_q[P.corr_off + i];
+      const CorrVec nf = corr_n[P.corr_off + i];
+      const double pd[3] = {pq.x, pq.y, pq.z};
+      const double qd[3] = {qf.x, qf.y, qf.z};
+      const double nd[3] = {nf.x, nf.y, nf.z};
+      pp_accumulate(acc, pd, qd, nd);
+    }
+    block_reduce_store_fixed<PP_NACC>(acc, out + (size_t)v * GQ_NACC);
   }
-  block_reduce_store<PP_NACC>(acc, partials + ((size_t)blockIdx.y * kAccumBlocks + blockIdx.x) * GQ_NACC);
 }
 
 // ------------------------------------------------------------------ K7: per-pair controller
 // fixed-order sum of the block partials, then the solver step and the PCL stopping rule.
 // One block per pair; the scalar solver runs on lane 0 with the record in LDS.
-__global__ void __launch_bounds__(128) s3d_icp_control_kernel(PairDev* pairs, const double* __restrict__ partials,
-                                                               int nblocks, RunParams rp, int* n_active) {
+constexpr int kCtrlGroups = 8;                                  // the root of the fixed summation tree: 8 groups of 8 virtual blocks
+constexpr int kCtrlThreads = ((kCtrlGroups * GQ_NACC + kWave - 1) / kWave) * kWave;   // 640
+__global__ void __launch_bounds__(kCtrlThreads) s3d_icp_control_kernel(PairDev* pairs, const double* __restrict__ partials,
+                                                                        RunParams rp, int* n_active) {
+  __shared__ double grp[kCtrlGroups][GQ_NACC];
   __shared__ double acc[GQ_NACC];
   PairDev& P = pairs[blockIdx.x];
   if (!P.active) return;
   const bool gicp = rp.algorithm != 0;
   const int nacc = gicp ? GQ_NACC : PP_NACC;
+  // root of the fixed tree: the kAccumVB virtual-block sums in 8 groups of 8 (ascending inside a group, one thread
+  // per (group, accumulator): all 64 loads of an accumulator are in flight at once), then the groups in ascending
+  // order.  One L2 round trip instead of eight on the critical path of every outer iteration.
+  {
+    const int g = (int)threadIdx.x / GQ_NACC, c = (int)threadIdx.x % GQ_NACC;
+    if (g < kCtrlGroups && c < nacc) {
+      const double* src = partials + ((size_t)blockIdx.x * kAccumVB + (size_t)g * (kAccumVB / kCtrlGroups)) * GQ_NACC + c;
+      grp[g][c] = ordered_partial_sum(src, kAccumVB / kCtrlGroups, GQ_NACC);
+    }
+  }
+  __syncthreads();
   if ((int)threadIdx.x < nacc) {
-    const double* src = partials + (size_t)blockIdx.x * kAccumBlocks * GQ_NACC + threadIdx.x;
-    acc[threadIdx.x] = ordered_partial_sum(src, nblocks, GQ_NACC);
+    double v = grp[0][threadIdx.x];
+#pragma unroll
+    for (int g = 1; g < kCtrlGroups; ++g) v += grp[g][threadIdx.x];
+    acc[threadIdx.x] = v;
   }
   __syncthreads();
   // Wave 0 runs the optimiser redundantly on all 64 lanes (identical inputs -> identical, uniform
@@ -1205,29 +1316,31 @@ __global__ void __launch_bounds__(kBlock) s3d_fitness_partial_kernel(const PairD
                                                                       const SlotDev* __restrict__ slots,
                                                                       const float* __restrict__ corr_d2,
                                                                       double* __restrict__ partials, RunParams rp) {
-  __shared__ double red[kBlock / kWave][2];
   const PairDev& P = pairs[blockIdx.y];
   const int M = slots[P.slot_t].n;
-  double s = 0.0, c = 0.0;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < M; i += gridDim.x * kBlock) {
-    const float d2 = corr_d2[P.corr_off + i];
-    if ((double)d2 <= rp.fit_range) { s += (double)d2; c += 1.0; }   // (no neighbour at all: d2 = 3e38)
-  }
-  s = wave_sum(s); c = wave_sum(c);
-  if (lane_id() == 0) { red[wave_id()][0] = s; red[wave_id()][1] = c; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < kBlock / kWave; ++w) { red[0][0] += red[w][0]; red[0][1] += red[w][1]; }
-    double* out = partials + ((size_t)blockIdx.y * kAccumBlocks + blockIdx.x) * GQ_NACC;
-    out[0] = red[0][0]; out[1] = red[0][1];
+  double* __restrict__ out = partials + (size_t)blockIdx.y * kAccumVB * GQ_NACC;
+  // the same virtual blocks as the accumulate kernels: the score does not depend on the launch geometry
+  for (int v = blockIdx.x; v < kAccumVB; v += gridDim.x) {
+    double acc[2] = {0.0, 0.0};
+    for (int i = v * kBlock + threadIdx.x; i < M; i += kAccumVB * kBlock) {
+      const float d2 = corr_d2[P.corr_off + i];
+      if ((double)d2 <= rp.fit_range) { acc[0] += (double)d2; acc[1] += 1.0; }   // (no neighbour at all: d2 = 3e38)
+    }
+    block_reduce_store_fixed<2>(acc, out + (size_t)v * GQ_NACC);
   }
 }
 
-__global__ void k_fitness_final(PairDev* pairs, const double* __restrict__ partials, int nblocks, int npairs) {
+__global__ void k_fitness_final(PairDev* pairs, const double* __restrict__ partials, int npairs) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npairs) return;
-  const double* in = partials + (size_t)p * kAccumBlocks * GQ_NACC;
-  const double s = ordered_partial_sum(in, nblocks, GQ_NACC), c = ordered_partial_sum(in + 1, nblocks, GQ_NACC);
+  const double* in = partials + (size_t)p * kAccumVB * GQ_NACC;
+  double s = 0.0, c = 0.0;   // the same root as the controller's: 8 groups of 8, ascending
+  for (int g = 0; g < kAccumVB / 8; ++g) {
+    const double* gi = in + (size_t)g * 8 * GQ_NACC;
+    const double sg = ordered_partial_sum(gi, 8, GQ_NACC), cg = ordered_partial_sum(gi + 1, 8, GQ_NACC);
+    s = g == 0 ? sg : s + sg;
+    c = g == 0 ? cg : c + cg;
+  }
   pairs[p].fitness = c > 0.0 ? s / c : 1.7976931348623157e308;
   pairs[p].fit_count = (int)c;
 }

@@ -41,6 +41,15 @@ def gpu_ctx():
     ctx.close()
 
 
+def rotation_angle(R):
+    """Angle of a (nearly) rotation matrix, well-conditioned near the identity.  The results under test are
+    float-rounded 4x4 matrices (PCL's Matrix4f final transformation, widened without re-orthonormalisation,
+    PointCloudSensor.cpp:80-81): their trace is off by ~1e-8, and arccos((trace - 1) / 2) turns THAT into up to
+    ~2e-4 rad of pure measurement noise.  The skew part carries the angle linearly: atan2(|skew| / 2, (tr - 1) / 2)."""
+    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / 2.0
+    return float(np.arctan2(np.linalg.norm(w), (np.trace(R) - 1.0) / 2.0))
+
+
 def transform_delta(A, B):
     d = np.linalg.inv(A) @ B
-    return float(np.linalg.norm(d[:3, 3])), float(np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)))
+    return float(np.linalg.norm(d[:3, 3])), rotation_angle(d[:3, :3])

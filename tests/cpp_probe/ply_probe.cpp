@@ -1,7 +1,7 @@
 // Host-only probe of slam3d::PointCloudSensor::readPLY (no context, no GPU): prints what loadPLY would wrap.
 #include <cstdio>
 
-#include "slam3d/sensor/hip/PointCloudSensor.hpp"
+#include "slam3d/sensor/pcl/PointCloudSensor.hpp"
 
 using namespace slam3d;
 

@@ -1,0 +1,94 @@
+"""GPU tests of the cross-call pre-pass cache (s3d_exec_options.cache_prepass, include/slam3d_hip.h).
+
+The reference re-filters both clouds in every align() (PointCloudSensor.cpp:127-131) although a mapper registers every
+scan several times (ScanSensor.cpp:113 against the previous scan, :179-201 against its neighbours).  With the option
+on, the voxel filter / search grid / k-NN normals of a device-resident cloud are kept in HBM per
+(cloud, point_cloud_density, grid budget, correspondence_randomness).  The bar: results are identical bit for bit
+with and without it, in every mix of cached and new clouds; entries die with their cloud."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _opts(s3d, cache, **kw):
+    return s3d.ExecOptions(cache_prepass=1 if cache else 0, **kw)
+
+
+def test_cached_equals_uncached_bit_for_bit(gpu_ctx, fixture_clouds):
+    import slam3d_amd as s3d
+    gpu_ctx.cache_control(clear=True)
+    base = gpu_ctx.cache_control()
+    cl = [gpu_ctx.upload(c) for c in fixture_clouds]
+    try:
+        chain = [(0, 1), (1, 2), (2, 3)]
+        for alg in (s3d.ALG_GICP, s3d.ALG_ICP, s3d.ALG_NDT):
+            p = s3d.default_params(registration_algorithm=alg, maximum_iterations=12)
+            want = gpu_ctx.align_batch([cl[a] for a, _ in chain], [cl[b] for _, b in chain], None, p, _opts(s3d, False))
+            # the mapper pattern: one new scan per call, registered against the previous one
+            got = [gpu_ctx.align_batch([cl[a]], [cl[b]], None, p, _opts(s3d, True))[0] for a, b in chain]
+            assert np.array_equal(np.array(got), want), alg
+            # everything cached now: a batch of hits only, and a mix of cached clouds with a new one
+            again = gpu_ctx.align_batch([cl[a] for a, _ in chain], [cl[b] for _, b in chain], None, p, _opts(s3d, True))
+            assert np.array_equal(again, want), alg
+            fresh = gpu_ctx.upload(fixture_clouds[3])
+            mixed = gpu_ctx.align_batch([cl[2], cl[0]], [fresh, cl[1]], None, p, _opts(s3d, True))
+            fresh.release()
+            assert np.array_equal(mixed[0], want[2]) and np.array_equal(mixed[1], want[0]), alg
+        st = gpu_ctx.cache_control()
+        assert st["hits"] > base["hits"] and st["entries"] >= 4 and st["bytes"] > 0
+        # the single-pair entry points on handles, coarse + fine (two densities -> two entries per cloud)
+        fine = s3d.default_params(registration_algorithm=s3d.ALG_ICP)
+        coarse = s3d.default_params(registration_algorithm=s3d.ALG_ICP, point_cloud_density=0.5,
+                                    max_correspondence_distance=5.0, max_translation=3.0)
+        ident = np.eye(4)
+        ref = gpu_ctx.create_constraint_clouds(cl[0], ident, cl[3], ident, ident, True, fine, coarse, 1.0, _opts(s3d, False))
+        for _ in range(2):
+            got = gpu_ctx.create_constraint_clouds(cl[0], ident, cl[3], ident, ident, True, fine, coarse, 1.0, _opts(s3d, True))
+            assert got[0] == ref[0] == 0 and np.array_equal(got[1], ref[1]) and got[3] == ref[3]
+        # normals computed with another k are not reused
+        p7 = s3d.default_params(correspondence_randomness=7, maximum_iterations=8)
+        w7 = gpu_ctx.align_batch([cl[0]], [cl[1]], None, p7, _opts(s3d, False))
+        assert np.array_equal(gpu_ctx.align_batch([cl[0]], [cl[1]], None, p7, _opts(s3d, True)), w7)
+        assert np.array_equal(gpu_ctx.align_batch([cl[0]], [cl[1]], None, p7, _opts(s3d, True)), w7)
+    finally:
+        for c in cl:
+            c.release()
+    assert gpu_ctx.cache_control()["entries"] == 0        # released clouds take their entries with them
+
+
+def test_cache_budget_and_eviction(gpu_ctx, fixture_clouds):
+    import slam3d_amd as s3d
+    gpu_ctx.cache_control(clear=True)
+    cl = [gpu_ctx.upload(c) for c in fixture_clouds]
+    try:
+        p = s3d.default_params(registration_algorithm=s3d.ALG_ICP, maximum_iterations=5)
+        want = gpu_ctx.align_batch([cl[0], cl[2]], [cl[1], cl[3]], None, p, _opts(s3d, False))
+        gpu_ctx.align_batch([cl[0]], [cl[1]], None, p, _opts(s3d, True))
+        one = gpu_ctx.cache_control()
+        assert one["entries"] == 2
+        per_entry = one["bytes"] // 2
+        # room for about three entries: the fourth cloud pushes the least recently used one out
+        gpu_ctx.cache_control(limit_bytes=int(3.5 * per_entry))
+        got = gpu_ctx.align_batch([cl[2]], [cl[3]], None, p, _opts(s3d, True))
+        st = gpu_ctx.cache_control()
+        assert st["entries"] == 3 and st["bytes"] <= int(3.5 * per_entry)
+        assert np.array_equal(got[0], want[1])
+        assert np.array_equal(gpu_ctx.align_batch([cl[0]], [cl[1]], None, p, _opts(s3d, True))[0], want[0])
+        # a budget below one entry: nothing is kept, results unchanged
+        gpu_ctx.cache_control(limit_bytes=1024, clear=True)
+        assert np.array_equal(gpu_ctx.align_batch([cl[0], cl[2]], [cl[1], cl[3]], None, p, _opts(s3d, True)), want)
+        assert gpu_ctx.cache_control()["entries"] == 0
+    finally:
+        gpu_ctx.cache_control(limit_bytes=16 << 30, clear=True)
+        for c in cl:
+            c.release()
+
+
+def test_host_buffer_entry_points_do_not_populate_the_cache(gpu_ctx, fixture_clouds):
+    """s3d_align on host buffers uploads temporary clouds: nothing to keep."""
+    import slam3d_amd as s3d
+    gpu_ctx.cache_control(clear=True)
+    p = s3d.default_params(registration_algorithm=s3d.ALG_ICP, maximum_iterations=5)
+    gpu_ctx.align(fixture_clouds[0], fixture_clouds[1], np.eye(4), p, _opts(s3d, True))
+    assert gpu_ctx.cache_control()["entries"] == 0

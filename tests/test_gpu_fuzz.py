@@ -59,3 +59,46 @@ def test_random_inputs_match_oracle(gpu_ctx, oracle_mod, seed):
             if so == 0:
                 dt, dr = transform_delta(To, Tg)
                 assert dt < 1e-4 and dr < 1e-4, (case, kind, dt, dr)
+
+
+def test_gicp_and_ndt_on_random_synthetic_pairs_match_oracle(gpu_ctx, oracle_mod):
+    """24 synthetic pairs of 8 / 20 / 40 k points at three densities, early exit enabled: GICP against the oracle's
+    smooth-objective mode (the function the device minimises) and NDT against its oracle, both at
+    the north-star tolerance (1e-4 m, 1e-4 rad; the rotation measured by the skew part - conftest.rotation_angle),
+    with identical statuses.  (Round 1 kept this loop as tools_dev/fuzz_reg.py and reported rotation misses of up to
+    2e-4 rad on such pairs: those were the noise of arccos(trace) on float-rounded matrices, not a disagreement.)"""
+    import slam3d_amd as s3d
+    from multiprocessing.pool import ThreadPool
+    cases = []
+    for i in range(24):
+        n = [8000, 20000, 40000][i % 3]
+        dens = [0.1, 0.2, 0.05][i % 3]
+        a, b, _ = s3d.make_pair(n, 500 + i)
+        cases.append((a, b, dens))
+
+    def ref(mode_alg):
+        def run(c):
+            a, b, dens = c
+            return oracle_mod.align(a, b, np.eye(4), oracle_mod.default_params(registration_algorithm=mode_alg,
+                                                                                  point_cloud_density=dens,
+                                                                                  maximum_iterations=30))
+        with ThreadPool(8) as pool:
+            return pool.map(run, cases)
+
+    oracle_mod.set_eval_precision(2)
+    try:
+        ref_gicp = ref(oracle_mod.ALG_GICP)
+    finally:
+        oracle_mod.set_eval_precision(0)
+    ref_ndt = ref(oracle_mod.ALG_NDT)
+    worst = {"gicp": [0.0, 0.0], "ndt": [0.0, 0.0]}
+    for (a, b, dens), rg, rn in zip(cases, ref_gicp, ref_ndt):
+        for name, alg, (so, To, io) in (("gicp", s3d.ALG_GICP, rg), ("ndt", s3d.ALG_NDT, rn)):
+            sg, Tg, ig = gpu_ctx.align(a, b, np.eye(4), s3d.default_params(registration_algorithm=alg,
+                                                                         point_cloud_density=dens, maximum_iterations=30))
+            assert sg == so, (name, dens, sg, so)
+            if so == 0:
+                dt, dr = transform_delta(To, Tg)
+                worst[name] = [max(worst[name][0], dt), max(worst[name][1], dr)]
+                assert dt < 1e-4 and dr < 1e-4, (name, len(a), dens, dt, dr, io["iterations"], ig["iterations"])
+    print("registration fuzz, worst |dt| m / |dr| rad vs oracle:", worst)

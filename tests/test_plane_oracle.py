@@ -98,7 +98,7 @@ def test_ring_points_lie_on_the_plane(oracle_mod):
     while r <= 5.0:
         rings, r = rings + 1, r + 0.1
     per, a = 0, 0.0
-    while a < 2 * math.pi:
+    while a < 2 * 3.141592654:          # the reference's own macro, #define PI 3.141592654 (PointCloudSensor.cpp:48, :376)
         per, a = per + 1, a + 0.1 / 5.0
     assert len(ring) == rings * per
     n, d = co[:3].astype(np.float64), float(co[3])
@@ -155,7 +155,7 @@ def test_cpp_mirror_ply_reader(tmp_path):
     exe = str(tmp_path / "ply_probe")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "cpp"), "-o", exe,
                            os.path.join(ROOT, "tests", "cpp_probe", "ply_probe.cpp"),
-                           os.path.join(ROOT, "cpp", "slam3d", "sensor", "hip", "PointCloudSensor.cpp"),
+                           os.path.join(ROOT, "cpp", "slam3d", "sensor", "pcl", "PointCloudSensor.cpp"),
                            "-L" + os.path.join(ROOT, "slam3d_amd", "lib"), "-lslam3d_hip",
                            "-Wl,-rpath," + os.path.join(ROOT, "slam3d_amd", "lib"), "-lpthread"])
     for name in write_test_plys(str(tmp_path)):
