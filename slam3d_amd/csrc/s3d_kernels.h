@@ -1029,8 +1029,9 @@ __global__ void __launch_bounds__(kBlock) k_export_normals(const SlotDev* __rest
 // ------------------------------------------------------------------ K6: per-correspondence terms + reduction
 
 // ---- fixed summation tree of the accumulate kernels --------------------------------------------------------
-// A pair's sums are defined over kAccumVB VIRTUAL blocks of 256 virtual threads: virtual thread t of virtual block
-// v folds the elements (v + 64 j) * 256 + t, j = 0, 1, ... in ascending j; the 256 per-thread sums of a virtual
+// A pair's sums are defined over kAccumVB VIRTUAL blocks of 256 virtual threads: virtual block v owns the 256-element
+// tiles [v n / 64, (v + 1) n / 64) of the pair's n tiles (vb_tile_begin) and its virtual thread t folds element t of
+// each of them in ascending order; the 256 per-thread sums of a virtual
 // block are combined by the butterfly below (64 lanes) and then over its four waves in ascending order; the
 // controller adds the kAccumVB block sums in 8 groups of 8 (ascending inside a group, then the groups in ascending
 // order: s3d_icp_control_kernel, k_fitness_final).  HOW MANY real blocks execute the virtual blocks (64 for
@@ -1070,9 +1071,19 @@ __device__ __forceinline__ int wrs_index(int lane, int slot) {
 }
 constexpr int wrs_half(int n, int levels) { return levels == 0 ? n : wrs_half((n + 1) / 2, levels - 1); }
 
+// the 256-element tiles [first, last) of virtual block v: the ntiles tiles of a pair dealt out contiguously and as
+// evenly as integers allow (6 or 7 tiles each for 100 k points), so that no virtual block runs masked steps
+__device__ __forceinline__ int vb_tile_begin(int v, int ntiles) { return (int)(((long long)v * ntiles) / kAccumVB); }
+
+#ifndef S3D_ACC_VARIANT
+#define S3D_ACC_VARIANT 1
+#endif
+// parity: 0 / 1 alternating between the consecutive virtual blocks of a real block.  The four wave results go through
+// one of two LDS buffers, so ONE block barrier per virtual block is enough: a wave that writes buffer p again (two
+// virtual blocks later) has passed the barrier in between, which waves 0-1 reach only after reading buffer p.
 template <int NACC>
-__device__ __forceinline__ void block_reduce_store_fixed(double (&acc)[NACC], double* __restrict__ out) {
-  __shared__ double red[kBlock / kWave][NACC];
+__device__ __forceinline__ void block_reduce_store_fixed(double (&acc)[NACC], double* __restrict__ out, int parity) {
+  __shared__ double red[2][kBlock / kWave][NACC];
   const int lane = lane_id(), w = wave_id();
   wrs_level<NACC, 32>(acc, lane);
   wrs_level<wrs_half(NACC, 1), 16>(acc, lane);
@@ -1081,21 +1092,31 @@ __device__ __forceinline__ void block_reduce_store_fixed(double (&acc)[NACC], do
   wrs_level<wrs_half(NACC, 4), 2>(acc, lane);
   wrs_level<wrs_half(NACC, 5), 1>(acc, lane);
   constexpr int kSlots = wrs_half(NACC, 6);
+#if S3D_ACC_VARIANT == 2
+  // experiment: every wave stores its own result (no LDS, no barrier); a combine kernel adds the four waves
 #pragma unroll
   for (int sl = 0; sl < kSlots; ++sl) {
     const int idx = wrs_index<NACC, 32>(lane, sl);
-    if (idx >= 0) red[w][idx] = acc[sl];
+    if (idx >= 0) out[(size_t)w * NACC + idx] = acc[sl];
+  }
+#else
+#pragma unroll
+  for (int sl = 0; sl < kSlots; ++sl) {
+    const int idx = wrs_index<NACC, 32>(lane, sl);
+    if (idx >= 0) red[parity][w][idx] = acc[sl];
   }
   __syncthreads();
   if (threadIdx.x < NACC) {
-    double v = red[0][threadIdx.x];
+    double v = red[parity][0][threadIdx.x];
 #pragma unroll
-    for (int ww = 1; ww < kBlock / kWave; ++ww) v += red[ww][threadIdx.x];
+    for (int ww = 1; ww < kBlock / kWave; ++ww) v += red[parity][ww][threadIdx.x];
     out[threadIdx.x] = v;
   }
-  __syncthreads();   // `red` is reused by the next virtual block of this real block
+#if S3D_ACC_VARIANT == 0
+  __syncthreads();
+#endif
+#endif
 }
-
 template <int NACC>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* __restrict__ out) {
   __shared__ double red[kBlock / kWave][NACC];
@@ -1145,15 +1166,27 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
   // The virtual blocks v = blockIdx.x, blockIdx.x + gridDim.x, ... of this pair (see block_reduce_store_fixed), one
   // after the other, as ONE software-pipelined stream: the five loads of the next element - the first element of
   // the next virtual block included - are in flight while the current one is folded into the 73 accumulators (the
-  // loads of one element per lane and wave do not cover the HBM latency-bandwidth product).  Every virtual block
-  // takes `per` steps; steps past the end of the cloud are masked.
-  const int per = (M + kAccumVB * kBlock - 1) / (kAccumVB * kBlock);
+  // loads of one element per lane and wave do not cover the HBM latency-bandwidth product).
+  const int ntiles = (M + kBlock - 1) / kBlock;
+#if S3D_ACC_VARIANT == 2
+  constexpr int kAccOutMul = kBlock / kWave;   // experiment: per-wave results in a second region, k_combine_waves adds them
+  double* __restrict__ out = partials + ((size_t)gridDim.y + (size_t)blockIdx.y * kAccOutMul) * kAccumVB * GQ_NACC;
+#else
+  constexpr int kAccOutMul = 1;
   double* __restrict__ out = partials + (size_t)blockIdx.y * kAccumVB * GQ_NACC;
-  int v = blockIdx.x;
-  for (; v < kAccumVB && v * kBlock >= M; v += gridDim.x)    // (virtual blocks past the end of a small cloud)
-    if (threadIdx.x < GQ_NACC) out[(size_t)v * GQ_NACC + threadIdx.x] = 0.0;
+#endif
+  // next virtual block of this real block that owns at least one tile, starting at `from`; the empty ones on the
+  // way (a cloud of fewer than 64 tiles) get their zero sums
+  auto next_nonempty = [&](int from) {
+    int u = from;
+    for (; u < kAccumVB && vb_tile_begin(u, ntiles) == vb_tile_begin(u + 1, ntiles); u += gridDim.x)
+      for (int t = threadIdx.x; t < GQ_NACC * kAccOutMul; t += kBlock) out[(size_t)u * GQ_NACC * kAccOutMul + t] = 0.0;
+    return u;
+  };
+  int v = next_nonempty(blockIdx.x);
   if (v >= kAccumVB) return;
-  int i = v * kBlock + threadIdx.x;
+  int tile = vb_tile_begin(v, ntiles);
+  int i = tile * kBlock + threadIdx.x;
   float d2 = 3.0e38f;
   CorrVec p0 = corr_vec(make_float4(0.f, 0.f, 0.f, 0.f)), qf = p0, na = p0, nb = p0;
   {
@@ -1162,15 +1195,17 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
     p0 = sorted[St.off + j]; qf = corr_q[P.corr_off + j];
     na = normals[St.off + j]; nb = corr_n[P.corr_off + j];
   }
+  int parity = 0;
   while (v < kAccumVB) {
     double acc[GQ_NACC];
 #pragma unroll
     for (int c = 0; c < GQ_NACC; ++c) acc[c] = 0.0;
-    int vn = v + gridDim.x;                // next virtual block with any element
-    if (vn * kBlock >= M) vn = kAccumVB;
-    for (int step = 0; step < per; ++step) {
-      const int in = step + 1 < per ? i + kAccumVB * kBlock : vn * kBlock + (int)threadIdx.x;
-      const int j = in < M ? in : M - 1;   // (masked steps re-read the last element: no branch around the loads)
+    const int vn = next_nonempty(v + gridDim.x);
+    const int tile_end = vb_tile_begin(v + 1, ntiles);
+    const int first_next = vn < kAccumVB ? vb_tile_begin(vn, ntiles) * kBlock + (int)threadIdx.x : i;
+    for (; tile < tile_end; ++tile) {
+      const int in = tile + 1 < tile_end ? i + kBlock : first_next;
+      const int j = in < M ? in : M - 1;   // (the last tile may be partial: no branch around the loads)
       const float d2n = corr_d2[P.corr_off + j];
       const CorrVec p0n = sorted[St.off + j], nan_ = normals[St.off + j], qfn = corr_q[P.corr_off + j], nbn = corr_n[P.corr_off + j];
       if (i < M && (double)d2 < rp.dist_threshold) {
@@ -1189,12 +1224,21 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
       d2 = d2n; p0 = p0n; qf = qfn; na = nan_; nb = nbn;
       i = in;
     }
-    block_reduce_store_fixed<GQ_NACC>(acc, out + (size_t)v * GQ_NACC);
-    for (int u = v + gridDim.x; u < kAccumVB && u < vn; u += gridDim.x)   // empty virtual blocks in between: none
-      if (threadIdx.x < GQ_NACC) out[(size_t)u * GQ_NACC + threadIdx.x] = 0.0;
+    block_reduce_store_fixed<GQ_NACC>(acc, out + (size_t)v * GQ_NACC * kAccOutMul, parity);
+    parity ^= 1;
     v = vn;
+    if (v < kAccumVB) tile = vb_tile_begin(v, ntiles);
   }
 }
+
+#if S3D_ACC_VARIANT == 2
+__global__ void k_combine_waves(double* __restrict__ partials, int npairs) {
+  const double* w = partials + ((size_t)npairs + (size_t)blockIdx.y * 4) * kAccumVB * GQ_NACC + (size_t)blockIdx.x * 4 * GQ_NACC;
+  double* o = partials + ((size_t)blockIdx.y * kAccumVB + blockIdx.x) * GQ_NACC;
+  const int c = threadIdx.x;
+  if (c < GQ_NACC) o[c] = ((w[c] + w[GQ_NACC + c]) + w[2 * GQ_NACC + c]) + w[3 * GQ_NACC + c];
+}
+#endif
 
 // point-to-plane: J^T J (21) + J^T r (6) + r^2 + count
 __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const PairDev* __restrict__ pairs,
@@ -1208,20 +1252,20 @@ __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const Pa
   if (!P.active) return;
   const SlotDev& St = slots[P.slot_t];
   const int M = St.n;
-  const int per = (M + kAccumVB * kBlock - 1) / (kAccumVB * kBlock);
+  const int ntiles = (M + kBlock - 1) / kBlock;
   double* __restrict__ out = partials + (size_t)blockIdx.y * kAccumVB * GQ_NACC;
   // virtual blocks of the fixed summation tree (block_reduce_store_fixed), gridDim.x of them at a time
+  int parity = 0;
   for (int v = blockIdx.x; v < kAccumVB; v += gridDim.x) {
-    if (v * kBlock >= M) {
+    const int t0 = vb_tile_begin(v, ntiles), t1 = vb_tile_begin(v + 1, ntiles);
+    if (t0 == t1) {   // (uniform over the block: no barrier is skipped by part of it)
       if (threadIdx.x < PP_NACC) out[(size_t)v * GQ_NACC + threadIdx.x] = 0.0;
       continue;
     }
     double acc[PP_NACC];
 #pragma unroll
     for (int c = 0; c < PP_NACC; ++c) acc[c] = 0.0;
-    int i = v * kBlock + threadIdx.x;
-    for (int step = 0; step < per; ++step, i += kAccumVB * kBlock) {
-      if (i >= M) break;
+    for (int i = t0 * kBlock + (int)threadIdx.x; i < t1 * kBlock && i < M; i += kBlock) {
       const float d2 = corr_d2[P.corr_off + i];
       if (!((double)d2 < rp.dist_threshold)) continue;
       const CorrVec p0 = sorted[St.off + i];
@@ -1234,15 +1278,16 @@ __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const Pa
       const double nd[3] = {nf.x, nf.y, nf.z};
       pp_accumulate(acc, pd, qd, nd);
     }
-    block_reduce_store_fixed<PP_NACC>(acc, out + (size_t)v * GQ_NACC);
+    block_reduce_store_fixed<PP_NACC>(acc, out + (size_t)v * GQ_NACC, parity);
+    parity ^= 1;
   }
 }
 
 // ------------------------------------------------------------------ K7: per-pair controller
 // fixed-order sum of the block partials, then the solver step and the PCL stopping rule.
 // One block per pair; the scalar solver runs on lane 0 with the record in LDS.
-constexpr int kCtrlGroups = 8;                                  // the root of the fixed summation tree: 8 groups of 8 virtual blocks
-constexpr int kCtrlThreads = ((kCtrlGroups * GQ_NACC + kWave - 1) / kWave) * kWave;   // 640
+constexpr int kCtrlGroups = 8;      // the root of the fixed summation tree: 8 groups of 8 virtual blocks
+constexpr int kCtrlThreads = 128;   // (two waves: more would cap the optimiser's registers below what it uses)
 __global__ void __launch_bounds__(kCtrlThreads) s3d_icp_control_kernel(PairDev* pairs, const double* __restrict__ partials,
                                                                         RunParams rp, int* n_active) {
   __shared__ double grp[kCtrlGroups][GQ_NACC];
@@ -1251,14 +1296,32 @@ __global__ void __launch_bounds__(kCtrlThreads) s3d_icp_control_kernel(PairDev* 
   if (!P.active) return;
   const bool gicp = rp.algorithm != 0;
   const int nacc = gicp ? GQ_NACC : PP_NACC;
-  // root of the fixed tree: the kAccumVB virtual-block sums in 8 groups of 8 (ascending inside a group, one thread
-  // per (group, accumulator): all 64 loads of an accumulator are in flight at once), then the groups in ascending
-  // order.  One L2 round trip instead of eight on the critical path of every outer iteration.
+  // root of the fixed tree: the kAccumVB virtual-block sums in 8 groups of 8 (ascending inside a group), then the
+  // groups in ascending order.  Every thread takes up to five (group, accumulator) cells and issues all of their
+  // loads before the first addition: one L2 round trip instead of eight on the critical path of every iteration.
   {
-    const int g = (int)threadIdx.x / GQ_NACC, c = (int)threadIdx.x % GQ_NACC;
-    if (g < kCtrlGroups && c < nacc) {
-      const double* src = partials + ((size_t)blockIdx.x * kAccumVB + (size_t)g * (kAccumVB / kCtrlGroups)) * GQ_NACC + c;
-      grp[g][c] = ordered_partial_sum(src, kAccumVB / kCtrlGroups, GQ_NACC);
+    constexpr int kCells = (kCtrlGroups * GQ_NACC + kCtrlThreads - 1) / kCtrlThreads;   // 5
+    constexpr int kPer = kAccumVB / kCtrlGroups;                                        // 8
+    double t[kCells][kPer];
+#pragma unroll
+    for (int u = 0; u < kCells; ++u) {
+      const int cell = (int)threadIdx.x + u * kCtrlThreads;
+      const int g = cell / GQ_NACC, c = cell % GQ_NACC;
+      const bool ok = g < kCtrlGroups && c < nacc;
+      const double* src = partials + ((size_t)blockIdx.x * kAccumVB + (size_t)(ok ? g : 0) * kPer) * GQ_NACC + (ok ? c : 0);
+#pragma unroll
+      for (int j = 0; j < kPer; ++j) t[u][j] = src[(size_t)j * GQ_NACC];
+    }
+#pragma unroll
+    for (int u = 0; u < kCells; ++u) {
+      const int cell = (int)threadIdx.x + u * kCtrlThreads;
+      const int g = cell / GQ_NACC, c = cell % GQ_NACC;
+      if (g < kCtrlGroups && c < nacc) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) v += t[u][j];
+        grp[g][c] = v;
+      }
     }
   }
   __syncthreads();
@@ -1320,13 +1383,15 @@ __global__ void __launch_bounds__(kBlock) s3d_fitness_partial_kernel(const PairD
   const int M = slots[P.slot_t].n;
   double* __restrict__ out = partials + (size_t)blockIdx.y * kAccumVB * GQ_NACC;
   // the same virtual blocks as the accumulate kernels: the score does not depend on the launch geometry
+  const int ntiles = (M + kBlock - 1) / kBlock;
   for (int v = blockIdx.x; v < kAccumVB; v += gridDim.x) {
     double acc[2] = {0.0, 0.0};
-    for (int i = v * kBlock + threadIdx.x; i < M; i += kAccumVB * kBlock) {
+    const int t1 = vb_tile_begin(v + 1, ntiles);
+    for (int i = vb_tile_begin(v, ntiles) * kBlock + (int)threadIdx.x; i < t1 * kBlock && i < M; i += kBlock) {
       const float d2 = corr_d2[P.corr_off + i];
       if ((double)d2 <= rp.fit_range) { acc[0] += (double)d2; acc[1] += 1.0; }   // (no neighbour at all: d2 = 3e38)
     }
-    block_reduce_store_fixed<2>(acc, out + (size_t)v * GQ_NACC);
+    block_reduce_store_fixed<2>(acc, out + (size_t)v * GQ_NACC, (v / (int)gridDim.x) & 1);
   }
 }
 
