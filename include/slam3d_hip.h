@@ -100,7 +100,9 @@ int  s3d_nn_search(s3d_context* ctx, const float* target_xyz, int n, int stride_
 
 /* ---- A6  GICP computeCovariances pre-pass (PointCloudSensor.cpp:63 setCorrespondenceRandomness):
  *          unit eigenvector of the smallest eigenvalue of the k-NN covariance, packed xyz.
- *          The regularised covariance PCL builds is C = I - (1 - 0.001) n n^T. */
+ *          The regularised covariance PCL builds is C = I - (1 - 0.001) n n^T.
+ *          Limit of the back-end: 1 <= k <= 64 (PCL accepts any k <= cloud size); k outside that range, here and as
+ *          correspondence_randomness of a registration, returns S3D_STATUS_INVALID_ARGUMENT. */
 int  s3d_knn_normals(s3d_context* ctx, const float* xyz, int n, int stride, int k, float* normals_xyz);
 
 /* ---- A2  align() (PointCloudSensor.cpp:119-174): downsample both, 100-point gate, doICP

@@ -157,6 +157,20 @@ struct s3d_context {
   DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, sorted3, normals, moments, cell_start, counts, digit_tot, blockcnt,
       corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active, knn_list;
   int* h_active = nullptr;  // pinned
+  // pinned staging of the slot / pair records (up and down): a copy from or to pageable memory stalls the stream for
+  // tens of microseconds, which a single-pair registration of ~1.5 ms notices
+  char* h_stage = nullptr;
+  size_t h_stage_cap = 0;
+  char* stage_host(size_t bytes) {
+    if (bytes > h_stage_cap) {
+      if (h_stage) HIPCHK(hipHostFree(h_stage));
+      h_stage = nullptr; h_stage_cap = 0;
+      const size_t want = std::max<size_t>(bytes + bytes / 2, 1 << 16);
+      HIPCHK(hipHostMalloc((void**)&h_stage, want));
+      h_stage_cap = want;
+    }
+    return h_stage;
+  }
   hipEvent_t ev[8] = {};
   std::vector<hipEvent_t> nn_ev;
 
@@ -466,8 +480,12 @@ struct Batch {
         sl.want_normals = 0;
       }
     }
-    if (C()) HIPCHK(hipMemcpyAsync(ctx->slots.p, h_slots.data(), sizeof(SlotDev) * C(), hipMemcpyHostToDevice, st));
-    if (P()) HIPCHK(hipMemcpyAsync(ctx->pairs.p, h_pairs.data(), sizeof(PairDev) * P(), hipMemcpyHostToDevice, st));
+    {
+      const size_t bs = sizeof(SlotDev) * (size_t)C(), bp = sizeof(PairDev) * (size_t)P();
+      char* stage = ctx->stage_host(bs + bp + 16);
+      if (bs) { std::memcpy(stage, h_slots.data(), bs); HIPCHK(hipMemcpyAsync(ctx->slots.p, stage, bs, hipMemcpyHostToDevice, st)); }
+      if (bp) { std::memcpy(stage + bs, h_pairs.data(), bp); HIPCHK(hipMemcpyAsync(ctx->pairs.p, stage + bs, bp, hipMemcpyHostToDevice, st)); }
+    }
     restore_from_cache();
   }
 
@@ -583,6 +601,29 @@ struct Batch {
       s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc, 0);
   }
 
+  // one outer iteration: correspondences (K5), accumulate (K6), controller (K7)
+  void launch_iteration(int it, float max_d, int prof_slot) {
+    // passes 3-5: a third of the lanes still search, scattered over all waves -> block-compacting variant
+    launch_nn(0, max_d, prof_slot, it >= 2 && it <= 4);   // (the counters cost two atomics per searching wave)
+    launch_iteration_after_nn();
+  }
+  void launch_iteration_after_nn() {
+    hipStream_t st = ctx->stream;
+    double* part = (double*)ctx->partials.p;
+    if (rp.algorithm)
+      s3d_gicp_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
+          d_pairs(), d_slots(), sorted3(), normals(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p,
+          (CorrVec*)ctx->corr_n.p, part, rp);
+#if S3D_ACC_VARIANT == 2
+    if (rp.algorithm) k_combine_waves<<<dim3(kAccumVB, P()), 128, 0, st>>>(part, P());
+#endif
+    if (!rp.algorithm)
+      s3d_p2plane_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
+          d_pairs(), d_slots(), sorted3(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p, (CorrVec*)ctx->corr_n.p,
+          part, rp);
+    s3d_icp_control_kernel<<<P(), kCtrlThreads, 0, st>>>(d_pairs(), part, rp, (int*)ctx->n_active.p);
+  }
+
   // K5-K7 loop.  The host only polls the active-pair counter every check_interval iterations.
   void stage_icp() {
     hipStream_t st = ctx->stream;
@@ -593,36 +634,29 @@ struct Batch {
     HIPCHK(hipMemsetAsync(ctx->corr_d2.p, 0xFF, 4 * std::max<size_t>(total_corr, 4), st));
     HIPCHK(hipMemsetAsync(ctx->corr_lb.p, 0, 4 * std::max<size_t>(total_corr, 4), st));
     const float max_d = (float)(rp.max_corr * 1.0001);
-    double* part = (double*)ctx->partials.p;
     const bool prof = opts.profile != 0;
     if (prof) HIPCHK(hipMemsetAsync((int*)ctx->n_active.p + 16, 0, 2 * 64 * sizeof(int), st));
-    for (int it = 0; it < rp.max_iterations; ++it) {
-      if (prof) {
-        if ((int)ctx->nn_ev.size() < 2 * (it + 1)) {
-          hipEvent_t a, b;
-          HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-          ctx->nn_ev.push_back(a); ctx->nn_ev.push_back(b);
+    // segments of iterations between two polls of the active-pair counter (all of them when the count is forced)
+    const int seg = rp.force_iterations ? std::max(rp.max_iterations, 1) : opts.check_interval;
+    for (int it0 = 0; it0 < rp.max_iterations; it0 += seg) {
+      const int it1 = std::min(it0 + seg, rp.max_iterations);
+      for (int it = it0; it < it1; ++it) {
+        if (prof) {
+          if ((int)ctx->nn_ev.size() < 2 * (it + 1)) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+            ctx->nn_ev.push_back(a); ctx->nn_ev.push_back(b);
+          }
+          HIPCHK(hipEventRecord(ctx->nn_ev[2 * it], st));
+          launch_nn(0, max_d, opts.profile >= 2 ? it : -1, it >= 2 && it <= 4);
+          HIPCHK(hipEventRecord(ctx->nn_ev[2 * it + 1], st));
+          launch_iteration_after_nn();
+        } else {
+          launch_iteration(it, max_d, -1);
         }
-        HIPCHK(hipEventRecord(ctx->nn_ev[2 * it], st));
       }
-      // passes 3-5: a third of the lanes still search, scattered over all waves -> block-compacting variant
-      launch_nn(0, max_d, opts.profile >= 2 ? it : -1, it >= 2 && it <= 4);   // (the counters cost two atomics per searching wave)
-      if (prof) HIPCHK(hipEventRecord(ctx->nn_ev[2 * it + 1], st));
-      if (rp.algorithm)
-        s3d_gicp_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
-            d_pairs(), d_slots(), sorted3(), normals(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p,
-            (CorrVec*)ctx->corr_n.p, part, rp);
-#if S3D_ACC_VARIANT == 2
-      if (rp.algorithm) k_combine_waves<<<dim3(kAccumVB, P()), 128, 0, st>>>(part, P());
-#endif
-      if (rp.algorithm) {}
-      else
-        s3d_p2plane_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
-            d_pairs(), d_slots(), sorted3(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p, (CorrVec*)ctx->corr_n.p,
-            part, rp);
-      s3d_icp_control_kernel<<<P(), kCtrlThreads, 0, st>>>(d_pairs(), part, rp, d_active);
-      ctx->prof.nn_launches = it + 1;
-      if (!rp.force_iterations && (it + 1) % opts.check_interval == 0 && it + 1 < rp.max_iterations) {
+      ctx->prof.nn_launches = it1;
+      if (!rp.force_iterations && it1 < rp.max_iterations) {
         HIPCHK(hipMemcpyAsync(ctx->h_active, d_active, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (*ctx->h_active <= 0) break;
@@ -644,10 +678,14 @@ struct Batch {
 
   void download() {
     hipStream_t st = ctx->stream;
-    if (C()) HIPCHK(hipMemcpyAsync(h_slots.data(), ctx->slots.p, sizeof(SlotDev) * C(), hipMemcpyDeviceToHost, st));
-    if (P()) HIPCHK(hipMemcpyAsync(h_pairs.data(), ctx->pairs.p, sizeof(PairDev) * P(), hipMemcpyDeviceToHost, st));
+    const size_t bs = sizeof(SlotDev) * (size_t)C(), bp = sizeof(PairDev) * (size_t)P();
+    char* stage = ctx->stage_host(bs + bp + 16);   // (the uploads of this call have completed by now: stream order)
+    if (bs) HIPCHK(hipMemcpyAsync(stage, ctx->slots.p, bs, hipMemcpyDeviceToHost, st));
+    if (bp) HIPCHK(hipMemcpyAsync(stage + bs, ctx->pairs.p, bp, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
+    if (bs) std::memcpy(h_slots.data(), stage, bs);
+    if (bp) std::memcpy(h_pairs.data(), stage + bs, bp);
   }
 
   void run_all() {
@@ -1227,6 +1265,7 @@ void s3d_context_destroy(s3d_context* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx->release_all();
   if (ctx->h_active) (void)hipHostFree(ctx->h_active);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->nn_ev) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -158,6 +158,44 @@ def test_knn_normals_match_oracle(gpu_ctx, oracle_mod, fixture_clouds):
         gpu_ctx.knn_normals(v1[:10], 20)          # PCL: k > cloud size is an error
 
 
+def test_knn_normals_large_k(gpu_ctx, oracle_mod, fixture_clouds):
+    """correspondence_randomness above 32 takes the LDS top-k kernel (k_normals; up to 64, the documented limit of the
+    back-end): same neighbour sets as the oracle, in s3d_knn_normals and inside a GICP registration; k = 65 is refused
+    with INVALID_ARGUMENT (PCL itself accepts any k <= cloud size)."""
+    import slam3d_amd as s3d
+    v1, _ = oracle_mod.voxel_downsample(fixture_clouds[0], 0.3)
+    for k in (33, 64):
+        n_gpu = gpu_ctx.knn_normals(v1, k).astype(np.float64)
+        _, n_ref = oracle_mod.gicp_covariances(v1, k)
+        dots = np.abs((n_gpu * n_ref).sum(1))
+        assert (dots < 1 - 1e-6).mean() < 2e-3, k
+    with pytest.raises(ValueError):
+        gpu_ctx.knn_normals(v1, 65)
+    p = s3d.default_params(correspondence_randomness=40, maximum_iterations=10, point_cloud_density=0.3)
+    po = oracle_mod.default_params(correspondence_randomness=40, maximum_iterations=10, point_cloud_density=0.3)
+    oracle_mod.set_eval_precision(2)
+    try:
+        so, To, io = oracle_mod.align(fixture_clouds[0], fixture_clouds[1], np.eye(4), po)
+    finally:
+        oracle_mod.set_eval_precision(0)
+    sg, Tg, ig = gpu_ctx.align(fixture_clouds[0], fixture_clouds[1], np.eye(4), p)
+    dt, dr = transform_delta(To, Tg)
+    assert sg == so == 0 and dt < TOL_T_GICP and dr < TOL_R_GICP, (dt, dr)
+    sg, _, _ = gpu_ctx.align(fixture_clouds[0], fixture_clouds[1], np.eye(4), s3d.default_params(correspondence_randomness=65))
+    assert sg == 7
+
+
+def test_check_interval_does_not_change_results(gpu_ctx, fixture_clouds):
+    """s3d_exec_options.check_interval (how often the host polls "all pairs converged"; 0 = default 4) is a polling
+    cadence only: converged pairs stop iterating on the device at once, whatever the interval."""
+    import slam3d_amd as s3d
+    p = s3d.default_params()
+    ref = gpu_ctx.align(fixture_clouds[0], fixture_clouds[1], np.eye(4), p)
+    for ci in (1, 2, 4, 7, 50):
+        got = gpu_ctx.align(fixture_clouds[0], fixture_clouds[1], np.eye(4), p, s3d.ExecOptions(check_interval=ci))
+        assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and got[2] == ref[2], ci
+
+
 # ------------------------------------------------------------------ NDT (SURVEY §8f rank 3)
 
 @pytest.mark.parametrize("pair,gx", [((0, 1), 0.0), ((1, 2), 0.0), ((2, 3), 0.0), ((0, 3), 2.0)])

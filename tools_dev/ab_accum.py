@@ -20,5 +20,5 @@ for blocks in os.environ.get('BLOCKS', '0,4,8,16,32,64').split(','):
         t0 = time.perf_counter(); rec = ctx.align_batch(a, b, None, p, o); t.append((time.perf_counter() - t0) * 1e3)
     pr = ctx.last_profile()
     if ref is None: ref = rec
-    print('blocks', blocks, 'step %.2f ms' % np.median(t), 'icp %.2f nn %.2f rest %.2f' % (pr['icp_ms'], pr['nn_ms'], pr['icp_ms'] - pr['nn_ms']),
+    print('blocks', blocks, 'step %.2f ms' % np.median(t), 'voxel %.2f grid %.2f normals %.2f icp %.2f nn %.2f rest %.2f' % (pr['voxel_ms'], pr['grid_ms'], pr['normals_ms'], pr['icp_ms'], pr['nn_ms'], pr['icp_ms'] - pr['nn_ms']),
           'identical', bool(np.array_equal(rec, ref)), flush=True)
