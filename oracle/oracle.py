@@ -345,5 +345,9 @@ def set_debug_perturbation(rel, seed=1):
     lib().s3o_set_debug_perturbation(C.c_double(float(rel)))
 
 
+def set_debug_float_normals(on):
+    lib().s3o_set_debug_float_normals(int(bool(on)))
+
+
 def set_trace(on):
     lib().s3o_set_trace(int(bool(on)))

@@ -456,6 +456,11 @@ void s3o_nn_search_brute(const float* tgt, int n, const float* qry, int m, int* 
 
 /* ------------------------------------------------------------------ covariances (A6) */
 
+/* diagnostic: build every covariance as I - (1 - eps) n n^T from the FLOAT-rounded unit normal, which is how the device
+ * stores it (12 bytes per point instead of 72); default off = PCL's U diag(1, 1, eps) U^T in double */
+static int g_float_normals = 0;
+void s3o_set_debug_float_normals(int on) { g_float_normals = on; }
+
 static int gicp_covariances_tree(const s3o_kdtree* tree, const float* xyz, int n, int k, double eps,
                                  double* cov, double* normals) {
   if (k > n) return -1; /* PCL gicp.hpp: "Number of points in cloud is less than k_correspondences_" */
@@ -491,6 +496,11 @@ static int gicp_covariances_tree(const s3o_kdtree* tree, const float* xyz, int n
       double v = kk == 2 ? eps : 1.0;
       for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b) out[a * 3 + b] += v * U[a * 3 + kk] * U[b * 3 + kk];
+    }
+    if (g_float_normals) { /* diagnostic (s3o_set_debug_float_normals): the covariance as the device stores it */
+      const double nf[3] = {(double)(float)U[0 * 3 + 2], (double)(float)U[1 * 3 + 2], (double)(float)U[2 * 3 + 2]};
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) out[a * 3 + b] = (a == b ? 1.0 : 0.0) - (1.0 - eps) * nf[a] * nf[b];
     }
     if (normals) for (int a = 0; a < 3; ++a) normals[(size_t)i * 3 + a] = U[a * 3 + 2];
   }

@@ -246,7 +246,7 @@ struct Batch {
   float4* sorted() { return (float4*)ctx->sorted.p; }
   CorrVec* sorted3() { return has_sorted3 ? (CorrVec*)ctx->sorted3.p : nullptr; }
   bool has_sorted3 = false;
-  CorrVec* normals() { return (CorrVec*)ctx->normals.p; }
+  NormalRec* normals() { return (NormalRec*)ctx->normals.p; }
   uint32_t* cells() { return (uint32_t*)ctx->cell_start.p; }
   int C() const { return (int)h_slots.size(); }
   int P() const { return (int)h_pairs.size(); }
@@ -369,7 +369,7 @@ struct Batch {
         HIPCHK(hipMemcpyAsync(sorted() + sl.off, e.block + e.o_sorted, 16 * n, hipMemcpyDeviceToDevice, st));
         if (has_sorted3) HIPCHK(hipMemcpyAsync(sorted3() + sl.off, e.block + e.o_sorted3, sizeof(CorrVec) * n, hipMemcpyDeviceToDevice, st));
         if (slot_has_normals[(size_t)j])
-          HIPCHK(hipMemcpyAsync(normals() + sl.off, e.block + e.o_normals, sizeof(CorrVec) * n, hipMemcpyDeviceToDevice, st));
+          HIPCHK(hipMemcpyAsync(normals() + sl.off, e.block + e.o_normals, sizeof(NormalRec) * n, hipMemcpyDeviceToDevice, st));
       }
       HIPCHK(hipMemcpyAsync(cells() + sl.cell_off, e.block + e.o_cells, 4 * ((size_t)sl.g.ncells + 1), hipMemcpyDeviceToDevice, st));
     }
@@ -387,7 +387,7 @@ struct Batch {
       if (j >= Cu) {   // restored from the cache: at most the normals are new
         CacheEntry& e = *slot_entry[(size_t)j];
         if (normals_now && n) {
-          HIPCHK(hipMemcpyAsync(e.block + e.o_normals, normals() + sl.off, sizeof(CorrVec) * n, hipMemcpyDeviceToDevice, st));
+          HIPCHK(hipMemcpyAsync(e.block + e.o_normals, normals() + sl.off, sizeof(NormalRec) * n, hipMemcpyDeviceToDevice, st));
           e.k_normals = k;
         }
         continue;
@@ -396,7 +396,7 @@ struct Batch {
       const size_t cells_n = (size_t)sl.g.ncells + 1;
       auto place = [&](size_t bytes) { const size_t o = e.bytes; e.bytes += (bytes + 255) & ~(size_t)255; return o; };
       e.o_filt = place(16 * n); e.o_sorted = place(16 * n); e.o_sorted3 = place(sizeof(CorrVec) * n);
-      e.o_normals = place(sizeof(CorrVec) * n); e.o_cells = place(4 * cells_n);
+      e.o_normals = place(sizeof(NormalRec) * n); e.o_cells = place(4 * cells_n);
       e.bytes = std::max<size_t>(e.bytes, 256);
       // make room: least-recently-used entries that this call does not use
       while (ctx->cache_bytes + e.bytes > ctx->cache_limit) {
@@ -414,7 +414,7 @@ struct Batch {
         HIPCHK(hipMemcpyAsync(e.block + e.o_filt, filt() + sl.off, 16 * n, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(e.block + e.o_sorted, sorted() + sl.off, 16 * n, hipMemcpyDeviceToDevice, st));
         if (has_sorted3) HIPCHK(hipMemcpyAsync(e.block + e.o_sorted3, sorted3() + sl.off, sizeof(CorrVec) * n, hipMemcpyDeviceToDevice, st));
-        if (normals_now) HIPCHK(hipMemcpyAsync(e.block + e.o_normals, normals() + sl.off, sizeof(CorrVec) * n, hipMemcpyDeviceToDevice, st));
+        if (normals_now) HIPCHK(hipMemcpyAsync(e.block + e.o_normals, normals() + sl.off, sizeof(NormalRec) * n, hipMemcpyDeviceToDevice, st));
       }
       HIPCHK(hipMemcpyAsync(e.block + e.o_cells, cells() + sl.cell_off, 4 * cells_n, hipMemcpyDeviceToDevice, st));
       e.k_normals = normals_now ? k : 0;
@@ -450,7 +450,7 @@ struct Batch {
     ctx->carve({{&ctx->slots, sizeof(SlotDev) * std::max(1, C())},
                 {&ctx->pairs, sizeof(PairDev) * std::max(1, P())},
                 {&ctx->keysA, 4 * np}, {&ctx->keysB, 4 * np}, {&ctx->valsA, 4 * np}, {&ctx->valsB, 4 * np},
-                {&ctx->filt, 16 * np}, {&ctx->sorted, 16 * np}, {&ctx->sorted3, 12 * npi}, {&ctx->normals, 12 * npi}, {&ctx->moments, 72 * npi},
+                {&ctx->filt, 16 * np}, {&ctx->sorted, 16 * np}, {&ctx->sorted3, 12 * npi}, {&ctx->normals, sizeof(NormalRec) * npi}, {&ctx->moments, 72 * npi},
                 {&ctx->cell_start, 4 * std::max<size_t>(total_cells, 4)},
                 {&ctx->counts, 4 * (size_t)std::max(1, C()) * 256 * nb_sort},
                 {&ctx->digit_tot, 4 * (size_t)std::max(1, C()) * 256},
@@ -584,7 +584,7 @@ struct Batch {
     NNArrays A;
     A.sorted = sorted(); A.sorted3 = sorted3(); A.cell_start = cells(); A.normals = normals();
     A.corr_idx = (int*)ctx->corr_idx.p; A.corr_d2 = (float*)ctx->corr_d2.p; A.corr_lb = (float*)ctx->corr_lb.p;
-    A.corr_q = (CorrVec*)ctx->corr_q.p; A.corr_n = (CorrVec*)ctx->corr_n.p;
+    A.corr_q = (CorrVec*)ctx->corr_q.p; A.corr_n = (NormalRec*)ctx->corr_n.p;
     return A;
   }
   void launch_nn(int mode, float max_d, int prof_slot = -1, bool compact = false) {
@@ -613,13 +613,13 @@ struct Batch {
     if (rp.algorithm)
       s3d_gicp_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
           d_pairs(), d_slots(), sorted3(), normals(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p,
-          (CorrVec*)ctx->corr_n.p, part, rp);
+          (NormalRec*)ctx->corr_n.p, part, rp);
 #if S3D_ACC_VARIANT == 2
     if (rp.algorithm) k_combine_waves<<<dim3(kAccumVB, P()), 128, 0, st>>>(part, P());
 #endif
     if (!rp.algorithm)
       s3d_p2plane_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
-          d_pairs(), d_slots(), sorted3(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p, (CorrVec*)ctx->corr_n.p,
+          d_pairs(), d_slots(), sorted3(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p,
           part, rp);
     s3d_icp_control_kernel<<<P(), kCtrlThreads, 0, st>>>(d_pairs(), part, rp, (int*)ctx->n_active.p);
   }
@@ -1972,18 +1972,7 @@ int s3d_profile_nn_kernel(s3d_context* ctx, int n_pairs, s3d_cloud* const* sourc
       HIPCHK(hipMemsetAsync(ctx->corr_d2.p, 0xFF, 4 * std::max<size_t>(b.total_corr, 4), ctx->stream));
       HIPCHK(hipMemsetAsync(ctx->corr_lb.p, 0, 4 * std::max<size_t>(b.total_corr, 4), ctx->stream));
       HIPCHK(hipEventRecord(e0, ctx->stream));
-      static const int probe = getenv("S3D_DBG_FIRSTPASS") ? atoi(getenv("S3D_DBG_FIRSTPASS")) : 0;
-      if (probe) {   // measurement aid: the lean first-pass kernels (s3d_kernels.h)
-        NNArrays A = b.nn_arrays();
-        const int chunks = cdiv(b.max_n_t, kBlock);
-        const int p8 = n_pairs >= 8 ? cdiv(n_pairs, 8) * 8 : n_pairs;
-        if (probe == 2)
-          s3d_nn_first_pass_probe_kernel<true><<<(unsigned)(p8 * chunks), kBlock, 0, ctx->stream>>>(b.d_pairs(), b.d_slots(), A, max_d, chunks, n_pairs);
-        else
-          s3d_nn_first_pass_probe_kernel<false><<<(unsigned)(p8 * chunks), kBlock, 0, ctx->stream>>>(b.d_pairs(), b.d_slots(), A, max_d, chunks, n_pairs);
-      } else {
-        b.launch_nn(0, max_d);
-      }
+      b.launch_nn(0, max_d);
       HIPCHK(hipEventRecord(e1, ctx->stream));
       HIPCHK(hipEventSynchronize(e1));
       float ms = 0;

@@ -349,7 +349,7 @@ constexpr float kNNRevalSlack = 0.25f;   // in cells
 // best, so that the examined radius exceeds the neighbour's distance and the NEXT pass can re-validate the
 // correspondence without a search (nn_still_nearest).  Without it every such query walks its whole ball again in
 // every ICP iteration: on the reference's fixture scans those 2 % of the queries were 75 % of the step time.
-template <typename F4T, bool ROWITER = false>
+template <typename F4T>
 S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ cell_start,
                              const F4T* __restrict__ pts, float qx, float qy, float qz, float max_d, float d_hint,
                              int seed_pos = -1, bool seed_trusted = false) {
@@ -399,59 +399,6 @@ S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ c
         float lim2 = limit2();
         // (layers / rows are visited centre-out, alternating sides: once BOTH sides have produced a slab beyond
         // the limit, every later one is beyond it too and the loop ends)
-        if constexpr (ROWITER) {
-        // (probe form, tools_dev/firstpass_probe.py: every lane on its OWN next row; not used by the product kernels)
-        int zfar = 0, yfar = 0, oz = 0, oy = 0, cz = 0;
-        float dz2 = 0.f;
-        bool layer_open = false;
-        auto advance = [&](uint32_t& s, uint32_t& e) -> bool {
-          for (;;) {
-            if (!layer_open) {
-              if (!(oz <= 2 * (z1 - z0) + 1 && zfar != 3)) return false;
-              cz = cz0 + ((oz & 1) ? -((oz + 1) >> 1) : (oz >> 1));
-              const int sz = (oz & 1) ? 1 : 2;
-              ++oz;
-              if (cz < z0 || cz > z1) { zfar |= sz; continue; }
-              const float zlo = g.origin[2] + (float)cz * g.h, zhi = zlo + g.h;
-              const float dz = fmaxf(fmaxf(zlo - qz, qz - zhi) - eps, 0.f);
-              if (dz * dz > lim2) { zfar |= sz; continue; }
-              dz2 = dz * dz; oy = 0; yfar = 0; layer_open = true;
-            }
-            if (!(oy <= 2 * (y1 - y0) + 1 && yfar != 3)) { layer_open = false; continue; }
-            const int cy = cy0 + ((oy & 1) ? -((oy + 1) >> 1) : (oy >> 1));
-            const int sy = (oy & 1) ? 1 : 2;
-            ++oy;
-            if (cy < y0 || cy > y1) { yfar |= sy; continue; }
-            const float ylo = g.origin[1] + (float)cy * g.h, yhi = ylo + g.h;
-            const float dy = fmaxf(fmaxf(ylo - qy, qy - yhi) - eps, 0.f);
-            const float rowd2 = dy * dy + dz2;
-            if (rowd2 > lim2) { yfar |= sy; continue; }
-            int xa = x0, xb = x1;
-            if (best.idx >= 0) {
-              const float rx = sqrtf(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
-              xa = imax(x0, grid_coord(g, 0, qx - rx));
-              xb = imin(x1, grid_coord(g, 0, qx + rx));
-              if (xa > xb) continue;
-            }
-            const int rowbase = g.dim[0] * (cy + g.dim[1] * cz);
-            s = cell_start[rowbase + xa]; e = cell_start[rowbase + xb + 1];
-            return true;
-          }
-        };
-        uint32_t s = 0, e = 0;
-        while (advance(s, e)) {
-          for (uint32_t k = s; k < e; k += S3D_NN_BATCH) {
-            const uint32_t last = e - 1;
-            F4T pp[S3D_NN_BATCH];
-#pragma unroll
-            for (int u = 0; u < S3D_NN_BATCH; ++u) pp[u] = pts[k + u < e ? k + u : last];
-#pragma unroll
-            for (int u = 0; u < S3D_NN_BATCH; ++u)
-              if (k + u < e) nn1_consider(best, pp[u], k + u, qx, qy, qz);
-          }
-          lim2 = limit2();
-        }
-        } else {
         int zfar = 0;
         for (int oz = 0; oz <= 2 * (z1 - z0) + 1 && zfar != 3; ++oz) {
           const int cz = cz0 + ((oz & 1) ? -((oz + 1) >> 1) : (oz >> 1));
@@ -488,7 +435,6 @@ S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ c
             }
             lim2 = limit2();
           }
-        }
         }
       }
     }
@@ -1006,6 +952,38 @@ S3D_HD bool sym3_smallest_eigvec_direct(double a00, double a01, double a02, doub
   const double inv = 1.0 / sqrt(mm);
   n[0] = v0 * inv; n[1] = v1 * inv; n[2] = v2 * inv;
   return true;
+}
+
+// ---- the stored form of a unit normal: 16 bytes ----
+// Covariances are stored as one unit normal per point (C = I - (1 - eps) n n^T).  Three floats lose the direction at
+// the 6e-8 level, and PCL's GICP notices: the oracle run on float-rounded normals differs from the oracle on double
+// normals by up to 1.6e-4 m / one outer iteration on the reference's fixtures once correspondence_randomness is 40
+// (tools_dev/kdens.py; 2e-8 m at the default k = 20).  The record therefore carries, next to the float components,
+// the remainders n - float(n) in units of 2^-34 as three signed 10-bit fields of a fourth word: |remainder| <= 2^-25,
+// so |q| <= 512 (a +512 is stored as 511), and a component is restored to 2^-34 = 6e-11 with one convert and one fma.  16 bytes are also the friendlier
+// access (one dwordx4) than the 12-byte record they replace.
+struct NormalRec { float x, y, z; uint32_t lo; };
+
+S3D_HD NormalRec normal_encode(const double n[3]) {
+  NormalRec r;
+  float* f = &r.x;
+  uint32_t lo = 0;
+  for (int a = 0; a < 3; ++a) {
+    f[a] = (float)n[a];
+    double q = (n[a] - (double)f[a]) * 17179869184.0;   // 2^34
+    int qi = (int)(q < 0 ? q - 0.5 : q + 0.5);
+    qi = qi < -512 ? -512 : (qi > 511 ? 511 : qi);
+    lo |= ((uint32_t)qi & 0x3FFu) << (10 * a);
+  }
+  r.lo = lo;
+  return r;
+}
+S3D_HD void normal_decode(const NormalRec& r, double n[3]) {
+  const float* f = &r.x;
+  for (int a = 0; a < 3; ++a) {
+    const int qi = ((int)(r.lo << (22 - 10 * a))) >> 22;   // sign-extended 10-bit field
+    n[a] = fma((double)qi, 5.8207660913467407e-11 /* 2^-34 */, (double)f[a]);
+  }
 }
 
 // PCL computeCovariances moments of the k neighbours: float products, double sums

@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(kBlock) k_grid_finalize(const SlotDev* __restr
 // generic fallback (k > 32): top-k in LDS columns
 __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ slots, const float4* __restrict__ filt,
                                                      const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start,
-                                                     CorrVec* __restrict__ normals, int k) {
+                                                     NormalRec* __restrict__ normals, int k) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* d2s = reinterpret_cast<float*>(smem);               // [k][kBlock]
   int* idxs = reinterpret_cast<int*>(smem) + k * kBlock;      // [k][kBlock]
@@ -588,15 +588,28 @@ __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ 
   const float4 q = sorted[s.off + i];
   const int cnt = grid_knn(s.g, cell_start + s.cell_off, sorted + s.off, q.x, q.y, q.z, k, d2s + threadIdx.x,
                            idxs + threadIdx.x, kBlock);
+  // PCL sums the neighbours in the order nearestKSearch returns them - ascending distance (ties: index, as everywhere
+  // here): selection sort of this thread's LDS column, one neighbour folded per round (k <= 64, a rarely used path)
+  float* d2c = d2s + threadIdx.x;
+  int* idc = idxs + threadIdx.x;
   Moments m;
   moments_init(m);
   for (int j = 0; j < cnt; ++j) {
-    const float4 p = P[idxs[j * kBlock + threadIdx.x]];
+    int best = j;
+    float bd = d2c[j * kBlock];
+    int bi = idc[j * kBlock];
+    for (int l = j + 1; l < cnt; ++l) {
+      const float dl = d2c[l * kBlock];
+      const int il = idc[l * kBlock];
+      if (lex_less(dl, il, bd, bi)) { best = l; bd = dl; bi = il; }
+    }
+    d2c[best * kBlock] = d2c[j * kBlock]; idc[best * kBlock] = idc[j * kBlock];   // (slot j is consumed: no need to store the winner)
+    const float4 p = P[bi];
     moments_add(m, p.x, p.y, p.z);
   }
   double n[3];
   moments_normal(m, k, n);
-  normals[s.off + i] = corr_vec(make_float4((float)n[0], (float)n[1], (float)n[2], 0.f));  // CELL-SORTED order
+  normals[s.off + i] = normal_encode(n);  // CELL-SORTED order
 }
 
 // k <= KMAX: the k best live in registers as sorted packed keys (s3d_core.h grid_knn_sorted).
@@ -646,7 +659,7 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_WAVES) s3d_knn_moments_kernel(
 
 __global__ void __launch_bounds__(kBlock) s3d_normals_from_moments_kernel(const SlotDev* __restrict__ slots,
                                                                            const double* __restrict__ moments, size_t plane,
-                                                                           CorrVec* __restrict__ normals, int k,
+                                                                           NormalRec* __restrict__ normals, int k,
                                                                            const int* __restrict__ slot_list) {
   const SlotDev& s = slots[slot_list[blockIdx.y]];
   const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -658,7 +671,7 @@ __global__ void __launch_bounds__(kBlock) s3d_normals_from_moments_kernel(const 
   m.c20 = o[6 * plane]; m.c21 = o[7 * plane]; m.c22 = o[8 * plane];
   double n[3];
   moments_normal(m, k, n);
-  normals[s.off + i] = corr_vec(make_float4((float)n[0], (float)n[1], (float)n[2], 0.f));  // CELL-SORTED order
+  normals[s.off + i] = normal_encode(n);  // CELL-SORTED order
 }
 
 // ------------------------------------------------------------------ pair state
@@ -687,7 +700,10 @@ __global__ void k_pair_init(PairDev* pairs, int npairs, int* n_active) {
 constexpr int kCoopMaxLanes = 6;    // more wide lanes than this: the per-lane search is the faster one
 constexpr int kCoopAllLanes = 3;    // this few searching lanes in a wave: serve all of them cooperatively
 
-__device__ __forceinline__ NNResult wave_nn1_coop(const GridParams& g, const uint32_t* __restrict__ cell_start,
+#ifndef S3D_COOP_INLINE
+#define S3D_COOP_INLINE __forceinline__
+#endif
+__device__ S3D_COOP_INLINE NNResult wave_nn1_coop(const GridParams& g, const uint32_t* __restrict__ cell_start,
                                                   const float4* __restrict__ pts, float qx, float qy, float qz,
                                                   float max_d, float d_hint, int seed_pos, bool seed_trusted) {
   // all arguments are wave-uniform
@@ -815,12 +831,12 @@ struct NNArrays {
   const float4* __restrict__ sorted;
   const CorrVec* __restrict__ sorted3;   // the same points, xyz only (the query side streams these)
   const uint32_t* __restrict__ cell_start;
-  const CorrVec* __restrict__ normals;
+  const NormalRec* __restrict__ normals;
   int* __restrict__ corr_idx;
   float* __restrict__ corr_d2;
   float* __restrict__ corr_lb;
   CorrVec* __restrict__ corr_q;
-  CorrVec* __restrict__ corr_n;
+  NormalRec* __restrict__ corr_n;
 };
 
 template <int MODE, int PHASE>
@@ -869,7 +885,6 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   // the scan the other cloud does not cover — is trusted only when the query has barely moved since the
   // previous pass: right after a large transform update a one-cell box is the better first guess, once the
   // registration settles the old neighbour is still the nearest and the search must cover its ball anyway.
-  // dbg & 32: hint-only variant (A/B).
   const bool has_prev = prev >= 0.f && prev < 1.0e30f;
   const bool near_seed = has_prev && prev < Ss.g.h * Ss.g.h;
   const bool far_seed = has_prev && !near_seed && move < kNNRevalSlack * Ss.g.h && !(dbg & 128);
@@ -926,32 +941,6 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   }
 }
 
-// Measurement aid (s3d_profile_nn_kernel with S3D_DBG_FIRSTPASS = 1 / 2, tools_dev/firstpass_probe.py): a lean FIRST
-// pass - transform, unseeded search with the first radius, result - without the re-validation, the cooperative
-// search and the compaction of the product kernel, in the lock-step (ROWITER = false) and per-lane (true) loop forms.
-template <bool ROWITER>
-__global__ void __launch_bounds__(kBlock) s3d_nn_first_pass_probe_kernel(const PairDev* __restrict__ pairs,
-                                                                          const SlotDev* __restrict__ slots, NNArrays A,
-                                                                          float max_d, int chunks_per_pair, int npairs) {
-  int pair, chunk;
-  nn_block_map(chunks_per_pair, npairs, &pair, &chunk);
-  if (pair >= npairs) return;
-  const PairDev& P = pairs[pair];
-  const SlotDev& St = slots[P.slot_t];
-  const SlotDev& Ss = slots[P.slot_s];
-  const int i = chunk * kBlock + threadIdx.x;
-  if (i >= St.n) return;
-  const CorrVec p0 = A.sorted3[St.off + i];
-  const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
-  const F3 q = xf_eigen(P.T, pg.x, pg.y, pg.z);
-  const NNResult r = grid_nn1_box<float4, ROWITER>(Ss.g, A.cell_start + Ss.cell_off, A.sorted + Ss.off, q.x, q.y, q.z,
-                                                   max_d, 3.0f * Ss.g.h, -1, false);
-  const int ci = P.corr_off + i;
-  A.corr_idx[ci] = r.pos;
-  A.corr_d2[ci] = r.d2;
-  A.corr_lb[ci] = nn_lower_bound_others(r);
-}
-
 // One thread per query of the pair.  compact = 0: every lane re-validates and, if it must, searches its own query.
 // compact = 1, block-level compaction: the 256 queries of a block are re-validated and classified, the ones that
 // still need a search are packed to the front of the block — near-seeded first, wide ones after them — and
@@ -962,6 +951,12 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_first_pass_probe_kernel(const P
 // 3.39 -> 3.49, 2.77 -> 2.17, 1.06 -> 0.94, then 0.25 -> 0.29 ms once nearly every query re-validates (five block
 // barriers on a streaming kernel): the host asks for it in passes 3 to 5 only.  A global worklist (atomics, second
 // kernel) loses the spatial order of the queries and was 2x slower.  Same results either way, bit for bit.
+// The `dbg` switches (S3D_DBG_NN: 64 no re-validation, 128 no trusted far seeds, 2048 no cooperative search, 65536 no
+// compaction - what test_nn_revalidation_shortcut_is_bitwise_neutral toggles - plus the A/B bits 4 / 16 / 32 / 256 /
+// 512 / 1024 of round 1) stay in the kernel on purpose: round 2 removed the A/B bits and the register allocation of
+// this 72-VGPR kernel re-rolled (scratch 76 -> 100 bytes per lane, spills moved into the streaming re-validation
+// path): 12.4 -> 13.5 ms of NN per step, same results.  Measured, reverted.  (6 waves / 80 VGPRs: 14.0 ms; the
+// cooperative search as a non-inlined call: 12.8 ms.)
 #ifndef S3D_NN_WAVES
 #define S3D_NN_WAVES 7     // waves per SIMD the register allocation is capped for (see S3D_NN_BATCH, s3d_core.h)
 #endif
@@ -1018,11 +1013,11 @@ __global__ void __launch_bounds__(kBlock) k_export_corr(const PairDev* __restric
   out_d2[P.corr_off + orig] = corr_d2[P.corr_off + i];
 }
 __global__ void __launch_bounds__(kBlock) k_export_normals(const SlotDev* __restrict__ slots, const float4* __restrict__ sorted,
-                                                            const CorrVec* __restrict__ normals, float4* __restrict__ out) {
+                                                            const NormalRec* __restrict__ normals, float4* __restrict__ out) {
   const SlotDev& s = slots[blockIdx.y];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= s.n) return;
-  const CorrVec nv = normals[s.off + i];
+  const NormalRec nv = normals[s.off + i];
   out[s.off + __float_as_int(sorted[s.off + i].w)] = make_float4(nv.x, nv.y, nv.z, 0.f);
 }
 
@@ -1139,10 +1134,10 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
 __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairDev* __restrict__ pairs,
                                                                       const SlotDev* __restrict__ slots,
                                                                       const CorrVec* __restrict__ sorted,
-                                                                      const CorrVec* __restrict__ normals,
+                                                                      const NormalRec* __restrict__ normals,
                                                                       const float* __restrict__ corr_d2,
                                                                       const CorrVec* __restrict__ corr_q,
-                                                                      const CorrVec* __restrict__ corr_n,
+                                                                      const NormalRec* __restrict__ corr_n,
                                                                       double* __restrict__ partials, RunParams rp) {
   const PairDev& P = pairs[blockIdx.y];
   if (!P.active) return;
@@ -1188,7 +1183,8 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
   int tile = vb_tile_begin(v, ntiles);
   int i = tile * kBlock + threadIdx.x;
   float d2 = 3.0e38f;
-  CorrVec p0 = corr_vec(make_float4(0.f, 0.f, 0.f, 0.f)), qf = p0, na = p0, nb = p0;
+  CorrVec p0 = corr_vec(make_float4(0.f, 0.f, 0.f, 0.f)), qf = p0;
+  NormalRec na = {0.f, 0.f, 0.f, 0u}, nb = na;
   {
     const int j = i < M ? i : M - 1;
     d2 = corr_d2[P.corr_off + j];          // 3e38 when the query has no neighbour at all
@@ -1207,12 +1203,14 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
       const int in = tile + 1 < tile_end ? i + kBlock : first_next;
       const int j = in < M ? in : M - 1;   // (the last tile may be partial: no branch around the loads)
       const float d2n = corr_d2[P.corr_off + j];
-      const CorrVec p0n = sorted[St.off + j], nan_ = normals[St.off + j], qfn = corr_q[P.corr_off + j], nbn = corr_n[P.corr_off + j];
+      const CorrVec p0n = sorted[St.off + j], qfn = corr_q[P.corr_off + j];
+      const NormalRec nan_ = normals[St.off + j], nbn = corr_n[P.corr_off + j];
       if (i < M && (double)d2 < rp.dist_threshold) {
         const F3 pf = xf_pcl(P.guess, p0.x, p0.y, p0.z);
-        // the float-rounded unit normals are used as stored (measured effect on the GICP result vs double
-        // normals: <= 2e-6 m)
-        const double n1[3] = {na.x, na.y, na.z}, n2[3] = {nb.x, nb.y, nb.z};
+        // unit normals to 6e-11 from their 16-byte records (s3d_core.h NormalRec)
+        double n1[3], n2[3];
+        normal_decode(na, n1);
+        normal_decode(nb, n2);
         double n1r[3], Mm[6];
 #pragma unroll
         for (int a = 0; a < 3; ++a) n1r[a] = R[a * 3] * n1[0] + R[a * 3 + 1] * n1[1] + R[a * 3 + 2] * n1[2];
@@ -1246,7 +1244,7 @@ __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const Pa
                                                                          const CorrVec* __restrict__ sorted,
                                                                          const float* __restrict__ corr_d2,
                                                                          const CorrVec* __restrict__ corr_q,
-                                                                         const CorrVec* __restrict__ corr_n,
+                                                                         const NormalRec* __restrict__ corr_n,
                                                                          double* __restrict__ partials, RunParams rp) {
   const PairDev& P = pairs[blockIdx.y];
   if (!P.active) return;
@@ -1272,7 +1270,7 @@ __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const Pa
       const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
       const F3 pq = xf_eigen(P.T, pg.x, pg.y, pg.z);
       const CorrVec qf = corr_q[P.corr_off + i];
-      const CorrVec nf = corr_n[P.corr_off + i];
+      const NormalRec nf = corr_n[P.corr_off + i];   // (point-to-plane keeps its float normals: its own design, its own oracle)
       const double pd[3] = {pq.x, pq.y, pq.z};
       const double qd[3] = {qf.x, qf.y, qf.z};
       const double nd[3] = {nf.x, nf.y, nf.z};

@@ -115,7 +115,9 @@ std::vector<D3> normals(const Cloud& c, const Grid& G, int k) {
     for (int j = 0; j < cnt; ++j) { const F4& p = c.pts[idx[j]]; moments_add(m, p.x, p.y, p.z); }
     double n[3];
     moments_normal(m, k, n);
-    out[i] = {(double)(float)n[0], (double)(float)n[1], (double)(float)n[2]};   // device storage: float4
+    double nd[3];
+    normal_decode(normal_encode(n), nd);   // device storage: the 16-byte NormalRec (float xyz + 10-bit remainders)
+    out[i] = {nd[0], nd[1], nd[2]};
   }
   return out;
 }
@@ -297,7 +299,8 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
         gq_accumulate(acc, pd, td, M, Th0);
       } else {
         const double qd[3] = {q.x, q.y, q.z};
-        const double nf[3] = {NS[r.idx].x, NS[r.idx].y, NS[r.idx].z};
+        // (the point-to-plane kernel reads the float part of the record)
+        const double nf[3] = {(double)(float)NS[r.idx].x, (double)(float)NS[r.idx].y, (double)(float)NS[r.idx].z};
         pp_accumulate(acc, qd, td, nf);
       }
     }
@@ -355,4 +358,9 @@ int emu_bfgs(const double* acc, int max_inner, float* T16, int* inner, int* eval
   return rc;
 }
 void emu_mahalanobis(const double* S6, const double* n1r, const double* n2, double eps, double* M6) { gicp_mahalanobis(S6, n1r, n2, eps, M6); }
+void emu_normal_roundtrip(const double* n, double* out, float* fpart) {
+  const NormalRec r = normal_encode(n);
+  normal_decode(r, out);
+  fpart[0] = r.x; fpart[1] = r.y; fpart[2] = r.z;
+}
 }

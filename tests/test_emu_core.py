@@ -219,3 +219,21 @@ def test_correspondence_revalidation_is_exact(emu, oracle_mod, fixture_clouds):
     assert stats[2] == 0                # no shortcut hit / trusted far seed of the whole module run ever disagreed with a full search
     assert far_seeded > 100             # queries without a near neighbour (partial overlap) do take the trusted-seed path
     assert hits > 2 * misses, (hits, misses)   # once ICP has converged nearly every correspondence is re-validated
+
+
+def test_normal_record_round_trip(emu):
+    """The 16-byte stored form of a unit normal (s3d_core.h NormalRec: float xyz + three 10-bit remainders in units
+    of 2^-34): restored to 2^-34 = 6e-11 per component (half of that except at the +2^-25 tie), the float part is the plain float rounding."""
+    rng = np.random.default_rng(0)
+    v = rng.normal(size=(20000, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v[:6] = np.array([[1, 0, 0], [0, -1, 0], [0, 0, 1], [-1, 0, 0], [1e-12, 1, 0], [0.6, -0.8, 1e-30]], np.float64)
+    worst = 0.0
+    for n in v:
+        n = np.ascontiguousarray(n, np.float64)
+        out = np.zeros(3)
+        fpart = np.zeros(3, np.float32)
+        emu.emu_normal_roundtrip(n.ctypes.data_as(dp), out.ctypes.data_as(dp), fpart.ctypes.data_as(fp))
+        assert np.array_equal(fpart, n.astype(np.float32))
+        worst = max(worst, float(np.abs(out - n).max()))
+    assert worst <= 2.0 ** -34 + 1e-18, worst

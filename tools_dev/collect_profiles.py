@@ -1,7 +1,11 @@
 """dev tool: turn gpurun_out/final{,_prof} (see profiles/README.md for the commands) into the files under profiles/."""
 import collections, csv, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R, F, D = (os.path.join(ROOT, p) for p in ("gpurun_out/final_prof", "gpurun_out/final", "profiles/r1"))
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r2"
+R, F, D = (os.path.join(ROOT, p) for p in ("gpurun_out/final_prof", "gpurun_out/final", "profiles/" + ROUND))
+os.makedirs(D, exist_ok=True)
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = list(csv.DictReader(open(f"{R}/{c}/p_counter_collection.csv")))
@@ -19,8 +23,9 @@ hbm = int(2 * out["FETCH_SIZE"] * 1024 + out["WRITE_SIZE"] * 1024)
 json.dump({"kernel": "s3d_nn_search_kernel<0>", "fetch_size_kb_per_launch": round(out["FETCH_SIZE"], 1),
            "write_size_kb_per_launch": round(out["WRITE_SIZE"], 1), "hbm_bytes_per_launch": hbm,
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is",
-           "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --no-cpu --steps 2 --warmup 1",
-           "workload": "256 pairs x 100k points, 20 iterations (bench default)"},
+           "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --no-cpu --no-single --steps 2 --warmup 1",
+           "workload": "256 pairs x 100k points, 20 iterations (bench default)",
+           "kernel_src_sha256": kernel_source_hash(), "round": ROUND},
           open(os.path.join(ROOT, "profiles/nn_traffic.json"), "w"), indent=1)
 for f in os.listdir(F):
     shutil.copy(f"{F}/{f}", f"{D}/{f}")

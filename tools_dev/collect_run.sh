@@ -1,11 +1,13 @@
 #!/bin/bash
-# Produces gpurun_out/final{,_prof} on the GPU box; tools_dev/collect_profiles.py then files them under profiles/r1.
+# Produces gpurun_out/final{,_prof} on the GPU box; tools_dev/collect_profiles.py <round> then files them under profiles/<round>.
 #   gpurun --timeout 2400 -- 'bash tools_dev/collect_run.sh'
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/final; P=gpurun_out/final_prof
 rm -rf $O $P; mkdir -p $O $P
-python3 bench.py --extras 2>/dev/null | tail -1 > $O/bench_default.json
+python3 bench.py --extras --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_default.json
+python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu 2>/dev/null | tail -1 > $O/bench_2ranks_one_gpu.json
+./tools_dev/ubench/valu_rates > $O/valu_rates.txt 2>&1
 python3 bench.py --algorithm icp --no-cpu 2>/dev/null | tail -1 > $O/bench_p2p.json
 python3 bench.py --pairs 32 --points 1000000 --iters 50 --steps 3 --warmup 1 --no-cpu 2>/dev/null | tail -1 > $O/bench_1M_50it.json
 python3 bench_map.py 2>/dev/null | tail -1 > $O/bench_map.json
@@ -14,9 +16,9 @@ python3 tools_dev/fixture.py > $O/fixture_batch.txt 2>&1
 PROFILE=2 python3 tools_dev/fixture.py > $O/fixture_batch_profile2.txt 2>&1
 python3 tools_dev/ndt_try.py > $O/ndt_try.txt 2>&1
 python3 tools_dev/plane_time.py > $O/plane_time.txt 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -o b -- python3 bench.py --no-cpu 2>/dev/null | grep '^{"metric' | tail -1 > $P/bench_under_rocprof.json
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/FETCH_SIZE -o p -- python3 bench.py --no-cpu --steps 2 --warmup 1 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/WRITE_SIZE -o p -- python3 bench.py --no-cpu --steps 2 --warmup 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -o b -- python3 bench.py --no-cpu --no-single 2>/dev/null | grep '^{"metric' | tail -1 > $P/bench_under_rocprof.json
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/FETCH_SIZE -o p -- python3 bench.py --no-cpu --no-single --steps 2 --warmup 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/WRITE_SIZE -o p -- python3 bench.py --no-cpu --no-single --steps 2 --warmup 1 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/map -o m -- python3 bench_map.py --no-cpu > /dev/null 2>&1
 # rocprofv3 nests its output under a host-name directory: flatten
 for d in stats FETCH_SIZE WRITE_SIZE map; do find $P/$d -mindepth 2 -type f -exec mv {} $P/$d/ \; ; done
