@@ -1042,14 +1042,41 @@ __global__ void __launch_bounds__(kBlock) k_export_normals(const SlotDev* __rest
 template <int N, int MASK>
 __device__ __forceinline__ void wrs_level(double* v, int lane) {
   constexpr int H = (N + 1) / 2;
-  const bool hi = (lane & MASK) != 0;
+  if constexpr (MASK == 32 || MASK == 16) {
+    // the two big levels (3/4 of all exchanges) as register-file swaps: v_permlane32_swap exchanges the upper half
+    // of its first operand with the lower half of its second, v_permlane16_swap the odd 16-lane rows of the first with
+    // the even rows of the second.  Applied to (low value, high value) every lane then holds the value it keeps in
+    // one register and its partner's copy of it in the other: no select, no LDS permute, one addition.
 #pragma unroll
-  for (int k = 0; k < H; ++k) {
-    const double lo_v = v[k];
-    const double hi_v = (H + k < N) ? v[H + k] : 0.0;
-    const double send = hi ? lo_v : hi_v;
-    const double keep = hi ? hi_v : lo_v;
-    v[k] = keep + __shfl_xor(send, MASK, kWave);
+    for (int k = 0; k < H; ++k) {
+      const double lo_v = v[k];
+      const double hi_v = (H + k < N) ? v[H + k] : 0.0;
+      unsigned a0 = (unsigned)__double2loint(lo_v), a1 = (unsigned)__double2hiint(lo_v);
+      unsigned b0 = (unsigned)__double2loint(hi_v), b1 = (unsigned)__double2hiint(hi_v);
+      if constexpr (MASK == 32) {
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        a0 = r0[0]; b0 = r0[1]; a1 = r1[0]; b1 = r1[1];
+      } else {
+        const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+        a0 = r0[0]; b0 = r0[1]; a1 = r1[0]; b1 = r1[1];
+      }
+      const double x = __hiloint2double((int)a1, (int)a0), y = __hiloint2double((int)b1, (int)b0);
+      // lanes with the bit clear: x = own low value, y = the partner's; lanes with it set: y = own high value,
+      // x = the partner's - the same two operands as "keep + received" of the generic form
+      v[k] = x + y;
+    }
+  } else {
+    const bool hi = (lane & MASK) != 0;
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+      const double lo_v = v[k];
+      const double hi_v = (H + k < N) ? v[H + k] : 0.0;
+      const double send = hi ? lo_v : hi_v;
+      const double keep = hi ? hi_v : lo_v;
+      v[k] = keep + __shfl_xor(send, MASK, kWave);
+    }
   }
 }
 // index (among the N inputs of the level with mask MASK) of the value whose wave total lane `lane` holds in
