@@ -154,7 +154,7 @@ struct s3d_context {
   s3d_profile prof{};
   s3d_map_profile map_prof{};
   // workspace (grown on demand, reused across calls)
-  DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, sorted3, normals, moments, cell_start, counts, digit_tot, blockcnt,
+  DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, sorted3, normals, moments, cell_start, counts, digit_tot, blockcnt, blockbb,
       corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active, knn_list;
   int* h_active = nullptr;  // pinned
   // pinned staging of the slot / pair records (up and down): a copy from or to pageable memory stalls the stream for
@@ -455,6 +455,7 @@ struct Batch {
                 {&ctx->counts, 4 * (size_t)std::max(1, C()) * 256 * nb_sort},
                 {&ctx->digit_tot, 4 * (size_t)std::max(1, C()) * 256},
                 {&ctx->blockcnt, 4 * (size_t)std::max(1, C()) * nb_head},
+                {&ctx->blockbb, 24 * (size_t)std::max(1, C()) * nb_head},
                 {&ctx->corr_idx, 4 * nc}, {&ctx->corr_d2, 4 * nc}, {&ctx->corr_lb, 4 * nc},
                 {&ctx->corr_q, 16 * nc}, {&ctx->corr_n, 16 * nc},
                 {&ctx->partials, 8 * (size_t)std::max(1, P()) * kAccumVB * GQ_NACC * (S3D_ACC_VARIANT == 2 ? 5 : 1)},
@@ -491,7 +492,8 @@ struct Batch {
 
   // segmented LSD radix sort of (keys, vals) of every slot; `passes` 8-bit digits.
   // input in A; result in A for even `passes`, in B for odd.
-  void sort(int passes, int nslots) {
+  // first_hist_done: k_keys_hist has produced the tile histogram of pass 0 together with the keys
+  void sort(int passes, int nslots, bool first_hist_done = false) {
     hipStream_t st = ctx->stream;
     if (nslots <= 0) return;
     uint32_t *ki = kA(), *vi = vA(), *ko = kB(), *vo = vB();
@@ -499,7 +501,7 @@ struct Batch {
     uint32_t* dtot = (uint32_t*)ctx->digit_tot.p;
     for (int p = 0; p < passes; ++p) {
       const int shift = 8 * p;
-      k_sort_hist<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(d_slots(), ki, cnt, shift, nb_sort);
+      if (p > 0 || !first_hist_done) k_sort_hist<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(d_slots(), ki, cnt, shift, nb_sort);
       k_sort_scan_rows<<<dim3(256 / (kBlock / kWave), nslots), kBlock, 0, st>>>(d_slots(), cnt, dtot, nb_sort);
       k_sort_scan_digits<<<nslots, kBlock, 0, st>>>(dtot);
       k_sort_scatter<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(d_slots(), ki, vi, ko, vo, cnt, dtot, shift, nb_sort);
@@ -517,12 +519,12 @@ struct Batch {
       k_slot_reset_bbox<<<NS, 64, 0, st>>>(d_slots());
       k_bbox<0><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), NS), kBlock, 0, st>>>(d_slots(), filt());
       k_voxel_params<<<cdiv(NS, 64), 64, 0, st>>>(d_slots(), rp, NS);
-      k_voxel_keys<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), kA(), vA());
-      sort(4, NS);
+      k_keys_hist<0><<<dim3(nb_sort, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA(), (uint32_t*)ctx->counts.p, nb_sort);
+      sort(4, NS, true);
       uint32_t* bc = (uint32_t*)ctx->blockcnt.p;
       k_heads_count<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), kA(), bc, nb_head);
       k_heads_scan<<<NS, kBlock, 0, st>>>(d_slots(), bc, nb_head);
-      k_centroids<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), kA(), vA(), bc, filt(), nb_head);
+      k_centroids<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), kA(), vA(), bc, filt(), (unsigned int*)ctx->blockbb.p, nb_head);
     } else {
       k_copy_raw<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), filt());
     }
@@ -533,12 +535,15 @@ struct Batch {
     hipStream_t st = ctx->stream;
     const int NS = Cu;
     if (NS == 0) return;
-    k_slot_reset_bbox<<<NS, 64, 0, st>>>(d_slots());
-    k_bbox<1><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), NS), kBlock, 0, st>>>(d_slots(), filt());
-    k_grid_params<<<cdiv(NS, 64), 64, 0, st>>>(d_slots(), rp, NS);
-    k_cell_keys<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA());
+    const int from_centroids = rp.leaf > 0.f ? 1 : 0;   // stage_voxel's k_centroids gathered the bbox already
+    if (!from_centroids) {
+      k_slot_reset_bbox<<<NS, 64, 0, st>>>(d_slots());
+      k_bbox<1><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), NS), kBlock, 0, st>>>(d_slots(), filt());
+    }
+    k_grid_params<<<NS, kWave, 0, st>>>(d_slots(), rp, from_centroids ? (const unsigned int*)ctx->blockbb.p : nullptr, nb_head);
+    k_keys_hist<1><<<dim3(nb_sort, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA(), (uint32_t*)ctx->counts.p, nb_sort);
     const bool wide = max_cell_cap > (1ll << 24);
-    sort(wide ? 4 : 3, NS);  // cell ids < 2^24 unless a map job raised the cap
+    sort(wide ? 4 : 3, NS, true);  // cell ids < 2^24 unless a map job raised the cap
     k_grid_finalize<<<dim3(cdiv(max_n + 1, kBlock), NS), kBlock, 0, st>>>(d_slots(), filt(), wide ? kA() : kB(),
                                                                           wide ? vA() : vB(), sorted(), sorted3(), cells());
   }

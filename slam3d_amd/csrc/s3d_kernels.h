@@ -167,6 +167,37 @@ __global__ void __launch_bounds__(kBlock) k_slot_reset_bbox(SlotDev* slots) {
   else if (threadIdx.x < 6) s.bb[threadIdx.x] = 0u;
 }
 
+// per-thread ordered-uint min / max -> the slot's bbox words: wave shuffle, LDS, then one candidate per block and axis,
+// and only if it would move the bound (a lone 10^7-point slot otherwise queues ~2*10^5 atomics on the same six
+// words: 2.5 ms).  Every thread of the block must call it.
+template <bool ATOMIC = true>
+__device__ __forceinline__ void block_bbox_merge(unsigned int (&mn)[3], unsigned int (&mx)[3], unsigned int* bb) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      mn[a] = min(mn[a], (unsigned int)__shfl_down((int)mn[a], o, kWave));
+      mx[a] = max(mx[a], (unsigned int)__shfl_down((int)mx[a], o, kWave));
+    }
+  }
+  __shared__ unsigned int red[kBlock / kWave][6];
+  if (lane_id() == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { red[wave_id()][a] = mn[a]; red[wave_id()][3 + a] = mx[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    unsigned int v = red[0][a];
+#pragma unroll
+    for (int w = 1; w < kBlock / kWave; ++w) v = a < 3 ? min(v, red[w][a]) : max(v, red[w][a]);
+    if (!ATOMIC) { bb[a] = v; return; }   // (bb: this block's own six words)
+    const unsigned int cur = __atomic_load_n(&bb[a], __ATOMIC_RELAXED);
+    if (a < 3) { if (v < cur) atomicMin(&bb[a], v); }
+    else       { if (v > cur) atomicMax(&bb[a], v); }
+  }
+}
+
 // which = 0: raw points (n_raw); 1: filtered points (n)
 template <int WHICH>
 __global__ void __launch_bounds__(kBlock) k_bbox(SlotDev* slots, const float4* __restrict__ filt) {
@@ -188,31 +219,7 @@ __global__ void __launch_bounds__(kBlock) k_bbox(SlotDev* slots, const float4* _
       }
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      mn[a] = min(mn[a], (unsigned int)__shfl_down((int)mn[a], o, kWave));
-      mx[a] = max(mx[a], (unsigned int)__shfl_down((int)mx[a], o, kWave));
-    }
-  }
-  // one candidate per block and axis, and only if it would move the bound: a lone 10^7-point slot otherwise
-  // queues ~2*10^5 atomics on the same six words (2.5 ms)
-  __shared__ unsigned int red[kBlock / kWave][6];
-  if (lane_id() == 0) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { red[wave_id()][a] = mn[a]; red[wave_id()][3 + a] = mx[a]; }
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    const int a = threadIdx.x;
-    unsigned int v = red[0][a];
-#pragma unroll
-    for (int w = 1; w < kBlock / kWave; ++w) v = a < 3 ? min(v, red[w][a]) : max(v, red[w][a]);
-    const unsigned int cur = __atomic_load_n(&s.bb[a], __ATOMIC_RELAXED);
-    if (a < 3) { if (v < cur) atomicMin(&s.bb[a], v); }
-    else       { if (v > cur) atomicMax(&s.bb[a], v); }
-  }
+  block_bbox_merge(mn, mx, s.bb);
 }
 
 __global__ void k_voxel_params(SlotDev* slots, RunParams rp, int nslots) {
@@ -228,18 +235,6 @@ __global__ void k_voxel_params(SlotDev* slots, RunParams rp, int nslots) {
     s.vp = voxel_params_from_bbox(mn, mx, rp.leaf);
   }
   s.n_sort = s.n_raw;
-}
-
-__global__ void __launch_bounds__(kBlock) k_voxel_keys(const SlotDev* __restrict__ slots, uint32_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ vals) {
-  const SlotDev& s = slots[blockIdx.y];
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= s.n_raw) return;
-  const float4 v = s.raw[i];
-  uint32_t key = kInvalidKey;
-  if (finite3(v.x, v.y, v.z)) key = s.vp.passthrough ? (uint32_t)i : voxel_key(s.vp, v.x, v.y, v.z);
-  keys[s.off + i] = key;
-  vals[s.off + i] = (uint32_t)i;
 }
 
 // leaf <= 0: the filtered cloud is the raw cloud (PointCloudSensor.cpp:125-131)
@@ -271,6 +266,44 @@ __global__ void __launch_bounds__(kBlock) k_sort_hist(const SlotDev* __restrict_
   for (int r = 0; r < kSortTile / kBlock; ++r) {
     const int i = base + r * kBlock + threadIdx.x;
     if (i < n) atomicAdd(&hist[(keys[s.off + i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  counts[((size_t)blockIdx.y * 256 + threadIdx.x) * nb_max + blockIdx.x] = hist[threadIdx.x];
+}
+
+// The keys of a sort and the tile histogram of its FIRST pass in one kernel (WHICH = 0: PCL voxel keys of the raw
+// points, 1: grid-cell ids of the filtered points): the keys are produced a 4096-element tile at a time and counted
+// as they are written, instead of being read back by k_sort_hist (one pass over the keys and one launch less per
+// sort: 0.2 ms of the 256-pair step).
+template <int WHICH>
+__global__ void __launch_bounds__(kBlock) k_keys_hist(const SlotDev* __restrict__ slots, const float4* __restrict__ filt,
+                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                       uint32_t* __restrict__ counts, int nb_max) {
+  __shared__ unsigned int hist[256];
+  const SlotDev& s = slots[blockIdx.y];
+  const int n = WHICH == 0 ? s.n_raw : s.n;
+  const int nb = (n + kSortTile - 1) / kSortTile;
+  if ((int)blockIdx.x >= nb) return;
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * kSortTile;
+#pragma unroll 4
+  for (int r = 0; r < kSortTile / kBlock; ++r) {
+    const int i = base + r * kBlock + threadIdx.x;
+    if (i < n) {
+      uint32_t key;
+      if (WHICH == 0) {
+        const float4 v = s.raw[i];
+        key = kInvalidKey;
+        if (finite3(v.x, v.y, v.z)) key = s.vp.passthrough ? (uint32_t)i : voxel_key(s.vp, v.x, v.y, v.z);
+      } else {
+        const float4 p = filt[s.off + i];
+        key = (uint32_t)grid_cell_of_point(s.g, p.x, p.y, p.z);
+      }
+      keys[s.off + i] = key;
+      vals[s.off + i] = (uint32_t)i;
+      atomicAdd(&hist[key & 255u], 1u);
+    }
   }
   __syncthreads();
   counts[((size_t)blockIdx.y * 256 + threadIdx.x) * nb_max + blockIdx.x] = hist[threadIdx.x];
@@ -486,7 +519,7 @@ __global__ void __launch_bounds__(kBlock) k_heads_scan(SlotDev* slots, uint32_t*
 // (pcl::VoxelGrid fourth pass: float sum in order, divided by float count)
 __global__ void __launch_bounds__(kBlock) k_centroids(const SlotDev* __restrict__ slots, const uint32_t* __restrict__ keys,
                                                        const uint32_t* __restrict__ vals, const uint32_t* __restrict__ blockcnt,
-                                                       float4* __restrict__ filt, int nb_max) {
+                                                       float4* __restrict__ filt, unsigned int* __restrict__ blockbb, int nb_max) {
   __shared__ int lds4[4];
   const SlotDev& s = slots[blockIdx.y];
   const int base = blockIdx.x * kBlock;
@@ -497,39 +530,63 @@ __global__ void __launch_bounds__(kBlock) k_centroids(const SlotDev* __restrict_
   const bool head = i < s.n_raw && voxel_head(k, i);
   int total;
   const int pos = block_excl_flag(head, &total, lds4) + (int)blockcnt[(size_t)blockIdx.y * nb_max + blockIdx.x];
-  if (!head) return;
-  const uint32_t key = k[i];
-  float sx = 0.f, sy = 0.f, sz = 0.f;
-  int j = i;
-  for (; j < s.n_raw && k[j] == key; ++j) {
-    const float4 p = s.raw[v[j]];
-    sx += p.x; sy += p.y; sz += p.z;
+  // the bounding box of the centroids (what the search grid is laid over) is gathered here, where they are written (a
+  // separate pass over the filtered cloud was 0.22 ms of the 256-pair step): six words per block, no atomics - with
+  // a block per 256 points, merging into the slot's words directly queued 1.2 M same-address accesses and cost
+  // 1.8 ms; k_grid_params reduces the block words
+  unsigned int mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
+  if (head) {
+    const uint32_t key = k[i];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    int j = i;
+    for (; j < s.n_raw && k[j] == key; ++j) {
+      const float4 p = s.raw[v[j]];
+      sx += p.x; sy += p.y; sz += p.z;
+    }
+    const float c = (float)(j - i);
+    const float4 q = make_float4(sx / c, sy / c, sz / c, 1.f);
+    filt[s.off + pos] = q;
+    if (finite3(q.x, q.y, q.z)) {
+      const unsigned int a = f2ord(q.x), b = f2ord(q.y), cc = f2ord(q.z);
+      mn[0] = a; mn[1] = b; mn[2] = cc; mx[0] = a; mx[1] = b; mx[2] = cc;
+    }
   }
-  const float c = (float)(j - i);
-  filt[s.off + pos] = make_float4(sx / c, sy / c, sz / c, 1.f);
+  block_bbox_merge<false>(mn, mx, blockbb + ((size_t)blockIdx.y * nb_max + blockIdx.x) * 6);
 }
 
 // ------------------------------------------------------------------ K3: search grid
 
-__global__ void k_grid_params(SlotDev* slots, RunParams rp, int nslots) {
-  const int si = blockIdx.x * blockDim.x + threadIdx.x;
-  if (si >= nslots) return;
-  SlotDev& s = slots[si];
+// One wave per slot.  blockbb != nullptr: the bbox of the filtered cloud comes as six words per 256-point block of
+// k_centroids and is reduced here; otherwise k_bbox<1> has left it in s.bb.
+__global__ void __launch_bounds__(kWave) k_grid_params(SlotDev* slots, RunParams rp, const unsigned int* __restrict__ blockbb,
+                                                       int nb_max) {
+  SlotDev& s = slots[blockIdx.x];
+  if (blockbb) {
+    const int nb = (s.n_raw + kBlock - 1) / kBlock;
+    unsigned int mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
+    for (int b = threadIdx.x; b < nb; b += kWave) {
+      const unsigned int* w = blockbb + ((size_t)blockIdx.x * nb_max + b) * 6;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { mn[a] = min(mn[a], w[a]); mx[a] = max(mx[a], w[3 + a]); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        mn[a] = min(mn[a], (unsigned int)__shfl_xor((int)mn[a], o, kWave));
+        mx[a] = max(mx[a], (unsigned int)__shfl_xor((int)mx[a], o, kWave));
+      }
+    }
+    if (threadIdx.x == 0)
+      for (int a = 0; a < 3; ++a) { s.bb[a] = mn[a]; s.bb[3 + a] = mx[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
   if (s.n > 0 && s.bb[0] != 0xFFFFFFFFu)
     for (int a = 0; a < 3; ++a) { mn[a] = ord2f(s.bb[a]); mx[a] = ord2f(s.bb[3 + a]); }
   s.g = grid_params_from_bbox(mn, mx, rp.h0, s.cell_cap);
   s.n_sort = s.n;
-}
-
-__global__ void __launch_bounds__(kBlock) k_cell_keys(const SlotDev* __restrict__ slots, const float4* __restrict__ filt,
-                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-  const SlotDev& s = slots[blockIdx.y];
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= s.n) return;
-  const float4 p = filt[s.off + i];
-  keys[s.off + i] = (uint32_t)grid_cell_of_point(s.g, p.x, p.y, p.z);
-  vals[s.off + i] = (uint32_t)i;
 }
 
 // cell-sorted copy of the points (w = index in filtered order) and cell_start[] by gap fill:
