@@ -53,7 +53,81 @@ PointCloudSensor::PointCloudSensor(const std::string& n, Logger* l, int device) 
   mContextHolder = std::make_shared<ContextHolder>(mContext);
 }
 
-PointCloudSensor::~PointCloudSensor() {}   // the context goes with mContextHolder
+PointCloudSensor::~PointCloudSensor() { releaseSweep(); }   // (the context goes with mContextHolder)
+
+void PointCloudSensor::releaseSweep() {
+  if (!mSweep) return;
+  for (auto& kv : mSweepClouds) s3d_sweep_cloud_release(mSweep, kv.second);
+  mSweepClouds.clear();
+  s3d_sweep_destroy(mSweep);
+  mSweep = nullptr;
+}
+
+std::vector<Constraint::Ptr> PointCloudSensor::createConstraints(const std::vector<Measurement::Ptr>& sources,
+                                                                 const std::vector<Measurement::Ptr>& targets,
+                                                                 const std::vector<Transform>& odometry,
+                                                                 const std::vector<int>& devices) {
+  if (sources.size() != targets.size() || sources.size() != odometry.size())
+    throw std::invalid_argument("createConstraints: sources, targets and odometry must have one entry per candidate");
+  const size_t n = sources.size();
+  std::vector<Constraint::Ptr> out(n);
+  if (n == 0) return out;
+  std::lock_guard<std::mutex> lock(mSweepMutex);
+  if (!mSweep || devices != mSweepDevices) {
+    releaseSweep();
+    if (s3d_sweep_create((int)devices.size(), devices.empty() ? nullptr : devices.data(), &mSweep) != S3D_STATUS_OK)
+      throw std::runtime_error("slam3d (MI355X build): no usable HIP devices / RCCL for the sweep, and there is no CPU fallback");
+    mSweepDevices = devices;
+  }
+  std::vector<s3d_sweep_cloud*> src(n), tgt(n);
+  std::vector<double> guesses(16 * n);
+  for (size_t i = 0; i < n; ++i) {
+    const Measurement::Ptr pair_m[2] = {sources[i], targets[i]};
+    s3d_sweep_cloud* pair_c[2];
+    for (int k = 0; k < 2; ++k) {
+      PointCloudMeasurement::Ptr pc = ptr::dynamic_pointer_cast<PointCloudMeasurement>(pair_m[k]);
+      if (!pc) {   // PointCloudSensor.cpp:279-283
+        mLogger->message(ERROR, "Measurement given to createConstraint() is not a PointCloud!");
+        throw BadMeasurementType();
+      }
+      auto it = mSweepClouds.find(pc->getUniqueId());
+      if (it == mSweepClouds.end()) {
+        const PointCloud::Ptr c = pc->getPointCloud();
+        static const float dummy[4] = {0, 0, 0, 0};
+        s3d_sweep_cloud* sc = nullptr;
+        if (s3d_sweep_cloud_create(mSweep, c->size() ? &c->points[0].x : dummy, (int)c->size(), 4, &sc) != S3D_STATUS_OK)
+          throw std::runtime_error("s3d_sweep_cloud_create failed");
+        it = mSweepClouds.emplace(pc->getUniqueId(), sc).first;
+      }
+      pair_c[k] = it->second;
+    }
+    src[i] = pair_c[0]; tgt[i] = pair_c[1];
+    const Transform guess = sources[i]->getInverseSensorPose() * odometry[i] * targets[i]->getSensorPose();   // :274
+    std::memcpy(&guesses[16 * i], guess.data(), 16 * sizeof(double));
+  }
+  std::vector<s3d_edge_record> rec(n);
+  s3d_exec_options opts;
+  std::memset(&opts, 0, sizeof opts);
+  opts.cache_prepass = mPrepassCache ? 1 : 0;
+  const int st = s3d_align_batch_multi(mSweep, (int)n, src.data(), tgt.data(), guesses.data(),
+                                       static_cast<const s3d_reg_params*>(&mFineConfiguration), &opts, rec.data());
+  if (st == S3D_STATUS_BACKEND_ERROR) throw std::runtime_error(std::string("HIP back-end error: ") + s3d_sweep_last_error(mSweep));
+  if (st == S3D_STATUS_UNKNOWN_ALGORITHM) throw std::runtime_error("Unknown registration algorithm specified.");   // :164
+  for (size_t i = 0; i < n; ++i) {
+    if ((int)rec[i].status != S3D_STATUS_OK) {   // NoMatch: ScanSensor::link logs a warning and goes on (ScanSensor.cpp:159-162)
+      mLogger->message(WARNING, "Failed to match candidate " + std::to_string(i) + " (status " + std::to_string((int)rec[i].status) + ")");
+      continue;
+    }
+    Transform icp = Transform::Identity();
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 3; ++r) icp(r, c) = rec[i].transform[c * 3 + r];
+    const Transform transform = sources[i]->getSensorPose() * icp * targets[i]->getInverseSensorPose();   // :295
+    Covariance<6> information = Covariance<6>::Identity();
+    for (unsigned d = 0; d < 6; ++d) information(d, d) = 1.0 / mCovarianceScale;
+    out[i] = Constraint::Ptr(new SE3Constraint(mName, transform, information));
+  }
+  return out;
+}
 
 PointCloud::Ptr PointCloudSensor::downsample(PointCloud::Ptr in, double leaf_size) {
   PointCloud::Ptr out(new PointCloud);

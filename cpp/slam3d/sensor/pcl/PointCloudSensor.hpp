@@ -160,6 +160,17 @@ class PointCloudSensor : public ScanSensor {
   // Returns 0 on success (like PLYReader::read), -1 otherwise.
   static int readPLY(const std::string& path, PointCloud& cloud, Transform& sensor_pose);
 
+  // Not in the reference: the candidate pairs of one ScanSensor::linkToNeighbors call (ScanSensor.cpp:179-201, which
+  // links them one blocking createConstraint at a time) registered as ONE sweep over the GPUs of the node
+  // (include/slam3d_hip.h, C1: one rank per device, contiguous blocks, RCCL all-gather of the edges).  Entry i is the
+  // constraint createConstraint(sources[i], targets[i], odometry[i], false) would return - bit for bit, whatever the
+  // number of GPUs - or null where that call would have thrown NoMatch (logged as ScanSensor.cpp:159-162 does).
+  // devices: HIP device of every rank; empty = every visible device.
+  std::vector<Constraint::Ptr> createConstraints(const std::vector<Measurement::Ptr>& sources,
+                                                 const std::vector<Measurement::Ptr>& targets,
+                                                 const std::vector<Transform>& odometry,
+                                                 const std::vector<int>& devices = std::vector<int>());
+
   // the same align() the reference keeps file-local (PointCloudSensor.cpp:119-174), exposed for tests
   Transform align(const PointCloudMeasurement::Ptr& source, const PointCloudMeasurement::Ptr& target,
                   const Transform& guess, const RegistrationParameters& config);
@@ -182,6 +193,12 @@ class PointCloudSensor : public ScanSensor {
   MeasurementStorage* mStorage = nullptr;
   bool mPrepassCache = true;
   PointCloudMeasurement::Ptr mInitialMap;
+  // the sweep (ranks, communicators) of the last device list and the sweep clouds of the measurements it has seen
+  s3d_sweep* mSweep = nullptr;
+  std::vector<int> mSweepDevices;
+  std::map<Uuid, s3d_sweep_cloud*> mSweepClouds;
+  std::mutex mSweepMutex;
+  void releaseSweep();
   std::shared_ptr<ContextHolder> mContextHolder;
   s3d_context* mContext;   // == mContextHolder->ctx: one HIP device + stream; calls are serialised inside the library,
                            // so createConstraint may be entered from the link thread (ScanSensor.cpp:210)

@@ -220,3 +220,28 @@ def test_config3_sweep_of_4096_pairs_in_8_shards(gpu_ctx):
     finally:
         for c in dev:
             c.release()
+
+
+def test_cpp_create_constraints_sweep_equals_sequential_create_constraint(fixture_clouds, tmp_path):
+    """The C++ mirror's PointCloudSensor::createConstraints (one s3d_align_batch_multi sweep, what a
+    ScanSensor::linkToNeighbors would call with its candidate list) against the reference's way - one blocking
+    createConstraint per candidate (ScanSensor.cpp:179-201): identical edges bit for bit, for one rank through RCCL,
+    two ranks on this GPU, and "every visible device" (cpp/example_link_neighbors.cpp)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "cpp", "example_link_neighbors")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "cpp")])
+    files = []
+    for i, c in enumerate(fixture_clouds):
+        f = tmp_path / ("scan%d.bin" % i)
+        c.astype(np.float32).tofile(f)
+        files.append(str(f))
+    for devices in ("0", "0,0", "all"):
+        out = subprocess.check_output([exe, devices] + files, stderr=subprocess.DEVNULL).decode().splitlines()
+        seq = [l.split(" ", 1)[1] for l in out if l.startswith("sequential ")]
+        swp = [l.split(" ", 1)[1] for l in out if l.startswith("sweep ")]
+        assert len(seq) == 5 and seq == swp, devices          # (0,1) (0,2) (1,2) (1,3) (2,3)
+        assert sum("NoMatch" in l for l in seq) <= 2           # scans two apart move ~1.4 m: the 1 m gate may reject them
+        assert "NoMatch" not in seq[0] and "NoMatch" not in seq[2] and "NoMatch" not in seq[4]
