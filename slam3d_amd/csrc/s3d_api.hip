@@ -465,7 +465,10 @@ struct Batch {
     hipStream_t st = ctx->stream;
     // which clouds need the k-NN pre-pass: GICP uses the covariances of both clouds of a pair, point-to-plane only
     // the normals of the searched one (PCL target = slam3d source); a batch without pairs is s3d_knn_normals
-    for (SlotDev& sl : h_slots) sl.want_normals = h_pairs.empty() ? 1 : 0;
+    for (SlotDev& sl : h_slots) {
+      sl.want_normals = h_pairs.empty() ? 1 : 0;
+      for (int a = 0; a < 3; ++a) { sl.bb[a] = 0xFFFFFFFFu; sl.bb[3 + a] = 0u; }   // empty bbox: k_bbox<0> starts from it
+    }
     for (const PairDev& pr : h_pairs) {
       h_slots[pr.slot_s].want_normals = 1;
       if (rp.algorithm != 0) h_slots[pr.slot_t].want_normals = 1;
@@ -503,7 +506,6 @@ struct Batch {
       const int shift = 8 * p;
       if (p > 0 || !first_hist_done) k_sort_hist<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(d_slots(), ki, cnt, shift, nb_sort);
       k_sort_scan_rows<<<dim3(256 / (kBlock / kWave), nslots), kBlock, 0, st>>>(d_slots(), cnt, dtot, nb_sort);
-      k_sort_scan_digits<<<nslots, kBlock, 0, st>>>(dtot);
       k_sort_scatter<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(d_slots(), ki, vi, ko, vo, cnt, dtot, shift, nb_sort);
       std::swap(ki, ko);
       std::swap(vi, vo);
@@ -516,7 +518,6 @@ struct Batch {
     const int NS = Cu;
     if (NS == 0) return;
     if (rp.leaf > 0.f) {
-      k_slot_reset_bbox<<<NS, 64, 0, st>>>(d_slots());
       k_bbox<0><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), NS), kBlock, 0, st>>>(d_slots(), filt());
       k_voxel_params<<<cdiv(NS, 64), 64, 0, st>>>(d_slots(), rp, NS);
       k_keys_hist<0><<<dim3(nb_sort, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA(), (uint32_t*)ctx->counts.p, nb_sort);

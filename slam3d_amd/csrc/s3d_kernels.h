@@ -310,8 +310,8 @@ __global__ void __launch_bounds__(kBlock) k_keys_hist(const SlotDev* __restrict_
 }
 
 // Offsets of one pass in two steps.  (1) one WAVE per (slot, digit) row of tile counts: exclusive scan of the row
-// in place, 64 tiles per step (four steps' loads in flight), row total -> digit_tot.  (2) one block per slot:
-// exclusive scan of the 256 row totals; the scatter adds that base to its tile's row offset.  A lone 10^7-point
+// in place, 64 tiles per step (four steps' loads in flight), row total -> digit_tot.  (2) the exclusive scan of the
+// slot's 256 row totals is redone by every scatter tile (k_sort_scatter), which adds it to its tile's row offset.  A lone 10^7-point
 // slot (map building) has ~10^4 tiles per row: the first version walked each row with one thread and took 5 ms
 // per pass there.
 __global__ void __launch_bounds__(kBlock) k_sort_scan_rows(const SlotDev* __restrict__ slots, uint32_t* __restrict__ counts,
@@ -345,23 +345,6 @@ __global__ void __launch_bounds__(kBlock) k_sort_scan_rows(const SlotDev* __rest
   if (lane == 0) digit_tot[(size_t)blockIdx.y * 256 + digit] = carry;
 }
 
-__global__ void __launch_bounds__(kBlock) k_sort_scan_digits(uint32_t* __restrict__ digit_tot) {
-  __shared__ unsigned int tot[256];
-  uint32_t* t = digit_tot + (size_t)blockIdx.x * 256;
-  const unsigned int own = t[threadIdx.x];
-  tot[threadIdx.x] = own;
-  __syncthreads();
-  unsigned int v = own;
-  for (int o = 1; o < 256; o <<= 1) {   // Hillis-Steele, 8 steps
-    const unsigned int u = (threadIdx.x >= (unsigned)o) ? tot[threadIdx.x - o] : 0u;
-    __syncthreads();
-    v += u;
-    tot[threadIdx.x] = v;
-    __syncthreads();
-  }
-  t[threadIdx.x] = v - own;
-}
-
 // Stable scatter of one 1024-element tile.  Every wave owns a CONTIGUOUS quarter of the tile (4 rounds
 // of 64 elements), so the output order (wave, round, lane) is the input order and the per-digit ranks
 // can be accumulated per wave without a block barrier per round: lanes holding the same digit find
@@ -372,7 +355,7 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
                                                           const uint32_t* __restrict__ vals_in,
                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                           const uint32_t* __restrict__ counts,
-                                                          const uint32_t* __restrict__ digit_base, int shift, int nb_max) {
+                                                          const uint32_t* __restrict__ digit_tot, int shift, int nb_max) {
   __shared__ unsigned int wave_cnt[kBlock / kWave][256];   // per wave: elements of each digit seen so far
   const SlotDev& s = slots[blockIdx.y];
   const int n = s.n_sort;
@@ -417,7 +400,7 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
   // digit = threadIdx.x: exclusive prefix over the waves (tile-local), the digit's first position inside the
   // tile (exclusive scan of the tile histogram over the 256 digits) and in the output (this tile's row offset
   // + the digit base of the pass)
-  __shared__ unsigned int dig_local[256], dig_global[256], wave_tot[kBlock / kWave];
+  __shared__ unsigned int dig_local[256], dig_global[256], wave_tot[kBlock / kWave], wave_tot2[kBlock / kWave];
   __shared__ uint32_t lkey[kSortTile], lval[kSortTile];
   {
     unsigned int run = 0;
@@ -434,13 +417,22 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
       if (lane >= o) incl += t;
     }
     if (lane == kWave - 1) wave_tot[w] = incl;
-    __syncthreads();
-    unsigned int before = 0;
+    // the digit's base in the output = exclusive scan of the slot's 256 digit totals: every tile redoes that small
+    // scan here instead of a kernel of its own between the row scan and the scatter (seven launches per step less)
+    const unsigned int dtot = digit_tot[(size_t)blockIdx.y * 256 + threadIdx.x];
+    unsigned int incl2 = dtot;
 #pragma unroll
-    for (int ww = 0; ww < kBlock / kWave; ++ww) before += ww < w ? wave_tot[ww] : 0u;
+    for (int o = 1; o < kWave; o <<= 1) {
+      const unsigned int t = __shfl_up(incl2, o, kWave);
+      if (lane >= o) incl2 += t;
+    }
+    if (lane == kWave - 1) wave_tot2[w] = incl2;
+    __syncthreads();
+    unsigned int before = 0, before2 = 0;
+#pragma unroll
+    for (int ww = 0; ww < kBlock / kWave; ++ww) { before += ww < w ? wave_tot[ww] : 0u; before2 += ww < w ? wave_tot2[ww] : 0u; }
     dig_local[threadIdx.x] = before + incl - run;
-    dig_global[threadIdx.x] = counts[((size_t)blockIdx.y * 256 + threadIdx.x) * nb_max + blockIdx.x] +
-                              digit_base[(size_t)blockIdx.y * 256 + threadIdx.x];
+    dig_global[threadIdx.x] = counts[((size_t)blockIdx.y * 256 + threadIdx.x) * nb_max + blockIdx.x] + (before2 + incl2 - dtot);
   }
   __syncthreads();
   // the tile is first put in digit order in LDS, then written out with consecutive threads on consecutive
