@@ -65,6 +65,27 @@ def test_no_cpu_fallback():
         slam3d_amd.Context(0)
     with pytest.raises(slam3d_amd.BackendError):
         slam3d_amd.backend_info(0)
+    with pytest.raises(slam3d_amd.BackendError):
+        slam3d_amd.Sweep([0])            # the multi-GPU sweep has no CPU path either
+    with pytest.raises(slam3d_amd.BackendError):
+        slam3d_amd.Sweep()
+
+
+def test_sweep_shard_arithmetic_matches_the_python_helper():
+    """s3d_sweep_shard_range (the C ABI's block arithmetic) == slam3d_amd.sweep.shard_range (what bench.py and the
+    gloo test use): contiguous blocks of ceil(n / ranks), short or empty at the end."""
+    import slam3d_amd
+    from slam3d_amd import sweep
+    L = slam3d_amd.load_library()
+    lo, hi = ctypes.c_int(), ctypes.c_int()
+    for n in (0, 1, 7, 8, 9, 512, 4096, 4097):
+        for world in (1, 2, 3, 8):
+            covered = []
+            for r in range(world):
+                L.s3d_sweep_shard_range(n, world, r, ctypes.byref(lo), ctypes.byref(hi))
+                assert (lo.value, hi.value) == sweep.shard_range(n, r, world)
+                covered += list(range(lo.value, hi.value))
+            assert covered == list(range(n))
 
 
 def test_product_does_not_reference_the_oracle():
