@@ -458,7 +458,7 @@ struct Batch {
                 {&ctx->blockbb, 24 * (size_t)std::max(1, C()) * nb_head},
                 {&ctx->corr_idx, 4 * nc}, {&ctx->corr_d2, 4 * nc}, {&ctx->corr_lb, 4 * nc},
                 {&ctx->corr_q, 16 * nc}, {&ctx->corr_n, 16 * nc},
-                {&ctx->partials, 8 * (size_t)std::max(1, P()) * kAccumVB * GQ_NACC * (S3D_ACC_VARIANT == 2 ? 5 : 1)},
+                {&ctx->partials, 8 * (size_t)std::max(1, P()) * kAccumVB * GQ_NACC},
                 {&ctx->n_active, 64 + 2 * 64 * sizeof(int)},
                 {&ctx->knn_list, sizeof(int) * (size_t)std::max(1, C())}});
     if (!ctx->h_active) HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
@@ -620,9 +620,6 @@ struct Batch {
       s3d_gicp_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
           d_pairs(), d_slots(), sorted3(), normals(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p,
           (NormalRec*)ctx->corr_n.p, part, rp);
-#if S3D_ACC_VARIANT == 2
-    if (rp.algorithm) k_combine_waves<<<dim3(kAccumVB, P()), 128, 0, st>>>(part, P());
-#endif
     if (!rp.algorithm)
       s3d_p2plane_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
           d_pairs(), d_slots(), sorted3(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p,

@@ -1078,7 +1078,7 @@ __global__ void __launch_bounds__(kBlock) k_export_normals(const SlotDev* __rest
 // each of them in ascending order; the 256 per-thread sums of a virtual
 // block are combined by the butterfly below (64 lanes) and then over its four waves in ascending order; the
 // controller adds the kAccumVB block sums in 8 groups of 8 (ascending inside a group, then the groups in ascending
-// order: s3d_icp_control_kernel, k_fitness_final).  HOW MANY real blocks execute the virtual blocks (64 for
+// order: icp_control_pair, k_fitness_final).  HOW MANY real blocks execute the virtual blocks (64 for
 // a single pair, 4 for a 256-pair batch: few long-running blocks are faster there) is a launch parameter that
 // cannot change a bit of the result: a pair registers to the same edge alone, in any batch and in any shard of a
 // multi-GPU sweep.
@@ -1146,12 +1146,10 @@ constexpr int wrs_half(int n, int levels) { return levels == 0 ? n : wrs_half((n
 // evenly as integers allow (6 or 7 tiles each for 100 k points), so that no virtual block runs masked steps
 __device__ __forceinline__ int vb_tile_begin(int v, int ntiles) { return (int)(((long long)v * ntiles) / kAccumVB); }
 
-#ifndef S3D_ACC_VARIANT
-#define S3D_ACC_VARIANT 1
-#endif
 // parity: 0 / 1 alternating between the consecutive virtual blocks of a real block.  The four wave results go through
 // one of two LDS buffers, so ONE block barrier per virtual block is enough: a wave that writes buffer p again (two
 // virtual blocks later) has passed the barrier in between, which waves 0-1 reach only after reading buffer p.
+// (Two barriers, or none with per-wave partials and a combine kernel, measured the same: DESIGN.md 6a.)
 template <int NACC>
 __device__ __forceinline__ void block_reduce_store_fixed(double (&acc)[NACC], double* __restrict__ out, int parity) {
   __shared__ double red[2][kBlock / kWave][NACC];
@@ -1163,14 +1161,6 @@ __device__ __forceinline__ void block_reduce_store_fixed(double (&acc)[NACC], do
   wrs_level<wrs_half(NACC, 4), 2>(acc, lane);
   wrs_level<wrs_half(NACC, 5), 1>(acc, lane);
   constexpr int kSlots = wrs_half(NACC, 6);
-#if S3D_ACC_VARIANT == 2
-  // experiment: every wave stores its own result (no LDS, no barrier); a combine kernel adds the four waves
-#pragma unroll
-  for (int sl = 0; sl < kSlots; ++sl) {
-    const int idx = wrs_index<NACC, 32>(lane, sl);
-    if (idx >= 0) out[(size_t)w * NACC + idx] = acc[sl];
-  }
-#else
 #pragma unroll
   for (int sl = 0; sl < kSlots; ++sl) {
     const int idx = wrs_index<NACC, 32>(lane, sl);
@@ -1183,10 +1173,6 @@ __device__ __forceinline__ void block_reduce_store_fixed(double (&acc)[NACC], do
     for (int ww = 1; ww < kBlock / kWave; ++ww) v += red[parity][ww][threadIdx.x];
     out[threadIdx.x] = v;
   }
-#if S3D_ACC_VARIANT == 0
-  __syncthreads();
-#endif
-#endif
 }
 template <int NACC>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* __restrict__ out) {
@@ -1204,6 +1190,99 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
     for (int ww = 1; ww < kBlock / kWave; ++ww) v += red[ww][threadIdx.x];
     out[threadIdx.x] = v;
   }
+}
+
+// ------------------------------------------------------------------ K7: per-pair controller
+// fixed-order sum of the block partials, then the solver step and the PCL stopping rule.  Called by ALL threads of a
+// block (kCtrlThreads of them) for one pair; the scalar solver runs on wave 0 with the record in LDS.
+constexpr int kCtrlGroups = 8;      // the root of the fixed summation tree: 8 groups of 8 virtual blocks
+constexpr int kCtrlThreads = 128;   // threads that load the tree root (the stand-alone kernel's block size: more
+                                    // would cap the optimiser's registers below the 256 it uses)
+__device__ __forceinline__ void icp_control_pair(PairDev& P, const double* __restrict__ pair_partials, const RunParams& rp,
+                                                 int* n_active) {
+  __shared__ double grp[kCtrlGroups][GQ_NACC];
+  __shared__ double acc[GQ_NACC];
+  const bool gicp = rp.algorithm != 0;
+  const int nacc = gicp ? GQ_NACC : PP_NACC;
+  // root of the fixed tree: the kAccumVB virtual-block sums in 8 groups of 8 (ascending inside a group), then the
+  // groups in ascending order.  Every thread takes up to five (group, accumulator) cells and issues all of their
+  // loads before the first addition: one L2 round trip instead of eight on the critical path of every iteration.
+  if (threadIdx.x < kCtrlThreads) {
+    constexpr int kCells = (kCtrlGroups * GQ_NACC + kCtrlThreads - 1) / kCtrlThreads;   // 5
+    constexpr int kPer = kAccumVB / kCtrlGroups;                                        // 8
+    double t[kCells][kPer];
+#pragma unroll
+    for (int u = 0; u < kCells; ++u) {
+      const int cell = (int)threadIdx.x + u * kCtrlThreads;
+      const int g = cell / GQ_NACC, c = cell % GQ_NACC;
+      const bool ok = g < kCtrlGroups && c < nacc;
+      const double* src = pair_partials + ((size_t)(ok ? g : 0) * kPer) * GQ_NACC + (ok ? c : 0);
+#pragma unroll
+      for (int j = 0; j < kPer; ++j) t[u][j] = src[(size_t)j * GQ_NACC];
+    }
+#pragma unroll
+    for (int u = 0; u < kCells; ++u) {
+      const int cell = (int)threadIdx.x + u * kCtrlThreads;
+      const int g = cell / GQ_NACC, c = cell % GQ_NACC;
+      if (g < kCtrlGroups && c < nacc) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) v += t[u][j];
+        grp[g][c] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nacc) {
+    double v = grp[0][threadIdx.x];
+#pragma unroll
+    for (int g = 1; g < kCtrlGroups; ++g) v += grp[g][threadIdx.x];
+    acc[threadIdx.x] = v;
+  }
+  __syncthreads();
+  // Wave 0 runs the optimiser redundantly on all 64 lanes (identical inputs -> identical, uniform
+  // control flow) so that gq_eval can spread its transcendental and dot-product work over the lanes;
+  // lane 0 alone writes the pair state back.
+  if (threadIdx.x >= kWave) return;
+  const bool writer = threadIdx.x == 0;
+  Mat4f T = P.T;
+  const Mat4f prev = T;
+  const int it = P.iterations + 1;
+  int rc, inner = 0, evals = 0, corr;
+  if (gicp) {
+    corr = (int)acc[GQ_CNT];
+    rc = gicp_estimate_bfgs(acc, rp.max_inner, T, &inner, &evals);
+  } else {
+    corr = (int)acc[PP_CNT];
+    rc = pp_update(acc, T);
+  }
+  const double delta = rc ? 0.0 : icp_delta(prev, T, rp.rotation_epsilon, rp.transformation_epsilon);
+  if (!writer) return;
+  P.correspondences = corr;
+  P.prev = prev;
+  P.T_nn = prev;
+  if (rc) {  // PCLException path: loop breaks, converged_ stays false
+    P.active = 0; P.converged = 0;
+    atomicSub(n_active, 1);
+    return;
+  }
+  P.inner_total += inner; P.evals_total += evals;
+  P.T = T;
+  P.iterations = it;
+  if (it >= rp.max_iterations || (!rp.force_iterations && delta < 1.0)) {
+    P.converged = 1; P.active = 0; P.prev = T;
+    atomicSub(n_active, 1);
+  }
+}
+
+// One block per pair.  (Measured dead end, round 2: running this body at the end of the accumulate kernels - the last
+// block of a pair to finish, a counter per pair - saves the launch, but the optimiser's 308 registers become the
+// accumulate kernel's: 240 -> 328, one wave per SIMD instead of two, which costs more than the launch.)
+__global__ void __launch_bounds__(kCtrlThreads) s3d_icp_control_kernel(PairDev* pairs, const double* __restrict__ partials,
+                                                                        RunParams rp, int* n_active) {
+  PairDev& P = pairs[blockIdx.x];
+  if (!P.active) return;
+  icp_control_pair(P, partials + (size_t)blockIdx.x * kAccumVB * GQ_NACC, rp, n_active);
 }
 
 // GICP: Mahalanobis matrix + 73-term quadratic form (s3d_core.h "GICP quadratic form")
@@ -1239,13 +1318,8 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
   // the next virtual block included - are in flight while the current one is folded into the 73 accumulators (the
   // loads of one element per lane and wave do not cover the HBM latency-bandwidth product).
   const int ntiles = (M + kBlock - 1) / kBlock;
-#if S3D_ACC_VARIANT == 2
-  constexpr int kAccOutMul = kBlock / kWave;   // experiment: per-wave results in a second region, k_combine_waves adds them
-  double* __restrict__ out = partials + ((size_t)gridDim.y + (size_t)blockIdx.y * kAccOutMul) * kAccumVB * GQ_NACC;
-#else
   constexpr int kAccOutMul = 1;
   double* __restrict__ out = partials + (size_t)blockIdx.y * kAccumVB * GQ_NACC;
-#endif
   // next virtual block of this real block that owns at least one tile, starting at `from`; the empty ones on the
   // way (a cloud of fewer than 64 tiles) get their zero sums
   auto next_nonempty = [&](int from) {
@@ -1305,14 +1379,6 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
   }
 }
 
-#if S3D_ACC_VARIANT == 2
-__global__ void k_combine_waves(double* __restrict__ partials, int npairs) {
-  const double* w = partials + ((size_t)npairs + (size_t)blockIdx.y * 4) * kAccumVB * GQ_NACC + (size_t)blockIdx.x * 4 * GQ_NACC;
-  double* o = partials + ((size_t)blockIdx.y * kAccumVB + blockIdx.x) * GQ_NACC;
-  const int c = threadIdx.x;
-  if (c < GQ_NACC) o[c] = ((w[c] + w[GQ_NACC + c]) + w[2 * GQ_NACC + c]) + w[3 * GQ_NACC + c];
-}
-#endif
 
 // point-to-plane: J^T J (21) + J^T r (6) + r^2 + count
 __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const PairDev* __restrict__ pairs,
@@ -1354,90 +1420,6 @@ __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const Pa
     }
     block_reduce_store_fixed<PP_NACC>(acc, out + (size_t)v * GQ_NACC, parity);
     parity ^= 1;
-  }
-}
-
-// ------------------------------------------------------------------ K7: per-pair controller
-// fixed-order sum of the block partials, then the solver step and the PCL stopping rule.
-// One block per pair; the scalar solver runs on lane 0 with the record in LDS.
-constexpr int kCtrlGroups = 8;      // the root of the fixed summation tree: 8 groups of 8 virtual blocks
-constexpr int kCtrlThreads = 128;   // (two waves: more would cap the optimiser's registers below what it uses)
-__global__ void __launch_bounds__(kCtrlThreads) s3d_icp_control_kernel(PairDev* pairs, const double* __restrict__ partials,
-                                                                        RunParams rp, int* n_active) {
-  __shared__ double grp[kCtrlGroups][GQ_NACC];
-  __shared__ double acc[GQ_NACC];
-  PairDev& P = pairs[blockIdx.x];
-  if (!P.active) return;
-  const bool gicp = rp.algorithm != 0;
-  const int nacc = gicp ? GQ_NACC : PP_NACC;
-  // root of the fixed tree: the kAccumVB virtual-block sums in 8 groups of 8 (ascending inside a group), then the
-  // groups in ascending order.  Every thread takes up to five (group, accumulator) cells and issues all of their
-  // loads before the first addition: one L2 round trip instead of eight on the critical path of every iteration.
-  {
-    constexpr int kCells = (kCtrlGroups * GQ_NACC + kCtrlThreads - 1) / kCtrlThreads;   // 5
-    constexpr int kPer = kAccumVB / kCtrlGroups;                                        // 8
-    double t[kCells][kPer];
-#pragma unroll
-    for (int u = 0; u < kCells; ++u) {
-      const int cell = (int)threadIdx.x + u * kCtrlThreads;
-      const int g = cell / GQ_NACC, c = cell % GQ_NACC;
-      const bool ok = g < kCtrlGroups && c < nacc;
-      const double* src = partials + ((size_t)blockIdx.x * kAccumVB + (size_t)(ok ? g : 0) * kPer) * GQ_NACC + (ok ? c : 0);
-#pragma unroll
-      for (int j = 0; j < kPer; ++j) t[u][j] = src[(size_t)j * GQ_NACC];
-    }
-#pragma unroll
-    for (int u = 0; u < kCells; ++u) {
-      const int cell = (int)threadIdx.x + u * kCtrlThreads;
-      const int g = cell / GQ_NACC, c = cell % GQ_NACC;
-      if (g < kCtrlGroups && c < nacc) {
-        double v = 0.0;
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) v += t[u][j];
-        grp[g][c] = v;
-      }
-    }
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < nacc) {
-    double v = grp[0][threadIdx.x];
-#pragma unroll
-    for (int g = 1; g < kCtrlGroups; ++g) v += grp[g][threadIdx.x];
-    acc[threadIdx.x] = v;
-  }
-  __syncthreads();
-  // Wave 0 runs the optimiser redundantly on all 64 lanes (identical inputs -> identical, uniform
-  // control flow) so that gq_eval can spread its transcendental and dot-product work over the lanes;
-  // lane 0 alone writes the pair state back.
-  if (threadIdx.x >= kWave) return;
-  const bool writer = threadIdx.x == 0;
-  Mat4f T = P.T;
-  const Mat4f prev = T;
-  const int it = P.iterations + 1;
-  int rc, inner = 0, evals = 0, corr;
-  if (gicp) {
-    corr = (int)acc[GQ_CNT];
-    rc = gicp_estimate_bfgs(acc, rp.max_inner, T, &inner, &evals);
-  } else {
-    corr = (int)acc[PP_CNT];
-    rc = pp_update(acc, T);
-  }
-  const double delta = rc ? 0.0 : icp_delta(prev, T, rp.rotation_epsilon, rp.transformation_epsilon);
-  if (!writer) return;
-  P.correspondences = corr;
-  P.prev = prev;
-  P.T_nn = prev;
-  if (rc) {  // PCLException path: loop breaks, converged_ stays false
-    P.active = 0; P.converged = 0;
-    atomicSub(n_active, 1);
-    return;
-  }
-  P.inner_total += inner; P.evals_total += evals;
-  P.T = T;
-  P.iterations = it;
-  if (it >= rp.max_iterations || (!rp.force_iterations && delta < 1.0)) {
-    P.converged = 1; P.active = 0; P.prev = T;
-    atomicSub(n_active, 1);
   }
 }
 
