@@ -110,8 +110,10 @@ Uuid generateUuid();        // defined in sensor/pcl/PointCloudSensor.cpp
 class Measurement {
  public:
   typedef ptr::shared_ptr<Measurement> Ptr;  // boost::shared_ptr where Boost is installed (Types.hpp:30)
-  Measurement(const std::string& r, const std::string& s, const Transform& p)
-      : mRobotName(r), mSensorName(s), mSensorPose(p), mInverseSensorPose(p.inverse()), mUniqueId(generateUuid()) {}
+  // id: the identifier of a reloaded measurement (Types.hpp:114-115; nil = draw a new one)
+  Measurement(const std::string& r, const std::string& s, const Transform& p, const Uuid& id = Uuid())
+      : mRobotName(r), mSensorName(s), mSensorPose(p), mInverseSensorPose(p.inverse()),
+        mUniqueId(id.empty() ? generateUuid() : id) {}
   virtual ~Measurement() {}
   Uuid getUniqueId() const { return mUniqueId; }
   std::string getRobotName() const { return mRobotName; }

@@ -176,6 +176,33 @@ std::shared_ptr<DeviceCloud> PointCloudSensor::deviceCloudOf(const PointCloudMea
   return d;
 }
 
+bool PointCloudSensor::saveDeviceCache(const PointCloudMeasurement::Ptr& m, const std::string& file) const {
+  std::shared_ptr<DeviceCloud> d = m->getDeviceCloud();
+  if (!d) return false;                                   // never registered on this device: nothing to keep
+  const long long need = s3d_cloud_cache_export(mContext, d->cloud, nullptr, 0);
+  if (need <= 0) return false;
+  std::vector<char> blob((size_t)need);
+  if (s3d_cloud_cache_export(mContext, d->cloud, blob.data(), need) != need) return false;
+  std::ofstream f(file, std::ios::binary | std::ios::trunc);
+  f.write(blob.data(), (std::streamsize)blob.size());
+  return (bool)f;
+}
+
+bool PointCloudSensor::loadDeviceCache(const PointCloudMeasurement::Ptr& m, const std::string& file) {
+  std::ifstream f(file, std::ios::binary | std::ios::ate);
+  if (!f) return false;
+  const std::streamsize size = f.tellg();
+  if (size <= 0) return false;
+  std::vector<char> blob((size_t)size);
+  f.seekg(0);
+  if (!f.read(blob.data(), size)) return false;
+  std::shared_ptr<DeviceCloud> d = deviceCloudOf(m);
+  const int st = s3d_cloud_cache_import(mContext, d->cloud, blob.data(), (long long)blob.size());
+  if (st == S3D_STATUS_BACKEND_ERROR) throw std::runtime_error(std::string("HIP back-end error: ") + s3d_last_error(mContext));
+  if (st != S3D_STATUS_OK) mLogger->message(WARNING, "Device cache file " + file + " not used: " + s3d_last_error(mContext));
+  return st == S3D_STATUS_OK;
+}
+
 PointCloud::Ptr PointCloudSensor::download(s3d_cloud* c) const {
   PointCloud::Ptr out(new PointCloud);
   const int n = s3d_cloud_size(c);

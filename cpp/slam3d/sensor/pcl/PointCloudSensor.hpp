@@ -85,8 +85,9 @@ struct DeviceCloud {
 class PointCloudMeasurement : public Measurement {
  public:
   typedef ptr::shared_ptr<PointCloudMeasurement> Ptr;   // boost::shared_ptr where Boost is installed
-  PointCloudMeasurement(const PointCloud::Ptr& cloud, const std::string& r, const std::string& s, const Transform& p)
-      : Measurement(r, s, p), mPointCloud(cloud) {}
+  PointCloudMeasurement(const PointCloud::Ptr& cloud, const std::string& r, const std::string& s, const Transform& p,
+                        const Uuid& id = Uuid())
+      : Measurement(r, s, p, id), mPointCloud(cloud) {}
   const PointCloud::Ptr getPointCloud() const { return mPointCloud; }
   const char* getTypeName() const override { return "slam3d::PointCloudMeasurement"; }
   // device-resident copy, attached lazily by the sensor (the host cloud must not be modified afterwards)
@@ -170,6 +171,18 @@ class PointCloudSensor : public ScanSensor {
                                                  const std::vector<Measurement::Ptr>& targets,
                                                  const std::vector<Transform>& odometry,
                                                  const std::vector<int>& devices = std::vector<int>());
+
+  // Not in the reference: checkpoints.  GraphSerialization::toFolder writes one <index>.s3dm archive per vertex
+  // (GraphSerialization.cpp:40-47) and fromFolder builds NEW measurement objects from them (:68-135): their device
+  // copies and cached pre-pass products (voxel filter, search grid, k-NN normals per registration configuration) would
+  // have to be computed again.  saveDeviceCache writes what the library holds for `m` into `file` (e.g.
+  // <index>.s3dc next to the archive; false and no file when nothing is cached), loadDeviceCache uploads the
+  // reloaded measurement and installs the file's content for it (false when the file is absent, damaged or was
+  // made from other points - the first registration then simply recomputes).  Results do not depend on either.
+  bool saveDeviceCache(const PointCloudMeasurement::Ptr& m, const std::string& file) const;
+  bool loadDeviceCache(const PointCloudMeasurement::Ptr& m, const std::string& file);
+  // entries / bytes / hits / misses of the context's pre-pass cache (s3d_context_cache_control)
+  s3d_cache_stats getCacheStats() const { s3d_cache_stats st = {0, 0, 0, 0}; s3d_context_cache_control(mContext, 0, 0, &st); return st; }
 
   // the same align() the reference keeps file-local (PointCloudSensor.cpp:119-174), exposed for tests
   Transform align(const PointCloudMeasurement::Ptr& source, const PointCloudMeasurement::Ptr& target,

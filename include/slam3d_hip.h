@@ -78,6 +78,17 @@ int  s3d_last_profile(const s3d_context* ctx, s3d_profile* out);
  * NULL): entries, bytes, hits, misses (per cloud and call, since the context was created). */
 typedef struct s3d_cache_stats { long long entries, bytes, hits, misses; } s3d_cache_stats;
 int  s3d_context_cache_control(s3d_context* ctx, long long limit_bytes, int clear, s3d_cache_stats* stats);
+/* Checkpoints.  The reference saves a graph as slam3d_graph.yml + one <index>.s3dm archive per vertex
+ * (GraphSerialization.cpp:14-66) and reloads it with fromFolder (:68-135); a reloaded PointCloudMeasurement is a new
+ * object, so its device copy and its cached pre-pass products are gone.  s3d_cloud_cache_export writes every cache
+ * entry of `cloud` (filtered points, cell-sorted copies, cell table, normals, grid / voxel parameters) into a
+ * caller-provided host buffer that can be stored next to the .s3dm file; it returns the byte size needed (0: nothing
+ * is cached for this cloud, < 0: a status code) and writes only when `capacity` suffices.  s3d_cloud_cache_import
+ * installs such a blob as the cache entries of `cloud` - a cloud with the same points, which is checked (point count
+ * and a hash of the coordinates; S3D_STATUS_INVALID_ARGUMENT otherwise, nothing installed) - so that the first
+ * registration after a reload starts from the cached products.  Results are bit-identical with or without. */
+long long s3d_cloud_cache_export(s3d_context* ctx, const s3d_cloud* cloud, void* buffer, long long capacity);
+int  s3d_cloud_cache_import(s3d_context* ctx, const s3d_cloud* cloud, const void* blob, long long size);
 void s3d_default_params(s3d_reg_params* p);          /* RegistrationParameters.hpp:36-97 defaults */
 
 /* ---- device-resident clouds ----------------------------------------------------- */

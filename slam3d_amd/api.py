@@ -123,6 +123,8 @@ def load_library():
         "s3d_backend_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
         "s3d_last_profile": (C.c_int, [vp, C.POINTER(Profile)]),
         "s3d_context_cache_control": (C.c_int, [vp, C.c_longlong, C.c_int, C.POINTER(CacheStats)]),
+        "s3d_cloud_cache_export": (C.c_longlong, [vp, vp, vp, C.c_longlong]),
+        "s3d_cloud_cache_import": (C.c_int, [vp, vp, vp, C.c_longlong]),
         "s3d_default_params": (None, [pp]),
         "s3d_cloud_upload": (C.c_int, [vp, fp, C.c_int, C.c_int, C.POINTER(vp)]),
         "s3d_cloud_wrap_device": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp)]),
@@ -499,6 +501,33 @@ class Context:
         st = CacheStats()
         self._check(self._L.s3d_context_cache_control(self._h, int(limit_bytes), int(bool(clear)), C.byref(st)))
         return {k: getattr(st, k) for k, _ in CacheStats._fields_}
+
+    def cache_export(self, cloud):
+        """s3d_cloud_cache_export: the cached pre-pass products of `cloud` as bytes (b"" when nothing is cached) -
+        what a checkpoint stores next to the measurement's .s3dm file."""
+        need = self._L.s3d_cloud_cache_export(self._h, cloud.handle, None, 0)
+        if need < 0:
+            self._check(int(need))
+            raise ValueError("s3d_cloud_cache_export: status %d" % need)
+        if need == 0:
+            return b""
+        buf = C.create_string_buffer(int(need))
+        got = self._L.s3d_cloud_cache_export(self._h, cloud.handle, buf, int(need))
+        if got != need:
+            self._check(int(got))
+            raise ValueError("s3d_cloud_cache_export: status %d" % got)
+        return buf.raw
+
+    def cache_import(self, cloud, blob):
+        """s3d_cloud_cache_import: install a blob of cache_export() as the cache entries of `cloud` (same points:
+        checked).  Returns the status (0 = installed, 1 = rejected: s3d_last_error says why)."""
+        if not blob:
+            return 0
+        buf = C.create_string_buffer(bytes(blob), len(blob))
+        return self._check(self._L.s3d_cloud_cache_import(self._h, cloud.handle, buf, len(blob)))
+
+    def last_error(self):
+        return self._L.s3d_last_error(self._h).decode()
 
     def last_profile(self):
         p = Profile()

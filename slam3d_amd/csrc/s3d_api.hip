@@ -1306,6 +1306,150 @@ int s3d_context_cache_control(s3d_context* ctx, long long limit_bytes, int clear
   return S3D_STATUS_OK;
 }
 
+// ---- the cached pre-pass products of one cloud as a host blob (checkpoints: GraphSerialization.cpp:14-66 writes one
+// <index>.s3dm per vertex; a caller can put this blob next to it and hand it back after fromFolder, :68-135)
+namespace {
+constexpr uint32_t kBlobMagic = 0x42443353u, kBlobEntryMagic = 0x45443353u, kBlobVersion = 1u;   // "S3DB", "S3DE"
+struct BlobHeader { uint32_t magic, version, entries, n_raw; unsigned long long points_hash; };
+struct BlobEntry {
+  uint32_t magic, leaf_bits, h0_bits; int cell_cap;
+  int n, ncells, k_normals, has_sorted3;
+  unsigned int bb[6];
+  s3d::VoxelParams vp;
+  s3d::GridParams g;
+  unsigned long long payload_bytes;   // filt 16 n | sorted 16 n | sorted3 sizeof(CorrVec) n | normals 16 n | cells 4 (ncells + 1)
+};
+unsigned long long fnv1a64(const void* data, size_t bytes) {
+  const unsigned char* p = (const unsigned char*)data;
+  unsigned long long h = 1469598103934665603ull;
+  for (size_t i = 0; i < bytes; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+  return h;
+}
+// hash of the cloud's points as they lie on the device (x, y, z of every point; the fourth float is not data)
+unsigned long long cloud_points_hash(s3d_context* ctx, const s3d_cloud* c) {
+  std::vector<float> h((size_t)c->n * 4);
+  if (c->n) {
+    HIPCHK(hipMemcpyAsync(h.data(), c->d, 16 * (size_t)c->n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  std::vector<float> xyz((size_t)c->n * 3);
+  for (int i = 0; i < c->n; ++i) for (int a = 0; a < 3; ++a) xyz[(size_t)i * 3 + a] = h[(size_t)i * 4 + a];
+  return fnv1a64(xyz.data(), xyz.size() * 4);
+}
+size_t blob_payload_bytes(int n, int ncells) {
+  return (size_t)n * (16 + 16 + sizeof(CorrVec) + sizeof(NormalRec)) + 4 * ((size_t)ncells + 1);
+}
+}  // namespace
+
+long long s3d_cloud_cache_export(s3d_context* ctx, const s3d_cloud* cloud, void* buffer, long long capacity) {
+  if (!ctx || !cloud) return S3D_STATUS_INVALID_ARGUMENT;
+  try {
+    ScopedDevice sd(ctx);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    size_t need = sizeof(BlobHeader);
+    uint32_t entries = 0;
+    auto first = ctx->cache.lower_bound(CacheKey{cloud->uid, 0, 0, 0});
+    for (auto it = first; it != ctx->cache.end() && it->first.uid == cloud->uid; ++it) {
+      need += sizeof(BlobEntry) + blob_payload_bytes(it->second.snap.n, it->second.snap.g.ncells);
+      ++entries;
+    }
+    if (entries == 0) return 0;                                   // nothing cached for this cloud
+    if (!buffer || capacity < (long long)need) return (long long)need;
+    char* out = (char*)buffer;
+    BlobHeader H;
+    H.magic = kBlobMagic; H.version = kBlobVersion; H.entries = entries; H.n_raw = (uint32_t)cloud->n;
+    H.points_hash = cloud_points_hash(ctx, cloud);
+    std::memcpy(out, &H, sizeof H); out += sizeof H;
+    for (auto it = first; it != ctx->cache.end() && it->first.uid == cloud->uid; ++it) {
+      const CacheEntry& e = it->second;
+      const size_t n = (size_t)e.snap.n, cells_n = (size_t)e.snap.g.ncells + 1;
+      BlobEntry E;
+      std::memset(&E, 0, sizeof E);
+      E.magic = kBlobEntryMagic; E.leaf_bits = it->first.leaf_bits; E.h0_bits = it->first.h0_bits; E.cell_cap = it->first.cell_cap;
+      E.n = e.snap.n; E.ncells = e.snap.g.ncells; E.k_normals = e.k_normals; E.has_sorted3 = e.has_sorted3 ? 1 : 0;
+      std::memcpy(E.bb, e.snap.bb, sizeof E.bb);
+      E.vp = e.snap.vp; E.g = e.snap.g;
+      E.payload_bytes = blob_payload_bytes(e.snap.n, e.snap.g.ncells);
+      std::memcpy(out, &E, sizeof E); out += sizeof E;
+      const size_t parts[5][2] = {{e.o_filt, 16 * n}, {e.o_sorted, 16 * n}, {e.o_sorted3, sizeof(CorrVec) * n},
+                                  {e.o_normals, sizeof(NormalRec) * n}, {e.o_cells, 4 * cells_n}};
+      for (int a = 0; a < 5; ++a) {
+        const bool valid = !((a == 2 && !e.has_sorted3) || (a == 3 && e.k_normals == 0));   // never written: zeros
+        if (parts[a][1] && valid) HIPCHK(hipMemcpyAsync(out, e.block + parts[a][0], parts[a][1], hipMemcpyDeviceToHost, ctx->stream));
+        else std::memset(out, 0, parts[a][1]);
+        out += parts[a][1];
+      }
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return (long long)need;
+  } catch (const HipError& e) {
+    return fail(ctx, e);
+  }
+}
+
+int s3d_cloud_cache_import(s3d_context* ctx, const s3d_cloud* cloud, const void* blob, long long size) {
+  if (!ctx || !cloud || !blob || size < (long long)sizeof(BlobHeader)) return S3D_STATUS_INVALID_ARGUMENT;
+  try {
+    ScopedDevice sd(ctx);
+    const char* in = (const char*)blob;
+    const char* const end = in + size;
+    BlobHeader H;
+    std::memcpy(&H, in, sizeof H); in += sizeof H;
+    if (H.magic != kBlobMagic || H.version != kBlobVersion) { ctx->err = "cache blob: bad magic / version"; return S3D_STATUS_INVALID_ARGUMENT; }
+    if ((int)H.n_raw != cloud->n || H.points_hash != cloud_points_hash(ctx, cloud)) {
+      ctx->err = "cache blob: made from a different point cloud";
+      return S3D_STATUS_INVALID_ARGUMENT;
+    }
+    // validate everything before anything is installed
+    const char* scan = in;
+    for (uint32_t i = 0; i < H.entries; ++i) {
+      BlobEntry E;
+      if (end - scan < (long long)sizeof E) { ctx->err = "cache blob: truncated"; return S3D_STATUS_INVALID_ARGUMENT; }
+      std::memcpy(&E, scan, sizeof E); scan += sizeof E;
+      if (E.magic != kBlobEntryMagic || E.n < 0 || E.n > cloud->n || E.ncells < 0 || E.ncells != E.g.ncells || E.ncells > E.cell_cap ||
+          E.payload_bytes != blob_payload_bytes(E.n, E.ncells) || (unsigned long long)(end - scan) < E.payload_bytes) {
+        ctx->err = "cache blob: corrupt entry";
+        return S3D_STATUS_INVALID_ARGUMENT;
+      }
+      scan += E.payload_bytes;
+    }
+    ++ctx->cache_clock;
+    for (uint32_t i = 0; i < H.entries; ++i) {
+      BlobEntry E;
+      std::memcpy(&E, in, sizeof E); in += sizeof E;
+      const CacheKey key{cloud->uid, E.leaf_bits, E.h0_bits, E.cell_cap};
+      auto old = ctx->cache.find(key);
+      if (old != ctx->cache.end()) { HIPCHK(hipStreamSynchronize(ctx->stream)); ctx->cache_drop(old); }
+      CacheEntry e;
+      const size_t n = (size_t)E.n, cells_n = (size_t)E.ncells + 1;
+      auto place = [&](size_t bytes) { const size_t o = e.bytes; e.bytes += (bytes + 255) & ~(size_t)255; return o; };
+      e.o_filt = place(16 * n); e.o_sorted = place(16 * n); e.o_sorted3 = place(sizeof(CorrVec) * n);
+      e.o_normals = place(sizeof(NormalRec) * n); e.o_cells = place(4 * cells_n);
+      e.bytes = std::max<size_t>(e.bytes, 256);
+      if (ctx->cache_bytes + e.bytes > ctx->cache_limit) { in += E.payload_bytes; continue; }   // over the budget: stays uncached
+      HIPCHK(hipMalloc((void**)&e.block, e.bytes));
+      const size_t parts[5][2] = {{e.o_filt, 16 * n}, {e.o_sorted, 16 * n}, {e.o_sorted3, sizeof(CorrVec) * n},
+                                  {e.o_normals, sizeof(NormalRec) * n}, {e.o_cells, 4 * cells_n}};
+      for (int a = 0; a < 5; ++a) {
+        if (parts[a][1]) HIPCHK(hipMemcpyAsync(e.block + parts[a][0], in, parts[a][1], hipMemcpyHostToDevice, ctx->stream));
+        in += parts[a][1];
+      }
+      HIPCHK(hipStreamSynchronize(ctx->stream));      // (the caller's buffer is pageable and may go away)
+      std::memset(&e.snap, 0, sizeof e.snap);
+      e.snap.n_raw = cloud->n; e.snap.cell_cap = E.cell_cap; e.snap.n = E.n;
+      std::memcpy(e.snap.bb, E.bb, sizeof E.bb);
+      e.snap.vp = E.vp; e.snap.g = E.g;
+      e.k_normals = E.k_normals; e.has_sorted3 = E.has_sorted3 != 0;
+      e.last_use = ctx->cache_clock;
+      ctx->cache_bytes += e.bytes;
+      ctx->cache[key] = e;
+    }
+    return S3D_STATUS_OK;
+  } catch (const HipError& e) {
+    return fail(ctx, e);
+  }
+}
+
 int s3d_cloud_upload(s3d_context* ctx, const float* xyz, int n, int stride, s3d_cloud** out) {
   if (!ctx || !out || n < 0 || stride < 3 || (n > 0 && !xyz)) return S3D_STATUS_INVALID_ARGUMENT;
   s3d_cloud* c = new s3d_cloud();

@@ -92,3 +92,84 @@ def test_host_buffer_entry_points_do_not_populate_the_cache(gpu_ctx, fixture_clo
     p = s3d.default_params(registration_algorithm=s3d.ALG_ICP, maximum_iterations=5)
     gpu_ctx.align(fixture_clouds[0], fixture_clouds[1], np.eye(4), p, _opts(s3d, True))
     assert gpu_ctx.cache_control()["entries"] == 0
+
+
+def test_checkpoint_round_trip_of_the_cached_products(gpu_ctx, fixture_clouds):
+    """s3d_cloud_cache_export / _import: what a checkpoint keeps next to a measurement's .s3dm file
+    (GraphSerialization.cpp:14-66 / :68-135).  A reloaded measurement is a NEW cloud handle; with its blob imported
+    the first registration is served from the cache (no misses) and gives the uncached result bit for bit."""
+    import slam3d_amd as s3d
+    gpu_ctx.cache_control(clear=True)
+    cl = [gpu_ctx.upload(c) for c in fixture_clouds[:3]]
+    p = s3d.default_params(registration_algorithm=s3d.ALG_GICP, maximum_iterations=10)
+    coarse = s3d.default_params(registration_algorithm=s3d.ALG_ICP, point_cloud_density=0.5, maximum_iterations=6)
+    want = gpu_ctx.align_batch([cl[0], cl[1]], [cl[1], cl[2]], None, p, _opts(s3d, False))
+    want_c = gpu_ctx.align_batch([cl[0]], [cl[1]], None, coarse, _opts(s3d, False))
+    assert gpu_ctx.cache_export(cl[0]) == b""                         # nothing cached yet
+    gpu_ctx.align_batch([cl[0], cl[1]], [cl[1], cl[2]], None, p, _opts(s3d, True))
+    gpu_ctx.align_batch([cl[0]], [cl[1]], None, coarse, _opts(s3d, True))   # a second entry (another density) for 0 and 1
+    blobs = [gpu_ctx.cache_export(c) for c in cl]
+    assert all(len(b) > 0 for b in blobs) and len(blobs[0]) > len(blobs[2])
+    assert gpu_ctx.cache_export(cl[0]) == blobs[0]                    # deterministic bytes
+    for c in cl:
+        c.release()
+    assert gpu_ctx.cache_control()["entries"] == 0
+    # "fromFolder": new handles for the same points, blobs handed back
+    re = [gpu_ctx.upload(c) for c in fixture_clouds[:3]]
+    try:
+        for c, b in zip(re, blobs):
+            assert gpu_ctx.cache_import(c, b) == 0
+        st0 = gpu_ctx.cache_control()
+        assert st0["entries"] == 5
+        got = gpu_ctx.align_batch([re[0], re[1]], [re[1], re[2]], None, p, _opts(s3d, True))
+        got_c = gpu_ctx.align_batch([re[0]], [re[1]], None, coarse, _opts(s3d, True))
+        st1 = gpu_ctx.cache_control()
+        assert np.array_equal(got, want) and np.array_equal(got_c, want_c)
+        assert st1["misses"] == st0["misses"] and st1["hits"] == st0["hits"] + 5
+        # a blob only fits the cloud it was made from; a damaged one is refused; nothing is installed in either case
+        other = gpu_ctx.upload(fixture_clouds[3])
+        try:
+            assert gpu_ctx.cache_import(other, blobs[0]) == 7 and "different point cloud" in gpu_ctx.last_error()
+            moved = gpu_ctx.upload(fixture_clouds[0][:, :3] + np.float32(1e-3))
+            assert gpu_ctx.cache_import(moved, blobs[0]) == 7
+            moved.release()
+            assert gpu_ctx.cache_import(other, blobs[0][:100]) == 7
+            bad = bytearray(gpu_ctx.cache_export(re[2])); bad[40] ^= 0xFF      # an entry header field
+            assert gpu_ctx.cache_import(re[2], bytes(bad[:len(bad) // 2])) == 7
+            assert gpu_ctx.cache_control()["entries"] == 5
+        finally:
+            other.release()
+        # importing over existing entries replaces them
+        assert gpu_ctx.cache_import(re[0], blobs[0]) == 0 and gpu_ctx.cache_control()["entries"] == 5
+        assert np.array_equal(gpu_ctx.align_batch([re[0]], [re[1]], None, coarse, _opts(s3d, True)), want_c)
+    finally:
+        for c in re:
+            c.release()
+
+
+def test_cpp_mirror_device_cache_across_a_checkpoint(fixture_clouds, tmp_path):
+    """cpp/example_checkpoint.cpp: PointCloudSensor::saveDeviceCache / loadDeviceCache around a save + reload of two
+    measurements (new objects carrying the stored uuids, GraphSerialization.cpp:40-47 / :68-135): the edge after the
+    reload equals the one before bit for bit and is served from the restored cache without a miss."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "cpp", "example_checkpoint")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "cpp")])
+    files = []
+    for i in (0, 1):
+        f = tmp_path / ("scan%d.bin" % i)
+        fixture_clouds[i].astype(np.float32).tofile(f)
+        files.append(str(f))
+    out = subprocess.check_output([exe, str(tmp_path)] + files, stderr=subprocess.DEVNULL).decode().splitlines()
+    get = lambda key: [l[len(key) + 1:] for l in out if l.startswith(key + " ")]
+    assert get("save before any registration") == ["0"]
+    assert get("save 0") == ["1"] and get("save 1") == ["1"]
+    assert get("entries after release") == ["0"]
+    assert get("uuid kept") == ["1", "1"]
+    assert get("load wrong scan") == ["0"] and get("load missing file") == ["0"]
+    assert get("load 0") == ["1"] and get("load 1") == ["1"]
+    assert len(get("first")) == 1 and get("first") == get("again")
+    assert get("entries")[-1] == "2 new hits 2 new misses 0"
+    assert os.path.getsize(tmp_path / "0.s3dc") > 16 * len(fixture_clouds[0]) // 8
