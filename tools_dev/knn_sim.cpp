@@ -25,6 +25,27 @@ int main(int argc, char** argv) {
   // per lane: the candidate sequence of phase 1 (5 rows) and phase 2 (4 corner rows, after pruning), lock-step per wave
   double steps1 = 0, steps2 = 0, chains = 0, cand_sum = 0, acc_sum = 0, acc_max_sum = 0, ring2 = 0, waves = 0, cand_max_sum = 0;
   double chains_b4 = 0, steps_b4 = 0;
+  std::vector<int> perm(n);
+  for (int i = 0; i < n; ++i) perm[i] = i;
+  if (getenv("BLOCKSORT")) {   // experiment: the queries of a 256-thread block dealt to its waves by candidate count
+    const int B = atoi(getenv("BLOCKSORT"));
+    std::vector<uint32_t> tot(n);
+    for (int i = 0; i < n; ++i) {
+      const F4& q = G.sorted[i];
+      const int ix = grid_coord(g, 0, q.x), iy = grid_coord(g, 1, q.y), iz = grid_coord(g, 2, q.z);
+      const int xa = std::max(ix - 1, 0), xb = std::min(ix + 1, g.dim[0] - 1);
+      uint32_t t = 0;
+      for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
+        const int cy = iy + dy, cz = iz + dz;
+        if (cy < 0 || cy >= g.dim[1] || cz < 0 || cz >= g.dim[2]) continue;
+        const int rb = g.dim[0] * (cy + g.dim[1] * cz);
+        t += G.cell_start[rb + xb + 1] - G.cell_start[rb + xa];
+      }
+      tot[i] = t;
+    }
+    for (int b0 = 0; b0 < n; b0 += B)
+      std::stable_sort(perm.begin() + b0, perm.begin() + std::min(n, b0 + B), [&](int a, int b) { return tot[a] < tot[b]; });
+  }
   for (int w0 = 0; w0 < n; w0 += 64) {
     const int nl = std::min(64, n - w0);
     std::vector<std::vector<uint32_t>> seq1(nl), seq2(nl);
@@ -33,7 +54,7 @@ int main(int argc, char** argv) {
     struct LaneGeo { int ix, iy, iz; float qx, qy, qz; uint32_t rs[9], re[9]; };
     std::vector<LaneGeo> L(nl);
     for (int l = 0; l < nl; ++l) {
-      const F4& q = G.sorted[w0 + l];
+      const F4& q = G.sorted[perm[w0 + l]];
       LaneGeo& A = L[l];
       A.qx = q.x; A.qy = q.y; A.qz = q.z;
       A.ix = grid_coord(g, 0, q.x); A.iy = grid_coord(g, 1, q.y); A.iz = grid_coord(g, 2, q.z);
