@@ -15,8 +15,8 @@ f = os.path.join(P, "single", "s_kernel_trace.csv")
 if os.path.exists(f):
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    last = [i for i, r in enumerate(rows) if "k_slot_reset_bbox" in r["Kernel_Name"]]
-    start = last[-2] if len(last) >= 2 else 0     # two resets per registration (voxel, grid)
+    last = [i for i, r in enumerate(rows) if "k_bbox<0>" in r["Kernel_Name"]]
+    start = last[-1] if last else 0               # one bbox kernel per registration (its first kernel)
     sel = rows[start:]
     t0 = int(sel[0]["Start_Timestamp"])
     with open(os.path.join(P, "single_last_registration_trace.csv"), "w") as o:
