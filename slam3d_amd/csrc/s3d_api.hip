@@ -155,7 +155,7 @@ struct s3d_context {
   s3d_map_profile map_prof{};
   // workspace (grown on demand, reused across calls)
   DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, sorted3, normals, moments, cell_start, counts, digit_tot, blockcnt, blockbb,
-      corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active, knn_list;
+      corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active, knn_list, knn_fallback;
   int* h_active = nullptr;  // pinned
   // pinned staging of the slot / pair records (up and down): a copy from or to pageable memory stalls the stream for
   // tens of microseconds, which a single-pair registration of ~1.5 ms notices
@@ -460,7 +460,8 @@ struct Batch {
                 {&ctx->corr_q, 16 * nc}, {&ctx->corr_n, 16 * nc},
                 {&ctx->partials, 8 * (size_t)std::max(1, P()) * kAccumVB * GQ_NACC},
                 {&ctx->n_active, 64 + 2 * 64 * sizeof(int)},
-                {&ctx->knn_list, sizeof(int) * (size_t)std::max(1, C())}});
+                {&ctx->knn_list, sizeof(int) * (size_t)std::max(1, C())},
+                {&ctx->knn_fallback, sizeof(int) * npi}});
     if (!ctx->h_active) HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
     hipStream_t st = ctx->stream;
     // which clouds need the k-NN pre-pass: GICP uses the covariances of both clouds of a pair, point-to-plane only
@@ -570,17 +571,21 @@ struct Batch {
     HIPCHK(hipMemcpyAsync(d_list, list.data(), sizeof(int) * (size_t)NL, hipMemcpyHostToDevice, st));
     const int slots8 = NL >= 8 ? cdiv(NL, 8) * 8 : NL;
     dim3 grid((unsigned)(slots8 * nb_head));
+    // the points whose normal the closed form declines (s3d_kernels.h): a device-side list, counted in n_active[4]
+    int* fb_count = (int*)ctx->n_active.p + 4;
+    int* fb_list = (int*)ctx->knn_fallback.p;
+    HIPCHK(hipMemsetAsync(fb_count, 0, sizeof(int), st));
     if (k <= 8)
-      s3d_knn_moments_kernel<8><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL);
+      s3d_knn_moments_kernel<8><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
     else if (k <= 16)
-      s3d_knn_moments_kernel<16><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL);
+      s3d_knn_moments_kernel<16><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
     else if (k == 20)   // the reference default (correspondence_randomness = 20): list length known at compile time
-      s3d_knn_moments_kernel<20, true><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL);
+      s3d_knn_moments_kernel<20, true><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
     else if (k < 20)
-      s3d_knn_moments_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL);
+      s3d_knn_moments_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
     else
-      s3d_knn_moments_kernel<32><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL);
-    s3d_normals_from_moments_kernel<<<dim3(nb_head, NL), kBlock, 0, st>>>(d_slots(), mom, mom_plane, normals(), k, d_list);
+      s3d_knn_moments_kernel<32><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
+    s3d_normals_fallback_kernel<<<256, kBlock, 0, st>>>(fb_count, fb_list, mom, mom_plane, normals(), k);
   }
 
   int dbg_nn = getenv("S3D_DBG_NN") ? atoi(getenv("S3D_DBG_NN")) : 0;

@@ -995,16 +995,31 @@ S3D_HD void moments_add(Moments& m, float x, float y, float z) {
   m.mean[0] += x; m.mean[1] += y; m.mean[2] += z;
   m.c00 += x * x; m.c10 += y * x; m.c11 += y * y; m.c20 += z * x; m.c21 += z * y; m.c22 += z * z;
 }
-S3D_HD void moments_normal(const Moments& m, int k, double n[3]) {
+// covariance of the k neighbours from their sums: c = {c00, c10, c11, c20, c21, c22}
+S3D_HD void moments_covariance(const Moments& m, int k, double c[6]) {
   const double kd = (double)k;
   const double mx = m.mean[0] / kd, my = m.mean[1] / kd, mz = m.mean[2] / kd;
-  const double c00 = m.c00 / kd - mx * mx, c10 = m.c10 / kd - my * mx, c11 = m.c11 / kd - my * my;
-  const double c20 = m.c20 / kd - mz * mx, c21 = m.c21 / kd - mz * my, c22 = m.c22 / kd - mz * mz;
+  c[0] = m.c00 / kd - mx * mx; c[1] = m.c10 / kd - my * mx; c[2] = m.c11 / kd - my * my;
+  c[3] = m.c20 / kd - mz * mx; c[4] = m.c21 / kd - mz * my; c[5] = m.c22 / kd - mz * mz;
+}
+// the closed form alone (what the k-NN kernel runs in place; false: the caller hands the point to moments_normal)
+S3D_HD bool moments_normal_direct(const Moments& m, int k, double n[3]) {
 #if defined(S3D_EIG_JACOBI_ONLY)
-  sym3_smallest_eigvec(c00, c10, c20, c11, c21, c22, n);
+  return false;
 #else
-  if (!sym3_smallest_eigvec_direct(c00, c10, c20, c11, c21, c22, n))
-    sym3_smallest_eigvec(c00, c10, c20, c11, c21, c22, n);
+  double c[6];
+  moments_covariance(m, k, c);
+  return sym3_smallest_eigvec_direct(c[0], c[1], c[3], c[2], c[4], c[5], n);
+#endif
+}
+S3D_HD void moments_normal(const Moments& m, int k, double n[3]) {
+  double c[6];
+  moments_covariance(m, k, c);
+#if defined(S3D_EIG_JACOBI_ONLY)
+  sym3_smallest_eigvec(c[0], c[1], c[3], c[2], c[4], c[5], n);
+#else
+  if (!sym3_smallest_eigvec_direct(c[0], c[1], c[3], c[2], c[4], c[5], n))
+    sym3_smallest_eigvec(c[0], c[1], c[3], c[2], c[4], c[5], n);
 #endif
 }
 

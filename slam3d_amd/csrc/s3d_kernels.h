@@ -663,9 +663,12 @@ __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ 
 
 // k <= KMAX: the k best live in registers as sorted packed keys (s3d_core.h grid_knn_sorted).
 // Threads walk the cloud in CELL-SORTED order: the 64 lanes of a wave sit in adjacent grid cells,
-// so their cell_start / candidate loads fall into a handful of cache lines.  The search kernel only
-// emits the neighbours' moments (9 doubles); the eigen-solve runs in its own kernel: keeping the
-// Jacobi iteration's registers out of the latency-bound search doubles its occupancy.
+// so their cell_start / candidate loads fall into a handful of cache lines.  The kernel sums the neighbours' moments
+// (9 doubles in registers) and turns them into the unit normal in place with the closed-form eigenvector
+// (moments_normal_direct: no register beyond the search's 94) - 16 bytes written per point.  The few points the
+// closed form declines (two smallest eigenvalues closer than 1e-6 of the spread, degenerate neighbourhoods) put their
+// moments into the nine planes of `moments` and their index on a list; s3d_normals_fallback_kernel runs the Jacobi
+// iteration on those: its registers would otherwise halve the occupancy of the search.
 // Slot -> XCD affinity as in nn_block_map: blocks of one cloud share one L2.
 #ifndef S3D_KNN_WAVES
 #define S3D_KNN_WAVES 4
@@ -677,7 +680,9 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_WAVES) s3d_knn_moments_kernel(
                                                                   const uint32_t* __restrict__ cell_start,
                                                                   double* __restrict__ moments, size_t plane, int k,
                                                                   int chunks_per_slot, const int* __restrict__ slot_list,
-                                                                  int nslots) {
+                                                                  int nslots, NormalRec* __restrict__ normals,
+                                                                  int* __restrict__ fallback_count,
+                                                                  int* __restrict__ fallback_list) {
   // slot_list: the clouds that need normals (all of them for GICP, the searched side of each pair for
   // point-to-plane), so that the block -> XCD map spreads exactly those over the chip
   int li, chunk;
@@ -699,28 +704,37 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_WAVES) s3d_knn_moments_kernel(
       moments_add(m, p.x, p.y, p.z);
     }
   }
-  // nine planes of `plane` doubles (the batch's point count): every store of a wave is one contiguous 512 bytes
+  double n[3];
+  if (moments_normal_direct(m, k, n)) {
+    normals[s.off + i] = normal_encode(n);  // CELL-SORTED order
+    return;
+  }
+  // nine planes of `plane` doubles (the batch's point count), and the point's place in them on the list
   double* o = moments + (size_t)(s.off + i);
   o[0] = m.mean[0]; o[plane] = m.mean[1]; o[2 * plane] = m.mean[2];
   o[3 * plane] = m.c00; o[4 * plane] = m.c10; o[5 * plane] = m.c11;
   o[6 * plane] = m.c20; o[7 * plane] = m.c21; o[8 * plane] = m.c22;
+  fallback_list[atomicAdd(fallback_count, 1)] = s.off + i;
 }
 
-__global__ void __launch_bounds__(kBlock) s3d_normals_from_moments_kernel(const SlotDev* __restrict__ slots,
-                                                                           const double* __restrict__ moments, size_t plane,
-                                                                           NormalRec* __restrict__ normals, int k,
-                                                                           const int* __restrict__ slot_list) {
-  const SlotDev& s = slots[slot_list[blockIdx.y]];
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= s.n) return;
-  const double* o = moments + (size_t)(s.off + i);
-  Moments m;
-  m.mean[0] = o[0]; m.mean[1] = o[plane]; m.mean[2] = o[2 * plane];
-  m.c00 = o[3 * plane]; m.c10 = o[4 * plane]; m.c11 = o[5 * plane];
-  m.c20 = o[6 * plane]; m.c21 = o[7 * plane]; m.c22 = o[8 * plane];
-  double n[3];
-  moments_normal(m, k, n);
-  normals[s.off + i] = normal_encode(n);  // CELL-SORTED order
+// the points s3d_knn_moments_kernel listed: full moments_normal (closed form, then cyclic Jacobi).  A fixed small
+// grid strides over the list; its length is read on the device (no host round trip).
+__global__ void __launch_bounds__(kBlock) s3d_normals_fallback_kernel(const int* __restrict__ fallback_count,
+                                                                       const int* __restrict__ fallback_list,
+                                                                       const double* __restrict__ moments, size_t plane,
+                                                                       NormalRec* __restrict__ normals, int k) {
+  const int count = *fallback_count;
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < count; j += gridDim.x * kBlock) {
+    const int gi = fallback_list[j];
+    const double* o = moments + (size_t)gi;
+    Moments m;
+    m.mean[0] = o[0]; m.mean[1] = o[plane]; m.mean[2] = o[2 * plane];
+    m.c00 = o[3 * plane]; m.c10 = o[4 * plane]; m.c11 = o[5 * plane];
+    m.c20 = o[6 * plane]; m.c21 = o[7 * plane]; m.c22 = o[8 * plane];
+    double n[3];
+    moments_normal(m, k, n);
+    normals[gi] = normal_encode(n);
+  }
 }
 
 // ------------------------------------------------------------------ pair state

@@ -158,6 +158,40 @@ def test_knn_normals_match_oracle(gpu_ctx, oracle_mod, fixture_clouds):
         gpu_ctx.knn_normals(v1[:10], 20)          # PCL: k > cloud size is an error
 
 
+def test_knn_normals_degenerate_neighbourhoods_take_the_fallback(gpu_ctx):
+    """The k-NN kernel computes the normal in place with the closed-form eigenvector and hands the points it
+    declines - two smallest eigenvalues not separated - to s3d_normals_fallback_kernel (Jacobi) through a device-side
+    list.  Points on a straight line are such points (every direction across the line is a smallest eigenvector, and
+    PCL's float products put rounding noise of the size of those eigenvalues into the covariance): whatever comes
+    out must be a unit vector whose Rayleigh quotient on the PCL-style covariance of the point's k neighbours is the
+    smallest eigenvalue up to 1e-6 of the largest.  Mixed with a plane (closed form) in one cloud."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(5)
+    t = np.sort(rng.uniform(0, 3, 4000))
+    d = np.array([0.6, 0.64, 0.48])
+    line = (t[:, None] * d[None, :] + np.array([0.1, -0.2, 0.05])).astype(np.float32)
+    plane = np.stack([rng.uniform(4, 6, 6000), rng.uniform(-1, 1, 6000), np.full(6000, 0.3)], 1).astype(np.float32)
+    cloud = np.concatenate([line, plane])
+    tree = cKDTree(cloud.astype(np.float64))
+    for k in (8, 20, 32):
+        n = gpu_ctx.knn_normals(cloud, k).astype(np.float64)
+        assert np.isfinite(n).all() and np.abs(np.linalg.norm(n, axis=1) - 1).max() < 1e-5
+        _, nb = tree.query(cloud.astype(np.float64), k)
+        P = cloud[nb]                                                      # (N, k, 3) float32
+        prod = (P[:, :, :, None] * P[:, :, None, :]).astype(np.float64)    # float products, double sums (PCL)
+        mean = P.astype(np.float64).mean(1)
+        C = prod.mean(1) - mean[:, :, None] * mean[:, None, :]
+        w = np.linalg.eigvalsh(C)
+        ray = np.einsum("ni,nij,nj->n", n, C, n)
+        sel = np.r_[50:3950, 4000:10000]                                   # (the ends of the line have ties in the k-th distance)
+        assert ((ray - w[:, 0])[sel] <= 1e-6 * w[sel, 2] + 1e-18).all(), k
+        assert (np.abs(n[4000:, 2]) > 1 - 1e-6).mean() > 0.99, k
+    # exact duplicates only: a zero covariance
+    same = np.tile(np.array([[1.0, 2.0, 3.0]], np.float32), (64, 1))
+    n = gpu_ctx.knn_normals(same, 20)
+    assert np.isfinite(n).all() and np.abs(np.linalg.norm(n.astype(np.float64), axis=1) - 1).max() < 1e-5
+
+
 def test_knn_normals_large_k(gpu_ctx, oracle_mod, fixture_clouds):
     """correspondence_randomness above 32 takes the LDS top-k kernel (k_normals; up to 64, the documented limit of the
     back-end): same neighbour sets as the oracle, in s3d_knn_normals and inside a GICP registration; k = 65 is refused
