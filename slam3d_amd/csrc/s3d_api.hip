@@ -171,6 +171,29 @@ struct s3d_context {
     }
     return h_stage;
   }
+  // descriptors of k_copy_many (cache restore / store): their own pinned and device buffers, grown on demand
+  char* h_copy = nullptr; size_t h_copy_cap = 0;
+  DevBuf d_copy;
+  void copy_many(const std::vector<s3d::CopyDesc>& descs) {
+    if (descs.empty()) return;
+    const size_t bytes = sizeof(s3d::CopyDesc) * descs.size();
+    if (bytes > h_copy_cap) {
+      HIPCHK(hipStreamSynchronize(stream));               // (an earlier upload may still read the old buffer)
+      if (h_copy) HIPCHK(hipHostFree(h_copy));
+      if (d_copy.p) HIPCHK(hipFree(d_copy.p));
+      h_copy = nullptr; d_copy.p = nullptr; h_copy_cap = 0;
+      const size_t want = std::max<size_t>(2 * bytes, 1 << 14);
+      HIPCHK(hipHostMalloc((void**)&h_copy, want));
+      HIPCHK(hipMalloc(&d_copy.p, want));
+      h_copy_cap = d_copy.cap = want;
+    }
+    std::memcpy(h_copy, descs.data(), bytes);
+    HIPCHK(hipMemcpyAsync(d_copy.p, h_copy, bytes, hipMemcpyHostToDevice, stream));
+    unsigned long long most = 0;
+    for (const s3d::CopyDesc& d : descs) most = std::max(most, d.bytes);
+    const unsigned bx = (unsigned)std::min<unsigned long long>(std::max<unsigned long long>(most / (16ull * s3d::kBlock * 4), 1), 256);
+    s3d::k_copy_many<<<dim3(bx, (unsigned)descs.size()), s3d::kBlock, 0, stream>>>((const s3d::CopyDesc*)d_copy.p);
+  }
   hipEvent_t ev[8] = {};
   std::vector<hipEvent_t> nn_ev;
 
@@ -359,20 +382,20 @@ struct Batch {
 
   // restore the cached clouds into this batch's arrays (after allocate() has carved them)
   void restore_from_cache() {
-    hipStream_t st = ctx->stream;
+    std::vector<CopyDesc> cp;
     for (int j = Cu; j < C(); ++j) {
       const CacheEntry& e = *slot_entry[(size_t)j];
       const SlotDev& sl = h_slots[(size_t)j];
       const size_t n = (size_t)sl.n;
       if (n) {
-        HIPCHK(hipMemcpyAsync(filt() + sl.off, e.block + e.o_filt, 16 * n, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(sorted() + sl.off, e.block + e.o_sorted, 16 * n, hipMemcpyDeviceToDevice, st));
-        if (has_sorted3) HIPCHK(hipMemcpyAsync(sorted3() + sl.off, e.block + e.o_sorted3, sizeof(CorrVec) * n, hipMemcpyDeviceToDevice, st));
-        if (slot_has_normals[(size_t)j])
-          HIPCHK(hipMemcpyAsync(normals() + sl.off, e.block + e.o_normals, sizeof(NormalRec) * n, hipMemcpyDeviceToDevice, st));
+        cp.push_back({e.block + e.o_filt, filt() + sl.off, 16 * n});
+        cp.push_back({e.block + e.o_sorted, sorted() + sl.off, 16 * n});
+        if (has_sorted3) cp.push_back({e.block + e.o_sorted3, sorted3() + sl.off, sizeof(CorrVec) * n});
+        if (slot_has_normals[(size_t)j]) cp.push_back({e.block + e.o_normals, normals() + sl.off, sizeof(NormalRec) * n});
       }
-      HIPCHK(hipMemcpyAsync(cells() + sl.cell_off, e.block + e.o_cells, 4 * ((size_t)sl.g.ncells + 1), hipMemcpyDeviceToDevice, st));
+      cp.push_back({e.block + e.o_cells, cells() + sl.cell_off, 4 * ((size_t)sl.g.ncells + 1)});
     }
+    ctx->copy_many(cp);     // one launch for all of them
   }
 
   // after download(): keep the products of the clouds this call computed (and normals a cached cloud lacked)
@@ -380,6 +403,7 @@ struct Batch {
     if (!use_cache) return;
     hipStream_t st = ctx->stream;
     const int k = (have_normals && rp.k >= 1 && rp.k <= 64) ? rp.k : 0;
+    std::vector<CopyDesc> cp;    // every copy of this call as one launch (after the loop)
     for (int j = 0; j < C(); ++j) {
       const SlotDev& sl = h_slots[(size_t)j];
       const size_t n = (size_t)sl.n;
@@ -387,7 +411,7 @@ struct Batch {
       if (j >= Cu) {   // restored from the cache: at most the normals are new
         CacheEntry& e = *slot_entry[(size_t)j];
         if (normals_now && n) {
-          HIPCHK(hipMemcpyAsync(e.block + e.o_normals, normals() + sl.off, sizeof(NormalRec) * n, hipMemcpyDeviceToDevice, st));
+          cp.push_back({normals() + sl.off, e.block + e.o_normals, sizeof(NormalRec) * n});
           e.k_normals = k;
         }
         continue;
@@ -411,12 +435,12 @@ struct Batch {
       if (ctx->cache_bytes + e.bytes > ctx->cache_limit) continue;   // does not fit: stay uncached
       HIPCHK(hipMalloc((void**)&e.block, e.bytes));
       if (n) {
-        HIPCHK(hipMemcpyAsync(e.block + e.o_filt, filt() + sl.off, 16 * n, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(e.block + e.o_sorted, sorted() + sl.off, 16 * n, hipMemcpyDeviceToDevice, st));
-        if (has_sorted3) HIPCHK(hipMemcpyAsync(e.block + e.o_sorted3, sorted3() + sl.off, sizeof(CorrVec) * n, hipMemcpyDeviceToDevice, st));
-        if (normals_now) HIPCHK(hipMemcpyAsync(e.block + e.o_normals, normals() + sl.off, sizeof(NormalRec) * n, hipMemcpyDeviceToDevice, st));
+        cp.push_back({filt() + sl.off, e.block + e.o_filt, 16 * n});
+        cp.push_back({sorted() + sl.off, e.block + e.o_sorted, 16 * n});
+        if (has_sorted3) cp.push_back({sorted3() + sl.off, e.block + e.o_sorted3, sizeof(CorrVec) * n});
+        if (normals_now) cp.push_back({normals() + sl.off, e.block + e.o_normals, sizeof(NormalRec) * n});
       }
-      HIPCHK(hipMemcpyAsync(e.block + e.o_cells, cells() + sl.cell_off, 4 * cells_n, hipMemcpyDeviceToDevice, st));
+      cp.push_back({cells() + sl.cell_off, e.block + e.o_cells, 4 * cells_n});
       e.k_normals = normals_now ? k : 0;
       e.snap = sl;
       e.has_sorted3 = has_sorted3;
@@ -424,6 +448,7 @@ struct Batch {
       ctx->cache_bytes += e.bytes;
       ctx->cache[cache_key(j)] = e;
     }
+    ctx->copy_many(cp);
     HIPCHK(hipStreamSynchronize(st));   // the arena may be re-carved by the next call on another stream order
   }
 
@@ -1274,6 +1299,8 @@ void s3d_context_destroy(s3d_context* ctx) {
   ctx->release_all();
   if (ctx->h_active) (void)hipHostFree(ctx->h_active);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  if (ctx->h_copy) (void)hipHostFree(ctx->h_copy);
+  if (ctx->d_copy.p) (void)hipFree(ctx->d_copy.p);
   for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->nn_ev) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -248,6 +248,23 @@ __global__ void __launch_bounds__(kBlock) k_copy_raw(SlotDev* slots, float4* __r
   filt[s.off + i] = v;
 }
 
+// Many device-to-device copies as ONE launch (the pre-pass cache moves five arrays per cloud: as hipMemcpyAsync calls
+// they cost a launch each, which is what a one-new-scan call is bound by).  blockIdx.y = copy, grid-stride in x.
+struct CopyDesc { const void* src; void* dst; unsigned long long bytes; };   // bytes: a multiple of 4
+__global__ void __launch_bounds__(kBlock) k_copy_many(const CopyDesc* __restrict__ descs) {
+  const CopyDesc d = descs[blockIdx.y];
+  const size_t stride = (size_t)gridDim.x * kBlock, t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if ((((size_t)d.src | (size_t)d.dst | (size_t)d.bytes) & 15) == 0) {
+    const uint4* __restrict__ s4 = (const uint4*)d.src;
+    uint4* __restrict__ d4 = (uint4*)d.dst;
+    for (size_t i = t; i < d.bytes / 16; i += stride) d4[i] = s4[i];
+  } else {
+    const uint32_t* __restrict__ s1 = (const uint32_t*)d.src;
+    uint32_t* __restrict__ d1 = (uint32_t*)d.dst;
+    for (size_t i = t; i < d.bytes / 4; i += stride) d1[i] = s1[i];
+  }
+}
+
 // ------------------------------------------------------------------ K2a: segmented stable LSD radix sort
 // 8-bit digits, (key, value) pairs, one segment per slot.  counts layout:
 // counts[(slot * 256 + digit) * nb_max + block]
