@@ -192,7 +192,10 @@ struct s3d_context {
     unsigned long long most = 0;
     for (const s3d::CopyDesc& d : descs) most = std::max(most, d.bytes);
     const unsigned bx = (unsigned)std::min<unsigned long long>(std::max<unsigned long long>(most / (16ull * s3d::kBlock * 4), 1), 256);
-    s3d::k_copy_many<<<dim3(bx, (unsigned)descs.size()), s3d::kBlock, 0, stream>>>((const s3d::CopyDesc*)d_copy.p);
+    for (size_t first = 0; first < descs.size(); first += 32768) {   // (gridDim.y is limited to 65535)
+      const unsigned ny = (unsigned)std::min<size_t>(descs.size() - first, 32768);
+      s3d::k_copy_many<<<dim3(bx, ny), s3d::kBlock, 0, stream>>>((const s3d::CopyDesc*)d_copy.p + first);
+    }
   }
   hipEvent_t ev[8] = {};
   std::vector<hipEvent_t> nn_ev;
