@@ -930,30 +930,35 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   F3 q;
   if (MODE == 0) q = xf_eigen(P.T, pg.x, pg.y, pg.z);
   else q = xf_pcl(P.final_T, p0.x, p0.y, p0.z);
-  // radius hint: this query's distance in the previous pass (NaN-filled before the first one)
-  const float prev = A.corr_d2[ci];
-  const float lb = A.corr_lb[ci];                // lower bound of all OTHER points at the previous position (0: none)
+  // corr_lb: the lower bound of all OTHER points at the previous position, its sign saying whether the previous pass
+  // found a neighbour (> 0) or none within max_d (< 0); 0: nothing is known.  The re-validation needs nothing else of
+  // the history - the previous distance (the radius hint of a search) is loaded only by the lanes that still search,
+  // four bytes per query less on the streaming passes.
+  const float lbs = A.corr_lb[ci];
+  const float lb = fabsf(lbs);
   float move = 3.0e38f;                          // how far this query moved since the previous pass (if known)
-  if (need && lb > 0.f && prev >= 0.f && !(dbg & 64)) {
+  if (need && lbs != 0.f && !(dbg & 64)) {
     // re-validate the previous result by the triangle inequality (s3d_core.h nn_still_nearest)
     const F3 qo = xf_eigen(P.T_nn, pg.x, pg.y, pg.z);   // where this query stood in the previous pass
     move = sqrtf(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
     if (PHASE != 2) {                                    // (a PHASE 2 query has failed this test already)
-      if (prev < 1.0e30f) {
+      if (lbs > 0.f) {
         const CorrVec ps = A.corr_q[ci];                  // the neighbour itself travels with the correspondence
         const float d2n = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z);
         if (nn_still_nearest(sqrtf(d2n), move, lb)) {
           A.corr_d2[ci] = d2n;                           // same point, its exact new distance
-          A.corr_lb[ci] = lb - move;                     // still a lower bound for the others
+          A.corr_lb[ci] = lb - move;                     // still a lower bound for the others (> 0: the test above)
           need = false;
         }
       } else if (nn_still_nearest(max_d, move, lb)) {
         // no point at all within lb of the previous position, lb > max_d: still none within max_d
-        A.corr_lb[ci] = lb - move;
+        A.corr_lb[ci] = move - lb;                       // (< 0)
         need = false;
       }
     }
   }
+  // radius hint: this query's distance in the previous pass (NaN-filled before the first one)
+  const float prev = need ? A.corr_d2[ci] : 0.f;
   if (PHASE == 3) {   // classify only: 0 = near seed, 1 = wide, 2 = nothing to do (block-level compaction follows)
     const bool near_c = need && prev >= 0.f && prev < 1.0e30f && prev < Ss.g.h * Ss.g.h;
     *out_class = need ? (near_c ? 0 : 1) : 2;
@@ -1012,7 +1017,8 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   // the target's cell-sorted array: every later access (K6, fitness) is then coalesced or a local gather
   A.corr_idx[ci] = r.pos;
   A.corr_d2[ci] = r.d2;
-  A.corr_lb[ci] = !(dbg & 4) ? nn_lower_bound_others(r) : 0.f;   // no neighbour at all: the scanned radius
+  const float lbv = !(dbg & 4) ? nn_lower_bound_others(r) : 0.f;   // no neighbour at all: the scanned radius
+  A.corr_lb[ci] = r.pos >= 0 ? lbv : -lbv;
   if (r.pos >= 0) {
     // a copy of the matched point and of its normal is kept with the correspondence: the re-validation
     // above and the accumulate kernel then stream them instead of gathering by index
