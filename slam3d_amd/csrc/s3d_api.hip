@@ -651,12 +651,10 @@ struct Batch {
     double* part = (double*)ctx->partials.p;
     if (rp.algorithm)
       s3d_gicp_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
-          d_pairs(), d_slots(), sorted3(), normals(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p,
-          (NormalRec*)ctx->corr_n.p, part, rp);
+          d_pairs(), d_slots(), sorted3(), normals(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp);
     if (!rp.algorithm)
       s3d_p2plane_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
-          d_pairs(), d_slots(), sorted3(), (float*)ctx->corr_d2.p, (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p,
-          part, rp);
+          d_pairs(), d_slots(), sorted3(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp);
     s3d_icp_control_kernel<<<P(), kCtrlThreads, 0, st>>>(d_pairs(), part, rp, (int*)ctx->n_active.p);
   }
 

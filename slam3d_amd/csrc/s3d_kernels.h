@@ -946,7 +946,9 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
         const CorrVec ps = A.corr_q[ci];                  // the neighbour itself travels with the correspondence
         const float d2n = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z);
         if (nn_still_nearest(sqrtf(d2n), move, lb)) {
-          A.corr_d2[ci] = d2n;                           // same point, its exact new distance
+          // same point, its exact new distance: the accumulate kernels recompute it from the copy of the neighbour
+          // (bit for bit: the same float operations), only the fitness kernel reads the stored value
+          if (MODE != 0) A.corr_d2[ci] = d2n;
           A.corr_lb[ci] = lb - move;                     // still a lower bound for the others (> 0: the test above)
           need = false;
         }
@@ -1024,6 +1026,12 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
     // above and the accumulate kernel then stream them instead of gathering by index
     A.corr_q[ci] = corr_vec(A.sorted[Ss.off + r.pos]);
     A.corr_n[ci] = A.normals[Ss.off + r.pos];
+  } else if (MODE == 0) {
+    // no neighbour within max_d: a neighbour at infinity, so that the distance the accumulate kernels compute from
+    // this copy fails their threshold like the stored 3e38 did
+    CorrVec none;
+    none.x = none.y = none.z = __int_as_float(0x7F800000);
+    A.corr_q[ci] = none;
   }
 }
 
@@ -1327,7 +1335,6 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
                                                                       const SlotDev* __restrict__ slots,
                                                                       const CorrVec* __restrict__ sorted,
                                                                       const NormalRec* __restrict__ normals,
-                                                                      const float* __restrict__ corr_d2,
                                                                       const CorrVec* __restrict__ corr_q,
                                                                       const NormalRec* __restrict__ corr_n,
                                                                       double* __restrict__ partials, RunParams rp) {
@@ -1369,12 +1376,10 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
   if (v >= kAccumVB) return;
   int tile = vb_tile_begin(v, ntiles);
   int i = tile * kBlock + threadIdx.x;
-  float d2 = 3.0e38f;
   CorrVec p0 = corr_vec(make_float4(0.f, 0.f, 0.f, 0.f)), qf = p0;
   NormalRec na = {0.f, 0.f, 0.f, 0u}, nb = na;
   {
     const int j = i < M ? i : M - 1;
-    d2 = corr_d2[P.corr_off + j];          // 3e38 when the query has no neighbour at all
     p0 = sorted[St.off + j]; qf = corr_q[P.corr_off + j];
     na = normals[St.off + j]; nb = corr_n[P.corr_off + j];
   }
@@ -1389,11 +1394,14 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
     for (; tile < tile_end; ++tile) {
       const int in = tile + 1 < tile_end ? i + kBlock : first_next;
       const int j = in < M ? in : M - 1;   // (the last tile may be partial: no branch around the loads)
-      const float d2n = corr_d2[P.corr_off + j];
       const CorrVec p0n = sorted[St.off + j], qfn = corr_q[P.corr_off + j];
       const NormalRec nan_ = normals[St.off + j], nbn = corr_n[P.corr_off + j];
+      // the squared distance of the correspondence as the NN kernel computed it (the same float operations on the
+      // same values; a query without a neighbour has one at infinity): not stored and read back, 4 bytes less
+      const F3 pf = xf_pcl(P.guess, p0.x, p0.y, p0.z);
+      const F3 qn = xf_eigen(P.T, pf.x, pf.y, pf.z);
+      const float d2 = dist2(qn.x, qn.y, qn.z, qf.x, qf.y, qf.z);
       if (i < M && (double)d2 < rp.dist_threshold) {
-        const F3 pf = xf_pcl(P.guess, p0.x, p0.y, p0.z);
         // unit normals to 6e-11 from their 16-byte records (s3d_core.h NormalRec)
         double n1[3], n2[3];
         normal_decode(na, n1);
@@ -1406,7 +1414,7 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
         const double qd[3] = {qf.x, qf.y, qf.z};
         gq_accumulate(acc, pd, qd, Mm, Th0);
       }
-      d2 = d2n; p0 = p0n; qf = qfn; na = nan_; nb = nbn;
+      p0 = p0n; qf = qfn; na = nan_; nb = nbn;
       i = in;
     }
     block_reduce_store_fixed<GQ_NACC>(acc, out + (size_t)v * GQ_NACC * kAccOutMul, parity);
@@ -1421,7 +1429,6 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
 __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const PairDev* __restrict__ pairs,
                                                                          const SlotDev* __restrict__ slots,
                                                                          const CorrVec* __restrict__ sorted,
-                                                                         const float* __restrict__ corr_d2,
                                                                          const CorrVec* __restrict__ corr_q,
                                                                          const NormalRec* __restrict__ corr_n,
                                                                          double* __restrict__ partials, RunParams rp) {
@@ -1443,12 +1450,12 @@ __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const Pa
 #pragma unroll
     for (int c = 0; c < PP_NACC; ++c) acc[c] = 0.0;
     for (int i = t0 * kBlock + (int)threadIdx.x; i < t1 * kBlock && i < M; i += kBlock) {
-      const float d2 = corr_d2[P.corr_off + i];
-      if (!((double)d2 < rp.dist_threshold)) continue;
       const CorrVec p0 = sorted[St.off + i];
       const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
       const F3 pq = xf_eigen(P.T, pg.x, pg.y, pg.z);
       const CorrVec qf = corr_q[P.corr_off + i];
+      const float d2 = dist2(pq.x, pq.y, pq.z, qf.x, qf.y, qf.z);   // as the NN kernel computed it (see the GICP kernel)
+      if (!((double)d2 < rp.dist_threshold)) continue;
       const NormalRec nf = corr_n[P.corr_off + i];   // (point-to-plane keeps its float normals: its own design, its own oracle)
       const double pd[3] = {pq.x, pq.y, pq.z};
       const double qd[3] = {qf.x, qf.y, qf.z};
