@@ -218,8 +218,8 @@ def main():
         # second, i.e. how far an exact grid search is from streaming its compulsory traffic.
         roofline = {"kernel": "s3d_nn_search_kernel<0>", "bound": "hbm", "achieved": round(achieved, 2),
                     "limiter": "VALU issue of divergent per-lane candidate walks in the first passes (82 % of the issue "
-                               "slots, 25 of 64 lanes active); HBM streaming (4.9 TB/s incl. write-back) in the "
-                               "re-validated passes",
+                               "slots, 25 of 64 lanes active); HBM streaming (32 bytes per query actually moved, 4.2 TB/s "
+                               "incl. write-back) in the re-validated passes",
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n_launch,
                     "algorithmic_bytes_per_launch": int(alg_bytes),
