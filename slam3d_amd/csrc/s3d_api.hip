@@ -554,7 +554,8 @@ struct Batch {
       uint32_t* bc = (uint32_t*)ctx->blockcnt.p;
       k_heads_count<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), kA(), bc, nb_head);
       k_heads_scan<<<NS, kBlock, 0, st>>>(d_slots(), bc, nb_head);
-      k_centroids<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), kA(), vA(), bc, filt(), (unsigned int*)ctx->blockbb.p, nb_head);
+      k_centroids<<<(unsigned)((NS >= 8 ? cdiv(NS, 8) * 8 : NS) * nb_head), kBlock, 0, st>>>(d_slots(), kA(), vA(), bc, filt(),
+                                                                                               (unsigned int*)ctx->blockbb.p, nb_head, NS);
     } else {
       k_copy_raw<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), filt());
     }
@@ -574,6 +575,7 @@ struct Batch {
     k_keys_hist<1><<<dim3(nb_sort, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA(), (uint32_t*)ctx->counts.p, nb_sort);
     const bool wide = max_cell_cap > (1ll << 24);
     sort(wide ? 4 : 3, NS, true);  // cell ids < 2^24 unless a map job raised the cap
+    // (a slot -> XCD block map as in k_centroids gains nothing here: vals[] runs nearly in step with the cell order)
     k_grid_finalize<<<dim3(cdiv(max_n + 1, kBlock), NS), kBlock, 0, st>>>(d_slots(), filt(), wide ? kA() : kB(),
                                                                           wide ? vA() : vB(), sorted(), sorted3(), cells());
   }

@@ -528,17 +528,23 @@ __global__ void __launch_bounds__(kBlock) k_heads_scan(SlotDev* slots, uint32_t*
 // (pcl::VoxelGrid fourth pass: float sum in order, divided by float count)
 __global__ void __launch_bounds__(kBlock) k_centroids(const SlotDev* __restrict__ slots, const uint32_t* __restrict__ keys,
                                                        const uint32_t* __restrict__ vals, const uint32_t* __restrict__ blockcnt,
-                                                       float4* __restrict__ filt, unsigned int* __restrict__ blockbb, int nb_max) {
+                                                       float4* __restrict__ filt, unsigned int* __restrict__ blockbb, int nb_max,
+                                                       int nslots) {
   __shared__ int lds4[4];
-  const SlotDev& s = slots[blockIdx.y];
-  const int base = blockIdx.x * kBlock;
+  // (slot, chunk) from a 1-D grid with slot -> XCD affinity (nn_block_map): the gathers raw[v[j]] of one cloud then
+  // hit ONE L2 instead of pulling the cloud into all eight
+  int slot_i, chunk_i;
+  nn_block_map(nb_max, nslots, &slot_i, &chunk_i);
+  if (slot_i >= nslots) return;
+  const SlotDev& s = slots[slot_i];
+  const int base = chunk_i * kBlock;
   if (base >= s.n_raw) return;
   const int i = base + threadIdx.x;
   const uint32_t* __restrict__ k = keys + s.off;
   const uint32_t* __restrict__ v = vals + s.off;
   const bool head = i < s.n_raw && voxel_head(k, i);
   int total;
-  const int pos = block_excl_flag(head, &total, lds4) + (int)blockcnt[(size_t)blockIdx.y * nb_max + blockIdx.x];
+  const int pos = block_excl_flag(head, &total, lds4) + (int)blockcnt[(size_t)slot_i * nb_max + chunk_i];
   // the bounding box of the centroids (what the search grid is laid over) is gathered here, where they are written (a
   // separate pass over the filtered cloud was 0.22 ms of the 256-pair step): six words per block, no atomics - with
   // a block per 256 points, merging into the slot's words directly queued 1.2 M same-address accesses and cost
@@ -560,7 +566,7 @@ __global__ void __launch_bounds__(kBlock) k_centroids(const SlotDev* __restrict_
       mn[0] = a; mn[1] = b; mn[2] = cc; mx[0] = a; mx[1] = b; mx[2] = cc;
     }
   }
-  block_bbox_merge<false>(mn, mx, blockbb + ((size_t)blockIdx.y * nb_max + blockIdx.x) * 6);
+  block_bbox_merge<false>(mn, mx, blockbb + ((size_t)slot_i * nb_max + chunk_i) * 6);
 }
 
 // ------------------------------------------------------------------ K3: search grid
