@@ -372,18 +372,24 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
                                                           const uint32_t* __restrict__ vals_in,
                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                           const uint32_t* __restrict__ counts,
-                                                          const uint32_t* __restrict__ digit_tot, int shift, int nb_max) {
+                                                          const uint32_t* __restrict__ digit_tot, int shift, int nb_max,
+                                                          int nslots) {
   __shared__ unsigned int wave_cnt[kBlock / kWave][256];   // per wave: elements of each digit seen so far
-  const SlotDev& s = slots[blockIdx.y];
+  // 1-D grid, slot -> XCD affinity (nn_block_map): the digit runs that the tiles of one cloud write next to each other
+  // meet in ONE L2
+  int slot_i, tile_i;
+  nn_block_map(nb_max, nslots, &slot_i, &tile_i);
+  if (slot_i >= nslots) return;
+  const SlotDev& s = slots[slot_i];
   const int n = s.n_sort;
   const int nb = (n + kSortTile - 1) / kSortTile;
-  if ((int)blockIdx.x >= nb) return;
+  if (tile_i >= nb) return;
   const int lane = lane_id(), w = wave_id();
   constexpr int kRounds = kSortTile / kBlock;               // 16
 #pragma unroll
   for (int ww = 0; ww < kBlock / kWave; ++ww) wave_cnt[ww][threadIdx.x] = 0;
   __syncthreads();
-  const int base = blockIdx.x * kSortTile + w * (kSortTile / (kBlock / kWave));
+  const int base = tile_i * kSortTile + w * (kSortTile / (kBlock / kWave));
   uint32_t key[kRounds], val[kRounds];
   unsigned int rank[kRounds];
 #pragma unroll
@@ -436,7 +442,7 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
     if (lane == kWave - 1) wave_tot[w] = incl;
     // the digit's base in the output = exclusive scan of the slot's 256 digit totals: every tile redoes that small
     // scan here instead of a kernel of its own between the row scan and the scatter (seven launches per step less)
-    const unsigned int dtot = digit_tot[(size_t)blockIdx.y * 256 + threadIdx.x];
+    const unsigned int dtot = digit_tot[(size_t)slot_i * 256 + threadIdx.x];
     unsigned int incl2 = dtot;
 #pragma unroll
     for (int o = 1; o < kWave; o <<= 1) {
@@ -449,7 +455,7 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
 #pragma unroll
     for (int ww = 0; ww < kBlock / kWave; ++ww) { before += ww < w ? wave_tot[ww] : 0u; before2 += ww < w ? wave_tot2[ww] : 0u; }
     dig_local[threadIdx.x] = before + incl - run;
-    dig_global[threadIdx.x] = counts[((size_t)blockIdx.y * 256 + threadIdx.x) * nb_max + blockIdx.x] + (before2 + incl2 - dtot);
+    dig_global[threadIdx.x] = counts[((size_t)slot_i * 256 + threadIdx.x) * nb_max + tile_i] + (before2 + incl2 - dtot);
   }
   __syncthreads();
   // the tile is first put in digit order in LDS, then written out with consecutive threads on consecutive
@@ -465,7 +471,7 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
     }
   }
   __syncthreads();
-  const int tile_n = min(kSortTile, n - (int)blockIdx.x * kSortTile);
+  const int tile_n = min(kSortTile, n - tile_i * kSortTile);
   for (int j = threadIdx.x; j < tile_n; j += kBlock) {
     const uint32_t kk = lkey[j];
     const unsigned int d = (kk >> shift) & 255u;
