@@ -534,7 +534,8 @@ struct Batch {
     for (int p = 0; p < passes; ++p) {
       const int shift = 8 * p;
       if (p > 0 || !first_hist_done) k_sort_hist<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(d_slots(), ki, cnt, shift, nb_sort);
-      k_sort_scan_rows<<<dim3(256 / (kBlock / kWave), nslots), kBlock, 0, st>>>(d_slots(), cnt, dtot, nb_sort);
+      if (nb_sort <= kSortTileMajor) k_sort_scan_tiles<<<nslots, 256, 0, st>>>(d_slots(), cnt, dtot, nb_sort);
+      else k_sort_scan_rows<<<dim3(256 / (kBlock / kWave), nslots), kBlock, 0, st>>>(d_slots(), cnt, dtot, nb_sort);
       k_sort_scatter<<<(unsigned)((nslots >= 8 ? cdiv(nslots, 8) * 8 : nslots) * nb_sort), kBlock, 0, st>>>(d_slots(), ki, vi, ko, vo, cnt, dtot,
                                                                                                           shift, nb_sort, nslots);
       std::swap(ki, ko);

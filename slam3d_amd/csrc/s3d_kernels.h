@@ -266,8 +266,17 @@ __global__ void __launch_bounds__(kBlock) k_copy_many(const CopyDesc* __restrict
 }
 
 // ------------------------------------------------------------------ K2a: segmented stable LSD radix sort
-// 8-bit digits, (key, value) pairs, one segment per slot.  counts layout:
-// counts[(slot * 256 + digit) * nb_max + block]
+// 8-bit digits, (key, value) pairs, one segment per slot.  The tile histograms `counts` come in two layouts:
+//   nb_max <= kSortTileMajor (clouds up to 262 k points): counts[(slot * nb_max + tile) * 256 + digit] - the 256
+//     counters a histogram kernel writes and a scatter tile reads are ONE contiguous kilobyte, and the scan over the
+//     tiles of a digit is a loop of a thread per digit (k_sort_scan_tiles);
+//   larger slots (map building: ~10^4 tiles): counts[(slot * 256 + digit) * nb_max + tile], a row per digit that a
+//     wave scans 256 tiles at a time (k_sort_scan_rows).
+constexpr int kSortTileMajor = 64;
+__device__ __forceinline__ size_t sort_count_index(int slot, int digit, int tile, int nb_max) {
+  return nb_max <= kSortTileMajor ? ((size_t)slot * nb_max + tile) * 256 + digit
+                                  : ((size_t)slot * 256 + digit) * nb_max + tile;
+}
 
 __global__ void __launch_bounds__(kBlock) k_sort_hist(const SlotDev* __restrict__ slots, const uint32_t* __restrict__ keys,
                                                        uint32_t* __restrict__ counts, int shift, int nb_max) {
@@ -285,7 +294,7 @@ __global__ void __launch_bounds__(kBlock) k_sort_hist(const SlotDev* __restrict_
     if (i < n) atomicAdd(&hist[(keys[s.off + i] >> shift) & 255u], 1u);
   }
   __syncthreads();
-  counts[((size_t)blockIdx.y * 256 + threadIdx.x) * nb_max + blockIdx.x] = hist[threadIdx.x];
+  counts[sort_count_index(blockIdx.y, threadIdx.x, blockIdx.x, nb_max)] = hist[threadIdx.x];
 }
 
 // The keys of a sort and the tile histogram of its FIRST pass in one kernel (WHICH = 0: PCL voxel keys of the raw
@@ -323,7 +332,7 @@ __global__ void __launch_bounds__(kBlock) k_keys_hist(const SlotDev* __restrict_
     }
   }
   __syncthreads();
-  counts[((size_t)blockIdx.y * 256 + threadIdx.x) * nb_max + blockIdx.x] = hist[threadIdx.x];
+  counts[sort_count_index(blockIdx.y, threadIdx.x, blockIdx.x, nb_max)] = hist[threadIdx.x];
 }
 
 // Offsets of one pass in two steps.  (1) one WAVE per (slot, digit) row of tile counts: exclusive scan of the row
@@ -360,6 +369,27 @@ __global__ void __launch_bounds__(kBlock) k_sort_scan_rows(const SlotDev* __rest
     }
   }
   if (lane == 0) digit_tot[(size_t)blockIdx.y * 256 + digit] = carry;
+}
+
+// nb_max <= kSortTileMajor: one block per slot, a thread per digit walks the tiles (coalesced over the digits); all
+// loads of a chunk of 16 tiles are issued before the first addition
+__global__ void __launch_bounds__(256) k_sort_scan_tiles(const SlotDev* __restrict__ slots, uint32_t* __restrict__ counts,
+                                                         uint32_t* __restrict__ digit_tot, int nb_max) {
+  const SlotDev& s = slots[blockIdx.x];
+  const int nb = (s.n_sort + kSortTile - 1) / kSortTile;
+  uint32_t* __restrict__ c = counts + (size_t)blockIdx.x * nb_max * 256 + threadIdx.x;
+  unsigned int carry = 0;
+  for (int t0 = 0; t0 < nb; t0 += 16) {
+    unsigned int v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = t0 + j < nb ? c[(size_t)(t0 + j) * 256] : 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (t0 + j < nb) c[(size_t)(t0 + j) * 256] = carry;
+      carry += v[j];
+    }
+  }
+  digit_tot[(size_t)blockIdx.x * 256 + threadIdx.x] = carry;
 }
 
 // Stable scatter of one 1024-element tile.  Every wave owns a CONTIGUOUS quarter of the tile (4 rounds
@@ -455,7 +485,7 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
 #pragma unroll
     for (int ww = 0; ww < kBlock / kWave; ++ww) { before += ww < w ? wave_tot[ww] : 0u; before2 += ww < w ? wave_tot2[ww] : 0u; }
     dig_local[threadIdx.x] = before + incl - run;
-    dig_global[threadIdx.x] = counts[((size_t)slot_i * 256 + threadIdx.x) * nb_max + tile_i] + (before2 + incl2 - dtot);
+    dig_global[threadIdx.x] = counts[sort_count_index(slot_i, threadIdx.x, tile_i, nb_max)] + (before2 + incl2 - dtot);
   }
   __syncthreads();
   // the tile is first put in digit order in LDS, then written out with consecutive threads on consecutive
