@@ -155,7 +155,7 @@ struct s3d_context {
   s3d_map_profile map_prof{};
   // workspace (grown on demand, reused across calls)
   DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, sorted3, normals, moments, cell_start, counts, digit_tot, blockcnt, blockbb,
-      corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active, knn_list, knn_fallback;
+      corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active, knn_list, knn_fallback, knn_redo;
   int* h_active = nullptr;  // pinned
   // pinned staging of the slot / pair records (up and down): a copy from or to pageable memory stalls the stream for
   // tens of microseconds, which a single-pair registration of ~1.5 ms notices
@@ -489,7 +489,7 @@ struct Batch {
                 {&ctx->partials, 8 * (size_t)std::max(1, P()) * kAccumVB * GQ_NACC},
                 {&ctx->n_active, 64 + 2 * 64 * sizeof(int)},
                 {&ctx->knn_list, sizeof(int) * (size_t)std::max(1, C())},
-                {&ctx->knn_fallback, sizeof(int) * npi}});
+                {&ctx->knn_fallback, sizeof(int) * npi}, {&ctx->knn_redo, sizeof(int2) * npi}});
     if (!ctx->h_active) HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
     hipStream_t st = ctx->stream;
     // which clouds need the k-NN pre-pass: GICP uses the covariances of both clouds of a pair, point-to-plane only
@@ -606,8 +606,16 @@ struct Batch {
     // the points whose normal the closed form declines (s3d_kernels.h): a device-side list, counted in n_active[4]
     int* fb_count = (int*)ctx->n_active.p + 4;
     int* fb_list = (int*)ctx->knn_fallback.p;
-    HIPCHK(hipMemsetAsync(fb_count, 0, sizeof(int), st));
-    if (k <= 8)
+    HIPCHK(hipMemsetAsync(fb_count, 0, 2 * sizeof(int), st));
+    // k = 20 (the reference default): 32-bit keys + med3 insertion; what it does not answer goes through the exact
+    // 64-bit search (redo list, counted in n_active[5]).  S3D_KNN_EXACT64=1: the 64-bit search for every point.
+    const bool exact64 = getenv("S3D_KNN_EXACT64") && atoi(getenv("S3D_KNN_EXACT64")) != 0;
+    if (k == 20 && !exact64 && max_n < kKnn3MaxPoints) {
+      int* redo_count = fb_count + 1;
+      int2* redo_list = (int2*)ctx->knn_redo.p;
+      s3d_knn3_moments_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), sorted(), cells(), mom, mom_plane, nb_head, d_list, NL, normals(), fb_count, fb_list, redo_count, redo_list);
+      s3d_knn_moments_redo_kernel<20, true><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list);
+    } else if (k <= 8)
       s3d_knn_moments_kernel<8><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
     else if (k <= 16)
       s3d_knn_moments_kernel<16><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
@@ -618,6 +626,12 @@ struct Batch {
     else
       s3d_knn_moments_kernel<32><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
     s3d_normals_fallback_kernel<<<256, kBlock, 0, st>>>(fb_count, fb_list, mom, mom_plane, normals(), k);
+    if (getenv("S3D_DBG_KNN")) {   // dev aid: how many points took the eigen fallback / the exact-search redo
+      int cnt[2];
+      HIPCHK(hipMemcpyAsync(cnt, fb_count, sizeof cnt, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      std::fprintf(stderr, "[s3d] k-NN pre-pass: %zu points, eigen fallback %d, exact-search redo %d\n", total_pts, cnt[0], cnt[1]);
+    }
   }
 
   int dbg_nn = getenv("S3D_DBG_NN") ? atoi(getenv("S3D_DBG_NN")) : 0;

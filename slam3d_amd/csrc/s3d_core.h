@@ -26,6 +26,9 @@
 #ifndef S3D_KNN_PREFETCH
 #define S3D_KNN_PREFETCH 1
 #endif
+#ifndef S3D_KNN3_DEPTH
+#define S3D_KNN3_DEPTH 2      // candidate loads in flight per lane in the round-3 k-NN scan (2 or 4)
+#endif
 
 #include <math.h>
 #include <stdint.h>
@@ -91,6 +94,22 @@ S3D_HD Mat4f mat4f_mul(const Mat4f& a, const Mat4f& b) {
 S3D_HD float dist2(float ax, float ay, float az, float bx, float by, float bz) {
   float dx = ax - bx, dy = ay - by, dz = az - bz;
   return (dx * dx + dy * dy) + dz * dz;
+}
+// the same value with the x / y halves as ONE packed subtraction and ONE packed multiplication (v_pk_add_f32,
+// v_pk_mul_f32: IEEE per component, so bit-identical); p: a point whose x, y sit in an even-aligned register pair,
+// which is what a 16-byte load delivers
+template <typename F4T>
+S3D_HD float dist2_xy(float ax, float ay, float az, const F4T& p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f a = {ax, ay}, b = {p.x, p.y};
+  v2f d = a - b;
+  d = d * d;
+  const float dz = az - p.z;
+  return (d.x + d.y) + dz * dz;
+#else
+  return dist2(ax, ay, az, p.x, p.y, p.z);
+#endif
 }
 
 // pcl::transformPointCloud with a Matrix4d (pcl::detail::Transformer<double>::se3): the product is carried in
@@ -831,6 +850,283 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) keys_out[j] = __builtin_bit_cast(unsigned long long, keys[j]);
   return cnt < k ? cnt : k;
+}
+
+// ------------------------------------------------------------------ K4, round 3: 32-bit keys, med3 insertion
+//
+// The list above pays 2 x 20 VALU instructions per insertion (64-bit keys: v_min_f64 + v_max_f64 per slot) and runs
+// the chain whenever ANY lane of the wave accepts a candidate.  This variant keeps the k + 1 best as 32-bit keys
+//     key = (float bits of d2 with the low 11 mantissa bits cleared) | (segment << 7) | offset
+// i.e. the distance truncated to 12 mantissa bits with the candidate's PLACE in the low bits: (segment, offset)
+// addresses a per-lane table of the row segments the search visits (LDS on the GPU), so neither the index nor
+// the position travels through the list.  On 32-bit keys an insertion into a sorted list is ONE instruction per
+// slot, new[j] = med3(old[j-1], old[j], c): the slots are independent of each other (no carried value), the chain
+// runs unconditionally (a candidate that is too far, or a masked tail slot carrying the sentinel, leaves the list
+// as it is) and the loop has no per-candidate branch.
+//
+// Exactness.  Truncation is monotone, so the k smallest keys are the k nearest points unless the k-th and the
+// (k+1)-th key agree in their distance bits - which slot k (the extra one) shows.  Such a query (about 20 x 2^-12 of
+// them), one whose k-th distance reaches beyond the examined cells, one with more row segments than the table holds
+// and one with fewer than k candidates are NOT answered here: the function returns false and the caller hands the
+// point to the exact 64-bit search above (grid_knn_sorted).  Everything answered here is the exact k-NN set with
+// the (d2, index) tie rule; the neighbours come out in ascending TRUNCATED distance, i.e. PCL's summation order up
+// to swaps inside a 2^-12 band.
+constexpr int kKnn3Segs = 16;         // table entries per lane
+constexpr int kKnn3OffBits = 7;       // a table entry covers at most 128 consecutive points
+constexpr uint32_t kKnn3OffMask = (1u << kKnn3OffBits) - 1u;
+constexpr int kKnn3IdBits = kKnn3OffBits + 4;
+constexpr uint32_t kKnn3IdMask = (1u << kKnn3IdBits) - 1u, kKnn3Sentinel = 0xFFFFFFFFu;
+constexpr int kKnn3MaxPoints = 1 << (32 - kKnn3OffBits);   // positions must fit a table entry
+
+S3D_HD uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+#else
+  const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+  return c < lo ? lo : (c > hi ? hi : c);
+#endif
+}
+
+// one candidate into the sorted list of KL keys (ascending)
+template <int KL>
+S3D_HD void knn3_insert(uint32_t (&keys)[KL], uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (KL == 21) {   // k = 20 (the reference default): the whole chain as ONE asm block, top slot first
+    asm("v_med3_u32 %20, %19, %20, %21\n\tv_med3_u32 %19, %18, %19, %21\n\tv_med3_u32 %18, %17, %18, %21\n\t"
+        "v_med3_u32 %17, %16, %17, %21\n\tv_med3_u32 %16, %15, %16, %21\n\tv_med3_u32 %15, %14, %15, %21\n\t"
+        "v_med3_u32 %14, %13, %14, %21\n\tv_med3_u32 %13, %12, %13, %21\n\tv_med3_u32 %12, %11, %12, %21\n\t"
+        "v_med3_u32 %11, %10, %11, %21\n\tv_med3_u32 %10, %9, %10, %21\n\tv_med3_u32 %9, %8, %9, %21\n\t"
+        "v_med3_u32 %8, %7, %8, %21\n\tv_med3_u32 %7, %6, %7, %21\n\tv_med3_u32 %6, %5, %6, %21\n\t"
+        "v_med3_u32 %5, %4, %5, %21\n\tv_med3_u32 %4, %3, %4, %21\n\tv_med3_u32 %3, %2, %3, %21\n\t"
+        "v_med3_u32 %2, %1, %2, %21\n\tv_med3_u32 %1, %0, %1, %21\n\tv_min_u32 %0, %0, %21"
+        : "+v"(keys[0]), "+v"(keys[1]), "+v"(keys[2]), "+v"(keys[3]), "+v"(keys[4]), "+v"(keys[5]), "+v"(keys[6]),
+          "+v"(keys[7]), "+v"(keys[8]), "+v"(keys[9]), "+v"(keys[10]), "+v"(keys[11]), "+v"(keys[12]), "+v"(keys[13]),
+          "+v"(keys[14]), "+v"(keys[15]), "+v"(keys[16]), "+v"(keys[17]), "+v"(keys[18]), "+v"(keys[19]), "+v"(keys[20])
+        : "v"(c));
+    return;
+  }
+#endif
+#pragma unroll
+  for (int j = KL - 1; j >= 1; --j) keys[j] = umed3(keys[j - 1], keys[j], c);
+  keys[0] = keys[0] < c ? keys[0] : c;
+}
+
+// a row range [s, e) of the cell-sorted cloud -> one table entry, tab[j * tstride] = (start << 7) | (len - 1).
+// false: the table is full or the range is longer than an entry can say (the caller gives the query up).
+S3D_HD bool knn3_push(uint32_t* tab, int tstride, int& nseg, uint32_t s, uint32_t e) {
+  if (s >= e) return true;
+  constexpr uint32_t kMax = kKnn3OffMask + 1u;
+  if (e - s > kMax) {          // a long range (coarse grids): two entries, beyond that the exact search
+    if (nseg >= kKnn3Segs || e - s > 2u * kMax) return false;
+    tab[nseg * tstride] = (s << kKnn3OffBits) | kKnn3OffMask;
+    ++nseg;
+    s += kMax;
+  }
+  if (nseg >= kKnn3Segs) return false;
+  tab[nseg * tstride] = (s << kKnn3OffBits) | (e - s - 1u);
+  ++nseg;
+  return true;
+}
+
+// scan the table entries [e0, nseg) of this lane into the list: ONE flat loop over all their points (a wave runs
+// max-over-lanes of the TOTAL, not of every row), two points per trip with the loads of the next two in flight.
+// A lane that has run out carries the invalid id: its key is the sentinel and the insertion leaves its list alone.
+template <int KL, typename F4T>
+S3D_HD void knn3_scan(uint32_t (&keys)[KL], const uint32_t* tab, int tstride, int e0, int nseg,
+                      const F4T* __restrict__ pts, float qx, float qy, float qz) {
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
+  int e = e0;
+  uint32_t pos = 0, end = 0, idelta = 0;
+  // [pos, end): what is left of the current entry; id of a point = pos + idelta.  The load itself is unconditional
+  // (a lane without a next point re-reads position 0) so that it stays in flight across the insertion below.
+#define S3D_KNN3_NEXT(P_, ID_)                                                                         \
+  {                                                                                                    \
+    if (pos == end && e < nseg) {                                                                      \
+      const uint32_t ent = tab[e * tstride];                                                           \
+      pos = ent >> kKnn3OffBits; end = pos + (ent & kKnn3OffMask) + 1u;                                \
+      idelta = ((uint32_t)e << kKnn3OffBits) - pos;                                                    \
+      ++e;                                                                                             \
+    }                                                                                                  \
+    const bool has_ = pos != end;                                                                      \
+    P_ = pts[has_ ? pos : 0u];                                                                         \
+    ID_ = has_ ? pos + idelta : kNone;                                                                 \
+    pos += has_ ? 1u : 0u;                                                                             \
+  }
+#define S3D_KNN3_USE(P_, ID_)                                                                          \
+  {                                                                                                    \
+    const float d2_ = dist2_xy(qx, qy, qz, P_);                                                        \
+    const uint32_t key_ = (__builtin_bit_cast(uint32_t, d2_) & ~kKnn3IdMask) | ID_;   /* kNone: the sentinel */ \
+    if (key_ < keys[KL - 1]) knn3_insert<KL>(keys, key_);                                              \
+  }
+#if S3D_KNN3_DEPTH == 4
+  F4T pa, pb, pc, pd;
+  uint32_t ia, ib, ic, id_;
+  S3D_KNN3_NEXT(pa, ia)
+  S3D_KNN3_NEXT(pb, ib)
+  S3D_KNN3_NEXT(pc, ic)
+  S3D_KNN3_NEXT(pd, id_)
+  while (ia != kNone) {
+    S3D_KNN3_USE(pa, ia)
+    S3D_KNN3_NEXT(pa, ia)
+    S3D_KNN3_USE(pb, ib)
+    S3D_KNN3_NEXT(pb, ib)
+    S3D_KNN3_USE(pc, ic)
+    S3D_KNN3_NEXT(pc, ic)
+    S3D_KNN3_USE(pd, id_)
+    S3D_KNN3_NEXT(pd, id_)
+  }
+#else
+  F4T pa, pb;
+  uint32_t ia, ib;
+  S3D_KNN3_NEXT(pa, ia)
+  S3D_KNN3_NEXT(pb, ib)
+  while (ia != kNone) {
+    S3D_KNN3_USE(pa, ia)
+    S3D_KNN3_NEXT(pa, ia)
+    S3D_KNN3_USE(pb, ib)
+    S3D_KNN3_NEXT(pb, ib)
+  }
+#endif
+#undef S3D_KNN3_NEXT
+#undef S3D_KNN3_USE
+}
+
+// the largest d2 a key can stand for
+S3D_HD float knn3_key_d2_upper(uint32_t key) { return __builtin_bit_cast(float, key | kKnn3IdMask); }
+
+// ---- the stages of the search (grid_knn_med3 below runs them back to back for one query; the block kernel
+// s3d_knn3_moments_kernel re-deals the queries of a block between them)
+
+// distance of the point to the nearest face of its cell, in cells, less the rounding margin
+S3D_HD float knn3_face(const GridParams& g, float qx, float qy, float qz) {
+  const float fx = (qx - g.origin[0]) * g.inv_h, fy = (qy - g.origin[1]) * g.inv_h,
+              fz = (qz - g.origin[2]) * g.inv_h;
+  const int ix = grid_coord(g, 0, qx), iy = grid_coord(g, 1, qy), iz = grid_coord(g, 2, qz);
+  const float ox = fx - (float)ix, oy = fy - (float)iy, oz = fz - (float)iz;
+  const float face = fminf(fminf(fminf(ox, 1.f - ox), fminf(oy, 1.f - oy)), fminf(oz, 1.f - oz));
+  return fmaxf(face - 2.0e-3f, 0.f);
+}
+
+// stage 1: the row segments of the 3x3x3 cells around the point -> table entries [0, nseg); total = their points.
+// false: a range the table cannot hold.
+S3D_HD bool knn3_build27(const GridParams& g, const uint32_t* __restrict__ cell_start, float qx, float qy, float qz,
+                         uint32_t* tab, int tstride, int& nseg, uint32_t& total) {
+  const int ix = grid_coord(g, 0, qx), iy = grid_coord(g, 1, qy), iz = grid_coord(g, 2, qz);
+  const int cix = imin(imax(ix, -1), g.dim[0]);
+  const int xa = imax(cix - 1, 0), xb = imin(cix + 1, g.dim[0] - 1);
+  uint32_t rs[9], re[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {          // nine row ranges fetched as one batch
+    const int cy = iy + (r % 3) - 1, cz = iz + (r / 3) - 1;
+    const bool in = xa <= xb && cy >= 0 && cy < g.dim[1] && cz >= 0 && cz < g.dim[2];
+    const int rowbase = in ? g.dim[0] * (cy + g.dim[1] * cz) : 0;
+    const uint32_t a = cell_start[rowbase + (in ? xa : 0)], b = cell_start[rowbase + (in ? xb + 1 : 0)];
+    rs[r] = a; re[r] = in ? b : a;
+  }
+  bool ok = true;
+  nseg = 0; total = 0;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    ok = knn3_push(tab, tstride, nseg, rs[r], re[r]) && ok;
+    total += re[r] - rs[r];
+  }
+  return ok;
+}
+
+// after stage 1's scan: 0 = the K nearest are found, 1 = the pruned 5x5x5 shell has to be looked at (lim2: the ball
+// that bounds it), 2 = not answerable here (fewer than K candidates, or the ball leaves the 5x5x5 cells)
+template <int KL>
+S3D_HD int knn3_after27(const GridParams& g, float face, const uint32_t (&keys)[KL], float& lim2) {
+  constexpr int K = KL - 1;
+  if (keys[K - 1] == kKnn3Sentinel) return 2;
+  lim2 = knn3_key_d2_upper(keys[K - 1]);
+  const float b1 = (1.0f + face) * g.h;
+  if (lim2 <= b1 * b1) return 0;
+  const float b2 = (2.0f + face) * g.h;
+  return lim2 <= b2 * b2 ? 1 : 2;
+}
+
+// stage 2: the row segments of the 5x5x5 shell that the ball of squared radius lim2 reaches, appended to the table
+// ([nseg on entry, nseg on return)); total = their points.  false: the table is full.
+S3D_HD bool knn3_build_shell(const GridParams& g, const uint32_t* __restrict__ cell_start, float qx, float qy, float qz,
+                             float lim2, uint32_t* tab, int tstride, int& nseg, uint32_t& total) {
+  const int ix = grid_coord(g, 0, qx), iy = grid_coord(g, 1, qy), iz = grid_coord(g, 2, qz);
+  const float eps = 2.0e-3f * g.h;
+  bool ok = true;
+  total = 0;
+  for (int dz = -2; dz <= 2; ++dz) {
+    const int cz = iz + dz;
+    if (cz < 0 || cz >= g.dim[2]) continue;
+    const float zlo = g.origin[2] + (float)cz * g.h;
+    const float fz2 = fmaxf(fmaxf(zlo - qz, qz - (zlo + g.h)) - eps, 0.f);
+    if (fz2 * fz2 > lim2) continue;
+    for (int dy = -2; dy <= 2; ++dy) {
+      const int cy = iy + dy;
+      if (cy < 0 || cy >= g.dim[1]) continue;
+      const float ylo = g.origin[1] + (float)cy * g.h;
+      const float fy2 = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.h)) - eps, 0.f);
+      const float rowd2 = fy2 * fy2 + fz2 * fz2;
+      if (rowd2 > lim2) continue;
+      const float rx = sqrtf(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
+      const int xa = imax(imax(ix - 2, grid_coord(g, 0, qx - rx)), 0);
+      const int xb = imin(imin(ix + 2, grid_coord(g, 0, qx + rx)), g.dim[0] - 1);
+      const bool inner = dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
+      const int rowbase = g.dim[0] * (cy + g.dim[1] * cz);
+      if (!inner) {
+        if (xa <= xb) {
+          const uint32_t a = cell_start[rowbase + xa], b = cell_start[rowbase + xb + 1];
+          ok = knn3_push(tab, tstride, nseg, a, b) && ok; total += b - a;
+        }
+      } else {
+        const int lb = imin(xb, ix - 2), ra = imax(xa, ix + 2);   // left / right of the cells already examined
+        if (xa <= lb) {
+          const uint32_t a = cell_start[rowbase + xa], b = cell_start[rowbase + lb + 1];
+          ok = knn3_push(tab, tstride, nseg, a, b) && ok; total += b - a;
+        }
+        if (ra <= xb) {
+          const uint32_t a = cell_start[rowbase + ra], b = cell_start[rowbase + xb + 1];
+          ok = knn3_push(tab, tstride, nseg, a, b) && ok; total += b - a;
+        }
+      }
+    }
+  }
+  return ok;
+}
+
+// the K-th and the (K+1)-th key in one distance band: the truncated order may not be the exact one
+template <int KL>
+S3D_HD bool knn3_unambiguous(const uint32_t (&keys)[KL]) {
+  return (keys[KL - 1] >> kKnn3IdBits) != (keys[KL - 2] >> kKnn3IdBits);
+}
+
+// Exact K-NN of a point of the cloud among the cloud (K = KL - 1).  true: keys[0..K-1] hold the K nearest in
+// ascending truncated distance, (key >> 7) & 15 = table entry, key & 127 = offset (knn3_position); false: not
+// answered (see above).  tab: kKnn3Segs entries of this lane, stride tstride.
+template <int KL, typename F4T>
+S3D_HD bool grid_knn_med3(const GridParams& g, const uint32_t* __restrict__ cell_start, const F4T* __restrict__ pts,
+                          float qx, float qy, float qz, uint32_t* tab, int tstride, uint32_t (&keys)[KL]) {
+#pragma unroll
+  for (int j = 0; j < KL; ++j) keys[j] = kKnn3Sentinel;
+  int nseg;
+  uint32_t total;
+  if (!knn3_build27(g, cell_start, qx, qy, qz, tab, tstride, nseg, total)) return false;
+  knn3_scan<KL>(keys, tab, tstride, 0, nseg, pts, qx, qy, qz);
+  float lim2 = 0.f;
+  const int st = knn3_after27<KL>(g, knn3_face(g, qx, qy, qz), keys, lim2);
+  if (st == 2) return false;
+  if (st == 1) {
+    const int first = nseg;
+    if (!knn3_build_shell(g, cell_start, qx, qy, qz, lim2, tab, tstride, nseg, total)) return false;
+    knn3_scan<KL>(keys, tab, tstride, first, nseg, pts, qx, qy, qz);
+  }
+  return knn3_unambiguous<KL>(keys);
+}
+
+// position (in the cell-sorted cloud) of the neighbour a key stands for
+S3D_HD uint32_t knn3_position(uint32_t key, const uint32_t* tab, int tstride) {
+  return (tab[((key >> kKnn3OffBits) & 15u) * tstride] >> kKnn3OffBits) + (key & kKnn3OffMask);
 }
 
 // ------------------------------------------------------------------ covariance -> normal (K4)

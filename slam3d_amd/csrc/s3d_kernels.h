@@ -732,24 +732,14 @@ __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ 
 #ifndef S3D_KNN_WAVES
 #define S3D_KNN_WAVES 4
 #endif
-template <int KMAX, bool FULL = false>
-__global__ void __launch_bounds__(kBlock, S3D_KNN_WAVES) s3d_knn_moments_kernel(const SlotDev* __restrict__ slots,
-                                                                  const float4* __restrict__ filt,
-                                                                  const float4* __restrict__ sorted,
-                                                                  const uint32_t* __restrict__ cell_start,
-                                                                  double* __restrict__ moments, size_t plane, int k,
-                                                                  int chunks_per_slot, const int* __restrict__ slot_list,
-                                                                  int nslots, NormalRec* __restrict__ normals,
-                                                                  int* __restrict__ fallback_count,
-                                                                  int* __restrict__ fallback_list) {
-  // slot_list: the clouds that need normals (all of them for GICP, the searched side of each pair for
-  // point-to-plane), so that the block -> XCD map spreads exactly those over the chip
-  int li, chunk;
-  nn_block_map(chunks_per_slot, nslots, &li, &chunk);
-  if (li >= nslots) return;
-  const SlotDev& s = slots[slot_list[li]];
-  const int i = chunk * kBlock + threadIdx.x;
-  if (i >= s.n) return;
+// one point of slot `s` (position i of its cell-sorted order) through the exact 64-bit search: neighbours, PCL
+// moments, closed-form normal; a point the closed form declines goes to the eigen fallback list
+template <int KMAX, bool FULL>
+__device__ __forceinline__ void knn_moments_point(const SlotDev& s, int i, const float4* __restrict__ filt,
+                                                  const float4* __restrict__ sorted,
+                                                  const uint32_t* __restrict__ cell_start, double* __restrict__ moments,
+                                                  size_t plane, int k, NormalRec* __restrict__ normals,
+                                                  int* __restrict__ fallback_count, int* __restrict__ fallback_list) {
   const float4* __restrict__ P = filt + s.off;
   const float4 q = sorted[s.off + i];
   unsigned long long keys[KMAX];
@@ -774,6 +764,105 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_WAVES) s3d_knn_moments_kernel(
   o[3 * plane] = m.c00; o[4 * plane] = m.c10; o[5 * plane] = m.c11;
   o[6 * plane] = m.c20; o[7 * plane] = m.c21; o[8 * plane] = m.c22;
   fallback_list[atomicAdd(fallback_count, 1)] = s.off + i;
+}
+
+template <int KMAX, bool FULL = false>
+__global__ void __launch_bounds__(kBlock, S3D_KNN_WAVES) s3d_knn_moments_kernel(const SlotDev* __restrict__ slots,
+                                                                  const float4* __restrict__ filt,
+                                                                  const float4* __restrict__ sorted,
+                                                                  const uint32_t* __restrict__ cell_start,
+                                                                  double* __restrict__ moments, size_t plane, int k,
+                                                                  int chunks_per_slot, const int* __restrict__ slot_list,
+                                                                  int nslots, NormalRec* __restrict__ normals,
+                                                                  int* __restrict__ fallback_count,
+                                                                  int* __restrict__ fallback_list) {
+  // slot_list: the clouds that need normals (all of them for GICP, the searched side of each pair for
+  // point-to-plane), so that the block -> XCD map spreads exactly those over the chip
+  int li, chunk;
+  nn_block_map(chunks_per_slot, nslots, &li, &chunk);
+  if (li >= nslots) return;
+  const SlotDev& s = slots[slot_list[li]];
+  const int i = chunk * kBlock + threadIdx.x;
+  if (i >= s.n) return;
+  knn_moments_point<KMAX, FULL>(s, i, filt, sorted, cell_start, moments, plane, k, normals, fallback_count, fallback_list);
+}
+
+// ---- K4, round 3 (k = K known at compile time): 32-bit keys + v_med3_u32 insertion + per-query segment table in LDS
+// (grid_knn_med3, s3d_core.h "K4, round 3").  One thread per query in the cloud's cell order: the 64 lanes of a wave are
+// spatial neighbours and their candidate loads fall into a handful of cache lines.  A query the fast path does not
+// answer (the k-th distance beyond the 5x5x5 cells, a tie of the truncated distance at the k-th place, a row range
+// longer than two table entries) is appended to `redo_list` as (slot, position) and served by
+// s3d_knn_moments_redo_kernel with the exact 64-bit search: 0.3 % of the benchmark's points.
+// Measured and dropped: dealing the 256 queries of a block to its threads by candidate count
+// (balances the scan loops, but the gathers of a wave no longer coalesce: slower), and the shell candidates of a wave
+// / block as one evenly shared pool with per-query inboxes in LDS (fewer instructions, slower).
+#ifndef S3D_KNN3_WAVES
+#define S3D_KNN3_WAVES 8
+#endif
+template <int K>
+__global__ void __launch_bounds__(kBlock, S3D_KNN3_WAVES) s3d_knn3_moments_kernel(const SlotDev* __restrict__ slots,
+                                                                   const float4* __restrict__ sorted,
+                                                                   const uint32_t* __restrict__ cell_start,
+                                                                   double* __restrict__ moments, size_t plane,
+                                                                   int chunks_per_slot, const int* __restrict__ slot_list,
+                                                                   int nslots, NormalRec* __restrict__ normals,
+                                                                   int* __restrict__ fallback_count,
+                                                                   int* __restrict__ fallback_list,
+                                                                   int* __restrict__ redo_count, int2* __restrict__ redo_list) {
+  constexpr int KL = K + 1;
+  __shared__ uint32_t tab[kKnn3Segs * kBlock];   // entry j of thread t at tab[j * kBlock + t]: conflict-free columns
+  int li, chunk;
+  nn_block_map(chunks_per_slot, nslots, &li, &chunk);
+  if (li >= nslots) return;
+  const int slot = slot_list[li];
+  const SlotDev& s = slots[slot];
+  const int i = chunk * kBlock + threadIdx.x;
+  if (i >= s.n) return;
+  const float4* __restrict__ pts = sorted + s.off;
+  const float4 q = pts[i];
+  uint32_t keys[KL];
+  uint32_t* ctab = tab + threadIdx.x;
+  if (!grid_knn_med3<KL>(s.g, cell_start + s.cell_off, pts, q.x, q.y, q.z, ctab, kBlock, keys)) {
+    redo_list[atomicAdd(redo_count, 1)] = make_int2(slot, i);
+    return;
+  }
+  Moments mo;
+  moments_init(mo);
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const float4 p = pts[knn3_position(keys[j], ctab, kBlock)];
+    moments_add(mo, p.x, p.y, p.z);
+  }
+  double n[3];
+  if (moments_normal_direct(mo, K, n)) {
+    normals[s.off + i] = normal_encode(n);  // CELL-SORTED order
+    return;
+  }
+  double* o = moments + (size_t)(s.off + i);
+  o[0] = mo.mean[0]; o[plane] = mo.mean[1]; o[2 * plane] = mo.mean[2];
+  o[3 * plane] = mo.c00; o[4 * plane] = mo.c10; o[5 * plane] = mo.c11;
+  o[6 * plane] = mo.c20; o[7 * plane] = mo.c21; o[8 * plane] = mo.c22;
+  fallback_list[atomicAdd(fallback_count, 1)] = s.off + i;
+}
+
+// the queries s3d_knn3_moments_kernel listed, through the exact search; a fixed grid strides over the list
+template <int KMAX, bool FULL>
+__global__ void __launch_bounds__(kBlock) s3d_knn_moments_redo_kernel(const SlotDev* __restrict__ slots,
+                                                                       const float4* __restrict__ filt,
+                                                                       const float4* __restrict__ sorted,
+                                                                       const uint32_t* __restrict__ cell_start,
+                                                                       double* __restrict__ moments, size_t plane, int k,
+                                                                       NormalRec* __restrict__ normals,
+                                                                       int* __restrict__ fallback_count,
+                                                                       int* __restrict__ fallback_list,
+                                                                       const int* __restrict__ redo_count,
+                                                                       const int2* __restrict__ redo_list) {
+  const int count = *redo_count;
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < count; j += gridDim.x * kBlock) {
+    const int2 e = redo_list[j];
+    knn_moments_point<KMAX, FULL>(slots[e.x], e.y, filt, sorted, cell_start, moments, plane, k, normals, fallback_count,
+                                  fallback_list);
+  }
 }
 
 // the points s3d_knn_moments_kernel listed: full moments_normal (closed form, then cyclic Jacobi).  A fixed small

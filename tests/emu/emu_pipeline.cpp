@@ -165,6 +165,32 @@ void emu_normals(const float* xyz, int n, int k, float h0, int cpp, float* out) 
   for (int i = 0; i < n; ++i) { out[i * 3] = (float)nr[i].x; out[i * 3 + 1] = (float)nr[i].y; out[i * 3 + 2] = (float)nr[i].z; }
 }
 
+// round-3 k-NN (grid_knn_med3: 32-bit keys, med3 insertion) against the exact 64-bit search on every point of a cloud.
+// out[0] = points, out[1] = points the fast path declines (served by the exact search on the device), out[2] = answered
+// points whose 20-neighbour SET differs from the exact one (must be 0), out[3] = answered points whose order differs
+void emu_knn3_check(const float* xyz, int n, float h0, int cpp, long long* out) {
+  Cloud c = voxel(xyz, n, 3, 0.0);
+  Grid G = build_grid(c, h0, cpp);
+  out[0] = n; out[1] = out[2] = out[3] = 0;
+  for (int i = 0; i < n; ++i) {
+    const F4& q = G.sorted[i];
+    uint32_t tab[kKnn3Segs], keys[21];
+    if (!grid_knn_med3<21>(G.g, G.cell_start.data(), G.sorted.data(), q.x, q.y, q.z, tab, 1, keys)) { ++out[1]; continue; }
+    unsigned long long ref[20];
+    const int cnt = grid_knn_sorted<20, true>(G.g, G.cell_start.data(), G.sorted.data(), q.x, q.y, q.z, 20, ref);
+    std::vector<uint32_t> a, b;
+    bool same_order = cnt == 20;
+    for (int j = 0; j < 20; ++j) {
+      const uint32_t idx = __builtin_bit_cast(uint32_t, G.sorted[knn3_position(keys[j], tab, 1)].w);
+      a.push_back(idx);
+      if (j < cnt) { b.push_back((uint32_t)(ref[j] & 0xFFFFFFFFull)); same_order = same_order && idx == b.back(); }
+    }
+    std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+    if (a != b) ++out[2];
+    if (!same_order) ++out[3];
+  }
+}
+
 // B1/B2 (patch accumulation, radius outlier removal) as the kernels run them ---------------------
 void emu_transform(const float* xyz, int n, const double* tf_colmajor, float* out) {
   double T[12];

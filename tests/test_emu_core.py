@@ -104,6 +104,21 @@ def test_device_knn_normals_match_oracle(emu, oracle_mod, fixture_clouds, h0, cp
     assert (dots < 1 - 1e-6).mean() < (1e-3 if k == 20 else 0.02)   # identical k-NN sets -> identical normals
 
 
+@pytest.mark.parametrize("leaf,h0,cpp", [(0.3, 0.6, 2), (0.3, 0.6, 16), (0.2, 0.4, 2), (0.5, 0.3, 64)])
+def test_device_knn_med3_answers_exactly_or_declines(emu, oracle_mod, fixture_clouds, leaf, h0, cpp):
+    """The round-3 k-NN pre-pass (grid_knn_med3: truncated 32-bit keys, v_med3 insertion, segment table) must return
+    the exact 20-neighbour SET of the 64-bit search for every point it answers - on coarse grids (long row ranges,
+    many declines), fine grids (the shell, rings beyond it) and with exact duplicates (ties of the distance)."""
+    v1, _ = oracle_mod.voxel_downsample(fixture_clouds[0], leaf)
+    out = np.zeros(4, np.int64)
+    emu.emu_knn3_check(v1.ctypes.data_as(fp), len(v1), C.c_float(h0), cpp, out.ctypes.data_as(C.POINTER(C.c_longlong)))
+    assert out[0] == len(v1) and out[2] == 0, out
+    assert out[1] < (0.9 if cpp == 64 else 0.6) * len(v1), out   # (a grid much coarser or finer than the 20-neighbour ball declines a lot)
+    dup = np.ascontiguousarray(np.concatenate([v1[:3000], v1[:3000], v1[:1500]]))   # every distance a tie
+    emu.emu_knn3_check(dup.ctypes.data_as(fp), len(dup), C.c_float(h0), cpp, out.ctypes.data_as(C.POINTER(C.c_longlong)))
+    assert out[0] == len(dup) and out[2] == 0, out
+
+
 def test_quadratic_form_equals_direct_sum(emu):
     rng = np.random.default_rng(0)
     m = 4000
