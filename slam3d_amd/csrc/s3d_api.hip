@@ -664,16 +664,26 @@ struct Batch {
     launch_nn(0, max_d, prof_slot, it >= 2 && it <= 4);   // (the counters cost two atomics per searching wave)
     launch_iteration_after_nn();
   }
+  // small batches: the controller rides on the accumulate kernel (s3d_kernels.h accumulate_then_control)
+  static constexpr int kSmallBatchPairs = 8;
   void launch_iteration_after_nn() {
     hipStream_t st = ctx->stream;
     double* part = (double*)ctx->partials.p;
-    if (rp.algorithm)
-      s3d_gicp_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
-          d_pairs(), d_slots(), sorted3(), normals(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp);
-    if (!rp.algorithm)
-      s3d_p2plane_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
-          d_pairs(), d_slots(), sorted3(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp);
-    s3d_icp_control_kernel<<<P(), kCtrlThreads, 0, st>>>(d_pairs(), part, rp, (int*)ctx->n_active.p);
+    int* act = (int*)ctx->n_active.p;
+    const bool attach = P() <= kSmallBatchPairs && !getenv("S3D_SEPARATE_CONTROL");
+    const dim3 grid(accum_blocks, P());
+    if (rp.algorithm) {
+      if (attach)
+        s3d_gicp_accumulate_kernel<true><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted3(), normals(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp, act);
+      else
+        s3d_gicp_accumulate_kernel<false><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted3(), normals(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp, act);
+    } else {
+      if (attach)
+        s3d_p2plane_accumulate_kernel<true><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted3(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp, act);
+      else
+        s3d_p2plane_accumulate_kernel<false><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted3(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp, act);
+    }
+    if (!attach) s3d_icp_control_kernel<<<P(), kCtrlThreads, 0, st>>>(d_pairs(), part, rp, act);
   }
 
   // K5-K7 loop.  The host only polls the active-pair counter every check_interval iterations.

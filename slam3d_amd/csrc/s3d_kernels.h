@@ -52,7 +52,7 @@ struct PairDev {          // one align() job
   Mat4f T_nn;             // transformation_ the last correspondence pass ran with (see nn_still_nearest)
   double fitness;
   int   fit_count;
-  int   pad;
+  int   blocks_done;      // accumulate kernels with the controller attached (small batches): blocks that have stored their sums
 };
 
 struct RunParams {        // per batch, passed by value
@@ -895,7 +895,7 @@ __global__ void k_pair_init(PairDev* pairs, int npairs, int* n_active) {
   P.active = 1; P.converged = 0; P.iterations = 0; P.correspondences = 0;
   P.inner_total = 0; P.evals_total = 0;
   P.T = mat4f_identity(); P.prev = mat4f_identity(); P.final_T = P.guess; P.T_nn = mat4f_identity();
-  P.fitness = 0.0; P.fit_count = 0;
+  P.fitness = 0.0; P.fit_count = 0; P.blocks_done = 0;
 }
 
 // ------------------------------------------------------------------ K5: transform + exact 1-NN
@@ -1461,14 +1461,39 @@ __global__ void __launch_bounds__(kCtrlThreads) s3d_icp_control_kernel(PairDev* 
   icp_control_pair(P, partials + (size_t)blockIdx.x * kAccumVB * GQ_NACC, rp, n_active);
 }
 
+// Small batches (the reference's own call pattern: ONE createConstraint per new scan, ScanSensor.cpp:113) are bound by
+// the chain of ~60 dependent launches of the ICP loop, not by the kernels: there the accumulate kernels run the
+// controller themselves - the block that stores a pair's last partial sums (a counter in the pair record) goes on
+// with icp_control_pair - one launch and one dispatch gap fewer per outer iteration.  The optimiser's registers become
+// the accumulate kernel's (one wave per SIMD instead of two), which a large batch cannot afford (DESIGN.md 6a viii)
+// and a small one does not notice.  Same code, same sums, same order: bit-identical to the separate controller.
+__device__ __forceinline__ void accumulate_then_control(PairDev* pairs, int pair, const double* __restrict__ partials,
+                                                        const RunParams& rp, int* n_active) {
+  __shared__ int s_last;
+  __threadfence();                                  // this block's partial sums are visible before its ticket
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int ticket = atomicAdd(&pairs[pair].blocks_done, 1);
+    s_last = ticket == (int)gridDim.x - 1;
+    if (s_last) pairs[pair].blocks_done = 0;        // (for the next outer iteration; nobody else touches it now)
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  icp_control_pair(pairs[pair], partials + (size_t)pair * kAccumVB * GQ_NACC, rp, n_active);
+}
+
 // GICP: Mahalanobis matrix + 73-term quadratic form (s3d_core.h "GICP quadratic form")
-__global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairDev* __restrict__ pairs,
+template <bool CTRL>
+__global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(PairDev* __restrict__ pairs_rw,
                                                                       const SlotDev* __restrict__ slots,
                                                                       const CorrVec* __restrict__ sorted,
                                                                       const NormalRec* __restrict__ normals,
                                                                       const CorrVec* __restrict__ corr_q,
                                                                       const NormalRec* __restrict__ corr_n,
-                                                                      double* __restrict__ partials, RunParams rp) {
+                                                                      double* __restrict__ partials, RunParams rp,
+                                                                      int* __restrict__ n_active) {
+  const PairDev* __restrict__ pairs = pairs_rw;
   const PairDev& P = pairs[blockIdx.y];
   if (!P.active) return;
   const SlotDev& St = slots[P.slot_t];
@@ -1504,7 +1529,10 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
     return u;
   };
   int v = next_nonempty(blockIdx.x);
-  if (v >= kAccumVB) return;
+  if (v >= kAccumVB) {
+    if (CTRL) accumulate_then_control(pairs_rw, blockIdx.y, partials, rp, n_active);
+    return;
+  }
   int tile = vb_tile_begin(v, ntiles);
   int i = tile * kBlock + threadIdx.x;
   CorrVec p0 = corr_vec(make_float4(0.f, 0.f, 0.f, 0.f)), qf = p0;
@@ -1553,16 +1581,20 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
     v = vn;
     if (v < kAccumVB) tile = vb_tile_begin(v, ntiles);
   }
+  if (CTRL) accumulate_then_control(pairs_rw, blockIdx.y, partials, rp, n_active);
 }
 
 
 // point-to-plane: J^T J (21) + J^T r (6) + r^2 + count
-__global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const PairDev* __restrict__ pairs,
+template <bool CTRL>
+__global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(PairDev* __restrict__ pairs_rw,
                                                                          const SlotDev* __restrict__ slots,
                                                                          const CorrVec* __restrict__ sorted,
                                                                          const CorrVec* __restrict__ corr_q,
                                                                          const NormalRec* __restrict__ corr_n,
-                                                                         double* __restrict__ partials, RunParams rp) {
+                                                                         double* __restrict__ partials, RunParams rp,
+                                                                         int* __restrict__ n_active) {
+  const PairDev* __restrict__ pairs = pairs_rw;
   const PairDev& P = pairs[blockIdx.y];
   if (!P.active) return;
   const SlotDev& St = slots[P.slot_t];
@@ -1596,6 +1628,7 @@ __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const Pa
     block_reduce_store_fixed<PP_NACC>(acc, out + (size_t)v * GQ_NACC, parity);
     parity ^= 1;
   }
+  if (CTRL) accumulate_then_control(pairs_rw, blockIdx.y, partials, rp, n_active);
 }
 
 // final_transformation_ = previous_transformation_ * guess

@@ -668,3 +668,24 @@ def test_concurrent_callers(gpu_ctx, fixture_clouds):
                 assert st == st2 and np.array_equal(T, T2) and info == info2
     finally:
         other.close()
+
+
+def test_million_point_registration_matches_oracle(gpu_ctx, oracle_mod):
+    """BASELINE.json configs[4] (1M-point scans, 50 GICP iterations) against the oracle itself, not only against the
+    ground truth: the same pair through oracle.align (smooth-objective mode, the function the device minimises,
+    DESIGN.md 5) and through the device path - identical statuses, filtered sizes and outer-iteration counts, the
+    transforms within the north star's 1e-4 m / 1e-4 rad.  Kept last in the file: the oracle needs about a minute."""
+    import slam3d_amd as s3d
+    src, tgt, T_true = s3d.make_pair(1_000_000, 7)
+    prm = dict(point_cloud_density=0.01, maximum_iterations=50)
+    st, T, info = gpu_ctx.align(src, tgt, np.eye(4), s3d.default_params(**prm), s3d.ExecOptions(force_iterations=1))
+    oracle_mod.set_eval_precision(2)
+    try:
+        so, To, io = oracle_mod.align(src, tgt, np.eye(4), oracle_mod.default_params(**prm), force_iterations=True)
+    finally:
+        oracle_mod.set_eval_precision(0)
+    dt, dr = transform_delta(To, T)
+    print("1M-point pair, 50 iterations, GPU vs oracle: |dt| %.2e m, |dr| %.2e rad" % (dt, dr))
+    assert st == so == 0 and info["iterations"] == io["iterations"] == 50
+    assert info["n_source_filtered"] == io["n_source_filtered"] and info["n_target_filtered"] == io["n_target_filtered"]
+    assert dt < TOL_T_GICP and dr < TOL_R_GICP, (dt, dr)

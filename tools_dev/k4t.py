@@ -14,4 +14,5 @@ for i in range(4):
     t = time.perf_counter(); out = ctx.align_batch(a, b, None, p, o); dt = (time.perf_counter() - t) * 1e3
     pr = ctx.last_profile(); r.append((dt, pr['voxel_ms'], pr['grid_ms'], pr['normals_ms'], pr['nn_ms'], pr['icp_ms']))
 r = np.array(r)[1:].mean(0)
+print('nn launches ms:', ' '.join('%.3f' % x for x in pr['nn_launch_ms'][:20]))
 print(os.path.basename(os.environ.get('S3D_LIB_PATH', 'default')), 'step %.2f voxel %.2f grid %.2f normals %.2f nn %.2f icp %.2f ms' % tuple(r), ' hash %.17g' % float(np.abs(out[:, :12]).sum()), flush=True)

@@ -13,4 +13,4 @@ for _ in range(2): ctx.align_batch(a, b, None, p, o)
 pr = ctx.last_profile()
 nq = pr['nn_queries'] / pr['nn_launches']
 for i in range(pr['nn_launches']):
-    print("pass %2d: %.3f ms  searched %5.1f %%  of which without a near seed %5.1f %%" % (i + 1, pr['nn_launch_ms'][i], 100.0 * pr['nn_searched'][i] / nq, 100.0 * pr['nn_unseeded'][i] / max(pr['nn_searched'][i], 1)))
+    print("pass %2d: %.3f ms  searched %7.4f %% (%d)  of which without a near seed %5.1f %%" % (i + 1, pr['nn_launch_ms'][i], 100.0 * pr["nn_searched"][i] / nq, pr["nn_searched"][i], 100.0 * pr['nn_unseeded'][i] / max(pr['nn_searched'][i], 1)))
