@@ -3,7 +3,9 @@
 // ScanSensor.cpp:179-201) and the candidates are registered twice: one blocking createConstraint after the other, as
 // the reference does, and as ONE sweep over the given devices ("0,0" = two ranks on GPU 0, "all" = every GPU) through
 // PointCloudSensor::createConstraints -> s3d_align_batch_multi (RCCL all-gather of the edges).  Prints both edge lists;
-// they are identical bit for bit.
+// they are identical bit for bit.  Then the same with loop = true (coarse registration first, ScanSensor::link's call,
+// ScanSensor.cpp:156), the number of sweep clouds kept before / after a sweep over short-lived patch measurements, and
+// the exception a reference built without pclomp throws for GICP_OMP.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -54,6 +56,47 @@ int main(int argc, char** argv) {
     }
     const std::vector<Constraint::Ptr> sweep = sensor.createConstraints(src, tgt, odo, devices);
     for (size_t i = 0; i < sweep.size(); ++i) print_edge("sweep", i, sweep[i]);
+    // loop closures: coarse then fine (PointCloudSensor.cpp:286-292)
+    RegistrationParameters coarse;
+    coarse.point_cloud_density = 0.5;
+    coarse.max_correspondence_distance = 5.0;
+    coarse.maximum_iterations = 10;
+    coarse.max_translation = 3.0;
+    sensor.setRegistrationParameters(coarse, true);
+    for (size_t i = 0; i < src.size(); ++i) {
+      Constraint::Ptr c;
+      try { c = sensor.createConstraint(src[i], tgt[i], odo[i], true); } catch (const NoMatch&) {}
+      print_edge("sequential_loop", i, c);
+    }
+    const std::vector<Constraint::Ptr> sweep_loop = sensor.createConstraints(src, tgt, odo, devices, true);
+    for (size_t i = 0; i < sweep_loop.size(); ++i) print_edge("sweep_loop", i, sweep_loop[i]);
+    // patches (ScanSensor::buildPatch) are new measurements with fresh uuids for every candidate: their sweep clouds
+    // must go when they do
+    const size_t kept_before = sensor.getSweepCloudCount();
+    {
+      std::vector<Measurement::Ptr> ps, pt;
+      std::vector<Transform> po;
+      for (size_t i = 0; i + 1 < scans.size(); ++i) {
+        PointCloudMeasurement::Ptr a = ptr::dynamic_pointer_cast<PointCloudMeasurement>(scans[i]);
+        PointCloudMeasurement::Ptr b = ptr::dynamic_pointer_cast<PointCloudMeasurement>(scans[i + 1]);
+        ps.push_back(Measurement::Ptr(new PointCloudMeasurement(a->getPointCloud(), "robot", sensor.getName(), Transform::Identity())));
+        pt.push_back(Measurement::Ptr(new PointCloudMeasurement(b->getPointCloud(), "robot", sensor.getName(), Transform::Identity())));
+        po.push_back(Transform::Identity());
+      }
+      sensor.createConstraints(ps, pt, po, devices);
+      std::printf("sweep_clouds_with_patches %zu\n", sensor.getSweepCloudCount());
+    }
+    sensor.createConstraints(std::vector<Measurement::Ptr>(1, src[0]), std::vector<Measurement::Ptr>(1, tgt[0]),
+                             std::vector<Transform>(1, odo[0]), devices);
+    std::printf("sweep_clouds %zu %zu\n", kept_before, sensor.getSweepCloudCount());
+    // GICP_OMP in a reference built without pclomp (PointCloudSensor.cpp:159-161)
+    RegistrationParameters omp;
+    omp.registration_algorithm = GICP_OMP;
+    sensor.setRegistrationParameters(omp, false);
+    sensor.setOmpAvailable(false);
+    try { sensor.createConstraint(src[0], tgt[0], odo[0], false); std::printf("omp served\n"); }
+    catch (const NoMatch&) { std::printf("omp nomatch\n"); }
+    catch (const std::runtime_error& e) { std::printf("omp %s\n", e.what()); }
   } catch (const std::exception& e) {
     std::printf("error %s\n", e.what());
     return 1;

@@ -32,9 +32,10 @@
 #include <boost/make_shared.hpp>
 #include <boost/pointer_cast.hpp>
 #include <boost/shared_ptr.hpp>
-namespace slam3d { namespace ptr { using boost::shared_ptr; using boost::make_shared; using boost::dynamic_pointer_cast; } }
+#include <boost/weak_ptr.hpp>
+namespace slam3d { namespace ptr { using boost::shared_ptr; using boost::weak_ptr; using boost::make_shared; using boost::dynamic_pointer_cast; } }
 #else
-namespace slam3d { namespace ptr { using std::shared_ptr; using std::make_shared; using std::dynamic_pointer_cast; } }
+namespace slam3d { namespace ptr { using std::shared_ptr; using std::weak_ptr; using std::make_shared; using std::dynamic_pointer_cast; } }
 #endif
 
 #if defined(S3D_MIRROR_HAVE_EIGEN)

@@ -48,6 +48,8 @@ PointCloudSensor::PointCloudSensor(const std::string& n, Logger* l, int device) 
   mMapResolution = 0.1;
   mMapOutlierRadius = 0.2;
   mMapOutlierNeighbors = 3;
+  if (s3d_abi_version() != S3D_ABI_VERSION)
+    throw std::runtime_error("slam3d (MI355X build): libslam3d_hip.so does not match the headers this mirror was built with");
   if (s3d_context_create(device, nullptr, &mContext) != S3D_STATUS_OK)
     throw std::runtime_error("slam3d (MI355X build): no usable HIP device, and there is no CPU fallback");
   mContextHolder = std::make_shared<ContextHolder>(mContext);
@@ -57,16 +59,56 @@ PointCloudSensor::~PointCloudSensor() { releaseSweep(); }   // (the context goes
 
 void PointCloudSensor::releaseSweep() {
   if (!mSweep) return;
-  for (auto& kv : mSweepClouds) s3d_sweep_cloud_release(mSweep, kv.second);
+  for (auto& kv : mSweepClouds) s3d_sweep_cloud_release(mSweep, kv.second.cloud);
   mSweepClouds.clear();
   s3d_sweep_destroy(mSweep);
   mSweep = nullptr;
 }
 
+// sweep clouds whose measurement is gone, then the least recently used ones beyond the limit (never one of the
+// current call: those carry the current clock)
+void PointCloudSensor::pruneSweepClouds() {
+  for (auto it = mSweepClouds.begin(); it != mSweepClouds.end();) {
+    if (it->second.owner.expired()) {
+      s3d_sweep_cloud_release(mSweep, it->second.cloud);
+      it = mSweepClouds.erase(it);
+    } else {
+      ++it;
+    }
+  }
+  while (mSweepClouds.size() > mSweepCloudLimit) {
+    auto lru = mSweepClouds.end();
+    for (auto it = mSweepClouds.begin(); it != mSweepClouds.end(); ++it)
+      if (it->second.last_use != mSweepClock && (lru == mSweepClouds.end() || it->second.last_use < lru->second.last_use)) lru = it;
+    if (lru == mSweepClouds.end()) break;
+    s3d_sweep_cloud_release(mSweep, lru->second.cloud);
+    mSweepClouds.erase(lru);
+  }
+}
+
+std::vector<s3d_edge_record> PointCloudSensor::runSweep(const std::vector<s3d_sweep_cloud*>& src,
+                                                        const std::vector<s3d_sweep_cloud*>& tgt,
+                                                        const std::vector<double>& guesses,
+                                                        const RegistrationParameters& config) {
+  std::vector<s3d_edge_record> rec(src.size());
+  if (src.empty()) return rec;
+  s3d_exec_options opts;
+  std::memset(&opts, 0, sizeof opts);
+  opts.cache_prepass = mPrepassCache ? 1 : 0;
+  opts.omp_unavailable = mOmpAvailable ? 0 : 1;
+  const int st = s3d_align_batch_multi(mSweep, (int)src.size(), src.data(), tgt.data(), guesses.data(),
+                                       static_cast<const s3d_reg_params*>(&config), &opts, rec.data());
+  if (st == S3D_STATUS_BACKEND_ERROR) throw std::runtime_error(std::string("HIP back-end error: ") + s3d_sweep_last_error(mSweep));
+  if (st == S3D_STATUS_UNKNOWN_ALGORITHM) throw std::runtime_error("Unknown registration algorithm specified.");   // :164
+  if (st == S3D_STATUS_OMP_UNAVAILABLE)   // :161
+    throw std::runtime_error("OMP is not available, you need to rebuild SLAM3D with OMP or use another matching algorithm.");
+  return rec;
+}
+
 std::vector<Constraint::Ptr> PointCloudSensor::createConstraints(const std::vector<Measurement::Ptr>& sources,
                                                                  const std::vector<Measurement::Ptr>& targets,
                                                                  const std::vector<Transform>& odometry,
-                                                                 const std::vector<int>& devices) {
+                                                                 const std::vector<int>& devices, bool loop) {
   if (sources.size() != targets.size() || sources.size() != odometry.size())
     throw std::invalid_argument("createConstraints: sources, targets and odometry must have one entry per candidate");
   const size_t n = sources.size();
@@ -79,6 +121,7 @@ std::vector<Constraint::Ptr> PointCloudSensor::createConstraints(const std::vect
       throw std::runtime_error("slam3d (MI355X build): no usable HIP devices / RCCL for the sweep, and there is no CPU fallback");
     mSweepDevices = devices;
   }
+  ++mSweepClock;
   std::vector<s3d_sweep_cloud*> src(n), tgt(n);
   std::vector<double> guesses(16 * n);
   for (size_t i = 0; i < n; ++i) {
@@ -97,30 +140,50 @@ std::vector<Constraint::Ptr> PointCloudSensor::createConstraints(const std::vect
         s3d_sweep_cloud* sc = nullptr;
         if (s3d_sweep_cloud_create(mSweep, c->size() ? &c->points[0].x : dummy, (int)c->size(), 4, &sc) != S3D_STATUS_OK)
           throw std::runtime_error("s3d_sweep_cloud_create failed");
-        it = mSweepClouds.emplace(pc->getUniqueId(), sc).first;
+        SweepEntry e;
+        e.cloud = sc; e.owner = pair_m[k]; e.last_use = mSweepClock;
+        it = mSweepClouds.emplace(pc->getUniqueId(), e).first;
       }
-      pair_c[k] = it->second;
+      it->second.last_use = mSweepClock;
+      pair_c[k] = it->second.cloud;
     }
     src[i] = pair_c[0]; tgt[i] = pair_c[1];
     const Transform guess = sources[i]->getInverseSensorPose() * odometry[i] * targets[i]->getSensorPose();   // :274
     std::memcpy(&guesses[16 * i], guess.data(), 16 * sizeof(double));
   }
-  std::vector<s3d_edge_record> rec(n);
-  s3d_exec_options opts;
-  std::memset(&opts, 0, sizeof opts);
-  opts.cache_prepass = mPrepassCache ? 1 : 0;
-  const int st = s3d_align_batch_multi(mSweep, (int)n, src.data(), tgt.data(), guesses.data(),
-                                       static_cast<const s3d_reg_params*>(&mFineConfiguration), &opts, rec.data());
-  if (st == S3D_STATUS_BACKEND_ERROR) throw std::runtime_error(std::string("HIP back-end error: ") + s3d_sweep_last_error(mSweep));
-  if (st == S3D_STATUS_UNKNOWN_ALGORITHM) throw std::runtime_error("Unknown registration algorithm specified.");   // :164
-  for (size_t i = 0; i < n; ++i) {
-    if ((int)rec[i].status != S3D_STATUS_OK) {   // NoMatch: ScanSensor::link logs a warning and goes on (ScanSensor.cpp:159-162)
-      mLogger->message(WARNING, "Failed to match candidate " + std::to_string(i) + " (status " + std::to_string((int)rec[i].status) + ")");
+  pruneSweepClouds();
+  // loop: the coarse sweep first, its transforms are the guesses of the fine one (:286-292)
+  std::vector<size_t> live(n);
+  for (size_t i = 0; i < n; ++i) live[i] = i;
+  if (loop) {
+    const std::vector<s3d_edge_record> coarse = runSweep(src, tgt, guesses, mCoarseConfiguration);
+    std::vector<size_t> ok;
+    for (size_t i = 0; i < n; ++i) {
+      if ((int)coarse[i].status != S3D_STATUS_OK) {   // createConstraint would have thrown NoMatch out of the coarse align()
+        mLogger->message(WARNING, "Failed to match candidate " + std::to_string(i) + " (coarse, status " + std::to_string((int)coarse[i].status) + ")");
+        continue;
+      }
+      double* g = &guesses[16 * ok.size()];
+      for (int c = 0; c < 4; ++c) {
+        for (int r = 0; r < 3; ++r) g[c * 4 + r] = coarse[i].transform[c * 3 + r];
+        g[c * 4 + 3] = c == 3 ? 1.0 : 0.0;
+      }
+      src[ok.size()] = src[i]; tgt[ok.size()] = tgt[i];
+      ok.push_back(i);
+    }
+    live.swap(ok);
+    src.resize(live.size()); tgt.resize(live.size()); guesses.resize(16 * live.size());
+  }
+  const std::vector<s3d_edge_record> rec = runSweep(src, tgt, guesses, mFineConfiguration);
+  for (size_t k = 0; k < live.size(); ++k) {
+    const size_t i = live[k];
+    if ((int)rec[k].status != S3D_STATUS_OK) {   // NoMatch: ScanSensor::link logs a warning and goes on (ScanSensor.cpp:159-162)
+      mLogger->message(WARNING, "Failed to match candidate " + std::to_string(i) + " (status " + std::to_string((int)rec[k].status) + ")");
       continue;
     }
     Transform icp = Transform::Identity();
     for (int c = 0; c < 4; ++c)
-      for (int r = 0; r < 3; ++r) icp(r, c) = rec[i].transform[c * 3 + r];
+      for (int r = 0; r < 3; ++r) icp(r, c) = rec[k].transform[c * 3 + r];
     const Transform transform = sources[i]->getSensorPose() * icp * targets[i]->getInverseSensorPose();   // :295
     Covariance<6> information = Covariance<6>::Identity();
     for (unsigned d = 0; d < 6; ++d) information(d, d) = 1.0 / mCovarianceScale;
@@ -445,6 +508,7 @@ Transform PointCloudSensor::align(const PointCloudMeasurement::Ptr& source, cons
   s3d_exec_options opts;
   std::memset(&opts, 0, sizeof opts);
   opts.cache_prepass = mPrepassCache ? 1 : 0;
+  opts.omp_unavailable = mOmpAvailable ? 0 : 1;
   const int st = s3d_align_clouds(mContext, s->cloud, t->cloud, guess.data(),
                                   static_cast<const s3d_reg_params*>(&config), &opts, result.data(), &info);
   switch (st) {
@@ -463,6 +527,8 @@ Transform PointCloudSensor::align(const PointCloudMeasurement::Ptr& source, cons
       throw std::runtime_error("Registration algorithm not available in this build.");
     case S3D_STATUS_UNKNOWN_ALGORITHM:  // :164
       throw std::runtime_error("Unknown registration algorithm specified.");
+    case S3D_STATUS_OMP_UNAVAILABLE:  // :161 (a reference built without pclomp; setOmpAvailable(false))
+      throw std::runtime_error("OMP is not available, you need to rebuild SLAM3D with OMP or use another matching algorithm.");
     case S3D_STATUS_INVALID_ARGUMENT:
       // PCL accepts these and fails later ("Number of points in cloud is less than k", an empty NDT grid); the
       // back-end refuses them up front: correspondence_randomness outside 1..64 or above the filtered cloud size,

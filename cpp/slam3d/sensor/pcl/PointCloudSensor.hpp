@@ -99,7 +99,14 @@ class PointCloudMeasurement : public Measurement {
   mutable std::shared_ptr<DeviceCloud> mDeviceCloud;
 };
 
-// the part of Sensor / ScanSensor (Sensor.hpp:84-168, ScanSensor.hpp:35-158) the path needs
+// the part of Sensor / ScanSensor (Sensor.hpp:84-168, ScanSensor.hpp:35-158) the path needs.  Inside a slam3d source
+// tree the real classes are used instead (define S3D_MIRROR_USE_SLAM3D_CORE, or let __has_include find
+// <slam3d/core/ScanSensor.hpp>): this header next to the real one would otherwise redefine them.  [That branch has
+// not been through a compiler here - slam3d's headers need Boost and Eigen, which this image lacks.]
+#if !defined(S3D_MIRROR_STANDALONE) && (defined(S3D_MIRROR_USE_SLAM3D_CORE) || \
+    (defined(__has_include) && __has_include(<slam3d/core/ScanSensor.hpp>)))
+#include <slam3d/core/ScanSensor.hpp>
+#else
 class Sensor {
  public:
   Sensor(const std::string& n, Logger* l) : mLogger(l), mName(n), mCovarianceScale(1.0) {}
@@ -121,6 +128,7 @@ class ScanSensor : public Sensor {
   virtual Constraint::Ptr createConstraint(const Measurement::Ptr& source, const Measurement::Ptr& target,
                                            const Transform& odometry, bool loop) = 0;
 };
+#endif
 
 class PointCloudSensor : public ScanSensor {
  public:
@@ -167,10 +175,23 @@ class PointCloudSensor : public ScanSensor {
   // constraint createConstraint(sources[i], targets[i], odometry[i], false) would return - bit for bit, whatever the
   // number of GPUs - or null where that call would have thrown NoMatch (logged as ScanSensor.cpp:159-162 does).
   // devices: HIP device of every rank; empty = every visible device.
+  // loop = true is what ScanSensor::link passes (ScanSensor.cpp:156: createConstraint(source_m, target_m, guess, true)):
+  // a first sweep with the COARSE configuration whose results are the guesses of the fine sweep
+  // (PointCloudSensor.cpp:286-292); a candidate whose coarse registration fails is a NoMatch, as in the reference.
+  // Sweep clouds are kept per measurement (uploaded once, pre-pass cached per rank) while the measurement is alive
+  // and recently used: entries of measurements that no longer exist (the patches ScanSensor::buildPatch makes for
+  // every candidate have a fresh uuid each) are released at the next call, and at most getSweepCloudLimit() are kept.
   std::vector<Constraint::Ptr> createConstraints(const std::vector<Measurement::Ptr>& sources,
                                                  const std::vector<Measurement::Ptr>& targets,
                                                  const std::vector<Transform>& odometry,
-                                                 const std::vector<int>& devices = std::vector<int>());
+                                                 const std::vector<int>& devices = std::vector<int>(), bool loop = false);
+  void setSweepCloudLimit(size_t n) { mSweepCloudLimit = n; }
+  size_t getSweepCloudLimit() const { return mSweepCloudLimit; }
+  size_t getSweepCloudCount() const { return mSweepClouds.size(); }
+  // GICP_OMP / NDT_OMP (PointCloudSensor.cpp:149-162).  true (default): like a reference built WITH pclomp, the two
+  // enumerators run (the GICP / NDT device code: same objectives).  false: like a reference built without it,
+  // align() throws std::runtime_error("OMP is not available, ...") (s3d_exec_options.omp_unavailable).
+  void setOmpAvailable(bool on) { mOmpAvailable = on; }
 
   // Not in the reference: checkpoints.  GraphSerialization::toFolder writes one <index>.s3dm archive per vertex
   // (GraphSerialization.cpp:40-47) and fromFolder builds NEW measurement objects from them (:68-135): their device
@@ -207,10 +228,17 @@ class PointCloudSensor : public ScanSensor {
   bool mPrepassCache = true;
   PointCloudMeasurement::Ptr mInitialMap;
   // the sweep (ranks, communicators) of the last device list and the sweep clouds of the measurements it has seen
+  struct SweepEntry { s3d_sweep_cloud* cloud; ptr::weak_ptr<Measurement> owner; unsigned long long last_use; };
   s3d_sweep* mSweep = nullptr;
   std::vector<int> mSweepDevices;
-  std::map<Uuid, s3d_sweep_cloud*> mSweepClouds;
+  std::map<Uuid, SweepEntry> mSweepClouds;
+  size_t mSweepCloudLimit = 1024;
+  unsigned long long mSweepClock = 0;
   std::mutex mSweepMutex;
+  bool mOmpAvailable = true;
+  void pruneSweepClouds();
+  std::vector<s3d_edge_record> runSweep(const std::vector<s3d_sweep_cloud*>& src, const std::vector<s3d_sweep_cloud*>& tgt,
+                                        const std::vector<double>& guesses, const RegistrationParameters& config);
   void releaseSweep();
   std::shared_ptr<ContextHolder> mContextHolder;
   s3d_context* mContext;   // == mContextHolder->ctx: one HIP device + stream; calls are serialised inside the library,

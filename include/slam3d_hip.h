@@ -46,7 +46,20 @@ typedef struct s3d_exec_options {
                                one, :179-201 to its neighbours) then pays the pre-pass once per scan.  Results are
                                bit-identical either way.  Entries die with s3d_cloud_release(ctx, cloud); see
                                s3d_context_cache_control.  A cloud must not be modified while it is cached.       */
+  int omp_unavailable;      /* GICP_OMP / NDT_OMP.  The reference has two behaviours, chosen when IT is built
+                               (PointCloudSensor.cpp:149-162): with the external pclomp package the two enumerators
+                               run pclomp's multi-threaded GICP / NDT - the same objectives as GICP / NDT - and
+                               without it align() throws std::runtime_error("OMP is not available, ...").
+                               0 (default): the pclomp build - both are served by the GICP / NDT device code.
+                               1: the build without pclomp - S3D_STATUS_OMP_UNAVAILABLE after the voxel filter and
+                               the 100-point gate (the reference's order), which the C++ mirror re-raises.           */
 } s3d_exec_options;
+
+/* The structs above grow at the END only.  A binding compiled against another revision of this header must not be
+ * used: compare S3D_ABI_VERSION with s3d_abi_version() once after loading the library (the Python binding and the
+ * C++ mirror do). */
+#define S3D_ABI_VERSION 3
+int  s3d_abi_version(void);
 
 typedef struct s3d_align_info {   /* diagnostics of one align() */
   int    n_source_filtered, n_target_filtered;   /* points after the voxel filter            */
@@ -243,6 +256,36 @@ int  s3d_align_batch_multi(s3d_sweep* sw, int n_pairs, s3d_sweep_cloud* const* s
                            const s3d_exec_options* opts, s3d_edge_record* records);
 /* the records of the last sweep as rank `rank` holds them in HBM after the all-gather (n_pairs, pair order) */
 int  s3d_sweep_gathered_records(s3d_sweep* sw, int rank, int n_pairs, s3d_edge_record* records);
+
+/* ---- candidate generation for a sweep (host only, no GPU): the part of ScanSensor::linkToNeighbors
+ *          (ScanSensor.cpp:170-202) that runs BEFORE the registration, on a plain description of the pose graph, so that a
+ *          C++ caller can fill the pair list of s3d_align_batch_multi / createConstraints without the Python helper.
+ *          Restated: Graph::getNearbyVertices (Graph.cpp:240-261: linear scan over the vertices of the link sensors
+ *          in insertion order, double norm of the translation difference < radius), the reverse walk over those
+ *          neighbours, "skip the vertex itself", "skip when an edge vertex -> neighbour of this sensor exists"
+ *          (BoostGraph::getEdge :156-176 on the out-edges as stored: addEdge stores an edge in both directions,
+ *          removeEdge drops one), BoostGraph::calculateGraphDistance (:301-324: Dijkstra over all stored edges, weight 1
+ *          for an SE(3) edge and 10000 for any other, float; an unreachable vertex keeps FLT_MAX), "skip when
+ *          dist <= 2 * patch_building_range or dist < min_loop_length", stop after max_neighbor_links candidates.
+ *          The candidates are the calls link(neighbour, vertex) of :198 in their order: out_sources[k] -> vertex.
+ *          Vertices are named by their insertion index 0 .. n_vertices-1 (boost vecS descriptors). */
+typedef struct s3d_graph_edge {
+  int source, target;       /* an out-edge as stored (both directions of an edge are two entries) */
+  int se3;                  /* != 0: an SE(3) constraint (weight 1 in the graph distance), 0: anything else (10000) */
+  int own_sensor;           /* != 0: the edge carries the linking sensor's name (getEdge(vertex, index, mName)) */
+} s3d_graph_edge;
+typedef struct s3d_link_policy {   /* ScanSensor's knobs, constructor defaults ScanSensor.cpp:34-41 */
+  float    neighbor_radius;        /* mNeighborRadius       (1.0) */
+  int      max_neighbor_links;     /* mMaxNeighorLinks      (1)   */
+  unsigned min_loop_length;        /* mMinLoopLength        (10)  */
+  unsigned patch_building_range;   /* mPatchBuildingRange   (0)   */
+} s3d_link_policy;
+/* positions: 3 doubles per vertex (translation of correctedPose); linkable: per vertex != 0 when its sensor is one of
+ * mLinkSensors (NULL: every vertex).  Writes at most `capacity` sources, *n_out = how many there are.
+ * Returns S3D_STATUS_OK or S3D_STATUS_INVALID_ARGUMENT (bad indices / NULL arguments). */
+int  s3d_link_candidates(int n_vertices, const double* positions, const unsigned char* linkable, int n_edges,
+                         const s3d_graph_edge* edges, int vertex, const s3d_link_policy* policy, int* out_sources,
+                         int capacity, int* n_out);
 
 /* ---- measurement hook (bench.py roofline): time `reps` launches of the NN-search kernel
  *          as a FIRST correspondence pass (transformation_ = I, no radius hints, no re-validation

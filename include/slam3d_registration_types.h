@@ -61,7 +61,9 @@ enum s3d_status {
   S3D_STATUS_UNKNOWN_ALGORITHM     = 5, /* :163-164 std::runtime_error("Unknown registration algorithm specified.") */
   S3D_STATUS_UNSUPPORTED_ALGORITHM = 6, /* reserved (NDT / NDT_OMP returned it before they were implemented) */
   S3D_STATUS_INVALID_ARGUMENT      = 7,
-  S3D_STATUS_BACKEND_ERROR         = 8  /* HIP runtime error; message via s3d_last_error() */
+  S3D_STATUS_BACKEND_ERROR         = 8, /* HIP runtime error; message via s3d_last_error() */
+  S3D_STATUS_OMP_UNAVAILABLE       = 9  /* :159-161 std::runtime_error("OMP is not available, ...") - a reference built
+                                           without pclomp; only with s3d_exec_options.omp_unavailable (slam3d_hip.h) */
 };
 
 /* One registration result ("edge record").  16 doubles = 128 bytes: the unit

@@ -13,7 +13,8 @@ _LIB_PATH = os.path.join(_HERE, "libs3d_oracle.so")
 
 ALG_ICP, ALG_GICP, ALG_GICP_OMP, ALG_NDT, ALG_NDT_OMP = range(5)
 (STATUS_OK, STATUS_TOO_FEW_POINTS, STATUS_NOT_CONVERGED, STATUS_FITNESS_EXCEEDED, STATUS_TOO_FAR_FROM_GUESS,
- STATUS_UNKNOWN_ALGORITHM, STATUS_UNSUPPORTED_ALGORITHM, STATUS_INVALID_ARGUMENT, STATUS_BACKEND_ERROR) = range(9)
+ STATUS_UNKNOWN_ALGORITHM, STATUS_UNSUPPORTED_ALGORITHM, STATUS_INVALID_ARGUMENT, STATUS_BACKEND_ERROR,
+ STATUS_OMP_UNAVAILABLE) = range(10)
 
 
 class RegParams(C.Structure):
@@ -337,6 +338,12 @@ def fill_ground_plane(xyz, radius, map_resolution=0.1, threshold=0.01):
 def set_eval_precision(mode):
     """0: PCL-literal float functor (default); 1: double arithmetic; 2: double matrix (see s3d_oracle.h)."""
     lib().s3o_set_eval_precision(int(mode))
+
+
+def set_omp_available(on):
+    """True (default): a reference built with pclomp, GICP_OMP / NDT_OMP run; False: built without it, they fail with
+    STATUS_OMP_UNAVAILABLE after the voxel filter and the 100-point gate (PointCloudSensor.cpp:159-161)."""
+    lib().s3o_set_omp_available(1 if on else 0)
 
 
 def set_debug_perturbation(rel, seed=1):

@@ -621,6 +621,9 @@ static double g_perturb = 0.0;   /* relative noise injected into the Mahalanobis
 static unsigned long long g_perturb_seed = 1;
 static int    g_trace = 0;
 void s3o_set_eval_precision(int mode) { g_eval_double = mode; }
+/* PCS.cpp:149-162: the reference is built with pclomp (1, default: GICP_OMP / NDT_OMP run) or without (0: they throw) */
+static int g_omp_available = 1;
+void s3o_set_omp_available(int on) { g_omp_available = on; }
 void s3o_set_debug_perturbation(double rel) { g_perturb = rel; }
 void s3o_set_debug_perturbation_seed(unsigned long long seed) { g_perturb_seed = seed; }
 /* the conditioning probe's noise: a pure function of (seed, outer iteration, correspondence, matrix entry), so that the
@@ -1655,16 +1658,21 @@ int s3o_align(const float* source, int n_source, int stride_source, const float*
   s3o_icp_result r;
   int rc;
   switch (cfg->registration_algorithm) { /* PCS.cpp:139-165 */
-    case S3D_ALG_GICP:
     case S3D_ALG_GICP_OMP:
+      if (!g_omp_available) { status = S3D_STATUS_OMP_UNAVAILABLE; goto done; }   /* PCS.cpp:159-161 */
+      /* pclomp's GICP minimises the same objective */
+      /* fall through */
+    case S3D_ALG_GICP:
       /* setInputSource(target); setInputTarget(source)  PCS.cpp:68-69 */
       rc = s3o_gicp(ft, nt, fs, ns, guess_f, cfg, force_iterations, &r);
       break;
     case S3D_ALG_ICP:
       rc = s3o_icp_point_to_plane(ft, nt, fs, ns, guess_f, cfg, force_iterations, &r);
       break;
-    case S3D_ALG_NDT:
     case S3D_ALG_NDT_OMP:
+      if (!g_omp_available) { status = S3D_STATUS_OMP_UNAVAILABLE; goto done; }   /* PCS.cpp:159-161 */
+      /* fall through */
+    case S3D_ALG_NDT:
       /* doNDT (PCS.cpp:84-117): same source/target swap */
       rc = s3o_ndt(ft, nt, fs, ns, guess_f, cfg, &r);
       break;

@@ -136,6 +136,7 @@ void s3o_mt19937_outputs(unsigned seed, int n, unsigned* out);   /* test hook fo
  * debug_perturbation: multiplies every Mahalanobis entry by (1 + rel*U(-.5,.5)); used by
  *                   tests/test_conditioning.py to measure how well-defined the reference result is. */
 void s3o_set_eval_precision(int mode);
+void s3o_set_omp_available(int on);   /* 0: a reference built without pclomp (GICP_OMP / NDT_OMP throw, PCS.cpp:159-161) */
 void s3o_set_debug_float_normals(int on);   /* diagnostic: covariances from float-rounded normals, as the device stores them */
 void s3o_set_debug_perturbation(double rel);
 void s3o_set_debug_perturbation_seed(unsigned long long seed);   /* the noise is a pure function of (seed, iteration, correspondence, entry) */

@@ -11,7 +11,8 @@ _CSRC = os.path.join(_HERE, "csrc")
 
 ALG_ICP, ALG_GICP, ALG_GICP_OMP, ALG_NDT, ALG_NDT_OMP = range(5)
 STATUS_NAMES = ["OK", "TOO_FEW_POINTS", "NOT_CONVERGED", "FITNESS_EXCEEDED", "TOO_FAR_FROM_GUESS",
-                "UNKNOWN_ALGORITHM", "UNSUPPORTED_ALGORITHM", "INVALID_ARGUMENT", "BACKEND_ERROR"]
+                "UNKNOWN_ALGORITHM", "UNSUPPORTED_ALGORITHM", "INVALID_ARGUMENT", "BACKEND_ERROR", "OMP_UNAVAILABLE"]
+ABI_VERSION = 3          # include/slam3d_hip.h S3D_ABI_VERSION (struct layouts of this binding)
 EDGE_RECORD_DOUBLES = 16
 
 
@@ -32,7 +33,7 @@ class RegParams(C.Structure):
 
 class ExecOptions(C.Structure):
     _fields_ = [("force_iterations", C.c_int), ("check_interval", C.c_int), ("grid_cells_per_point", C.c_int),
-                ("profile", C.c_int), ("cache_prepass", C.c_int)]
+                ("profile", C.c_int), ("cache_prepass", C.c_int), ("omp_unavailable", C.c_int)]
 
 
 class CacheStats(C.Structure):
@@ -102,6 +103,15 @@ def build(force=False, verbose=False):
     return _LIB
 
 
+class GraphEdge(C.Structure):       # include/slam3d_hip.h s3d_graph_edge
+    _fields_ = [("source", C.c_int), ("target", C.c_int), ("se3", C.c_int), ("own_sensor", C.c_int)]
+
+
+class LinkPolicyC(C.Structure):     # include/slam3d_hip.h s3d_link_policy
+    _fields_ = [("neighbor_radius", C.c_float), ("max_neighbor_links", C.c_int), ("min_loop_length", C.c_uint),
+                ("patch_building_range", C.c_uint)]
+
+
 _lib = None
 
 
@@ -117,6 +127,7 @@ def load_library():
     vp, fp, dp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int)
     pp, op = C.POINTER(RegParams), C.POINTER(ExecOptions)
     sig = {
+        "s3d_abi_version": (C.c_int, []),
         "s3d_context_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
         "s3d_context_destroy": (None, [vp]),
         "s3d_last_error": (C.c_char_p, [vp]),
@@ -165,11 +176,16 @@ def load_library():
         "s3d_align_batch_multi": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, pp, op,
                                             C.POINTER(EdgeRecord)]),
         "s3d_sweep_gathered_records": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(EdgeRecord)]),
+        "s3d_link_candidates": (C.c_int, [C.c_int, dp, C.POINTER(C.c_ubyte), C.c_int, C.POINTER(GraphEdge), C.c_int,
+                                          C.POINTER(LinkPolicyC), ip, C.c_int, ip]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)  # AttributeError if the symbol is not exported
         f.restype = res
         f.argtypes = args
+    if L.s3d_abi_version() != ABI_VERSION:
+        raise BackendError("libslam3d_hip.so has ABI version %d, this binding %d: rebuild the library" %
+                           (L.s3d_abi_version(), ABI_VERSION))
     L._s3d_symbols = sorted(sig)
     _lib = L
     return L
@@ -360,7 +376,7 @@ class Context:
         st = self._check(self._L.s3d_align_batch(self._h, n, self._handles(sources), self._handles(targets), _dp(g),
                                                  C.byref(params), C.byref(opts) if opts else None,
                                                  rec.ctypes.data_as(C.POINTER(EdgeRecord)), infos))
-        if st not in (0, 5, 6):
+        if st not in (0, 5, 6, 9):
             raise ValueError(STATUS_NAMES[st])
         rec = rec[:n]
         if want_infos:
@@ -535,6 +551,29 @@ class Context:
         return p.asdict()
 
 
+def link_candidates(positions, edges, vertex, neighbor_radius=1.0, max_neighbor_links=1, min_loop_length=10,
+                    patch_building_range=0, linkable=None):
+    """s3d_link_candidates (host only): the sources of ScanSensor::linkToNeighbors' link(source, vertex) calls.
+    positions: (n, 3) translations of the corrected poses in vertex insertion order; edges: (source, target, se3,
+    own_sensor) out-edges as stored."""
+    pos = np.ascontiguousarray(np.asarray(positions, np.float64).reshape(-1, 3))
+    n = len(pos)
+    E = (GraphEdge * max(len(edges), 1))()
+    for k, e in enumerate(edges):
+        E[k] = GraphEdge(int(e[0]), int(e[1]), int(e[2]), int(e[3]))
+    pol = LinkPolicyC(float(neighbor_radius), int(max_neighbor_links), int(min_loop_length), int(patch_building_range))
+    lk = None
+    if linkable is not None:
+        lk = np.ascontiguousarray(np.asarray(linkable, np.uint8)).ctypes.data_as(C.POINTER(C.c_ubyte))
+    out = np.zeros(max(n, 1), np.int32)
+    cnt = C.c_int(0)
+    st = load_library().s3d_link_candidates(n, _dp(pos), lk, len(edges), E, int(vertex), C.byref(pol),
+                                            out.ctypes.data_as(C.POINTER(C.c_int)), len(out), C.byref(cnt))
+    if st:
+        raise ValueError(STATUS_NAMES[st])
+    return out[:cnt.value].tolist()
+
+
 def record_transform(rec):
     """(16,) edge record -> 4x4 transform."""
     T = np.eye(4)
@@ -585,7 +624,7 @@ class Sweep:
                                            rec.ctypes.data_as(C.POINTER(EdgeRecord)))
         if st == 8:
             raise BackendError(self._L.s3d_sweep_last_error(self._h).decode())
-        if st not in (0, 5, 6):
+        if st not in (0, 5, 6, 9):
             raise ValueError(STATUS_NAMES[st])
         return rec[:n]
 

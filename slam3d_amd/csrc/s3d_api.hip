@@ -481,7 +481,7 @@ struct Batch {
                 {&ctx->filt, 16 * np}, {&ctx->sorted, 16 * np}, {&ctx->sorted3, 12 * npi}, {&ctx->normals, sizeof(NormalRec) * npi}, {&ctx->moments, 72 * npi},
                 {&ctx->cell_start, 4 * std::max<size_t>(total_cells, 4)},
                 {&ctx->counts, 4 * (size_t)std::max(1, C()) * 256 * nb_sort},
-                {&ctx->digit_tot, 4 * (size_t)std::max(1, C()) * 256},
+                {&ctx->digit_tot, 4 * (size_t)std::max(1, C()) * 256 * kSortPlaces},
                 {&ctx->blockcnt, 4 * (size_t)std::max(1, C()) * nb_head},
                 {&ctx->blockbb, 24 * (size_t)std::max(1, C()) * nb_head},
                 {&ctx->corr_idx, 4 * nc}, {&ctx->corr_d2, 4 * nc}, {&ctx->corr_lb, 4 * nc},
@@ -524,20 +524,40 @@ struct Batch {
 
   // segmented LSD radix sort of (keys, vals) of every slot; `passes` 8-bit digits.
   // input in A; result in A for even `passes`, in B for odd.
-  // first_hist_done: k_keys_hist has produced the tile histogram of pass 0 together with the keys
-  void sort(int passes, int nslots, bool first_hist_done = false) {
+  // One sweep per pass (k_sort_onesweep, decoupled look-back); hist_done: the kernel that produced the keys has
+  // counted the digit totals of all passes (k_keys_hist with sweep_passes) and zeroed the look-back rows.
+  // S3D_SORT_CLASSIC=1 (A/B): the three-kernels-per-pass form.
+  bool sort_classic = getenv("S3D_SORT_CLASSIC") && atoi(getenv("S3D_SORT_CLASSIC")) != 0;
+  void sort_prepare(int nslots) {   // before the kernel that counts the digit totals
+    if (!sort_classic && nslots > 0)
+      HIPCHK(hipMemsetAsync(ctx->digit_tot.p, 0, sizeof(uint32_t) * (size_t)nslots * kSortPlaces * 256, ctx->stream));
+  }
+  void sort(int passes, int nslots, bool hist_done = false) {
     hipStream_t st = ctx->stream;
     if (nslots <= 0) return;
     uint32_t *ki = kA(), *vi = vA(), *ko = kB(), *vo = vB();
     uint32_t* cnt = (uint32_t*)ctx->counts.p;
     uint32_t* dtot = (uint32_t*)ctx->digit_tot.p;
+    const unsigned blocks = (unsigned)((nslots >= 8 ? cdiv(nslots, 8) * 8 : nslots) * nb_sort);
+    if (!sort_classic) {
+      if (!hist_done) {
+        sort_prepare(nslots);
+        k_sort_hist_all<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(d_slots(), ki, dtot, cnt, passes, nb_sort);
+      }
+      int* err = (int*)ctx->n_active.p + 6;
+      for (int p = 0; p < passes; ++p) {
+        k_sort_onesweep<<<blocks, kBlock, 0, st>>>(d_slots(), ki, vi, ko, vo, cnt, dtot, p, nb_sort, nslots, err);
+        std::swap(ki, ko);
+        std::swap(vi, vo);
+      }
+      return;
+    }
     for (int p = 0; p < passes; ++p) {
       const int shift = 8 * p;
-      if (p > 0 || !first_hist_done) k_sort_hist<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(d_slots(), ki, cnt, shift, nb_sort);
+      if (p > 0 || !hist_done) k_sort_hist<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(d_slots(), ki, cnt, shift, nb_sort);
       if (nb_sort <= kSortTileMajor) k_sort_scan_tiles<<<nslots, 256, 0, st>>>(d_slots(), cnt, dtot, nb_sort);
       else k_sort_scan_rows<<<dim3(256 / (kBlock / kWave), nslots), kBlock, 0, st>>>(d_slots(), cnt, dtot, nb_sort);
-      k_sort_scatter<<<(unsigned)((nslots >= 8 ? cdiv(nslots, 8) * 8 : nslots) * nb_sort), kBlock, 0, st>>>(d_slots(), ki, vi, ko, vo, cnt, dtot,
-                                                                                                          shift, nb_sort, nslots);
+      k_sort_scatter<<<blocks, kBlock, 0, st>>>(d_slots(), ki, vi, ko, vo, cnt, dtot, shift, nb_sort, nslots);
       std::swap(ki, ko);
       std::swap(vi, vo);
     }
@@ -551,7 +571,9 @@ struct Batch {
     if (rp.leaf > 0.f) {
       k_bbox<0><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), NS), kBlock, 0, st>>>(d_slots(), filt());
       k_voxel_params<<<cdiv(NS, 64), 64, 0, st>>>(d_slots(), rp, NS);
-      k_keys_hist<0><<<dim3(nb_sort, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA(), (uint32_t*)ctx->counts.p, nb_sort);
+      sort_prepare(NS);
+      k_keys_hist<0><<<dim3(nb_sort, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA(), (uint32_t*)ctx->counts.p, nb_sort,
+                                                             sort_classic ? 0 : 4, (uint32_t*)ctx->digit_tot.p);
       sort(4, NS, true);
       uint32_t* bc = (uint32_t*)ctx->blockcnt.p;
       k_heads_count<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), kA(), bc, nb_head);
@@ -574,8 +596,10 @@ struct Batch {
       k_bbox<1><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), NS), kBlock, 0, st>>>(d_slots(), filt());
     }
     k_grid_params<<<NS, kWave, 0, st>>>(d_slots(), rp, from_centroids ? (const unsigned int*)ctx->blockbb.p : nullptr, nb_head);
-    k_keys_hist<1><<<dim3(nb_sort, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA(), (uint32_t*)ctx->counts.p, nb_sort);
     const bool wide = max_cell_cap > (1ll << 24);
+    sort_prepare(NS);
+    k_keys_hist<1><<<dim3(nb_sort, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA(), (uint32_t*)ctx->counts.p, nb_sort,
+                                                           sort_classic ? 0 : (wide ? 4 : 3), (uint32_t*)ctx->digit_tot.p);
     sort(wide ? 4 : 3, NS, true);  // cell ids < 2^24 unless a map job raised the cap
     // (a slot -> XCD block map as in k_centroids gains nothing here: vals[] runs nearly in step with the cell order)
     k_grid_finalize<<<dim3(cdiv(max_n + 1, kBlock), NS), kBlock, 0, st>>>(d_slots(), filt(), wide ? kA() : kB(),
@@ -664,26 +688,16 @@ struct Batch {
     launch_nn(0, max_d, prof_slot, it >= 2 && it <= 4);   // (the counters cost two atomics per searching wave)
     launch_iteration_after_nn();
   }
-  // small batches: the controller rides on the accumulate kernel (s3d_kernels.h accumulate_then_control)
-  static constexpr int kSmallBatchPairs = 8;
   void launch_iteration_after_nn() {
     hipStream_t st = ctx->stream;
     double* part = (double*)ctx->partials.p;
-    int* act = (int*)ctx->n_active.p;
-    const bool attach = P() <= kSmallBatchPairs && !getenv("S3D_SEPARATE_CONTROL");
-    const dim3 grid(accum_blocks, P());
-    if (rp.algorithm) {
-      if (attach)
-        s3d_gicp_accumulate_kernel<true><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted3(), normals(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp, act);
-      else
-        s3d_gicp_accumulate_kernel<false><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted3(), normals(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp, act);
-    } else {
-      if (attach)
-        s3d_p2plane_accumulate_kernel<true><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted3(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp, act);
-      else
-        s3d_p2plane_accumulate_kernel<false><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), sorted3(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp, act);
-    }
-    if (!attach) s3d_icp_control_kernel<<<P(), kCtrlThreads, 0, st>>>(d_pairs(), part, rp, act);
+    if (rp.algorithm)
+      s3d_gicp_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
+          d_pairs(), d_slots(), sorted3(), normals(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp);
+    if (!rp.algorithm)
+      s3d_p2plane_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
+          d_pairs(), d_slots(), sorted3(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp);
+    s3d_icp_control_kernel<<<P(), kCtrlThreads, 0, st>>>(d_pairs(), part, rp, (int*)ctx->n_active.p);
   }
 
   // K5-K7 loop.  The host only polls the active-pair counter every check_interval iterations.
@@ -825,10 +839,11 @@ struct Batch {
   }
 };
 
-int check_algorithm(const s3d_reg_params* p) {
+int check_algorithm(const s3d_reg_params* p, const s3d_exec_options* o) {
   switch (p->registration_algorithm) {  // PointCloudSensor.cpp:139-165
-    case S3D_ALG_ICP: case S3D_ALG_GICP: case S3D_ALG_GICP_OMP: return S3D_STATUS_OK;
-    case S3D_ALG_NDT: case S3D_ALG_NDT_OMP: return S3D_STATUS_OK;   // host-driven, see align_ndt()
+    case S3D_ALG_ICP: case S3D_ALG_GICP: case S3D_ALG_NDT: return S3D_STATUS_OK;   // (NDT: host-driven, see align_ndt())
+    case S3D_ALG_GICP_OMP: case S3D_ALG_NDT_OMP:      // :149-162: pclomp build (served by the same code) or not
+      return (o && o->omp_unavailable) ? S3D_STATUS_OMP_UNAVAILABLE : S3D_STATUS_OK;
     default: return S3D_STATUS_UNKNOWN_ALGORITHM;
   }
 }
@@ -1198,7 +1213,7 @@ void align_ndt_pairs(Batch& b, const s3d_reg_params* params, const double* guess
 // host-buffer entry points, whose device copies die with the call
 int align_dev(s3d_context* ctx, s3d_cloud* ps, s3d_cloud* pt, const double guess[16], const s3d_reg_params* params,
               const s3d_exec_options* opts, double result[16], s3d_align_info* info, bool persistent) {
-  const int alg = check_algorithm(params);
+  const int alg = check_algorithm(params, opts);
   Batch b;
   b.ctx = ctx;
   b.use_cache = persistent && opts && opts->cache_prepass != 0 && alg == S3D_STATUS_OK;
@@ -1275,6 +1290,8 @@ void s3d_default_params(s3d_reg_params* p) {
   p->step_size = 0.05;
   p->outlier_ratio = 0.35;
 }
+
+int s3d_abi_version(void) { return S3D_ABI_VERSION; }
 
 int s3d_backend_info(int device, char* buf, int len) {
   int count = 0;
@@ -1558,7 +1575,7 @@ int s3d_align_batch(s3d_context* ctx, int n_pairs, s3d_cloud* const* sources, s3
                     s3d_edge_record* records, s3d_align_info* infos) {
   if (!ctx || n_pairs < 0 || !params || (n_pairs > 0 && (!sources || !targets || !guesses || !records)))
     return S3D_STATUS_INVALID_ARGUMENT;
-  const int alg = check_algorithm(params);
+  const int alg = check_algorithm(params, opts);
   if (alg != S3D_STATUS_OK) {
     for (int p = 0; p < n_pairs; ++p) {
       std::memset(&records[p], 0, sizeof records[p]);
@@ -2204,3 +2221,4 @@ int s3d_profile_nn_kernel(s3d_context* ctx, int n_pairs, s3d_cloud* const* sourc
 }  // extern "C"
 
 #include "s3d_sweep.h"
+#include "s3d_candidates.h"

@@ -52,7 +52,7 @@ struct PairDev {          // one align() job
   Mat4f T_nn;             // transformation_ the last correspondence pass ran with (see nn_still_nearest)
   double fitness;
   int   fit_count;
-  int   blocks_done;      // accumulate kernels with the controller attached (small batches): blocks that have stored their sums
+  int   pad;
 };
 
 struct RunParams {        // per batch, passed by value
@@ -301,16 +301,21 @@ __global__ void __launch_bounds__(kBlock) k_sort_hist(const SlotDev* __restrict_
 // points, 1: grid-cell ids of the filtered points): the keys are produced a 4096-element tile at a time and counted
 // as they are written, instead of being read back by k_sort_hist (one pass over the keys and one launch less per
 // sort: 0.2 ms of the 256-pair step).
+// sweep_passes > 0 (the one-sweep sort below): the digit totals of that many 8-bit places go to digit_tot_all instead,
+// and `counts` is the look-back state, whose row of this tile is zeroed.
+constexpr int kSortPlacesFwd = 4;
 template <int WHICH>
 __global__ void __launch_bounds__(kBlock) k_keys_hist(const SlotDev* __restrict__ slots, const float4* __restrict__ filt,
                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                       uint32_t* __restrict__ counts, int nb_max) {
-  __shared__ unsigned int hist[256];
+                                                       uint32_t* __restrict__ counts, int nb_max, int sweep_passes,
+                                                       uint32_t* __restrict__ digit_tot_all) {
+  __shared__ unsigned int hist[kSortPlacesFwd][256];
   const SlotDev& s = slots[blockIdx.y];
   const int n = WHICH == 0 ? s.n_raw : s.n;
   const int nb = (n + kSortTile - 1) / kSortTile;
   if ((int)blockIdx.x >= nb) return;
-  hist[threadIdx.x] = 0;
+#pragma unroll
+  for (int p = 0; p < kSortPlacesFwd; ++p) hist[p][threadIdx.x] = 0;
   __syncthreads();
   const int base = blockIdx.x * kSortTile;
 #pragma unroll 4
@@ -328,11 +333,20 @@ __global__ void __launch_bounds__(kBlock) k_keys_hist(const SlotDev* __restrict_
       }
       keys[s.off + i] = key;
       vals[s.off + i] = (uint32_t)i;
-      atomicAdd(&hist[key & 255u], 1u);
+      atomicAdd(&hist[0][key & 255u], 1u);
+      for (int p = 1; p < sweep_passes; ++p) atomicAdd(&hist[p][(key >> (8 * p)) & 255u], 1u);
     }
   }
   __syncthreads();
-  counts[sort_count_index(blockIdx.y, threadIdx.x, blockIdx.x, nb_max)] = hist[threadIdx.x];
+  if (sweep_passes > 0) {
+    for (int p = 0; p < sweep_passes; ++p) {
+      const unsigned int v = hist[p][threadIdx.x];
+      if (v) atomicAdd(&digit_tot_all[((size_t)blockIdx.y * kSortPlacesFwd + p) * 256 + threadIdx.x], v);
+    }
+    counts[((size_t)blockIdx.y * nb_max + blockIdx.x) * 256 + threadIdx.x] = 0u;
+    return;
+  }
+  counts[sort_count_index(blockIdx.y, threadIdx.x, blockIdx.x, nb_max)] = hist[0][threadIdx.x];
 }
 
 // Offsets of one pass in two steps.  (1) one WAVE per (slot, digit) row of tile counts: exclusive scan of the row
@@ -490,6 +504,193 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
   __syncthreads();
   // the tile is first put in digit order in LDS, then written out with consecutive threads on consecutive
   // addresses of each digit run (a direct scatter issues 64 unrelated 4-byte stores per wave and array)
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int i = base + r * kWave + lane;
+    if (i < n) {
+      const unsigned int d = (key[r] >> shift) & 255u;
+      const unsigned int lp = dig_local[d] + wave_cnt[w][d] + rank[r];
+      lkey[lp] = key[r];
+      lval[lp] = val[r];
+    }
+  }
+  __syncthreads();
+  const int tile_n = min(kSortTile, n - tile_i * kSortTile);
+  for (int j = threadIdx.x; j < tile_n; j += kBlock) {
+    const uint32_t kk = lkey[j];
+    const unsigned int d = (kk >> shift) & 255u;
+    const unsigned int pos = dig_global[d] + ((unsigned int)j - dig_local[d]);
+    keys_out[s.off + pos] = kk;
+    vals_out[s.off + pos] = lval[j];
+  }
+}
+
+// ------------------------------------------------------------------ K2a', round 3: the same sort in ONE sweep per pass
+// (decoupled look-back: Merrill & Garland's chained scan, as in Adinets & Merrill's Onesweep).  Above, a pass is
+// three kernels - tile histograms, their scan over the tiles, the scatter - and the keys are read twice.  Here the
+// digit totals of ALL passes of a sort are counted once up front (k_sort_hist_all, or the kernel that produces the
+// keys), and a pass is one kernel: a tile ranks its elements, publishes its 256 digit counts (AGGREGATE), walks back
+// over the tiles before it adding their counts until it meets one that has published its INCLUSIVE prefix, publishes
+// its own, and scatters - one read and one write of keys and values per pass, 5 launches instead of 11 for the
+// four-pass voxel sort.  A state word is (tag << 28 | count): tag = 2 * pass + 1 (aggregate) / + 2 (inclusive), so a
+// word left by an earlier pass reads as "not there yet"; the rows are zeroed once per sort by the histogram kernel.
+// Tiles wait only for tiles with a smaller block index of the same launch (nn_block_map keeps a cloud's tiles in
+// ascending block order), which the dispatcher has started before them.
+constexpr int kSortPlaces = kSortPlacesFwd;
+constexpr uint32_t kSweepValMask = 0x0FFFFFFFu;
+
+// digit totals of `passes` 8-bit places of every slot's keys, and zeroed look-back rows.  digit_tot_all must be zero.
+__device__ __forceinline__ void sort_hist_all_block(unsigned int (*hist)[256], int passes, uint32_t* __restrict__ digit_tot_all,
+                                                    uint32_t* __restrict__ state, int slot, int tile, int nb_max) {
+  __syncthreads();
+  for (int p = 0; p < passes; ++p) {
+    const unsigned int v = hist[p][threadIdx.x];
+    if (v) atomicAdd(&digit_tot_all[((size_t)slot * kSortPlaces + p) * 256 + threadIdx.x], v);
+  }
+  state[((size_t)slot * nb_max + tile) * 256 + threadIdx.x] = 0u;
+}
+__global__ void __launch_bounds__(kBlock) k_sort_hist_all(const SlotDev* __restrict__ slots, const uint32_t* __restrict__ keys,
+                                                           uint32_t* __restrict__ digit_tot_all, uint32_t* __restrict__ state,
+                                                           int passes, int nb_max) {
+  __shared__ unsigned int hist[kSortPlaces][256];
+  const SlotDev& s = slots[blockIdx.y];
+  const int n = s.n_sort;
+  const int nb = (n + kSortTile - 1) / kSortTile;
+  if ((int)blockIdx.x >= nb) return;
+  for (int p = 0; p < kSortPlaces; ++p) hist[p][threadIdx.x] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * kSortTile;
+#pragma unroll 4
+  for (int r = 0; r < kSortTile / kBlock; ++r) {
+    const int i = base + r * kBlock + threadIdx.x;
+    if (i < n) {
+      const uint32_t key = keys[s.off + i];
+      for (int p = 0; p < passes; ++p) atomicAdd(&hist[p][(key >> (8 * p)) & 255u], 1u);
+    }
+  }
+  sort_hist_all_block(hist, passes, digit_tot_all, state, blockIdx.y, blockIdx.x, nb_max);
+}
+
+__global__ void __launch_bounds__(kBlock) k_sort_onesweep(const SlotDev* __restrict__ slots,
+                                                           const uint32_t* __restrict__ keys_in,
+                                                           const uint32_t* __restrict__ vals_in,
+                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                           uint32_t* __restrict__ state,
+                                                           const uint32_t* __restrict__ digit_tot_all, int pass, int nb_max,
+                                                           int nslots, int* __restrict__ error_flag) {
+  __shared__ unsigned int wave_cnt[kBlock / kWave][256];   // per wave: elements of each digit seen so far
+  int slot_i, tile_i;
+  nn_block_map(nb_max, nslots, &slot_i, &tile_i);
+  if (slot_i >= nslots) return;
+  const SlotDev& s = slots[slot_i];
+  const int n = s.n_sort;
+  const int nb = (n + kSortTile - 1) / kSortTile;
+  if (tile_i >= nb) return;
+  const int shift = 8 * pass;
+  const int lane = lane_id(), w = wave_id();
+  constexpr int kRounds = kSortTile / kBlock;               // 16
+#pragma unroll
+  for (int ww = 0; ww < kBlock / kWave; ++ww) wave_cnt[ww][threadIdx.x] = 0;
+  __syncthreads();
+  const int base = tile_i * kSortTile + w * (kSortTile / (kBlock / kWave));
+  uint32_t key[kRounds], val[kRounds];
+  unsigned int rank[kRounds];
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {                       // all loads up front (independent)
+    const int i = base + r * kWave + lane;
+    key[r] = 0; val[r] = 0;
+    if (i < n) { key[r] = keys_in[s.off + i]; val[r] = vals_in[s.off + i]; }
+  }
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {                       // ranks within the wave's quarter (see k_sort_scatter)
+    const int i = base + r * kWave + lane;
+    const bool act = i < n;
+    const unsigned int d = (key[r] >> shift) & 255u;
+    unsigned long long peers = __ballot(act);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long m = __ballot(act && ((d >> b) & 1u));
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    const int in_round = __popcll(peers & ((1ull << lane) - 1ull));
+    unsigned int before = 0;
+    if (act) before = wave_cnt[w][d];
+    __builtin_amdgcn_wave_barrier();
+    if (act && in_round == 0) wave_cnt[w][d] = before + (unsigned int)__popcll(peers);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    rank[r] = before + (unsigned int)in_round;
+  }
+  __syncthreads();
+  __shared__ unsigned int dig_local[256], dig_global[256], wave_tot[kBlock / kWave], wave_tot2[kBlock / kWave];
+  __shared__ uint32_t lkey[kSortTile], lval[kSortTile];
+  {
+    // digit = threadIdx.x: this tile's count, published at once; then the look-back over the earlier tiles
+    unsigned int run = 0;
+#pragma unroll
+    for (int ww = 0; ww < kBlock / kWave; ++ww) {
+      const unsigned int c = wave_cnt[ww][threadIdx.x];
+      wave_cnt[ww][threadIdx.x] = run;      // elements of this digit in earlier waves of the tile
+      run += c;
+    }
+    const uint32_t tag_agg = (uint32_t)(2 * pass + 1) << 28, tag_inc = (uint32_t)(2 * pass + 2) << 28;
+    uint32_t* __restrict__ row = state + ((size_t)slot_i * nb_max) * 256 + threadIdx.x;     // [tile * 256]
+    __hip_atomic_store(row + (size_t)tile_i * 256, (tile_i == 0 ? tag_inc : tag_agg) | run, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int excl = 0;
+    {
+      int t = tile_i - 1;                    // (tile 0 has published an inclusive prefix: the walk ends there at the latest)
+      unsigned int spins = 0;
+      bool found = t < 0;
+      while (!found) {
+        // four earlier tiles per round trip, used in order until an inclusive prefix or a word that is not there yet
+        uint32_t wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          wv[u] = __hip_atomic_load(row + (size_t)(t - u >= 0 ? t - u : 0) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int consumed = 0;
+        bool stop = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (stop || t - u < 0) continue;
+          const uint32_t tg = wv[u] & ~kSweepValMask;
+          if (tg == tag_inc) { excl += wv[u] & kSweepValMask; found = true; stop = true; }
+          else if (tg == tag_agg) { excl += wv[u] & kSweepValMask; ++consumed; }
+          else stop = true;
+        }
+        t -= consumed;
+        if (!found && consumed == 0) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 22)) { if (error_flag) atomicOr(error_flag, 1); break; }   // (never hang the device)
+        }
+      }
+    }
+    if (tile_i != 0)
+      __hip_atomic_store(row + (size_t)tile_i * 256, tag_inc | (excl + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int incl = run;                // tile histogram -> inclusive scan over the digits
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const unsigned int t2 = __shfl_up(incl, o, kWave);
+      if (lane >= o) incl += t2;
+    }
+    if (lane == kWave - 1) wave_tot[w] = incl;
+    const unsigned int dtot = digit_tot_all[((size_t)slot_i * kSortPlaces + pass) * 256 + threadIdx.x];
+    unsigned int incl2 = dtot;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const unsigned int t2 = __shfl_up(incl2, o, kWave);
+      if (lane >= o) incl2 += t2;
+    }
+    if (lane == kWave - 1) wave_tot2[w] = incl2;
+    __syncthreads();
+    unsigned int before = 0, before2 = 0;
+#pragma unroll
+    for (int ww = 0; ww < kBlock / kWave; ++ww) { before += ww < w ? wave_tot[ww] : 0u; before2 += ww < w ? wave_tot2[ww] : 0u; }
+    dig_local[threadIdx.x] = before + incl - run;
+    dig_global[threadIdx.x] = excl + (before2 + incl2 - dtot);
+  }
+  __syncthreads();
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const int i = base + r * kWave + lane;
@@ -895,7 +1096,7 @@ __global__ void k_pair_init(PairDev* pairs, int npairs, int* n_active) {
   P.active = 1; P.converged = 0; P.iterations = 0; P.correspondences = 0;
   P.inner_total = 0; P.evals_total = 0;
   P.T = mat4f_identity(); P.prev = mat4f_identity(); P.final_T = P.guess; P.T_nn = mat4f_identity();
-  P.fitness = 0.0; P.fit_count = 0; P.blocks_done = 0;
+  P.fitness = 0.0; P.fit_count = 0;
 }
 
 // ------------------------------------------------------------------ K5: transform + exact 1-NN
@@ -1461,39 +1662,14 @@ __global__ void __launch_bounds__(kCtrlThreads) s3d_icp_control_kernel(PairDev* 
   icp_control_pair(P, partials + (size_t)blockIdx.x * kAccumVB * GQ_NACC, rp, n_active);
 }
 
-// Small batches (the reference's own call pattern: ONE createConstraint per new scan, ScanSensor.cpp:113) are bound by
-// the chain of ~60 dependent launches of the ICP loop, not by the kernels: there the accumulate kernels run the
-// controller themselves - the block that stores a pair's last partial sums (a counter in the pair record) goes on
-// with icp_control_pair - one launch and one dispatch gap fewer per outer iteration.  The optimiser's registers become
-// the accumulate kernel's (one wave per SIMD instead of two), which a large batch cannot afford (DESIGN.md 6a viii)
-// and a small one does not notice.  Same code, same sums, same order: bit-identical to the separate controller.
-__device__ __forceinline__ void accumulate_then_control(PairDev* pairs, int pair, const double* __restrict__ partials,
-                                                        const RunParams& rp, int* n_active) {
-  __shared__ int s_last;
-  __threadfence();                                  // this block's partial sums are visible before its ticket
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int ticket = atomicAdd(&pairs[pair].blocks_done, 1);
-    s_last = ticket == (int)gridDim.x - 1;
-    if (s_last) pairs[pair].blocks_done = 0;        // (for the next outer iteration; nobody else touches it now)
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  icp_control_pair(pairs[pair], partials + (size_t)pair * kAccumVB * GQ_NACC, rp, n_active);
-}
-
 // GICP: Mahalanobis matrix + 73-term quadratic form (s3d_core.h "GICP quadratic form")
-template <bool CTRL>
-__global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(PairDev* __restrict__ pairs_rw,
+__global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairDev* __restrict__ pairs,
                                                                       const SlotDev* __restrict__ slots,
                                                                       const CorrVec* __restrict__ sorted,
                                                                       const NormalRec* __restrict__ normals,
                                                                       const CorrVec* __restrict__ corr_q,
                                                                       const NormalRec* __restrict__ corr_n,
-                                                                      double* __restrict__ partials, RunParams rp,
-                                                                      int* __restrict__ n_active) {
-  const PairDev* __restrict__ pairs = pairs_rw;
+                                                                      double* __restrict__ partials, RunParams rp) {
   const PairDev& P = pairs[blockIdx.y];
   if (!P.active) return;
   const SlotDev& St = slots[P.slot_t];
@@ -1529,10 +1705,7 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(PairDev* __
     return u;
   };
   int v = next_nonempty(blockIdx.x);
-  if (v >= kAccumVB) {
-    if (CTRL) accumulate_then_control(pairs_rw, blockIdx.y, partials, rp, n_active);
-    return;
-  }
+  if (v >= kAccumVB) return;
   int tile = vb_tile_begin(v, ntiles);
   int i = tile * kBlock + threadIdx.x;
   CorrVec p0 = corr_vec(make_float4(0.f, 0.f, 0.f, 0.f)), qf = p0;
@@ -1581,20 +1754,16 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(PairDev* __
     v = vn;
     if (v < kAccumVB) tile = vb_tile_begin(v, ntiles);
   }
-  if (CTRL) accumulate_then_control(pairs_rw, blockIdx.y, partials, rp, n_active);
 }
 
 
 // point-to-plane: J^T J (21) + J^T r (6) + r^2 + count
-template <bool CTRL>
-__global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(PairDev* __restrict__ pairs_rw,
+__global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(const PairDev* __restrict__ pairs,
                                                                          const SlotDev* __restrict__ slots,
                                                                          const CorrVec* __restrict__ sorted,
                                                                          const CorrVec* __restrict__ corr_q,
                                                                          const NormalRec* __restrict__ corr_n,
-                                                                         double* __restrict__ partials, RunParams rp,
-                                                                         int* __restrict__ n_active) {
-  const PairDev* __restrict__ pairs = pairs_rw;
+                                                                         double* __restrict__ partials, RunParams rp) {
   const PairDev& P = pairs[blockIdx.y];
   if (!P.active) return;
   const SlotDev& St = slots[P.slot_t];
@@ -1628,7 +1797,6 @@ __global__ void __launch_bounds__(kBlock) s3d_p2plane_accumulate_kernel(PairDev*
     block_reduce_store_fixed<PP_NACC>(acc, out + (size_t)v * GQ_NACC, parity);
     parity ^= 1;
   }
-  if (CTRL) accumulate_then_control(pairs_rw, blockIdx.y, partials, rp, n_active);
 }
 
 // final_transformation_ = previous_transformation_ * guess

@@ -219,6 +219,34 @@ def test_knn_normals_large_k(gpu_ctx, oracle_mod, fixture_clouds):
     assert sg == 7
 
 
+def test_omp_enumerators_follow_the_build_switch(gpu_ctx, oracle_mod):
+    """GICP_OMP / NDT_OMP (PointCloudSensor.cpp:149-162): a reference built with pclomp runs them - here the GICP / NDT
+    code, the same objectives - and one built without throws std::runtime_error("OMP is not available, ...") AFTER the
+    voxel filter and the 100-point gate.  The switch is explicit on both sides: s3d_exec_options.omp_unavailable and
+    oracle.set_omp_available; default = the pclomp build."""
+    import slam3d_amd as s3d
+    src, tgt, _ = s3d.make_pair(6000, 11)
+    for alg_omp, alg in ((s3d.ALG_GICP_OMP, s3d.ALG_GICP), (s3d.ALG_NDT_OMP, s3d.ALG_NDT)):
+        prm = dict(point_cloud_density=0.2, maximum_iterations=5)
+        ref = gpu_ctx.align(src, tgt, np.eye(4), s3d.default_params(registration_algorithm=alg, **prm))
+        got = gpu_ctx.align(src, tgt, np.eye(4), s3d.default_params(registration_algorithm=alg_omp, **prm))
+        assert got[0] == ref[0] and np.array_equal(got[1], ref[1])                     # served by the same code
+        off = s3d.ExecOptions(omp_unavailable=1)
+        st, _, _ = gpu_ctx.align(src, tgt, np.eye(4), s3d.default_params(registration_algorithm=alg_omp, **prm), off)
+        st_few, _, _ = gpu_ctx.align(src[:60], tgt[:60], np.eye(4), s3d.default_params(registration_algorithm=alg_omp, **prm), off)
+        st_plain, _, _ = gpu_ctx.align(src, tgt, np.eye(4), s3d.default_params(registration_algorithm=alg, **prm), off)
+        oracle_mod.set_omp_available(False)
+        try:
+            so = oracle_mod.align(src, tgt, np.eye(4), oracle_mod.default_params(registration_algorithm=alg_omp, **prm))[0]
+            so_few = oracle_mod.align(src[:60], tgt[:60], np.eye(4), oracle_mod.default_params(registration_algorithm=alg_omp, **prm))[0]
+        finally:
+            oracle_mod.set_omp_available(True)
+        assert st == so == 9 and st_few == so_few == 1 and st_plain == ref[0], (st, so, st_few, so_few)
+    rec = gpu_ctx.align_batch([gpu_ctx.upload(src)], [gpu_ctx.upload(tgt)], None,
+                              s3d.default_params(registration_algorithm=s3d.ALG_GICP_OMP), s3d.ExecOptions(omp_unavailable=1))
+    assert rec[0, 15] == 9
+
+
 def test_check_interval_does_not_change_results(gpu_ctx, fixture_clouds):
     """s3d_exec_options.check_interval (how often the host polls "all pairs converged"; 0 = default 4) is a polling
     cadence only: converged pairs stop iterating on the device at once, whatever the interval."""

@@ -247,3 +247,15 @@ def test_cpp_create_constraints_sweep_equals_sequential_create_constraint(fixtur
         assert len(seq) == 5 and seq == swp, devices          # (0,1) (0,2) (1,2) (1,3) (2,3)
         assert sum("NoMatch" in l for l in seq) <= 2           # scans two apart move ~1.4 m: the 1 m gate may reject them
         assert "NoMatch" not in seq[0] and "NoMatch" not in seq[2] and "NoMatch" not in seq[4]
+        # loop = true (ScanSensor::link's call): the coarse sweep feeds the fine one, equal to createConstraint(..., true)
+        seql = [l.split(" ", 1)[1] for l in out if l.startswith("sequential_loop ")]
+        swpl = [l.split(" ", 1)[1] for l in out if l.startswith("sweep_loop ")]
+        assert len(seql) == 5 and seql == swpl, devices
+        assert sum("NoMatch" in l for l in seql) <= sum("NoMatch" in l for l in seq)   # the coarse stage can only help
+        # sweep clouds of measurements that no longer exist are released (they used to accumulate)
+        kept = [l.split() for l in out if l.startswith("sweep_clouds ")][0]
+        with_patches = [l.split() for l in out if l.startswith("sweep_clouds_with_patches ")][0]
+        assert int(with_patches[1]) == int(kept[1]) + 2 * (len(files) - 1) and int(kept[2]) == int(kept[1]), (kept, with_patches)
+        # a reference built without pclomp throws for GICP_OMP (PointCloudSensor.cpp:159-161)
+        assert [l for l in out if l.startswith("omp ")] == [
+            "omp OMP is not available, you need to rebuild SLAM3D with OMP or use another matching algorithm."]

@@ -105,3 +105,51 @@ def test_sweep_candidates_deduplicates_both_directions():
     for s, t in c:
         assert np.linalg.norm(g.pose[s][:3, 3] - g.pose[t][:3, 3]) < 3.5
         assert g.calculate_graph_distance(s, t) >= 10
+
+
+def _c_abi_candidates(g, vertex, pol):
+    """The same query through the C ABI (s3d_link_candidates, include/slam3d_hip.h): vertices by insertion index."""
+    from slam3d_amd import api
+    idx = {v: k for k, v in enumerate(g.ids)}
+    pos = np.array([g.pose[v][:3, 3] for v in g.ids])
+    edges = [(idx[u], idx[t], int(ty == SE3), int(s == pol.name)) for u in g.ids for t, s, ty in g.out[u]]
+    linkable = [int(g.sensor[v] in pol.link_sensors) for v in g.ids]
+    src = api.link_candidates(pos, edges, idx[vertex], pol.neighbor_radius, pol.max_neighbor_links, pol.min_loop_length,
+                              pol.patch_building_range, linkable)
+    return [(g.ids[s], vertex) for s in src]
+
+
+def test_c_abi_link_candidates_equal_the_python_restatement():
+    """s3d_link_candidates (C ABI, host code of libslam3d_hip.so, no GPU involved) against posegraph.link_candidates on
+    the loop graph with other-sensor / tentative / removed edges and on random graphs: same candidates, same order."""
+    n = 40
+    g = loop_graph(n, 10.0, extra=[(3, 30, "gps", "GPS"), (5, 25, "velodyne", TENTATIVE), (12, 39, "velodyne", SE3)])
+    g.remove_edge(39, 12, "velodyne")          # removeEdge drops ONE direction: 12 -> 39 is still stored
+    g.add_vertex(100, pose(9.5, 0.5), sensor="camera")
+    for pol in (LinkPolicy(neighbor_radius=3.5, max_neighbor_links=5, min_loop_length=10),
+                LinkPolicy(neighbor_radius=25.0, max_neighbor_links=100, min_loop_length=4, patch_building_range=3),
+                LinkPolicy(neighbor_radius=6.0, max_neighbor_links=2, min_loop_length=0),
+                LinkPolicy(neighbor_radius=6.0, max_neighbor_links=0),
+                LinkPolicy(neighbor_radius=8.0, max_neighbor_links=9, link_sensors={"velodyne", "camera"})):
+        for v in (39, 20, 12, 0, 100):
+            assert _c_abi_candidates(g, v, pol) == link_candidates(g, v, pol), (v, vars(pol))
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        m = int(rng.integers(5, 60))
+        r = PoseGraph()
+        for i in range(m):
+            r.add_vertex(i, pose(*rng.uniform(-6, 6, 2)), sensor=["velodyne", "cam"][int(rng.integers(0, 4) == 0)])
+        for i in range(m - 1):
+            if rng.random() < 0.9:
+                r.add_edge(i, i + 1, "velodyne", SE3)
+        for _ in range(m // 3):
+            a, b = rng.integers(0, m, 2)
+            if a != b:
+                r.add_edge(int(a), int(b), ["velodyne", "gps"][int(rng.integers(0, 2))], [SE3, "GPS", TENTATIVE][int(rng.integers(0, 3))])
+        pol = LinkPolicy(neighbor_radius=float(rng.uniform(1, 8)), max_neighbor_links=int(rng.integers(1, 6)),
+                         min_loop_length=int(rng.integers(0, 8)), patch_building_range=int(rng.integers(0, 3)))
+        for v in rng.integers(0, m, 6):
+            assert _c_abi_candidates(r, int(v), pol) == link_candidates(r, int(v), pol), (trial, int(v))
+    with pytest.raises(ValueError):
+        from slam3d_amd import api
+        api.link_candidates(np.zeros((3, 3)), [(0, 7, 1, 1)], 0)
