@@ -290,9 +290,39 @@ def main():
             single["other_algorithm"] = {"algorithm": "icp (point-to-plane)" if other == s3d.ALG_ICP else "gicp",
                                          "ms_per_step": round(ms2, 3),
                                          "registrations_per_s": round(args.pairs / ms2 * 1e3, 2)}
+        # ---- N > 1: the same sweep through the C ABI in ONE process (s3d_align_batch_multi: one rank = context + host
+        # thread per device, RCCL all-gather of the records) - the layout a C++ ScanSensor::linkToNeighbors binds
+        # (INTEGRATION.md).  Run by rank 0 after the timed region while the other ranks wait at the final barrier;
+        # with fewer GPUs than ranks the device list repeats devices and the gather is device-to-device copies.
+        sweep_abi = None
+        if world > 1:
+            try:
+                ndev_all = max(torch.cuda.device_count(), 1)
+                devs = [r % ndev_all for r in range(world)]
+                sw = s3d.Sweep(devs)
+                s_src = [sw.upload(p[0]) for p in pairs]
+                s_tgt = [sw.upload(p[1]) for p in pairs]
+                n_all = world * args.pairs                       # every rank's block: the pair list of rank 0 again
+                g_all = np.tile(np.eye(4), (n_all, 1, 1))
+                sw.align_batch(s_src * world, s_tgt * world, g_all, params, opts)          # uploads + warm-up
+                reps = 2
+                ts = time.perf_counter()
+                for _ in range(reps):
+                    rec_sw = sw.align_batch(s_src * world, s_tgt * world, g_all, params, opts)
+                ms_sw = (time.perf_counter() - ts) / reps * 1e3
+                sweep_abi = {"entry_point": "s3d_align_batch_multi (one process, one rank per device)",
+                             "ranks": sw.ranks, "devices": devs, "collective": sw.collective, "pairs": n_all,
+                             "ms_per_sweep": round(ms_sw, 3), "registrations_per_s": round(n_all / ms_sw * 1e3, 2),
+                             "equals_single_context": bool(np.array_equal(rec_sw[:args.pairs], rec_local[:args.pairs])),
+                             "note": "not the driver's metric: measured after the timed region, other ranks idle"}
+                sw.close()
+            except Exception as e:   # never let the secondary measurement take the contract line down
+                sweep_abi = {"error": str(e)[:200]}
         # ---- CPU baseline: the oracle (a port of the reference path), one thread, same inputs/iterations
         cpu = None
         cpu_par = None
+        cpu_pcl = None
+        pcl_state = "not checked"
         if not args.no_cpu and world == 1:
             import oracle
             op = oracle.default_params(registration_algorithm=alg, point_cloud_density=args.density,
@@ -316,6 +346,15 @@ def main():
                 cpu_par = {"value": round(nthr / tpar, 3), "unit": "registrations/s", "cores": nthr, "kind": "port",
                            "sample": "%d pairs of this workload registered concurrently, one oracle thread each, %.1f s"
                                      % (nthr, tpar)}
+            # the reference's own arithmetic, where this host has PCL (oracle/pcl, built by __graft_entry__.build())
+            from oracle import pcl_pin
+            pcl_state = pcl_pin.status()
+            if pcl_state != "absent":
+                pb = pcl_pin.bench(pairs[0][0], pairs[0][1], args.density, args.iters, reps=2)
+                if pb:
+                    cpu_pcl = {"value": round(pb["registrations_per_s"], 4), "unit": "registrations/s", "cores": 1,
+                               "kind": "reference", "sample": "pair 0 of this workload through pcl::GeneralizedIterative"
+                               "ClosestPoint (oracle/pcl/pcl_gicp bench), %d repetitions" % pb.get("reps", 2)}
             cpu = {"value": round(1.0 / float(np.median(times)), 4), "unit": "registrations/s", "cores": 1,
                    "kind": "port",
                    "sample": "%d of the %d pairs of this workload, oracle/s3d_oracle.c align() (kd-tree + "
@@ -343,8 +382,11 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "cpu_baseline_parallel": cpu_par,
+            "cpu_baseline_pcl": cpu_pcl,
+            "pcl": pcl_state,
             "single_pair": single,
             "mapper_pattern": mapper,
+            "sweep_abi": sweep_abi,
             "step_ms": step_ms,
             "stage_ms": {k: round(v, 3) for k, v in prof.items() if k.endswith("_ms") and k != "nn_launch_ms"},
             "nn_launch_ms": prof["nn_launch_ms"],

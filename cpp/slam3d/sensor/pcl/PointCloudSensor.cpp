@@ -50,7 +50,10 @@ PointCloudSensor::PointCloudSensor(const std::string& n, Logger* l, int device) 
   mMapOutlierNeighbors = 3;
   if (s3d_abi_version() != S3D_ABI_VERSION)
     throw std::runtime_error("slam3d (MI355X build): libslam3d_hip.so does not match the headers this mirror was built with");
-  if (s3d_context_create(device, nullptr, &mContext) != S3D_STATUS_OK)
+  // createConstraint - the application thread's blocking call per new scan (ScanSensor.cpp:113) - runs on a HIGH-priority
+  // context: the detached linkToNeighbors thread (:209-210) sweeps its candidates on the sweep's own contexts
+  // (createConstraints), and the dispatcher takes this context's kernels before their queued blocks
+  if (s3d_context_create_priority(device, 1, &mContext) != S3D_STATUS_OK)
     throw std::runtime_error("slam3d (MI355X build): no usable HIP device, and there is no CPU fallback");
   mContextHolder = std::make_shared<ContextHolder>(mContext);
 }

@@ -81,6 +81,12 @@ typedef struct s3d_profile {      /* milliseconds, HIP events on the context's s
 /* ---- context ------------------------------------------------------------------ */
 /* hip_stream: a hipStream_t to run on (e.g. torch's current stream) or NULL for a private stream. */
 int  s3d_context_create(int device, void* hip_stream, s3d_context** out);
+/* A context on a private stream of the given priority class: 0 = default, 1 = high.  The reference is entered from
+ * two threads at once (ScanSensor.cpp:209-210: the application thread registers every new scan against the previous
+ * one, a detached thread runs linkToNeighbors), and one s3d_context serialises its callers: the latency-critical
+ * sequential registration belongs on its own HIGH-priority context, so that the device's dispatcher takes its
+ * kernels before the queued blocks of a loop-closure batch running on another context.  Results do not depend on it. */
+int  s3d_context_create_priority(int device, int priority_class, s3d_context** out);
 void s3d_context_destroy(s3d_context* ctx);
 const char* s3d_last_error(const s3d_context* ctx);
 /* fills "name|gcnArch|CUs|HBM bytes"; returns S3D_STATUS_BACKEND_ERROR without a device */

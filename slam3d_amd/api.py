@@ -129,6 +129,7 @@ def load_library():
     sig = {
         "s3d_abi_version": (C.c_int, []),
         "s3d_context_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
+        "s3d_context_create_priority": (C.c_int, [C.c_int, C.c_int, C.POINTER(vp)]),
         "s3d_context_destroy": (None, [vp]),
         "s3d_last_error": (C.c_char_p, [vp]),
         "s3d_backend_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
@@ -258,10 +259,15 @@ class Cloud:
 class Context:
     """One HIP device + stream + workspace (s3d_context)."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, high_priority=False):
+        """high_priority: a private stream of the device's highest priority (s3d_context_create_priority) - for the
+        latency-critical sequential registration while a loop-closure batch runs on another context."""
         self._L = load_library()
         h = C.c_void_p()
-        st = self._L.s3d_context_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if high_priority and not stream:
+            st = self._L.s3d_context_create_priority(int(device), 1, C.byref(h))
+        else:
+            st = self._L.s3d_context_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
         if st != 0 or not h:
             raise BackendError("s3d_context_create failed: no usable HIP device %d (no CPU fallback)" % device)
         self._h = h

@@ -134,7 +134,7 @@ struct CacheEntry {
 
 struct s3d_context {
   std::map<CacheKey, CacheEntry> cache;
-  size_t cache_bytes = 0, cache_limit = (size_t)16 << 30;
+  size_t cache_bytes = 0, cache_limit = (size_t)16 << 30;   // (context_create lowers it to a quarter of the free HBM if that is less)
   unsigned long long cache_clock = 0;
   long long cache_hits = 0, cache_misses = 0;
   void cache_drop(std::map<CacheKey, CacheEntry>::iterator it) {
@@ -345,7 +345,7 @@ struct Batch {
   }
 
   // cached clouds to the back of the slot list (the staging kernels then cover the first Cu slots only)
-  void order_slots_for_cache() {
+  void order_slots_for_cache(bool need_sorted3) {
     const int n = C();
     Cu = n;
     slot_entry.assign((size_t)n, nullptr);
@@ -356,7 +356,8 @@ struct Batch {
     int hits = 0;
     for (int i = 0; i < n; ++i) {
       auto it = ctx->cache.find(cache_key(i));
-      if (it != ctx->cache.end()) { ent[i] = &it->second; it->second.last_use = ctx->cache_clock; ++hits; }
+      // (an entry made by a map job has no xyz-only copy: a registration treats it as a miss and replaces it)
+      if (it != ctx->cache.end() && (it->second.has_sorted3 || !need_sorted3)) { ent[i] = &it->second; it->second.last_use = ctx->cache_clock; ++hits; }
     }
     ctx->cache_hits += hits; ctx->cache_misses += n - hits;
     if (hits == 0) return;
@@ -419,6 +420,10 @@ struct Batch {
         }
         continue;
       }
+      {   // an entry this call could not use (no xyz-only copy: made by a map job) is replaced
+        auto stale = ctx->cache.find(cache_key(j));
+        if (stale != ctx->cache.end()) { HIPCHK(hipStreamSynchronize(st)); ctx->cache_drop(stale); }
+      }
       CacheEntry e;
       const size_t cells_n = (size_t)sl.g.ncells + 1;
       auto place = [&](size_t bytes) { const size_t o = e.bytes; e.bytes += (bytes + 255) & ~(size_t)255; return o; };
@@ -436,7 +441,9 @@ struct Batch {
         ctx->cache_drop(victim);
       }
       if (ctx->cache_bytes + e.bytes > ctx->cache_limit) continue;   // does not fit: stay uncached
-      HIPCHK(hipMalloc((void**)&e.block, e.bytes));
+      // best effort: the registration results are already on the host - a full (or shared) GPU must not turn an
+      // optional optimisation into a failed call
+      if (hipMalloc((void**)&e.block, e.bytes) != hipSuccess) { (void)hipGetLastError(); e.block = nullptr; continue; }
       if (n) {
         cp.push_back({filt() + sl.off, e.block + e.o_filt, 16 * n});
         cp.push_back({sorted() + sl.off, e.block + e.o_sorted, 16 * n});
@@ -456,7 +463,7 @@ struct Batch {
   }
 
   void allocate(bool icp_buffers = true) {
-    order_slots_for_cache();
+    order_slots_for_cache(icp_buffers);
     if (total_pts > (size_t)0x7FFFFFF0 || total_cells > (size_t)0x7FFFFFF0 || total_corr > (size_t)0x7FFFFFF0)
       throw HipError{hipErrorInvalidValue, "batch too large for 32-bit offsets", __LINE__};
     nb_sort = std::max(1, cdiv(max_n, kSortTile));
@@ -668,13 +675,21 @@ struct Batch {
     A.corr_q = (CorrVec*)ctx->corr_q.p; A.corr_n = (NormalRec*)ctx->corr_n.p;
     return A;
   }
-  void launch_nn(int mode, float max_d, int prof_slot = -1, bool compact = false) {
+  // it: outer iteration (0-based) of an ICP-loop pass, -1 otherwise.  The first pass has a kernel of its own
+  // (s3d_nn_first_kernel); S3D_DBG_NN bit 262144 = the one kernel for every pass (A/B; the bits that switch the
+  // re-validation or the seeds off imply it).
+  void launch_nn(int mode, float max_d, int prof_slot = -1, bool compact = false, int it = -1) {
     hipStream_t st = ctx->stream;
     const int chunks = cdiv(std::max(max_n_t, 1), kBlock);
     const int pairs8 = P() >= 8 ? cdiv(P(), 8) * 8 : P();
     dim3 grid((unsigned)(pairs8 * chunks));
     NNArrays A = nn_arrays();
     int* pc = (prof_slot >= 0 && prof_slot < 64) ? (int*)ctx->n_active.p + 16 + 2 * prof_slot : nullptr;
+    const bool family = mode == 0 && it >= 0 && !(dbg_nn & (262144 | 64 | 32 | 4));
+    if (family && it == 0) {
+      s3d_nn_first_kernel<<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc);
+      return;
+    }
     const int cmp = (compact && mode == 0 && !(dbg_nn & 65536)) ? 1 : 0;
     if (mode == 0)
       s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc, cmp);
@@ -685,7 +700,7 @@ struct Batch {
   // one outer iteration: correspondences (K5), accumulate (K6), controller (K7)
   void launch_iteration(int it, float max_d, int prof_slot) {
     // passes 3-5: a third of the lanes still search, scattered over all waves -> block-compacting variant
-    launch_nn(0, max_d, prof_slot, it >= 2 && it <= 4);   // (the counters cost two atomics per searching wave)
+    launch_nn(0, max_d, prof_slot, it >= 2 && it <= 4, it);   // (the counters cost two atomics per searching wave)
     launch_iteration_after_nn();
   }
   void launch_iteration_after_nn() {
@@ -724,7 +739,7 @@ struct Batch {
             ctx->nn_ev.push_back(a); ctx->nn_ev.push_back(b);
           }
           HIPCHK(hipEventRecord(ctx->nn_ev[2 * it], st));
-          launch_nn(0, max_d, opts.profile >= 2 ? it : -1, it >= 2 && it <= 4);
+          launch_nn(0, max_d, opts.profile >= 2 ? it : -1, it >= 2 && it <= 4, it);
           HIPCHK(hipEventRecord(ctx->nn_ev[2 * it + 1], st));
           launch_iteration_after_nn();
         } else {
@@ -1307,7 +1322,13 @@ int s3d_backend_info(int device, char* buf, int len) {
   return S3D_STATUS_OK;
 }
 
-int s3d_context_create(int device, void* hip_stream, s3d_context** out) {
+static int context_create(int device, void* hip_stream, int priority_class, s3d_context** out);
+int s3d_context_create(int device, void* hip_stream, s3d_context** out) { return context_create(device, hip_stream, 0, out); }
+int s3d_context_create_priority(int device, int priority_class, s3d_context** out) {
+  if (priority_class < 0 || priority_class > 1) return S3D_STATUS_INVALID_ARGUMENT;
+  return context_create(device, nullptr, priority_class, out);
+}
+static int context_create(int device, void* hip_stream, int priority_class, s3d_context** out) {
   if (!out) return S3D_STATUS_INVALID_ARGUMENT;
   *out = nullptr;
   int count = 0;
@@ -1320,8 +1341,18 @@ int s3d_context_create(int device, void* hip_stream, s3d_context** out) {
     if (hip_stream) {
       ctx->stream = (hipStream_t)hip_stream;
     } else {
-      HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+      if (priority_class > 0) {
+        int least = 0, greatest = 0;     // (numerically lower = higher priority)
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest));
+      } else {
+        HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+      }
       ctx->own_stream = true;
+    }
+    {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 4 < ctx->cache_limit) ctx->cache_limit = free_b / 4;
     }
     if (const char* pre = getenv("S3D_ARENA_PREALLOC_MB")) {   // experiment: reserve the workspace before any cloud upload
       const size_t want = (size_t)atoll(pre) << 20;
@@ -1387,7 +1418,7 @@ int s3d_context_cache_control(s3d_context* ctx, long long limit_bytes, int clear
 // ---- the cached pre-pass products of one cloud as a host blob (checkpoints: GraphSerialization.cpp:14-66 writes one
 // <index>.s3dm per vertex; a caller can put this blob next to it and hand it back after fromFolder, :68-135)
 namespace {
-constexpr uint32_t kBlobMagic = 0x42443353u, kBlobEntryMagic = 0x45443353u, kBlobVersion = 1u;   // "S3DB", "S3DE"
+constexpr uint32_t kBlobMagic = 0x42443353u, kBlobEntryMagic = 0x45443353u, kBlobVersion = 2u;   // "S3DB", "S3DE"; 2: payload hash per entry
 struct BlobHeader { uint32_t magic, version, entries, n_raw; unsigned long long points_hash; };
 struct BlobEntry {
   uint32_t magic, leaf_bits, h0_bits; int cell_cap;
@@ -1396,6 +1427,7 @@ struct BlobEntry {
   s3d::VoxelParams vp;
   s3d::GridParams g;
   unsigned long long payload_bytes;   // filt 16 n | sorted 16 n | sorted3 sizeof(CorrVec) n | normals 16 n | cells 4 (ncells + 1)
+  unsigned long long payload_hash;    // FNV-1a of those bytes: a damaged checkpoint is refused, not installed
 };
 unsigned long long fnv1a64(const void* data, size_t bytes) {
   const unsigned char* p = (const unsigned char*)data;
@@ -1438,8 +1470,10 @@ long long s3d_cloud_cache_export(s3d_context* ctx, const s3d_cloud* cloud, void*
     H.magic = kBlobMagic; H.version = kBlobVersion; H.entries = entries; H.n_raw = (uint32_t)cloud->n;
     H.points_hash = cloud_points_hash(ctx, cloud);
     std::memcpy(out, &H, sizeof H); out += sizeof H;
+    std::vector<char*> entry_at;
     for (auto it = first; it != ctx->cache.end() && it->first.uid == cloud->uid; ++it) {
       const CacheEntry& e = it->second;
+      entry_at.push_back(out);
       const size_t n = (size_t)e.snap.n, cells_n = (size_t)e.snap.g.ncells + 1;
       BlobEntry E;
       std::memset(&E, 0, sizeof E);
@@ -1459,6 +1493,12 @@ long long s3d_cloud_cache_export(s3d_context* ctx, const s3d_cloud* cloud, void*
       }
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (char* at : entry_at) {     // the payloads have arrived: their hashes into the entry headers
+      BlobEntry E;
+      std::memcpy(&E, at, sizeof E);
+      E.payload_hash = fnv1a64(at + sizeof E, (size_t)E.payload_bytes);
+      std::memcpy(at, &E, sizeof E);
+    }
     return (long long)need;
   } catch (const HipError& e) {
     return fail(ctx, e);
@@ -1489,6 +1529,31 @@ int s3d_cloud_cache_import(s3d_context* ctx, const s3d_cloud* cloud, const void*
         ctx->err = "cache blob: corrupt entry";
         return S3D_STATUS_INVALID_ARGUMENT;
       }
+      // the payload is what the kernels will index with: its checksum, then the invariants they rely on (a cell
+      // table that is monotone and ends at n, grid dimensions that multiply to the cell count, sorted positions that
+      // name points of the cloud) - a blob that fails any of them is refused as a whole
+      bool ok = fnv1a64(scan, (size_t)E.payload_bytes) == E.payload_hash &&
+                (long long)E.g.dim[0] * E.g.dim[1] * E.g.dim[2] == (long long)E.ncells && E.g.dim[0] > 0 && E.g.dim[1] > 0 &&
+                E.g.dim[2] > 0;
+      if (ok) {
+        const size_t n = (size_t)E.n;
+        const char* sorted_at = scan + 16 * n;
+        const char* cells_at = scan + n * (16 + 16 + sizeof(CorrVec) + sizeof(NormalRec));
+        uint32_t prev = 0;
+        for (size_t c = 0; ok && c <= (size_t)E.ncells; ++c) {
+          uint32_t v;
+          std::memcpy(&v, cells_at + 4 * c, 4);
+          ok = v >= prev && v <= (uint32_t)E.n && (c > 0 || v == 0);
+          prev = v;
+        }
+        ok = ok && prev == (uint32_t)E.n;
+        for (size_t k = 0; ok && k < n; ++k) {
+          uint32_t w;
+          std::memcpy(&w, sorted_at + 16 * k + 12, 4);
+          ok = w < (uint32_t)E.n;
+        }
+      }
+      if (!ok) { ctx->err = "cache blob: damaged payload (checksum / cell table / indices)"; return S3D_STATUS_INVALID_ARGUMENT; }
       scan += E.payload_bytes;
     }
     ++ctx->cache_clock;
@@ -1505,7 +1570,7 @@ int s3d_cloud_cache_import(s3d_context* ctx, const s3d_cloud* cloud, const void*
       e.o_normals = place(sizeof(NormalRec) * n); e.o_cells = place(4 * cells_n);
       e.bytes = std::max<size_t>(e.bytes, 256);
       if (ctx->cache_bytes + e.bytes > ctx->cache_limit) { in += E.payload_bytes; continue; }   // over the budget: stays uncached
-      HIPCHK(hipMalloc((void**)&e.block, e.bytes));
+      if (hipMalloc((void**)&e.block, e.bytes) != hipSuccess) { (void)hipGetLastError(); in += E.payload_bytes; continue; }
       const size_t parts[5][2] = {{e.o_filt, 16 * n}, {e.o_sorted, 16 * n}, {e.o_sorted3, sizeof(CorrVec) * n},
                                   {e.o_normals, sizeof(NormalRec) * n}, {e.o_cells, 4 * cells_n}};
       for (int a = 0; a < 5; ++a) {

@@ -1266,7 +1266,8 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   // found a neighbour (> 0) or none within max_d (< 0); 0: nothing is known.  The re-validation needs nothing else of
   // the history - the previous distance (the radius hint of a search) is loaded only by the lanes that still search,
   // four bytes per query less on the streaming passes.
-  const float lbs = A.corr_lb[ci];
+  // PHASE 5 (the first pass of a registration, s3d_nn_first_kernel): nothing is known, nothing is loaded
+  const float lbs = PHASE == 5 ? 0.f : A.corr_lb[ci];
   const float lb = fabsf(lbs);
   float move = 3.0e38f;                          // how far this query moved since the previous pass (if known)
   if (need && lbs != 0.f && !(dbg & 64)) {
@@ -1292,7 +1293,7 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
     }
   }
   // radius hint: this query's distance in the previous pass (NaN-filled before the first one)
-  const float prev = need ? A.corr_d2[ci] : 0.f;
+  const float prev = PHASE == 5 ? __int_as_float(0x7FC00000) : (need ? A.corr_d2[ci] : 0.f);
   if (PHASE == 3) {   // classify only: 0 = near seed, 1 = wide, 2 = nothing to do (block-level compaction follows)
     const bool near_c = need && prev >= 0.f && prev < 1.0e30f && prev < Ss.g.h * Ss.g.h;
     *out_class = need ? (near_c ? 0 : 1) : 2;
@@ -1421,6 +1422,28 @@ __global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_search_kernel(con
   const bool need = (int)threadIdx.x < n0 + n1;
   const int j = chunk * kBlock + (need ? order[threadIdx.x] : 0);
   nn_query<MODE, 2>(P, St, Ss, pair, j, need, A, max_d, dbg, prof_counts);
+}
+
+// ---- the FIRST pass of a registration has a kernel of its own (round 3): no history to load, no re-validation, no
+// seeds - nn_query<0, 5>.  Inside the one kernel above the same path cost every other pass a register re-roll
+// (DESIGN.md 6a x); as a separate __global__ it takes 0.13 ms off the first pass of 128 pairs and touches nothing
+// else.  S3D_DBG_NN bit 262144 switches it off (A/B).
+// Measured and dropped: the settled passes as a 24-VGPR stream kernel of the re-validation alone plus a worklist
+// kernel for the ~13 queries per pair whose proof fails in every pass - the stream is bound by its 32 bytes per query
+// (4.1 TB/s with either kernel), and the second launch costs more than the search code in the stream did.
+__global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_first_kernel(const PairDev* __restrict__ pairs,
+                                                               const SlotDev* __restrict__ slots, NNArrays A,
+                                                               float max_d, int chunks_per_pair, int npairs, int dbg,
+                                                               int* __restrict__ prof_counts) {
+  int pair, chunk;
+  nn_block_map(chunks_per_pair, npairs, &pair, &chunk);
+  if (pair >= npairs) return;
+  const PairDev& P = pairs[pair];
+  if (!P.active) return;
+  const SlotDev& St = slots[P.slot_t];
+  const int i = chunk * kBlock + threadIdx.x;
+  if (chunk * kBlock >= St.n) return;
+  nn_query<0, 5>(P, St, slots[P.slot_s], pair, i, i < St.n, A, max_d, dbg, prof_counts);
 }
 
 // API export (s3d_nn_search / s3d_knn_normals): back from cell-sorted order to the caller's point order

@@ -19,11 +19,13 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
+#include <functional>
 #include <thread>
 
 struct s3d_sweep_cloud {
-  std::vector<float> xyz;             // host copy (stride floats per point): uploaded to a rank on first use
-  int n = 0, stride = 3;
+  float* xyz = nullptr;               // PINNED host copy (stride floats per point): uploaded to a rank on first use
+  int n = 0, stride = 3;              // by DMA straight from here (a pageable copy goes through a staging bounce)
   std::vector<s3d_cloud*> dev;        // per rank, nullptr until a pair of that rank's block references the cloud
 };
 
@@ -55,7 +57,50 @@ struct RcclApi {
 
 }  // namespace
 
+// the host thread of a rank: started once with the sweep and kept between calls (a sweep of a few hundred short
+// registrations should not pay thread creation and the first-touch of a new thread's HIP state every time)
+struct RankWorker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false, stop = false, done = true;
+  void start() {
+    th = std::thread([this] {
+      std::unique_lock<std::mutex> lk(m);
+      for (;;) {
+        cv.wait(lk, [this] { return has_job || stop; });
+        if (stop) return;
+        std::function<void()> j = std::move(job);
+        has_job = false;
+        lk.unlock();
+        j();
+        lk.lock();
+        done = true;
+        cv.notify_all();
+      }
+    });
+  }
+  void post(std::function<void()> j) {
+    std::lock_guard<std::mutex> lk(m);
+    job = std::move(j); has_job = true; done = false;
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [this] { return done; });
+  }
+  void shutdown() {
+    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+  }
+};
+
 struct s3d_sweep {
+  std::vector<std::unique_ptr<RankWorker>> workers;   // one per rank (none for a single rank: the caller's thread)
+  std::vector<s3d_edge_record*> stage;                // pinned staging of a rank's records
+  std::vector<size_t> stage_cap;
   std::vector<int> devices;           // rank -> HIP device
   std::vector<s3d_context*> ctx;      // one context (stream + workspace) per rank
   std::vector<hipStream_t> coll;      // the stream the collective of a rank runs on
@@ -81,6 +126,8 @@ void s3d_sweep_shard_range(int n_pairs, int n_ranks, int rank, int* lo, int* hi)
 
 void s3d_sweep_destroy(s3d_sweep* sw) {
   if (!sw) return;
+  for (auto& w : sw->workers) if (w) w->shutdown();
+  for (s3d_edge_record* p : sw->stage) if (p) (void)hipHostFree(p);
   for (int r = 0; r < sw->R(); ++r) {
     (void)hipSetDevice(sw->devices[r]);
     if (r < (int)sw->comms.size() && sw->comms[r]) (void)sw->rccl.CommDestroy(sw->comms[r]);
@@ -113,6 +160,9 @@ int s3d_sweep_create(int n_devices, const int* devices, s3d_sweep** out) {
   sw->ctx.assign(R, nullptr); sw->coll.assign(R, nullptr);
   sw->sendbuf.assign(R, nullptr); sw->recvbuf.assign(R, nullptr);
   sw->send_cap.assign(R, 0); sw->recv_cap.assign(R, 0);
+  sw->stage.assign(R, nullptr); sw->stage_cap.assign(R, 0);
+  if (R > 1)
+    for (int r = 0; r < R; ++r) { sw->workers.emplace_back(new RankWorker()); sw->workers.back()->start(); }
   for (int r = 0; r < R; ++r) {
     if (s3d_context_create(sw->devices[r], nullptr, &sw->ctx[r]) != S3D_STATUS_OK ||
         hipSetDevice(sw->devices[r]) != hipSuccess ||
@@ -156,7 +206,14 @@ int s3d_sweep_cloud_create(s3d_sweep* sw, const float* xyz, int n, int stride, s
   if (!sw || !out || n < 0 || stride < 3 || (n > 0 && !xyz)) return S3D_STATUS_INVALID_ARGUMENT;
   s3d_sweep_cloud* c = new s3d_sweep_cloud();
   c->n = n; c->stride = stride;
-  if (n > 0) c->xyz.assign(xyz, xyz + ((size_t)(n - 1) * stride + 3));
+  if (n > 0) {
+    // n * stride floats (the upload of stride-4 points copies whole 16-byte records), the caller's last point may
+    // end after its third float
+    const size_t count = (size_t)(n - 1) * stride + 3, full = (size_t)n * stride;
+    if (hipHostMalloc((void**)&c->xyz, full * sizeof(float)) != hipSuccess) { delete c; return S3D_STATUS_BACKEND_ERROR; }
+    std::memcpy(c->xyz, xyz, count * sizeof(float));
+    for (size_t k = count; k < full; ++k) c->xyz[k] = 0.f;
+  }
   c->dev.assign(sw->R(), nullptr);
   *out = c;
   return S3D_STATUS_OK;
@@ -169,6 +226,7 @@ void s3d_sweep_cloud_release(s3d_sweep* sw, s3d_sweep_cloud* c) {
     for (int r = 0; r < sw->R() && r < (int)c->dev.size(); ++r)
       if (c->dev[r]) s3d_cloud_release(sw->ctx[r], c->dev[r]);
   }
+  if (c->xyz) (void)hipHostFree(c->xyz);
   delete c;
 }
 
@@ -210,15 +268,21 @@ int s3d_align_batch_multi(s3d_sweep* sw, int n_pairs, s3d_sweep_cloud* const* so
       if (!hipok(hipMalloc(&sw->recvbuf[r], (size_t)per * R * rec_bytes), "hipMalloc(recv)")) return;
       sw->recv_cap[r] = (size_t)per * R * rec_bytes;
     }
-    std::vector<s3d_edge_record> local((size_t)per);
-    std::memset(local.data(), 0, local.size() * rec_bytes);          // padding of a short block
+    if (sw->stage_cap[r] < (size_t)per) {
+      if (sw->stage[r]) (void)hipHostFree(sw->stage[r]);
+      sw->stage[r] = nullptr; sw->stage_cap[r] = 0;
+      if (!hipok(hipHostMalloc((void**)&sw->stage[r], (size_t)per * rec_bytes), "hipHostMalloc(records)")) return;
+      sw->stage_cap[r] = (size_t)per;
+    }
+    s3d_edge_record* local = sw->stage[r];
+    std::memset(local, 0, (size_t)per * rec_bytes);                  // padding of a short block
     if (m > 0) {
       std::vector<s3d_cloud*> src((size_t)m), tgt((size_t)m);
       for (int p = 0; p < m; ++p) {
         s3d_sweep_cloud* pair_clouds[2] = {sources[lo + p], targets[lo + p]};
         for (s3d_sweep_cloud* c : pair_clouds) {
           if (!c->dev[r]) {   // first use on this GPU: upload (only this rank's thread touches dev[r])
-            const int st = s3d_cloud_upload(sw->ctx[r], c->xyz.data(), c->n, c->stride, &c->dev[r]);
+            const int st = s3d_cloud_upload(sw->ctx[r], c->xyz, c->n, c->stride, &c->dev[r]);
             if (st != S3D_STATUS_OK) { status[r] = st; errs[r] = s3d_last_error(sw->ctx[r]); return; }
           }
         }
@@ -226,23 +290,22 @@ int s3d_align_batch_multi(s3d_sweep* sw, int n_pairs, s3d_sweep_cloud* const* so
         tgt[p] = targets[lo + p]->dev[r];
       }
       const int st = s3d_align_batch(sw->ctx[r], m, src.data(), tgt.data(), guesses + (size_t)lo * 16, params, opts,
-                                     local.data(), nullptr);
+                                     local, nullptr);
       if (st != S3D_STATUS_OK) {   // (unknown algorithm: the records carry the status, as in s3d_align_batch)
         status[r] = st;
         if (st == S3D_STATUS_BACKEND_ERROR) { errs[r] = s3d_last_error(sw->ctx[r]); return; }
       }
       if (!hipok(hipSetDevice(sw->devices[r]), "hipSetDevice")) return;
     }
-    if (!hipok(hipMemcpyAsync(sw->sendbuf[r], local.data(), (size_t)per * rec_bytes, hipMemcpyHostToDevice, sw->coll[r]),
+    if (!hipok(hipMemcpyAsync(sw->sendbuf[r], local, (size_t)per * rec_bytes, hipMemcpyHostToDevice, sw->coll[r]),
                "hipMemcpyAsync(records)")) return;
-    (void)hipok(hipStreamSynchronize(sw->coll[r]), "hipStreamSynchronize");   // `local` is pageable
+    (void)hipok(hipStreamSynchronize(sw->coll[r]), "hipStreamSynchronize");   // (the next call reuses the staging)
   };
   if (R == 1) {
     work(0);
   } else {
-    std::vector<std::thread> th;
-    for (int r = 0; r < R; ++r) th.emplace_back(work, r);
-    for (auto& t : th) t.join();
+    for (int r = 0; r < R; ++r) sw->workers[(size_t)r]->post([&work, r] { work(r); });
+    for (int r = 0; r < R; ++r) sw->workers[(size_t)r]->wait();
   }
   int worst = S3D_STATUS_OK;
   for (int r = 0; r < R; ++r) {

@@ -136,6 +136,13 @@ def test_checkpoint_round_trip_of_the_cached_products(gpu_ctx, fixture_clouds):
             assert gpu_ctx.cache_import(other, blobs[0][:100]) == 7
             bad = bytearray(gpu_ctx.cache_export(re[2])); bad[40] ^= 0xFF      # an entry header field
             assert gpu_ctx.cache_import(re[2], bytes(bad[:len(bad) // 2])) == 7
+            # bit rot INSIDE a payload with every header intact: the per-entry checksum refuses it - a
+            # flipped cell-table or index word would otherwise send the kernels out of bounds
+            good = gpu_ctx.cache_export(re[2])
+            for at in (len(good) // 2, len(good) - 8, 200):
+                rot = bytearray(good); rot[at] ^= 0x10
+                assert gpu_ctx.cache_import(re[2], bytes(rot)) == 7 and "damaged payload" in gpu_ctx.last_error(), at
+            assert gpu_ctx.cache_import(re[2], good) == 0
             assert gpu_ctx.cache_control()["entries"] == 5
         finally:
             other.release()

@@ -259,3 +259,59 @@ def test_cpp_create_constraints_sweep_equals_sequential_create_constraint(fixtur
         # a reference built without pclomp throws for GICP_OMP (PointCloudSensor.cpp:159-161)
         assert [l for l in out if l.startswith("omp ")] == [
             "omp OMP is not available, you need to rebuild SLAM3D with OMP or use another matching algorithm."]
+
+
+def test_sequential_registration_overtakes_a_batch_on_another_context(gpu_ctx):
+    """The reference is entered from two threads (ScanSensor.cpp:209-210): the application thread registers every new
+    scan (one pair, latency-critical), a detached thread links to neighbours (a batch of candidates).  One pair on a
+    HIGH-priority context (s3d_context_create_priority) issued while a 128-pair batch runs on another context must
+    return the same bits as alone and take less than 3x its idle latency (it would wait ~17 ms behind the batch
+    on a shared context)."""
+    import threading
+    import time
+    import slam3d_amd as s3d
+    pairs = _pairs(128, 100_000)
+    fast = s3d.Context(0, high_priority=True)
+    p = s3d.default_params(registration_algorithm=s3d.ALG_GICP, point_cloud_density=0.02, maximum_iterations=20)
+    opts = s3d.ExecOptions(force_iterations=1)
+    src = [gpu_ctx.upload(q[0]) for q in pairs]
+    tgt = [gpu_ctx.upload(q[1]) for q in pairs]
+    a, b = fast.upload(pairs[5][0]), fast.upload(pairs[5][1])
+    try:
+        for _ in range(3):
+            alone = fast.align_batch([a], [b], None, p, opts)
+        t = time.perf_counter()
+        for _ in range(10):
+            fast.align_batch([a], [b], None, p, opts)
+        idle_ms = (time.perf_counter() - t) * 100
+        gpu_ctx.align_batch(src, tgt, None, p, opts)                      # warm-up of the big workspace
+        stop = threading.Event()
+        done = []
+
+        def sweep():
+            while not stop.is_set():
+                done.append(gpu_ctx.align_batch(src, tgt, None, p, opts))
+
+        th = threading.Thread(target=sweep)
+        th.start()
+        try:
+            time.sleep(0.05)                                              # the batch is in flight
+            lat = []
+            for _ in range(20):
+                t = time.perf_counter()
+                rec = fast.align_batch([a], [b], None, p, opts)
+                lat.append((time.perf_counter() - t) * 1e3)
+                assert np.array_equal(rec, alone)
+                time.sleep(0.003)
+        finally:
+            stop.set()
+            th.join()
+        busy_ms = float(np.median(lat))
+        print("one pair: idle %.2f ms, during a 128-pair batch on another context %.2f ms (median of 20, max %.2f); "
+              "batches completed meanwhile: %d" % (idle_ms, busy_ms, max(lat), len(done)))
+        assert len(done) >= 1 and np.array_equal(done[0][5], alone[0])   # (and the batch returns the same edge)
+        assert busy_ms < 3.0 * idle_ms, (idle_ms, busy_ms)
+    finally:
+        for c in src + tgt + [a, b]:
+            c.release()
+        fast.close()
