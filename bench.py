@@ -216,7 +216,11 @@ def main():
         # "bound": the roofline the contract prices this path against (no dense contraction -> HBM).  What actually
         # limits the kernel is in "limiter" (PMC evidence in profiles/README.md): `achieved` is ALGORITHMIC bytes per
         # second, i.e. how far an exact grid search is from streaming its compulsory traffic.
-        roofline = {"kernel": "s3d_nn_search_kernel<0>", "bound": "hbm", "achieved": round(achieved, 2),
+        # The correspondence pass is a kernel FAMILY since round 3: the first pass of a registration runs
+        # s3d_nn_first_kernel, passes 2..I s3d_nn_search_kernel<0>; avg_launch_ms is over all I launches of a step
+        # (cross-check against rocprofv3: (1 x AverageNs(first) + (I - 1) x AverageNs(search<0>)) / I).
+        roofline = {"kernel": "s3d_nn_first_kernel (pass 1) + s3d_nn_search_kernel<0> (passes 2-%d)" % n_launch,
+                    "bound": "hbm", "achieved": round(achieved, 2),
                     "limiter": "VALU issue of divergent per-lane candidate walks in the first passes (82 % of the issue "
                                "slots, 25 of 64 lanes active); HBM streaming (32 bytes per query actually moved, 4.2 TB/s "
                                "incl. write-back) in the re-validated passes",

@@ -81,11 +81,14 @@ typedef struct s3d_profile {      /* milliseconds, HIP events on the context's s
 /* ---- context ------------------------------------------------------------------ */
 /* hip_stream: a hipStream_t to run on (e.g. torch's current stream) or NULL for a private stream. */
 int  s3d_context_create(int device, void* hip_stream, s3d_context** out);
-/* A context on a private stream of the given priority class: 0 = default, 1 = high.  The reference is entered from
- * two threads at once (ScanSensor.cpp:209-210: the application thread registers every new scan against the previous
- * one, a detached thread runs linkToNeighbors), and one s3d_context serialises its callers: the latency-critical
- * sequential registration belongs on its own HIGH-priority context, so that the device's dispatcher takes its
- * kernels before the queued blocks of a loop-closure batch running on another context.  Results do not depend on it. */
+/* A context on a private stream of the given priority class: 0 = default, 1 = the device's highest.  The reference is
+ * entered from two threads at once (ScanSensor.cpp:209-210: the application thread registers every new scan against
+ * the previous one, a detached thread runs linkToNeighbors), and one s3d_context serialises its callers: the
+ * latency-critical sequential registration belongs on a context of its own, not on the one a loop-closure batch runs
+ * on (measured: 7.8 ms instead of ~20 ms next to a 128-pair batch, 1.7 ms idle).  Whether the device's dispatcher
+ * honours the stream priority on top of that is up to the driver - on the MI355X pool this was built on it made no
+ * measurable difference (tests/test_gpu_sweep.py::test_sequential_registration_next_to_a_batch).  Results do not
+ * depend on it. */
 int  s3d_context_create_priority(int device, int priority_class, s3d_context** out);
 void s3d_context_destroy(s3d_context* ctx);
 const char* s3d_last_error(const s3d_context* ctx);

@@ -1428,7 +1428,9 @@ __global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_search_kernel(con
 // seeds - nn_query<0, 5>.  Inside the one kernel above the same path cost every other pass a register re-roll
 // (DESIGN.md 6a x); as a separate __global__ it takes 0.13 ms off the first pass of 128 pairs and touches nothing
 // else.  S3D_DBG_NN bit 262144 switches it off (A/B).
-// Measured and dropped: the settled passes as a 24-VGPR stream kernel of the re-validation alone plus a worklist
+// Measured and dropped: (a) for a one-pair batch, 16 queries per wave with EVERY search served by the whole wave
+// (wave_nn1_coop: four times the waves, two latencies per query) - 35 us slower per registration than the per-lane
+// search; (b) the settled passes as a 24-VGPR stream kernel of the re-validation alone plus a worklist
 // kernel for the ~13 queries per pair whose proof fails in every pass - the stream is bound by its 32 bytes per query
 // (4.1 TB/s with either kernel), and the second launch costs more than the search code in the stream did.
 __global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_first_kernel(const PairDev* __restrict__ pairs,
