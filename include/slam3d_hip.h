@@ -85,7 +85,7 @@ int  s3d_context_create(int device, void* hip_stream, s3d_context** out);
  * entered from two threads at once (ScanSensor.cpp:209-210: the application thread registers every new scan against
  * the previous one, a detached thread runs linkToNeighbors), and one s3d_context serialises its callers: the
  * latency-critical sequential registration belongs on a context of its own, not on the one a loop-closure batch runs
- * on (measured: 7.8 ms instead of ~20 ms next to a 128-pair batch, 1.7 ms idle).  Whether the device's dispatcher
+ * on (measured: 6.2 ms instead of 15.7 ms next to a 128-pair batch, 1.6 ms idle).  Whether the device's dispatcher
  * honours the stream priority on top of that is up to the driver - on the MI355X pool this was built on it made no
  * measurable difference (tests/test_gpu_sweep.py::test_sequential_registration_next_to_a_batch).  Results do not
  * depend on it. */

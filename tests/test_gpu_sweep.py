@@ -266,10 +266,10 @@ def test_sequential_registration_next_to_a_batch(gpu_ctx):
     scan (one pair, latency-critical), a detached thread links to neighbours (a batch of candidates).  One pair issued
     while a 128-pair batch is running returns the same bits as alone, and it comes back sooner on a context of its own
     (what the C++ mirror does: createConstraint on mContext, createConstraints on the sweep's contexts) than on the
-    batch's context, where it waits for the whole batch.  Measured (printed): ~1.7 ms idle, ~7.8 ms next to the batch on
-    its own context - a chain of ~80 dependent launches, each waiting for blocks of the batch to retire - and ~20 ms on
+    batch's context, where it waits for the whole batch.  Measured (printed): 1.6 ms idle, 6.2 ms next to the batch on
+    its own context - a chain of ~80 dependent launches, each waiting for blocks of the batch to retire - and 15.7 ms on
     the shared one.  A HIGH-priority stream (s3d_context_create_priority) makes no measurable difference on this
-    driver (7.9 ms); the API stays, the claim does not."""
+    driver (6.1 ms); the API stays, the claim does not."""
     import threading
     import time
     import slam3d_amd as s3d
