@@ -26,6 +26,10 @@ constexpr int kAccumVB = 64;       // VIRTUAL blocks per pair in the accumulate 
                                    // fixed summation tree (block_reduce_store_fixed); a launch runs them on 1..64 real blocks
 constexpr uint32_t kInvalidKey = 0xFFFFFFFFu;
 
+#ifndef S3D_NN_AB
+#define S3D_NN_AB 1        // the round-1 A/B switches of the NN kernel (S3D_DBG_NN bits 4, 16, 32, 256, 512, 1024)
+#endif
+
 // ------------------------------------------------------------------ device-side records
 
 struct SlotDev {          // one cloud of the batch
@@ -1308,10 +1312,10 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   const bool has_prev = prev >= 0.f && prev < 1.0e30f;
   const bool near_seed = has_prev && prev < Ss.g.h * Ss.g.h;
   const bool far_seed = has_prev && !near_seed && move < kNNRevalSlack * Ss.g.h && !(dbg & 128);
-  const int seed = ((near_seed || far_seed) && !(dbg & 32)) ? A.corr_idx[ci] : -1;
+  const int seed = ((near_seed || far_seed) && !(S3D_NN_AB && (dbg & 32))) ? A.corr_idx[ci] : -1;
   // first pass (nothing known yet): a generous three-cell box — the shrinking-ball scan makes a large
   // initial radius cheap, while a small one costs a second scan for every badly aligned query
-  const float first = ((dbg & 256) ? 1.0f : (dbg & 512) ? 1.5f : (dbg & 1024) ? 2.0f : 3.0f) * Ss.g.h;
+  const float first = (!S3D_NN_AB ? 3.0f : (dbg & 256) ? 1.0f : (dbg & 512) ? 1.5f : (dbg & 1024) ? 2.0f : 3.0f) * Ss.g.h;
   const float hint = has_prev ? fminf(sqrtf(prev) * 1.25f + 0.05f * Ss.g.h, Ss.g.h) : first;
   if (prof_counts) {   // profile >= 2 only: how many queries search, how many of them without a near seed
     const unsigned long long all = __ballot(need), un = __ballot(need && !near_seed);
@@ -1324,7 +1328,7 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   r.idx = -1; r.d2 = 3.0e38f; r.pos = -1; r.second_d2 = 3.0e38f; r.radius = 0.f;
   const uint32_t* __restrict__ cs = A.cell_start + Ss.cell_off;
   const float4* __restrict__ tp = A.sorted + Ss.off;
-  if (dbg & 4) {
+  if (S3D_NN_AB && (dbg & 4)) {
     if (need) r = grid_nn1(Ss.g, cs, tp, q.x, q.y, q.z, max_d);
   } else {
     // served by the whole wave, one query after the other: the queries that will walk a wide box when they are
@@ -1352,7 +1356,7 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   // the target's cell-sorted array: every later access (K6, fitness) is then coalesced or a local gather
   A.corr_idx[ci] = r.pos;
   A.corr_d2[ci] = r.d2;
-  const float lbv = !(dbg & 4) ? nn_lower_bound_others(r) : 0.f;   // no neighbour at all: the scanned radius
+  const float lbv = !(S3D_NN_AB && (dbg & 4)) ? nn_lower_bound_others(r) : 0.f;   // no neighbour at all: the scanned radius
   A.corr_lb[ci] = r.pos >= 0 ? lbv : -lbv;
   if (r.pos >= 0) {
     // a copy of the matched point and of its normal is kept with the correspondence: the re-validation
@@ -1395,7 +1399,7 @@ __global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_search_kernel(con
   __shared__ int order[kBlock];
   __shared__ int lds4[4];
   int pair, chunk;
-  if (dbg & 16) { pair = blockIdx.x / chunks_per_pair; chunk = blockIdx.x % chunks_per_pair; }  // A/B: plain map
+  if (S3D_NN_AB && (dbg & 16)) { pair = blockIdx.x / chunks_per_pair; chunk = blockIdx.x % chunks_per_pair; }  // A/B: plain map
   else nn_block_map(chunks_per_pair, npairs, &pair, &chunk);
   if (pair >= npairs) return;
   const PairDev& P = pairs[pair];
