@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/final; P=gpurun_out/final_prof
 rm -rf $O $P; mkdir -p $O $P
 python3 bench.py --extras --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_default.json
-python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu 2>/dev/null | tail -1 > $O/bench_2ranks_one_gpu.json
+python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu 2>/dev/null | grep "^{\"metric" | tail -1 > $O/bench_2ranks_one_gpu.json
 ./tools_dev/ubench/valu_rates > $O/valu_rates.txt 2>&1
 python3 bench.py --algorithm icp --no-cpu 2>/dev/null | tail -1 > $O/bench_p2p.json
 python3 bench.py --pairs 32 --points 1000000 --iters 50 --steps 3 --warmup 1 --no-cpu 2>/dev/null | tail -1 > $O/bench_1M_50it.json

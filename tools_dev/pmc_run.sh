@@ -19,7 +19,7 @@ for r in rows:
 with open(sys.argv[2], "w") as f:
     f.write("kernel,counter,mean_per_launch,launches\n")
     for k, d in agg.items():
-        if "nn_search" in k or "knn_moments" in k or "gicp_accumulate" in k:
+        if "nn_search" in k or "nn_first" in k or "knn" in k or "gicp_accumulate" in k or "onesweep" in k:
             for c, v in d.items():
                 f.write('"%s",%s,%.1f,%d\n' % (k, c, sum(v) / len(v), len(v)))
 PY
