@@ -535,6 +535,7 @@ struct Batch {
   // counted the digit totals of all passes (k_keys_hist with sweep_passes) and zeroed the look-back rows.
   // S3D_SORT_CLASSIC=1 (A/B): the three-kernels-per-pass form.
   bool sort_classic = getenv("S3D_SORT_CLASSIC") && atoi(getenv("S3D_SORT_CLASSIC")) != 0;
+  bool sort_used = false;
   void sort_prepare(int nslots) {   // before the kernel that counts the digit totals
     if (!sort_classic && nslots > 0)
       HIPCHK(hipMemsetAsync(ctx->digit_tot.p, 0, sizeof(uint32_t) * (size_t)nslots * kSortPlaces * 256, ctx->stream));
@@ -547,6 +548,10 @@ struct Batch {
     uint32_t* dtot = (uint32_t*)ctx->digit_tot.p;
     const unsigned blocks = (unsigned)((nslots >= 8 ? cdiv(nslots, 8) * 8 : nslots) * nb_sort);
     if (!sort_classic) {
+      if (!sort_used) {     // the first sort of this batch clears the error word (stream order: before any look-back)
+        HIPCHK(hipMemsetAsync((int*)ctx->n_active.p + 6, 0, sizeof(int), st));
+        sort_used = true;
+      }
       if (!hist_done) {
         sort_prepare(nslots);
         k_sort_hist_all<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(d_slots(), ki, dtot, cnt, passes, nb_sort);
@@ -773,8 +778,13 @@ struct Batch {
     char* stage = ctx->stage_host(bs + bp + 16);   // (the uploads of this call have completed by now: stream order)
     if (bs) HIPCHK(hipMemcpyAsync(stage, ctx->slots.p, bs, hipMemcpyDeviceToHost, st));
     if (bp) HIPCHK(hipMemcpyAsync(stage + bs, ctx->pairs.p, bp, hipMemcpyDeviceToHost, st));
+    // the one-sweep sort's look-back gives up after ~4 M polls instead of hanging the device: that must not pass silently
+    int* sort_err = (int*)(stage + bs + bp);
+    *sort_err = 0;
+    if (sort_used) HIPCHK(hipMemcpyAsync(sort_err, (int*)ctx->n_active.p + 6, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
+    if (*sort_err) throw HipError{hipErrorLaunchFailure, "radix sort: a tile waited for its predecessor beyond the poll limit", __LINE__};
     if (bs) std::memcpy(h_slots.data(), stage, bs);
     if (bp) std::memcpy(h_pairs.data(), stage + bs, bp);
   }
