@@ -216,10 +216,12 @@ def main():
         # "bound": the roofline the contract prices this path against (no dense contraction -> HBM).  What actually
         # limits the kernel is in "limiter" (PMC evidence in profiles/README.md): `achieved` is ALGORITHMIC bytes per
         # second, i.e. how far an exact grid search is from streaming its compulsory traffic.
-        # The correspondence pass is a kernel FAMILY since round 3: the first pass of a registration runs
-        # s3d_nn_first_kernel, passes 2..I s3d_nn_search_kernel<0>; avg_launch_ms is over all I launches of a step
-        # (cross-check against rocprofv3: (1 x AverageNs(first) + (I - 1) x AverageNs(search<0>)) / I).
-        roofline = {"kernel": "s3d_nn_first_kernel (pass 1) + s3d_nn_search_kernel<0> (passes 2-%d)" % n_launch,
+        # The correspondence pass is a kernel FAMILY since round 3: pass 1 of a registration runs s3d_nn_first_kernel,
+        # passes 2 and 3 s3d_nn_scan27_kernel (+ s3d_nn_worklist_kernel for the queries it declines), passes 4..I
+        # s3d_nn_search_kernel<0>; avg_launch_ms is (the time of all of them in one step) / I, HIP events around every
+        # pass (cross-check against rocprofv3: the TotalDurationNs of those five kernel names / (I x steps)).
+        roofline = {"kernel": "s3d_nn_first_kernel (pass 1) + s3d_nn_scan27_kernel<*> + s3d_nn_worklist_kernel (passes 2-3) "
+                              "+ s3d_nn_search_kernel<0> (passes 4-%d)" % n_launch,
                     "bound": "hbm", "achieved": round(achieved, 2),
                     "limiter": "VALU issue of divergent per-lane candidate walks in the first passes (82 % of the issue "
                                "slots, 25 of 64 lanes active); HBM streaming (32 bytes per query actually moved, 4.2 TB/s "

@@ -695,6 +695,24 @@ struct Batch {
       s3d_nn_first_kernel<<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc);
       return;
     }
+    // passes 2 and 3: the flat 27-cell scan + a worklist for what it declines (S3D_DBG_NN bit 524288 = off; the bits
+    // that switch the re-validation off imply it)
+    // (measured per 128 pairs: pass 2 1.47 -> 0.99 ms, pass 3 0.90 -> 0.80 ms with the compacting form; passes 4 and 5,
+    // where 2 % and 0.1 % of the queries search, are slower this way: 0.39 -> 0.55, 0.15 -> 0.19 ms)
+    static const int scan27_passes = getenv("S3D_SCAN27_PASSES") ? atoi(getenv("S3D_SCAN27_PASSES")) : 2;
+    if (family && it >= 1 && it <= scan27_passes && !(dbg_nn & (524288 | 128 | 2048)) && max_n < kKnn3MaxPoints) {
+      int* wc = (int*)ctx->n_active.p + 8;              // eight counters, used in turn (zeroed by stage_icp / the drain)
+      static const bool compact27 = !(getenv("S3D_SCAN27_COMPACT") && atoi(getenv("S3D_SCAN27_COMPACT")) == 0);
+      if (it == 1)
+        s3d_nn_scan27_kernel<false, false><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), wc + (it & 7), kA(), kB(), pc);
+      else if (compact27)
+        s3d_nn_scan27_kernel<true, true><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), wc + (it & 7), kA(), kB(), pc);
+      else
+        s3d_nn_scan27_kernel<true, false><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), wc + (it & 7), kA(), kB(), pc);
+      s3d_nn_worklist_kernel<<<4096, kWave, 0, st>>>(d_pairs(), d_slots(), A, max_d, dbg_nn, wc + (it & 7), kA(), kB(),
+                                                      wc + ((it + 1) & 7));
+      return;
+    }
     const int cmp = (compact && mode == 0 && !(dbg_nn & 65536)) ? 1 : 0;
     if (mode == 0)
       s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc, cmp);
@@ -729,6 +747,7 @@ struct Batch {
     // no radius hint for the first NN pass: fill the distances with NaN (0xFF bytes)
     HIPCHK(hipMemsetAsync(ctx->corr_d2.p, 0xFF, 4 * std::max<size_t>(total_corr, 4), st));
     HIPCHK(hipMemsetAsync(ctx->corr_lb.p, 0, 4 * std::max<size_t>(total_corr, 4), st));
+    HIPCHK(hipMemsetAsync((int*)ctx->n_active.p + 8, 0, 8 * sizeof(int), st));   // worklist counters of the scan27 passes
     const float max_d = (float)(rp.max_corr * 1.0001);
     const bool prof = opts.profile != 0;
     if (prof) HIPCHK(hipMemsetAsync((int*)ctx->n_active.p + 16, 0, 2 * 64 * sizeof(int), st));

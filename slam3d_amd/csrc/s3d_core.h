@@ -1129,6 +1129,97 @@ S3D_HD uint32_t knn3_position(uint32_t key, const uint32_t* tab, int tstride) {
   return (tab[((key >> kKnn3OffBits) & 15u) * tstride] >> kKnn3OffBits) + (key & kKnn3OffMask);
 }
 
+// ------------------------------------------------------------------ K5, round 3: 1-NN by a flat scan of the 27 cells
+//
+// The second and third pass of a registration search (nearly) every query again - the first transform update has
+// moved them all - but with the clouds roughly aligned by then the neighbour lies within one cell: the seeded box
+// search above visits the same ~50 candidates of the 27 cells around the query through per-row loops (a wave runs
+// max-over-lanes of EVERY row) and a 15-instruction consider() per candidate.  Here the nine row segments go into the
+// per-lane LDS table of the k-NN pre-pass (knn3_build27) and ONE flat loop scans them (max-over-lanes of the total),
+// keeping the best and the runner-up as packed 64-bit keys ((d2 bits + 2^23) << 32 | position, held as doubles:
+// v_min_f64 / v_max_f64; the low word is the candidate's position) - no seed, no radius, no retry.  The result is proven when the neighbour is nearer than
+// the 27 cells' guaranteed reach (1 + face) h, which is then also the radius the re-validation of later passes builds
+// on; anything else (a query outside the grid, empty cells, a farther neighbour, a row range beyond the table) returns
+// false and goes through grid_nn1_box.  Same neighbour, same float d2, same tie rule (lowest index).
+S3D_HD double f64_min_raw(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return a < b ? a : b;
+#endif
+}
+S3D_HD double f64_max_raw(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return a < b ? b : a;
+#endif
+}
+
+template <typename F4T>
+S3D_HD bool grid_nn1_scan27(const GridParams& g, const uint32_t* __restrict__ cell_start, const F4T* __restrict__ pts,
+                            float qx, float qy, float qz, uint32_t* tab, int tstride, NNResult& r) {
+  r.idx = -1; r.d2 = 3.0e38f; r.pos = -1; r.second_d2 = 3.0e38f; r.radius = 0.f;
+  const int ix = grid_coord(g, 0, qx), iy = grid_coord(g, 1, qy), iz = grid_coord(g, 2, qz);
+  if (ix < 0 || ix >= g.dim[0] || iy < 0 || iy >= g.dim[1] || iz < 0 || iz >= g.dim[2]) return false;
+  int nseg;
+  uint32_t total;
+  if (!knn3_build27(g, cell_start, qx, qy, qz, tab, tstride, nseg, total) || total == 0) return false;
+  const double kInf = __builtin_bit_cast(double, 0x7FDFFFFFFFFFFFFFull);
+  double best = kInf, second = kInf;
+  // the iterator of knn3_scan without ids: [pos, end) = what is left of the current entry
+  int e = 0;
+  uint32_t pos = 0, end = 0;
+#define S3D_NN27_NEXT(P_, K_, V_)                                                                      \
+  {                                                                                                    \
+    if (pos == end && e < nseg) {                                                                      \
+      const uint32_t ent = tab[e * tstride];                                                           \
+      pos = ent >> kKnn3OffBits; end = pos + (ent & kKnn3OffMask) + 1u;                                \
+      ++e;                                                                                             \
+    }                                                                                                  \
+    V_ = pos != end;                                                                                   \
+    K_ = V_ ? pos : 0u;                                                                                \
+    P_ = pts[K_];                                                                                      \
+    pos += V_ ? 1u : 0u;                                                                               \
+  }
+#define S3D_NN27_USE(P_, K_, V_)                                                                       \
+  {                                                                                                    \
+    const float d2_ = dist2_xy(qx, qy, qz, P_);                                                        \
+    const unsigned long long kb_ = ((unsigned long long)(__builtin_bit_cast(uint32_t, d2_) + 0x00800000u) << 32) | \
+                                   (unsigned long long)K_;                                             \
+    const double c_ = V_ ? __builtin_bit_cast(double, kb_) : kInf;                                     \
+    second = f64_min_raw(second, f64_max_raw(c_, best));                                               \
+    best = f64_min_raw(best, c_);                                                                      \
+  }
+  F4T pa, pb;
+  uint32_t ka, kb;
+  bool va, vb;
+  S3D_NN27_NEXT(pa, ka, va)
+  S3D_NN27_NEXT(pb, kb, vb)
+  while (va) {
+    S3D_NN27_USE(pa, ka, va)
+    S3D_NN27_NEXT(pa, ka, va)
+    S3D_NN27_USE(pb, kb, vb)
+    S3D_NN27_NEXT(pb, kb, vb)
+  }
+#undef S3D_NN27_NEXT
+#undef S3D_NN27_USE
+  // the low word of a key is the candidate's POSITION (what the loop has at hand), while the tie rule of the search is
+  // the lowest point INDEX: two candidates at the same distance are therefore not decided here (declined)
+  const unsigned long long bb = __builtin_bit_cast(unsigned long long, best);
+  r.pos = (int)(uint32_t)(bb & 0xFFFFFFFFull);
+  r.idx = __builtin_bit_cast(int, pts[r.pos].w);
+  r.d2 = knn_key_d2(best);
+  if (second != kInf) r.second_d2 = knn_key_d2(second);
+  const float r1 = (1.0f + knn3_face(g, qx, qy, qz)) * g.h;
+  r.radius = r1;
+  return r.d2 <= r1 * r1 && r.second_d2 != r.d2;
+}
+
 // ------------------------------------------------------------------ covariance -> normal (K4)
 
 // cyclic Jacobi on a symmetric 3x3; returns the unit eigenvector of the SMALLEST

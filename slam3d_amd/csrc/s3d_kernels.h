@@ -1388,6 +1388,9 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
 // this 72-VGPR kernel re-rolled (scratch 76 -> 100 bytes per lane, spills moved into the streaming re-validation
 // path): 12.4 -> 13.5 ms of NN per step, same results.  Measured, reverted.  (6 waves / 80 VGPRs: 14.0 ms; the
 // cooperative search as a non-inlined call: 12.8 ms.)
+#ifndef S3D_NN27_WAVES
+#define S3D_NN27_WAVES 8    // s3d_nn_scan27_kernel
+#endif
 #ifndef S3D_NN_WAVES
 #define S3D_NN_WAVES 7     // waves per SIMD the register allocation is capped for (see S3D_NN_BATCH, s3d_core.h)
 #endif
@@ -1450,6 +1453,122 @@ __global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_first_kernel(cons
   const int i = chunk * kBlock + threadIdx.x;
   if (chunk * kBlock >= St.n) return;
   nn_query<0, 5>(P, St, slots[P.slot_s], pair, i, i < St.n, A, max_d, dbg, prof_counts);
+}
+
+// ---- passes 2 and 3 of the ICP loop: the flat 27-cell scan (grid_nn1_scan27, s3d_core.h "K5, round 3").
+// REVAL (pass 3): a query first tries the re-validation of nn_query - two thirds of them pass by then.  A query the
+// scan does not answer (its neighbour farther than the 27 cells reach, a query outside the target's grid, empty cells)
+// is appended to a worklist - one atomic per wave that has any - which s3d_nn_worklist_kernel serves right after with
+// the general search.  Same neighbours, same distances: bit-identical registrations (S3D_DBG_NN bit 524288 = off).
+// COMPACT (pass 3, where a third of the queries still search, scattered over all waves): the queries of a block that
+// failed their re-validation are packed to the front of the block (one block scan, as in s3d_nn_search_kernel's
+// compact mode) and only the first waves scan - every lane of them busy.
+template <bool REVAL, bool COMPACT>
+__global__ void __launch_bounds__(kBlock, S3D_NN27_WAVES) s3d_nn_scan27_kernel(const PairDev* __restrict__ pairs,
+                                                                  const SlotDev* __restrict__ slots, NNArrays A,
+                                                                  float max_d, int chunks_per_pair, int npairs,
+                                                                  int* __restrict__ work_count,
+                                                                  uint32_t* __restrict__ work_pair,
+                                                                  uint32_t* __restrict__ work_index,
+                                                                  int* __restrict__ prof_counts) {
+  __shared__ uint32_t tab[kKnn3Segs * kBlock];
+  __shared__ int order[COMPACT ? kBlock : 1];
+  __shared__ int lds4[4];
+  int pair, chunk;
+  nn_block_map(chunks_per_pair, npairs, &pair, &chunk);
+  if (pair >= npairs) return;
+  const PairDev& P = pairs[pair];
+  if (!P.active) return;
+  const SlotDev& St = slots[P.slot_t];
+  if (chunk * kBlock >= St.n) return;                                         // (the whole block)
+  int i = chunk * kBlock + threadIdx.x;
+  if (!COMPACT && (chunk * kBlock + (int)(threadIdx.x & ~(kWave - 1))) >= St.n) return;   // (whole waves: the worklist append votes)
+  const SlotDev& Ss = slots[P.slot_s];
+  bool need = i < St.n;
+  int ci = P.corr_off + (need ? i : 0);
+  CorrVec p0 = A.sorted3[St.off + (need ? i : 0)];
+  F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
+  F3 q = xf_eigen(P.T, pg.x, pg.y, pg.z);
+  if (REVAL && need) {
+    const float lbs = A.corr_lb[ci];
+    if (lbs != 0.f) {               // nn_query's re-validation, the same float operations
+      const float lb = fabsf(lbs);
+      const F3 qo = xf_eigen(P.T_nn, pg.x, pg.y, pg.z);
+      const float move = sqrtf(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
+      if (lbs > 0.f) {
+        const CorrVec ps = A.corr_q[ci];
+        const float d2n = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z);
+        if (nn_still_nearest(sqrtf(d2n), move, lb)) { A.corr_lb[ci] = lb - move; need = false; }
+      } else if (nn_still_nearest(max_d, move, lb)) {
+        A.corr_lb[ci] = move - lb;
+        need = false;
+      }
+    }
+  }
+  if (COMPACT) {
+    int total;
+    const int at = block_excl_flag(need, &total, lds4);
+    if (total == 0) return;
+    if (need) order[at] = (int)threadIdx.x;
+    __syncthreads();
+    if ((int)(threadIdx.x & ~(kWave - 1)) >= total) return;                   // whole wave without work
+    need = (int)threadIdx.x < total;
+    i = chunk * kBlock + (need ? order[threadIdx.x] : 0);
+    ci = P.corr_off + i;
+    p0 = A.sorted3[St.off + i];
+    pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
+    q = xf_eigen(P.T, pg.x, pg.y, pg.z);
+  }
+  const unsigned long long nmask = __ballot(need);
+  if (nmask == 0ull) return;
+  if (prof_counts && lane_id() == 0) atomicAdd(&prof_counts[0], (int)__popcll(nmask));
+  NNResult r;
+  bool ok = false;
+  if (need) ok = grid_nn1_scan27(Ss.g, A.cell_start + Ss.cell_off, A.sorted + Ss.off, q.x, q.y, q.z, tab + threadIdx.x, kBlock, r);
+  if (need && ok) {                 // (the stores of nn_query; a scan27 answer always has a neighbour)
+    A.corr_idx[ci] = r.pos;
+    A.corr_d2[ci] = r.d2;
+    A.corr_lb[ci] = nn_lower_bound_others(r);
+    A.corr_q[ci] = corr_vec(A.sorted[Ss.off + r.pos]);
+    A.corr_n[ci] = A.normals[Ss.off + r.pos];
+  }
+  const bool fail = need && !ok;
+  const unsigned long long m = __ballot(fail);
+  if (m == 0ull) return;
+  int base = 0;
+  if (lane_id() == 0) {
+    base = atomicAdd(work_count, (int)__popcll(m));
+    if (prof_counts) atomicAdd(&prof_counts[1], (int)__popcll(m));   // (profile >= 2: the second counter = declined here)
+  }
+  base = __shfl(base, 0, kWave);
+  if (fail) {
+    const int k = base + (int)__popcll(m & ((1ull << lane_id()) - 1ull));
+    work_pair[k] = (uint32_t)pair;
+    work_index[k] = (uint32_t)i;
+  }
+}
+
+// the queries s3d_nn_scan27_kernel listed, through the general search (nn_query PHASE 2: "has failed its re-validation
+// already").  One wave per block; a short list is dealt 8 entries per wave (their searches diverge, and a wave
+// serialises its lanes' paths: the list's latency is what counts), a long one 64.  The lanes of a wave serve
+// different pairs here: no wave-cooperative search, whose grid arguments are wave-uniform.
+__global__ void __launch_bounds__(kWave) s3d_nn_worklist_kernel(const PairDev* __restrict__ pairs,
+                                                                 const SlotDev* __restrict__ slots, NNArrays A,
+                                                                 float max_d, int dbg, const int* __restrict__ work_count,
+                                                                 const uint32_t* __restrict__ work_pair,
+                                                                 const uint32_t* __restrict__ work_index,
+                                                                 int* __restrict__ work_count_next) {
+  const int count = *work_count;
+  const int per = count <= 8 * (int)gridDim.x ? 8 : kWave;
+  for (int j0 = blockIdx.x * per; j0 < count; j0 += gridDim.x * per) {   // (whole waves stay: nn_query votes)
+    const int j = j0 + (int)threadIdx.x;
+    const bool need = (int)threadIdx.x < per && j < count;
+    const int pair = (int)work_pair[need ? j : 0];
+    const int i = (int)work_index[need ? j : 0];
+    const PairDev& P = pairs[pair];
+    nn_query<0, 2>(P, slots[P.slot_t], slots[P.slot_s], pair, i, need, A, max_d, dbg | 2048, nullptr);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *work_count_next = 0;   // the counter the next scan27 pass appends to
 }
 
 // API export (s3d_nn_search / s3d_knn_normals): back from cell-sorted order to the caller's point order

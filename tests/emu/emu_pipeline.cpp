@@ -165,6 +165,21 @@ void emu_normals(const float* xyz, int n, int k, float h0, int cpp, float* out) 
   for (int i = 0; i < n; ++i) { out[i * 3] = (float)nr[i].x; out[i * 3 + 1] = (float)nr[i].y; out[i * 3 + 2] = (float)nr[i].z; }
 }
 
+// round-3 1-NN by a flat scan of the 27 cells (grid_nn1_scan27): idx / d2 of the answered queries (flag 1), -1 / 0 flag 0
+void emu_nn_scan27(const float* tgt, int n, const float* qry, int m, float h0, int cpp, int* idx, float* d2, int* answered,
+                   float* lower_bound) {
+  Cloud c = voxel(tgt, n, 3, 0.0);
+  Grid G = build_grid(c, h0, cpp);
+  for (int i = 0; i < m; ++i) {
+    uint32_t tab[kKnn3Segs];
+    NNResult r;
+    const bool ok = grid_nn1_scan27(G.g, G.cell_start.data(), G.sorted.data(), qry[i * 3], qry[i * 3 + 1], qry[i * 3 + 2], tab, 1, r);
+    answered[i] = ok ? 1 : 0;
+    idx[i] = ok ? r.idx : -1; d2[i] = ok ? r.d2 : 0.f;
+    lower_bound[i] = ok ? nn_lower_bound_others(r) : 0.f;
+  }
+}
+
 // round-3 k-NN (grid_knn_med3: 32-bit keys, med3 insertion) against the exact 64-bit search on every point of a cloud.
 // out[0] = points, out[1] = points the fast path declines (served by the exact search on the device), out[2] = answered
 // points whose 20-neighbour SET differs from the exact one (must be 0), out[3] = answered points whose order differs

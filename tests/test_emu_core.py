@@ -75,6 +75,33 @@ def test_device_grid_nn_is_exact(emu, oracle_mod, fixture_clouds, h0, cpp):
     assert np.all((idx[~m] == -1) | (d2[~m] >= 2.5 ** 2))
 
 
+@pytest.mark.parametrize("h0,cpp,shift", [(0.4, 2, 0.0), (0.4, 2, 0.3), (0.4, 16, 0.1), (1.0, 64, 0.0)])
+def test_device_scan27_nn_is_exact_when_it_answers(emu, oracle_mod, fixture_clouds, h0, cpp, shift):
+    """grid_nn1_scan27 (the flat 27-cell scan of the second and third correspondence pass): every query it answers has
+    the oracle's neighbour and float d2 (ties: lowest index); the lower bound it reports for the OTHER points is valid;
+    far / outside queries are declined, never answered wrongly."""
+    from scipy.spatial import cKDTree
+    v1, _ = oracle_mod.voxel_downsample(fixture_clouds[0], 0.2)
+    v2, _ = oracle_mod.voxel_downsample(fixture_clouds[1], 0.2)
+    rng = np.random.default_rng(4)
+    far = rng.uniform(-150, 150, (400, 3)).astype(np.float32)
+    dup = np.repeat(v1[:200], 2, axis=0) + np.float32(0.01)        # pairs of queries with identical neighbours
+    q = np.ascontiguousarray(np.concatenate([v2[::3] + np.float32(shift), far, dup, v1[:500]]))   # (v1 itself: d2 = 0)
+    idx = np.empty(len(q), np.int32); d2 = np.empty(len(q), np.float32)
+    ans = np.empty(len(q), np.int32); lb = np.empty(len(q), np.float32)
+    tgt = np.ascontiguousarray(np.concatenate([v1, v1[:50]]))       # duplicate target points: ties of the distance
+    emu.emu_nn_scan27(tgt.ctypes.data_as(fp), len(tgt), q.ctypes.data_as(fp), len(q), C.c_float(h0), cpp,
+                      idx.ctypes.data_as(ip), d2.ctypes.data_as(fp), ans.ctypes.data_as(ip), lb.ctypes.data_as(fp))
+    oi, od = oracle_mod.nn_search(tgt, q)
+    a = ans == 1
+    assert a.mean() > (0.2 if shift > 0.2 or h0 > 0.9 else 0.5), a.mean()
+    assert np.array_equal(idx[a], oi[a]) and np.array_equal(d2[a], od[a])
+    # the bound on every other point: the second-nearest distance of a kd-tree query is not below it
+    dd, _ = cKDTree(tgt.astype(np.float64)).query(q[a].astype(np.float64), 2)
+    assert (dd[:, 1] >= lb[a] * (1 - 1e-5) - 1e-6).all()
+    assert not a[len(v2[::3]):len(v2[::3]) + 400].all()            # the far queries are not all answerable
+
+
 @pytest.mark.parametrize("hint_kind", ["tiny", "exact", "huge", "random"])
 def test_device_box_nn_is_exact_for_any_hint(emu, oracle_mod, fixture_clouds, hint_kind):
     """grid_nn1_box (the kernel's hot variant) must return the exact NN whatever the radius hint."""

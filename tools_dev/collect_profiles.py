@@ -19,10 +19,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for k, m, n in summ:
             f.write('"%s",%.1f,%d\n' % (k, m, n))
     # the NN family of the ICP loop: s3d_nn_first_kernel + s3d_nn_search_kernel<0>, per launch over all their launches
-    fam = [x for x in summ if "nn_search_kernel<0>" in x[0] or "nn_first_kernel" in x[0]]
-    out[c] = sum(m * n for _, m, n in fam) / sum(n for _, _, n in fam)
+    # per PASS of the ICP loop (a scan27 pass is two launches: the scan and its worklist)
+    fam = [x for x in summ if any(k in x[0] for k in ("nn_search_kernel<0>", "nn_first_kernel", "nn_scan27_kernel", "nn_worklist_kernel"))]
+    passes = sum(n for k, _, n in fam if "nn_worklist_kernel" not in k)
+    out[c] = sum(m * n for _, m, n in fam) / passes
 hbm = int(2 * out["FETCH_SIZE"] * 1024 + out["WRITE_SIZE"] * 1024)
-json.dump({"kernel": "s3d_nn_first_kernel + s3d_nn_search_kernel<0> (all launches of the ICP loop)", "fetch_size_kb_per_launch": round(out["FETCH_SIZE"], 1),
+json.dump({"kernel": "s3d_nn_first_kernel + s3d_nn_scan27_kernel + s3d_nn_worklist_kernel + s3d_nn_search_kernel<0> (per pass of the ICP loop)", "fetch_size_kb_per_launch": round(out["FETCH_SIZE"], 1),
            "write_size_kb_per_launch": round(out["WRITE_SIZE"], 1), "hbm_bytes_per_launch": hbm,
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is",
            "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --no-cpu --no-single --steps 2 --warmup 1",
