@@ -1160,15 +1160,55 @@ S3D_HD double f64_max_raw(double a, double b) {
 #endif
 }
 
+// seed_d2 (3e38: none): the squared distance of a point KNOWN to exist - the previous pass's neighbour under the new
+// transform, read from the copy that travels with the correspondence, no gather.  The nine rows are then cut to the
+// ball of that radius (+ the re-validation shell, as grid_nn1_box does): a slab test per row, the x-range of its
+// chord - a stale neighbour half a cell away leaves ~8 of the 27 cells.
 template <typename F4T>
 S3D_HD bool grid_nn1_scan27(const GridParams& g, const uint32_t* __restrict__ cell_start, const F4T* __restrict__ pts,
-                            float qx, float qy, float qz, uint32_t* tab, int tstride, NNResult& r) {
+                            float qx, float qy, float qz, uint32_t* tab, int tstride, NNResult& r,
+                            float seed_d2 = 3.0e38f) {
   r.idx = -1; r.d2 = 3.0e38f; r.pos = -1; r.second_d2 = 3.0e38f; r.radius = 0.f;
   const int ix = grid_coord(g, 0, qx), iy = grid_coord(g, 1, qy), iz = grid_coord(g, 2, qz);
   if (ix < 0 || ix >= g.dim[0] || iy < 0 || iy >= g.dim[1] || iz < 0 || iz >= g.dim[2]) return false;
-  int nseg;
-  uint32_t total;
-  if (!knn3_build27(g, cell_start, qx, qy, qz, tab, tstride, nseg, total) || total == 0) return false;
+  int nseg = 0;
+  uint32_t total = 0;
+  float reach = 3.0e38f;            // every point nearer than this lies in an examined cell (if it lies in the 27 at all)
+  {
+    const bool cut = seed_d2 < 1.0e30f;
+    const float br = cut ? sqrtf(seed_d2) * 1.0001f + 1.0e-6f + kNNRevalSlack * g.h : 0.f;
+    const float b2 = cut ? br * br : 3.0e38f;
+    if (cut) reach = br * 0.9999f;
+    const float eps = 2.0e-3f * g.h;
+    uint32_t rs[9], re[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {   // nine row ranges fetched as one batch
+      const int cy = iy + (k % 3) - 1, cz = iz + (k / 3) - 1;
+      bool in = cy >= 0 && cy < g.dim[1] && cz >= 0 && cz < g.dim[2];
+      int xa = imax(ix - 1, 0), xb = imin(ix + 1, g.dim[0] - 1);
+      if (cut) {
+        const float ylo = g.origin[1] + (float)cy * g.h, zlo = g.origin[2] + (float)cz * g.h;
+        const float fy = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.h)) - eps, 0.f);
+        const float fz = fmaxf(fmaxf(zlo - qz, qz - (zlo + g.h)) - eps, 0.f);
+        const float rowd2 = fy * fy + fz * fz;
+        in = in && rowd2 <= b2;
+        const float rx = sqrtf(fmaxf(b2 - rowd2, 0.f)) * 1.0001f + eps;
+        xa = imax(xa, grid_coord(g, 0, qx - rx));
+        xb = imin(xb, grid_coord(g, 0, qx + rx));
+      }
+      in = in && xa <= xb;
+      const int rowbase = in ? g.dim[0] * (cy + g.dim[1] * cz) : 0;
+      const uint32_t a = cell_start[rowbase + (in ? xa : 0)], b = cell_start[rowbase + (in ? xb + 1 : 0)];
+      rs[k] = a; re[k] = in ? b : a;
+    }
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      ok = knn3_push(tab, tstride, nseg, rs[k], re[k]) && ok;
+      total += re[k] - rs[k];
+    }
+    if (!ok || total == 0) return false;
+  }
   const double kInf = __builtin_bit_cast(double, 0x7FDFFFFFFFFFFFFFull);
   double best = kInf, second = kInf;
   // the iterator of knn3_scan without ids: [pos, end) = what is left of the current entry
@@ -1215,7 +1255,7 @@ S3D_HD bool grid_nn1_scan27(const GridParams& g, const uint32_t* __restrict__ ce
   r.idx = __builtin_bit_cast(int, pts[r.pos].w);
   r.d2 = knn_key_d2(best);
   if (second != kInf) r.second_d2 = knn_key_d2(second);
-  const float r1 = (1.0f + knn3_face(g, qx, qy, qz)) * g.h;
+  const float r1 = fminf((1.0f + knn3_face(g, qx, qy, qz)) * g.h, reach);
   r.radius = r1;
   return r.d2 <= r1 * r1 && r.second_d2 != r.d2;
 }

@@ -1391,6 +1391,9 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
 #ifndef S3D_NN27_WAVES
 #define S3D_NN27_WAVES 8    // s3d_nn_scan27_kernel
 #endif
+#ifndef S3D_NN27_SEED
+#define S3D_NN27_SEED 1     // s3d_nn_scan27_kernel cuts the 27 cells to the ball of the previous neighbour's new distance
+#endif
 #ifndef S3D_NN_WAVES
 #define S3D_NN_WAVES 7     // waves per SIMD the register allocation is capped for (see S3D_NN_BATCH, s3d_core.h)
 #endif
@@ -1489,7 +1492,29 @@ __global__ void __launch_bounds__(kBlock, S3D_NN27_WAVES) s3d_nn_scan27_kernel(c
   CorrVec p0 = A.sorted3[St.off + (need ? i : 0)];
   F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
   F3 q = xf_eigen(P.T, pg.x, pg.y, pg.z);
-  if (REVAL && need) {
+  // the previous pass's neighbour under the new transform: its distance is an upper bound that cuts the 27 cells to
+  // the ball it spans (grid_nn1_scan27).  The copy of the neighbour travels with the correspondence: a streamed load.
+  float seed_d2 = 3.0e38f;
+  constexpr bool kSeed = S3D_NN27_SEED && REVAL;   // (pass 2's neighbours are a transform update away: the cut costs more than it saves)
+  if (kSeed && need) {
+    const float lbs = A.corr_lb[ci];
+    if (lbs > 0.f) {
+      const CorrVec ps = A.corr_q[ci];
+      seed_d2 = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z);
+    }
+    if (REVAL && lbs != 0.f) {      // nn_query's re-validation, the same float operations
+      const float lb = fabsf(lbs);
+      const F3 qo = xf_eigen(P.T_nn, pg.x, pg.y, pg.z);
+      const float move = sqrtf(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
+      if (lbs > 0.f) {
+        if (nn_still_nearest(sqrtf(seed_d2), move, lb)) { A.corr_lb[ci] = lb - move; need = false; }
+      } else if (nn_still_nearest(max_d, move, lb)) {
+        A.corr_lb[ci] = move - lb;
+        need = false;
+      }
+    }
+  }
+  if (!kSeed && REVAL && need) {
     const float lbs = A.corr_lb[ci];
     if (lbs != 0.f) {               // nn_query's re-validation, the same float operations
       const float lb = fabsf(lbs);
@@ -1518,13 +1543,18 @@ __global__ void __launch_bounds__(kBlock, S3D_NN27_WAVES) s3d_nn_scan27_kernel(c
     p0 = A.sorted3[St.off + i];
     pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
     q = xf_eigen(P.T, pg.x, pg.y, pg.z);
+    seed_d2 = 3.0e38f;
+    if (kSeed && need && A.corr_lb[ci] > 0.f) {    // (the query has changed hands: its own neighbour copy)
+      const CorrVec ps = A.corr_q[ci];
+      seed_d2 = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z);
+    }
   }
   const unsigned long long nmask = __ballot(need);
   if (nmask == 0ull) return;
   if (prof_counts && lane_id() == 0) atomicAdd(&prof_counts[0], (int)__popcll(nmask));
   NNResult r;
   bool ok = false;
-  if (need) ok = grid_nn1_scan27(Ss.g, A.cell_start + Ss.cell_off, A.sorted + Ss.off, q.x, q.y, q.z, tab + threadIdx.x, kBlock, r);
+  if (need) ok = grid_nn1_scan27(Ss.g, A.cell_start + Ss.cell_off, A.sorted + Ss.off, q.x, q.y, q.z, tab + threadIdx.x, kBlock, r, seed_d2);
   if (need && ok) {                 // (the stores of nn_query; a scan27 answer always has a neighbour)
     A.corr_idx[ci] = r.pos;
     A.corr_d2[ci] = r.d2;

@@ -90,16 +90,23 @@ def test_device_scan27_nn_is_exact_when_it_answers(emu, oracle_mod, fixture_clou
     idx = np.empty(len(q), np.int32); d2 = np.empty(len(q), np.float32)
     ans = np.empty(len(q), np.int32); lb = np.empty(len(q), np.float32)
     tgt = np.ascontiguousarray(np.concatenate([v1, v1[:50]]))       # duplicate target points: ties of the distance
-    emu.emu_nn_scan27(tgt.ctypes.data_as(fp), len(tgt), q.ctypes.data_as(fp), len(q), C.c_float(h0), cpp,
-                      idx.ctypes.data_as(ip), d2.ctypes.data_as(fp), ans.ctypes.data_as(ip), lb.ctypes.data_as(fp))
     oi, od = oracle_mod.nn_search(tgt, q)
-    a = ans == 1
-    assert a.mean() > (0.2 if shift > 0.2 or h0 > 0.9 else 0.5), a.mean()
-    assert np.array_equal(idx[a], oi[a]) and np.array_equal(d2[a], od[a])
-    # the bound on every other point: the second-nearest distance of a kd-tree query is not below it
-    dd, _ = cKDTree(tgt.astype(np.float64)).query(q[a].astype(np.float64), 2)
-    assert (dd[:, 1] >= lb[a] * (1 - 1e-5) - 1e-6).all()
-    assert not a[len(v2[::3]):len(v2[::3]) + 400].all()            # the far queries are not all answerable
+    tree = cKDTree(tgt.astype(np.float64))
+    # seeds: none / the true neighbour / the 5th neighbour (a stale one) / a random point of the cloud
+    _, nb5 = tree.query(q.astype(np.float64), 5)
+    seeds = {"none": None, "exact": oi.astype(np.int32), "stale": nb5[:, 4].astype(np.int32),
+             "random": rng.integers(0, len(tgt), len(q)).astype(np.int32)}
+    for kind, sd in seeds.items():
+        emu.emu_nn_scan27(tgt.ctypes.data_as(fp), len(tgt), q.ctypes.data_as(fp), len(q), C.c_float(h0), cpp,
+                          idx.ctypes.data_as(ip), d2.ctypes.data_as(fp), ans.ctypes.data_as(ip), lb.ctypes.data_as(fp),
+                          sd.ctypes.data_as(ip) if sd is not None else None)
+        a = ans == 1
+        assert a.mean() > (0.2 if shift > 0.2 or h0 > 0.9 else 0.5), (kind, a.mean())
+        assert np.array_equal(idx[a], oi[a]) and np.array_equal(d2[a], od[a]), kind
+        # the bound on every other point: the second-nearest distance of a kd-tree query is not below it
+        dd, _ = tree.query(q[a].astype(np.float64), 2)
+        assert (dd[:, 1] >= lb[a] * (1 - 1e-5) - 1e-6).all(), kind
+        assert not a[len(v2[::3]):len(v2[::3]) + 400].all(), kind     # the far queries are not all answerable
 
 
 @pytest.mark.parametrize("hint_kind", ["tiny", "exact", "huge", "random"])
