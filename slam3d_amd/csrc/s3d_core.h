@@ -1472,24 +1472,27 @@ S3D_HD int gq_sym(int c, int d) {  // c <= d in 0..2
 // Mahalanobis matrix of one correspondence (PCL gicp.hpp computeTransformation):
 //   M = (R C1 R^T + C2)^-1,  C = I - (1-eps) n n^T  (== U diag(1,1,eps) U^T)
 // S = R R^T (sym, 6 values: 00 01 02 11 12 22), n1r = R n1 (already rotated), n2 unit.
+// (Products and sums are written as explicit fma(): the library is compiled with -ffp-contract=off for the float code
+// that has to round like the reference stack; this double arithmetic has no reference bit pattern - PCL's depends on
+// Eigen's vectorisation - and un-fused it was 47 of the accumulate kernel's 213 double-precision instructions.)
 S3D_HD void gicp_mahalanobis(const double S[6], const double n1r[3], const double n2[3], double eps, double M[6]) {
   const double w = 1.0 - eps;
-  double t00 = S[0] + 1.0 - w * (n1r[0] * n1r[0] + n2[0] * n2[0]);
-  double t01 = S[1] - w * (n1r[0] * n1r[1] + n2[0] * n2[1]);
-  double t02 = S[2] - w * (n1r[0] * n1r[2] + n2[0] * n2[2]);
-  double t11 = S[3] + 1.0 - w * (n1r[1] * n1r[1] + n2[1] * n2[1]);
-  double t12 = S[4] - w * (n1r[1] * n1r[2] + n2[1] * n2[2]);
-  double t22 = S[5] + 1.0 - w * (n1r[2] * n1r[2] + n2[2] * n2[2]);
+  const double t00 = fma(-w, fma(n2[0], n2[0], n1r[0] * n1r[0]), S[0] + 1.0);
+  const double t01 = fma(-w, fma(n2[0], n2[1], n1r[0] * n1r[1]), S[1]);
+  const double t02 = fma(-w, fma(n2[0], n2[2], n1r[0] * n1r[2]), S[2]);
+  const double t11 = fma(-w, fma(n2[1], n2[1], n1r[1] * n1r[1]), S[3] + 1.0);
+  const double t12 = fma(-w, fma(n2[1], n2[2], n1r[1] * n1r[2]), S[4]);
+  const double t22 = fma(-w, fma(n2[2], n2[2], n1r[2] * n1r[2]), S[5] + 1.0);
   // symmetric cofactor inverse
-  double c00 = t11 * t22 - t12 * t12;
-  double c01 = t02 * t12 - t01 * t22;
-  double c02 = t01 * t12 - t02 * t11;
-  double det = t00 * c00 + t01 * c01 + t02 * c02;
-  double id = 1.0 / det;
+  const double c00 = fma(t11, t22, -(t12 * t12));
+  const double c01 = fma(t02, t12, -(t01 * t22));
+  const double c02 = fma(t01, t12, -(t02 * t11));
+  const double det = fma(t00, c00, fma(t01, c01, t02 * c02));
+  const double id = 1.0 / det;
   M[0] = c00 * id; M[1] = c01 * id; M[2] = c02 * id;
-  M[3] = (t00 * t22 - t02 * t02) * id;
-  M[4] = (t01 * t02 - t00 * t12) * id;
-  M[5] = (t00 * t11 - t01 * t01) * id;
+  M[3] = fma(t00, t22, -(t02 * t02)) * id;
+  M[4] = fma(t01, t02, -(t00 * t12)) * id;
+  M[5] = fma(t00, t11, -(t01 * t01)) * id;
 }
 
 // add one correspondence (p = guess-transformed query, q = matched target, M sym) to acc[76].
@@ -1503,7 +1506,7 @@ S3D_HD void gq_accumulate(double* acc, const double p[3], const double qt[3], co
   const double P[4] = {p[0], p[1], p[2], 1.0};
   double q[3];  // q := -(r) so that the code below accumulates with the residual: B <- -(M r) P, see gq_eval
   for (int c = 0; c < 3; ++c)
-    q[c] = qt[c] - (Th0[c * 4 + 0] * P[0] + Th0[c * 4 + 1] * P[1] + Th0[c * 4 + 2] * P[2] + Th0[c * 4 + 3]);
+    q[c] = qt[c] - fma(Th0[c * 4 + 0], P[0], fma(Th0[c * 4 + 1], P[1], fma(Th0[c * 4 + 2], P[2], Th0[c * 4 + 3])));
   int o = 0;
   for (int a = 0; a < 4; ++a)
     for (int b = a; b < 4; ++b) {
@@ -1511,15 +1514,15 @@ S3D_HD void gq_accumulate(double* acc, const double p[3], const double qt[3], co
       for (int s = 0; s < 6; ++s) acc[o + s] = fma(pp, M[s], acc[o + s]);
       o += 6;
     }
-  const double Mq0 = M[0] * q[0] + M[1] * q[1] + M[2] * q[2];
-  const double Mq1 = M[1] * q[0] + M[3] * q[1] + M[4] * q[2];
-  const double Mq2 = M[2] * q[0] + M[4] * q[1] + M[5] * q[2];
+  const double Mq0 = fma(M[0], q[0], fma(M[1], q[1], M[2] * q[2]));
+  const double Mq1 = fma(M[1], q[0], fma(M[3], q[1], M[4] * q[2]));
+  const double Mq2 = fma(M[2], q[0], fma(M[4], q[1], M[5] * q[2]));
   for (int a = 0; a < 4; ++a) {
     acc[GQ_B + 0 * 4 + a] = fma(Mq0, P[a], acc[GQ_B + 0 * 4 + a]);
     acc[GQ_B + 1 * 4 + a] = fma(Mq1, P[a], acc[GQ_B + 1 * 4 + a]);
     acc[GQ_B + 2 * 4 + a] = fma(Mq2, P[a], acc[GQ_B + 2 * 4 + a]);
   }
-  acc[GQ_C0] += q[0] * Mq0 + q[1] * Mq1 + q[2] * Mq2;
+  acc[GQ_C0] = fma(q[0], Mq0, fma(q[1], Mq1, fma(q[2], Mq2, acc[GQ_C0])));
   acc[GQ_CNT] += 1.0;
 }
 
@@ -1932,8 +1935,8 @@ S3D_HD void gicp_rotation(const Mat4f& T, const Mat4f& guess, double R[9], doubl
 enum { PP_NACC = 32, PP_B = 21, PP_R2 = 27, PP_CNT = 28 };
 
 S3D_HD void pp_accumulate(double* acc, const double p[3], const double q[3], const double n[3]) {
-  const double r = n[0] * (p[0] - q[0]) + n[1] * (p[1] - q[1]) + n[2] * (p[2] - q[2]);
-  const double J[6] = {p[1] * n[2] - p[2] * n[1], p[2] * n[0] - p[0] * n[2], p[0] * n[1] - p[1] * n[0],
+  const double r = fma(n[0], p[0] - q[0], fma(n[1], p[1] - q[1], n[2] * (p[2] - q[2])));
+  const double J[6] = {fma(p[1], n[2], -(p[2] * n[1])), fma(p[2], n[0], -(p[0] * n[2])), fma(p[0], n[1], -(p[1] * n[0])),
                        n[0], n[1], n[2]};
   int o = 0;
   for (int a = 0; a < 6; ++a) {

@@ -1918,7 +1918,7 @@ __global__ void __launch_bounds__(kBlock) s3d_gicp_accumulate_kernel(const PairD
         normal_decode(nb, n2);
         double n1r[3], Mm[6];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) n1r[a] = R[a * 3] * n1[0] + R[a * 3 + 1] * n1[1] + R[a * 3 + 2] * n1[2];
+        for (int a = 0; a < 3; ++a) n1r[a] = fma(R[a * 3], n1[0], fma(R[a * 3 + 1], n1[1], R[a * 3 + 2] * n1[2]));
         gicp_mahalanobis(S, n1r, n2, rp.gicp_epsilon, Mm);
         const double pd[3] = {pf.x, pf.y, pf.z};
         const double qd[3] = {qf.x, qf.y, qf.z};
