@@ -1359,9 +1359,13 @@ S3D_HD bool sym3_smallest_eigvec_direct(double a00, double a01, double a02, doub
   const double c00 = b00 * ip, c01 = a01 * ip, c02 = a02 * ip, c11 = b11 * ip, c12 = a12 * ip, c22 = b22 * ip;
   double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
   r = fmin(fmax(r, -1.0), 1.0);
-  const double phi = acos(r) / 3.0;
-  const double emax = q + 2.0 * pp * cos(phi);
-  const double emin = q + 2.0 * pp * cos(phi + 2.0943951023931953);   // + 2 pi / 3
+  // phi = acos(r) / 3 lies in [0, pi / 3]: cos(phi + 2 pi / 3) = -cos(phi) / 2 - sin(phi) sqrt(3) / 2 with
+  // sin(phi) = sqrt(1 - cos^2(phi)) >= 0 - one cosine and a square root instead of two cosines
+  const double phi = acos(r) * 0.33333333333333333;
+  const double cphi = cos(phi);
+  const double sphi = sqrt(fmax(fma(-cphi, cphi, 1.0), 0.0));
+  const double emax = fma(2.0 * pp, cphi, q);
+  const double emin = fma(2.0 * pp, fma(-0.8660254037844386, sphi, -0.5 * cphi), q);
   const double emid = 3.0 * q - emax - emin;
   if (!(emid - emin > 1e-6 * (emax - emin))) return false;
   // rows of A - emin I
@@ -1591,8 +1595,8 @@ S3D_HD void gq_eval(const double* acc, const double* Th0, const double x[6], dou
   // the float rounding is applied once per outer iteration instead (gicp_apply_state),
   // where PCL stores transformation_ as Matrix4f.
   double Th[3][4];
-  Th[0][0] = cpsi * cth; Th[0][1] = cpsi * sth * sphi - spsi * cphi; Th[0][2] = cpsi * sth * cphi + spsi * sphi;
-  Th[1][0] = spsi * cth; Th[1][1] = spsi * sth * sphi + cpsi * cphi; Th[1][2] = spsi * sth * cphi - cpsi * sphi;
+  Th[0][0] = cpsi * cth; Th[0][1] = fma(cpsi * sth, sphi, -(spsi * cphi)); Th[0][2] = fma(cpsi * sth, cphi, spsi * sphi);
+  Th[1][0] = spsi * cth; Th[1][1] = fma(spsi * sth, sphi, cpsi * cphi); Th[1][2] = fma(spsi * sth, cphi, -(cpsi * sphi));
   Th[2][0] = -sth; Th[2][1] = cth * sphi; Th[2][2] = cth * cphi;
   Th[0][3] = x[0]; Th[1][3] = x[1]; Th[2][3] = x[2];
   for (int c = 0; c < 3; ++c)
@@ -1633,7 +1637,7 @@ S3D_HD void gq_eval(const double* acc, const double* Th0, const double x[6], dou
 #endif
   double fsum = 0.0;
   for (int a = 0; a < 4; ++a)
-    for (int c = 0; c < 3; ++c) fsum += Th[c][a] * (G[a][c] - acc[GQ_B + c * 4 + a]);
+    for (int c = 0; c < 3; ++c) fsum = fma(Th[c][a], G[a][c] - acc[GQ_B + c * 4 + a], fsum);
   const double m = acc[GQ_CNT];
   *f = (fsum + acc[GQ_C0]) / m;
   const double sc = 2.0 / m;
@@ -1654,9 +1658,9 @@ S3D_HD void gq_eval(const double* acc, const double* Th0, const double x[6], dou
   double g3 = 0, g4 = 0, g5 = 0;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) {
-      g3 += dPhi[j][i] * Rs[i][j];
-      g4 += dTh[j][i] * Rs[i][j];
-      g5 += dPsi[j][i] * Rs[i][j];
+      g3 = fma(dPhi[j][i], Rs[i][j], g3);
+      g4 = fma(dTh[j][i], Rs[i][j], g4);
+      g5 = fma(dPsi[j][i], Rs[i][j], g5);
     }
   g[3] = g3; g[4] = g4; g[5] = g5;
 }
@@ -1679,17 +1683,17 @@ enum { BFGS_RUNNING = -1, BFGS_SUCCESS = 0, BFGS_NOPROGRESS = 1 };
 
 S3D_HD double v6norm(const double* v) {
   double s = 0;
-  for (int i = 0; i < 6; ++i) s += v[i] * v[i];
+  for (int i = 0; i < 6; ++i) s = fma(v[i], v[i], s);
   return sqrt(s);
 }
 S3D_HD double v6dot(const double* a, const double* b) {
   double s = 0;
-  for (int i = 0; i < 6; ++i) s += a[i] * b[i];
+  for (int i = 0; i < 6; ++i) s = fma(a[i], b[i], s);
   return s;
 }
 S3D_HD void bfgs_eval(Bfgs& b, double alpha) {
   if (alpha == b.c_alpha) return;
-  for (int i = 0; i < 6; ++i) b.c_x[i] = b.x0[i] + alpha * b.p[i];
+  for (int i = 0; i < 6; ++i) b.c_x[i] = fma(alpha, b.p[i], b.x0[i]);
   gq_eval(b.acc, b.th0, b.c_x, &b.c_f, b.c_g);
   b.c_df = v6dot(b.c_g, b.p);
   b.c_alpha = alpha;
