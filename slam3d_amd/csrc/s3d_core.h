@@ -308,9 +308,47 @@ S3D_HD NNResult grid_nn1(const GridParams& g, const uint32_t* __restrict__ cell_
 // nearest neighbour is at most as far as that candidate: rescan with exactly that radius (or
 // double the radius when nothing was found).  With the previous ICP iteration's distance as the
 // hint almost every query resolves in one tight scan.  Same result as grid_nn1 (ties: lowest index).
-template <typename F4T>
-S3D_HD void nn1_consider(NNResult& best, const F4T& p, uint32_t k, float qx, float qy, float qz) {
+// v_min_f64 / v_max_f64 on packed keys held as doubles (every key here is a normal, finite double)
+S3D_HD double f64_min_raw(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return a < b ? a : b;
+#endif
+}
+S3D_HD double f64_max_raw(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return a < b ? b : a;
+#endif
+}
+
+// FAST (the first pass of a registration, which needs neither the runner-up nor a re-scan of the incumbent): the best
+// candidate is ONE packed key, (d2 bits + 2^23) << 32 | index, held as a double - v_min_f64 keeps the smaller, the
+// same compare moves the position along: 4 instructions after the distance instead of ~15.  Same order as lex_less
+// (distance, then index); best.d2 / best.idx are refreshed from the key by nn1_fast_sync where the search reads them.
+constexpr unsigned long long kNNFastNone = 0x7FDFFFFFFFFFFFFFull;   // (low word = -1: "no index")
+S3D_HD void nn1_fast_sync(NNResult& best, double bkey) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, bkey);
+  best.d2 = __builtin_bit_cast(float, (uint32_t)(b >> 32) - 0x00800000u);
+  best.idx = (int)(uint32_t)(b & 0xFFFFFFFFull);
+}
+template <bool FAST = false, typename F4T>
+S3D_HD void nn1_consider(NNResult& best, double& bkey, const F4T& p, uint32_t k, float qx, float qy, float qz) {
   const float d2 = dist2(qx, qy, qz, p.x, p.y, p.z);
+  if (FAST) {
+    const unsigned long long kb = ((unsigned long long)(__builtin_bit_cast(uint32_t, d2) + 0x00800000u) << 32) |
+                                  (unsigned long long)__builtin_bit_cast(uint32_t, p.w);
+    const double c = __builtin_bit_cast(double, kb);
+    best.pos = c < bkey ? (int)k : best.pos;
+    bkey = f64_min_raw(bkey, c);
+    return;
+  }
   const int pi = __builtin_bit_cast(int, p.w);
   if (pi == best.idx) return;  // (a rescan meets the incumbent again)
   if (lex_less(d2, pi, best.d2, best.idx < 0 ? 2147483647 : best.idx)) {
@@ -324,8 +362,8 @@ S3D_HD void nn1_consider(NNResult& best, const F4T& p, uint32_t k, float qx, flo
 // scan the (<= NR x NR) rows of a tight box with the memory accesses issued as three independent
 // BATCHES (all row ranges, then the first point of every row, then the rest) instead of one dependent
 // load per step: the kernel is bound by memory latency x chain length and by the L1 access rate.
-template <int NR, typename F4T>
-S3D_HD void nn1_scan_rows(NNResult& best, const GridParams& g, const uint32_t* __restrict__ cell_start,
+template <int NR, bool FAST = false, typename F4T>
+S3D_HD void nn1_scan_rows(NNResult& best, double& bkey, const GridParams& g, const uint32_t* __restrict__ cell_start,
                           const F4T* __restrict__ pts, float qx, float qy, float qz, int x0, int x1, int y0, int ny,
                           int z0, int nz) {
   uint32_t rs[NR * NR], re[NR * NR];
@@ -342,7 +380,7 @@ S3D_HD void nn1_scan_rows(NNResult& best, const GridParams& g, const uint32_t* _
   for (int r = 0; r < NR * NR; ++r) first[r] = pts[rs[r] < re[r] ? rs[r] : 0];
 #pragma unroll
   for (int r = 0; r < NR * NR; ++r)
-    if (rs[r] < re[r]) nn1_consider(best, first[r], rs[r], qx, qy, qz);
+    if (rs[r] < re[r]) nn1_consider<FAST>(best, bkey, first[r], rs[r], qx, qy, qz);
 #pragma unroll
   for (int r = 0; r < NR * NR; ++r) {
     for (uint32_t k = rs[r] + 1; k < re[r]; k += S3D_NN_BATCH) {      // S3D_NN_BATCH loads in flight per step
@@ -352,9 +390,10 @@ S3D_HD void nn1_scan_rows(NNResult& best, const GridParams& g, const uint32_t* _
       for (int u = 0; u < S3D_NN_BATCH; ++u) pp[u] = pts[k + u < e ? k + u : last];
 #pragma unroll
       for (int u = 0; u < S3D_NN_BATCH; ++u)
-        if (k + u < e) nn1_consider(best, pp[u], k + u, qx, qy, qz);
+        if (k + u < e) nn1_consider<FAST>(best, bkey, pp[u], k + u, qx, qy, qz);
     }
   }
+  if (FAST) nn1_fast_sync(best, bkey);
 }
 
 // seed_pos >= 0: position (in pts) of a point known to be near the query — the previous ICP
@@ -368,19 +407,21 @@ constexpr float kNNRevalSlack = 0.25f;   // in cells
 // best, so that the examined radius exceeds the neighbour's distance and the NEXT pass can re-validate the
 // correspondence without a search (nn_still_nearest).  Without it every such query walks its whole ball again in
 // every ICP iteration: on the reference's fixture scans those 2 % of the queries were 75 % of the step time.
-template <typename F4T>
+template <bool FAST = false, typename F4T>
 S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ cell_start,
                              const F4T* __restrict__ pts, float qx, float qy, float qz, float max_d, float d_hint,
                              int seed_pos = -1, bool seed_trusted = false) {
   NNResult best;
   best.idx = -1; best.d2 = 3.0e38f; best.pos = -1; best.second_d2 = 3.0e38f; best.radius = 0.f;
+  double bkey = __builtin_bit_cast(double, kNNFastNone);   // (FAST only)
   // the last attempt looks one shell beyond max_d: a query with NO neighbour in range then carries a radius
   // > max_d, which is what lets the next pass prove "still none" without a search
   const float cap = max_d + kNNRevalSlack * g.h;
   const float shell = seed_trusted ? kNNRevalSlack * g.h : 0.f;
   float d = fminf(fmaxf(d_hint, 0.25f * g.h), cap);
   if (seed_pos >= 0) {
-    nn1_consider(best, pts[seed_pos], (uint32_t)seed_pos, qx, qy, qz);
+    nn1_consider<FAST>(best, bkey, pts[seed_pos], (uint32_t)seed_pos, qx, qy, qz);
+    if (FAST) nn1_fast_sync(best, bkey);
     // examine a little more than the seed's distance: the extra shell is what later lets
     // nn_still_nearest() prove the correspondence without a search (lower bound of the other points).
     // (an untrusted seed that ended up far away — the transform just moved — must not blow the box up)
@@ -398,9 +439,9 @@ S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ c
     bool pruned = false;
     if (x0 <= x1 && ny > 0 && nz > 0) {
       if (ny <= 2 && nz <= 2) {
-        nn1_scan_rows<2>(best, g, cell_start, pts, qx, qy, qz, x0, x1, y0, ny, z0, nz);
+        nn1_scan_rows<2, FAST>(best, bkey, g, cell_start, pts, qx, qy, qz, x0, x1, y0, ny, z0, nz);
       } else if (ny <= 3 && nz <= 3) {
-        nn1_scan_rows<3>(best, g, cell_start, pts, qx, qy, qz, x0, x1, y0, ny, z0, nz);
+        nn1_scan_rows<3, FAST>(best, bkey, g, cell_start, pts, qx, qy, qz, x0, x1, y0, ny, z0, nz);
       } else {
         // wide box (badly aligned clouds, first passes): shrinking-ball scan.  Rows are visited from the
         // query's own row outwards; a row whose slab is farther than the best distance so far (+ shell) is
@@ -450,8 +491,9 @@ S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ c
               for (int u = 0; u < S3D_NN_BATCH; ++u) pp[u] = pts[k + u < e ? k + u : last];
 #pragma unroll
               for (int u = 0; u < S3D_NN_BATCH; ++u)
-                if (k + u < e) nn1_consider(best, pp[u], k + u, qx, qy, qz);
+                if (k + u < e) nn1_consider<FAST>(best, bkey, pp[u], k + u, qx, qy, qz);
             }
+            if (FAST) nn1_fast_sync(best, bkey);
             lim2 = limit2();
           }
         }
@@ -1141,25 +1183,6 @@ S3D_HD uint32_t knn3_position(uint32_t key, const uint32_t* tab, int tstride) {
 // the 27 cells' guaranteed reach (1 + face) h, which is then also the radius the re-validation of later passes builds
 // on; anything else (a query outside the grid, empty cells, a farther neighbour, a row range beyond the table) returns
 // false and goes through grid_nn1_box.  Same neighbour, same float d2, same tie rule (lowest index).
-S3D_HD double f64_min_raw(double a, double b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  double r;
-  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-#else
-  return a < b ? a : b;
-#endif
-}
-S3D_HD double f64_max_raw(double a, double b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  double r;
-  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-#else
-  return a < b ? b : a;
-#endif
-}
-
 // seed_d2 (3e38: none): the squared distance of a point KNOWN to exist - the previous pass's neighbour under the new
 // transform, read from the copy that travels with the correspondence, no gather.  The nine rows are then cut to the
 // ball of that radius (+ the re-validation shell, as grid_nn1_box does): a slab test per row, the x-range of its

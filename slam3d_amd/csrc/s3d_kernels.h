@@ -1130,8 +1130,9 @@ __device__ S3D_COOP_INLINE NNResult wave_nn1_coop(const GridParams& g, const uin
   // every seeded search examines a shell beyond the neighbour: that is what the next pass re-validates against
   const float shell = seed_pos >= 0 ? kNNRevalSlack * g.h : 0.f;
   float d = fminf(fmaxf(d_hint, 0.25f * g.h), cap);
+  double unused_key = 0.0;   // (nn1_consider's packed key: the FAST variant only)
   if (seed_pos >= 0) {
-    nn1_consider(best, pts[seed_pos], (uint32_t)seed_pos, qx, qy, qz);
+    nn1_consider(best, unused_key, pts[seed_pos], (uint32_t)seed_pos, qx, qy, qz);
     d = sqrtf(best.d2) * 1.0001f + 1.0e-6f + kNNRevalSlack * g.h;
     d = fminf(seed_trusted ? d : fminf(d, g.h), cap);
   }
@@ -1197,7 +1198,7 @@ __device__ S3D_COOP_INLINE NNResult wave_nn1_coop(const GridParams& g, const uin
           const uint32_t row_rs = __shfl(rs, lo, kWave);
           if (t < total) {
             const uint32_t k = row_rs + (t - (row_incl - row_len));
-            nn1_consider(mine, pts[k], k, qx, qy, qz);
+            nn1_consider(mine, unused_key, pts[k], k, qx, qy, qz);
           }
         }
       }
@@ -1339,7 +1340,8 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
     const bool wide = need && (all_coop || !near_seed);
     unsigned long long wmask = __ballot(wide);
     const bool coop = wmask != 0ull && __popcll(wmask) <= kCoopMaxLanes && !(dbg & 2048);
-    if (need && !(coop && wide)) r = grid_nn1_box(Ss.g, cs, tp, q.x, q.y, q.z, max_d, hint, seed, far_seed);
+    // (the first pass keeps its best candidate as one packed key and no runner-up: nn1_consider<FAST>)
+    if (need && !(coop && wide)) r = grid_nn1_box<PHASE == 5>(Ss.g, cs, tp, q.x, q.y, q.z, max_d, hint, seed, far_seed);
     if (coop) {
       while (wmask) {
         const int src = __ffsll((long long)wmask) - 1;
@@ -1357,7 +1359,9 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   A.corr_idx[ci] = r.pos;
   A.corr_d2[ci] = r.d2;
   const float lbv = !(S3D_NN_AB && (dbg & 4)) ? nn_lower_bound_others(r) : 0.f;   // no neighbour at all: the scanned radius
-  A.corr_lb[ci] = r.pos >= 0 ? lbv : -lbv;
+  // (first pass: the runner-up is not tracked - "nothing known" about the others; the second pass searches every
+  // query again anyway, the first transform update has moved them all)
+  A.corr_lb[ci] = r.pos >= 0 ? (PHASE == 5 ? 0.f : lbv) : -lbv;
   if (r.pos >= 0) {
     // a copy of the matched point and of its normal is kept with the correspondence: the re-validation
     // above and the accumulate kernel then stream them instead of gathering by index

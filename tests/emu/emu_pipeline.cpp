@@ -148,15 +148,22 @@ void emu_nn(const float* tgt, int n, const float* qry, int m, float h0, int cpp,
     idx[i] = r.idx; d2[i] = r.d2;
   }
 }
+// fast != 0: the first-pass variant (nn1_consider<FAST>: one packed key, no runner-up); pos_ok (may be null) counts the
+// results whose position names the returned index
 void emu_nn_box(const float* tgt, int n, const float* qry, int m, float h0, int cpp, float max_d, const float* hint,
-                int* idx, float* d2) {
+                int* idx, float* d2, int fast, int* pos_ok) {
   Cloud c = voxel(tgt, n, 3, 0.0);
   Grid G = build_grid(c, h0, cpp);
+  int ok = 0;
   for (int i = 0; i < m; ++i) {
-    NNResult r = grid_nn1_box(G.g, G.cell_start.data(), G.sorted.data(), qry[i * 3], qry[i * 3 + 1], qry[i * 3 + 2],
-                              max_d, hint[i]);
+    NNResult r = fast ? grid_nn1_box<true>(G.g, G.cell_start.data(), G.sorted.data(), qry[i * 3], qry[i * 3 + 1],
+                                           qry[i * 3 + 2], max_d, hint[i])
+                      : grid_nn1_box(G.g, G.cell_start.data(), G.sorted.data(), qry[i * 3], qry[i * 3 + 1],
+                                     qry[i * 3 + 2], max_d, hint[i]);
     idx[i] = r.idx; d2[i] = r.d2;
+    if (r.idx < 0 ? r.pos < 0 : (r.pos >= 0 && __builtin_bit_cast(int, G.sorted[r.pos].w) == r.idx)) ++ok;
   }
+  if (pos_ok) *pos_ok = ok;
 }
 void emu_normals(const float* xyz, int n, int k, float h0, int cpp, float* out) {
   Cloud c = voxel(xyz, n, 3, 0.0);

@@ -109,9 +109,11 @@ def test_device_scan27_nn_is_exact_when_it_answers(emu, oracle_mod, fixture_clou
         assert not a[len(v2[::3]):len(v2[::3]) + 400].all(), kind     # the far queries are not all answerable
 
 
+@pytest.mark.parametrize("fast", [0, 1])
 @pytest.mark.parametrize("hint_kind", ["tiny", "exact", "huge", "random"])
-def test_device_box_nn_is_exact_for_any_hint(emu, oracle_mod, fixture_clouds, hint_kind):
-    """grid_nn1_box (the kernel's hot variant) must return the exact NN whatever the radius hint."""
+def test_device_box_nn_is_exact_for_any_hint(emu, oracle_mod, fixture_clouds, hint_kind, fast):
+    """grid_nn1_box (the kernel's hot variant) must return the exact NN whatever the radius hint - also in the
+    first-pass form that keeps the best candidate as one packed key (fast)."""
     v1, _ = oracle_mod.voxel_downsample(fixture_clouds[0], 0.2)
     v2, _ = oracle_mod.voxel_downsample(fixture_clouds[1], 0.2)
     rng = np.random.default_rng(2)
@@ -121,8 +123,10 @@ def test_device_box_nn_is_exact_for_any_hint(emu, oracle_mod, fixture_clouds, hi
             "random": rng.uniform(0.0, 3.0, len(q))}[hint_kind].astype(np.float32)
     idx = np.empty(len(q), np.int32)
     d2 = np.empty(len(q), np.float32)
+    pos_ok = C.c_int(0)
     emu.emu_nn_box(v1.ctypes.data_as(fp), len(v1), q.ctypes.data_as(fp), len(q), C.c_float(0.4), 16, C.c_float(2.5),
-                   hint.ctypes.data_as(fp), idx.ctypes.data_as(ip), d2.ctypes.data_as(fp))
+                   hint.ctypes.data_as(fp), idx.ctypes.data_as(ip), d2.ctypes.data_as(fp), fast, C.byref(pos_ok))
+    assert pos_ok.value == len(q)          # the position names the same point as the index
     m = od < 2.5 ** 2
     assert np.array_equal(idx[m], oi[m]) and np.array_equal(d2[m], od[m])
     assert np.all((idx[~m] == -1) | (d2[~m] >= 2.5 ** 2))
