@@ -1062,8 +1062,16 @@ __global__ void __launch_bounds__(kBlock) s3d_knn_moments_redo_kernel(const Slot
                                                                        int* __restrict__ fallback_list,
                                                                        const int* __restrict__ redo_count,
                                                                        const int2* __restrict__ redo_list) {
+  // a short list is dealt thinly - one entry per wave while the waves last: an exact search is a long chain of
+  // dependent steps and the lanes of a wave serialise their different paths, so the list's LATENCY is what a lone
+  // registration waits for (600 entries of one pair: 161 -> 40 us); a long list: full waves, throughput counts
   const int count = *redo_count;
-  for (int j = blockIdx.x * kBlock + threadIdx.x; j < count; j += gridDim.x * kBlock) {
+  const int waves = (int)gridDim.x * (kBlock / kWave);
+  const int per = count <= waves ? 1 : count <= 8 * waves ? 8 : kWave;
+  const int wave = (int)blockIdx.x * (kBlock / kWave) + wave_id();
+  for (int j0 = wave * per; j0 < count; j0 += waves * per) {
+    const int j = j0 + lane_id();
+    if (lane_id() >= per || j >= count) continue;
     const int2 e = redo_list[j];
     knn_moments_point<KMAX, FULL>(slots[e.x], e.y, filt, sorted, cell_start, moments, plane, k, normals, fallback_count,
                                   fallback_list);
