@@ -784,6 +784,10 @@ __global__ void __launch_bounds__(kBlock) k_centroids(const SlotDev* __restrict_
   const uint32_t* __restrict__ k = keys + s.off;
   const uint32_t* __restrict__ v = vals + s.off;
   const bool head = i < s.n_raw && voxel_head(k, i);
+  // the first point of this position's run is fetched before the block scan (its index, then the gather: two
+  // dependent round trips that otherwise follow the scan's barriers); a position that is no head has wasted a load
+  float4 p_first = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < s.n_raw) p_first = s.raw[v[i]];
   int total;
   const int pos = block_excl_flag(head, &total, lds4) + (int)blockcnt[(size_t)slot_i * nb_max + chunk_i];
   // the bounding box of the centroids (what the search grid is laid over) is gathered here, where they are written (a
@@ -793,8 +797,8 @@ __global__ void __launch_bounds__(kBlock) k_centroids(const SlotDev* __restrict_
   unsigned int mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
   if (head) {
     const uint32_t key = k[i];
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    int j = i;
+    float sx = 0.f + p_first.x, sy = 0.f + p_first.y, sz = 0.f + p_first.z;   // (0 + x: the sums start as they always did)
+    int j = i + 1;
     for (; j < s.n_raw && k[j] == key; ++j) {
       const float4 p = s.raw[v[j]];
       sx += p.x; sy += p.y; sz += p.z;
@@ -1455,7 +1459,10 @@ __global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_search_kernel(con
 // search; (b) the settled passes as a 24-VGPR stream kernel of the re-validation alone plus a worklist
 // kernel for the ~13 queries per pair whose proof fails in every pass - the stream is bound by its 32 bytes per query
 // (4.1 TB/s with either kernel), and the second launch costs more than the search code in the stream did.
-__global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_first_kernel(const PairDev* __restrict__ pairs,
+#ifndef S3D_NN_FIRST_WAVES
+#define S3D_NN_FIRST_WAVES 8      // (8 waves, 64 registers: 1.58 -> 1.54 ms per 128 pairs against 7; 5 and 6 are slower)
+#endif
+__global__ void __launch_bounds__(kBlock, S3D_NN_FIRST_WAVES) s3d_nn_first_kernel(const PairDev* __restrict__ pairs,
                                                                const SlotDev* __restrict__ slots, NNArrays A,
                                                                float max_d, int chunks_per_pair, int npairs, int dbg,
                                                                int* __restrict__ prof_counts) {
