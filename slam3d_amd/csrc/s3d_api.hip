@@ -533,8 +533,15 @@ struct Batch {
   // input in A; result in A for even `passes`, in B for odd.
   // One sweep per pass (k_sort_onesweep, decoupled look-back); hist_done: the kernel that produced the keys has
   // counted the digit totals of all passes (k_keys_hist with sweep_passes) and zeroed the look-back rows.
-  // S3D_SORT_CLASSIC=1 (A/B): the three-kernels-per-pass form.
-  bool sort_classic = getenv("S3D_SORT_CLASSIC") && atoi(getenv("S3D_SORT_CLASSIC")) != 0;
+  // The three-kernels-per-pass form (k_sort_hist / scan / scatter) reads the keys twice but never waits for another
+  // tile: it is the faster one once the batch is large (256 pairs of 100 k points: voxel + grid 4.22 -> 4.07 ms,
+  // equal at 128 pairs, 0.03 ms slower at 32), the one-sweep form - 5 launches instead of 11 per sort - for a small
+  // batch and a lone pair (-25 us).  S3D_SORT_CLASSIC=1 / 0 forces one or the other (A/B).
+  bool sort_classic = false;
+  void sort_choose() {
+    const char* e = getenv("S3D_SORT_CLASSIC");
+    sort_classic = e ? atoi(e) != 0 : (long long)Cu * (long long)max_n >= 40000000ll;
+  }
   bool sort_used = false;
   void sort_prepare(int nslots) {   // before the kernel that counts the digit totals
     if (!sort_classic && nslots > 0)
@@ -580,6 +587,7 @@ struct Batch {
     hipStream_t st = ctx->stream;
     const int NS = Cu;
     if (NS == 0) return;
+    sort_choose();
     if (rp.leaf > 0.f) {
       k_bbox<0><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), NS), kBlock, 0, st>>>(d_slots(), filt());
       k_voxel_params<<<cdiv(NS, 64), 64, 0, st>>>(d_slots(), rp, NS);
