@@ -136,6 +136,21 @@ int main() {
     std::vector<float> one(n, 1.0f); CHK(hipMemcpy(lb, one.data(), n * 4, hipMemcpyHostToDevice));
     const int chunks = (NQ + 255) / 256;
     run("settled pass, pairs, 1 chunk/blk", n * 32.0, [&] { k_reval_pairs<1><<<NP * chunks, 256>>>(dp, ds, c, d, lb, chunks, NP, fail); });
+    {  // the same pass with 1.4 GB of other traffic between two launches (as the accumulate kernel does in the product)
+      float4* fl; CHK(hipMalloc(&fl, (size_t)90000000 * 16)); CHK(hipMemset(fl, 0, (size_t)90000000 * 16));
+      hipEvent_t a0, a1; CHK(hipEventCreate(&a0)); CHK(hipEventCreate(&a1));
+      float tot = 0.f;
+      for (int it = 0; it < 12; ++it) {
+        k_read4u<1><<<(unsigned)(90000000 / 256), 256>>>(fl, 90000000, out);
+        hipEventRecord(a0, 0);
+        k_reval_pairs<1><<<NP * chunks, 256>>>(dp, ds, c, d, lb, chunks, NP, fail);
+        hipEventRecord(a1, 0); hipEventSynchronize(a1);
+        float ms; hipEventElapsedTime(&ms, a0, a1);
+        if (it >= 2) tot += ms;
+      }
+      printf("%-34s %8.3f ms  %6.2f TB/s\n", "settled pass after 1.4 GB of reads", tot / 10, n * 32.0 / (tot / 10 * 1e-3) / 1e12);
+      CHK(hipFree(fl));
+    }
     run("settled pass, pairs, 2 chunk/blk", n * 32.0, [&] { k_reval_pairs<2><<<NP * ((chunks + 1) / 2), 256>>>(dp, ds, c, d, lb, (chunks + 1) / 2, NP, fail); });
     run("settled pass, pairs, 4 chunk/blk", n * 32.0, [&] { k_reval_pairs<4><<<NP * ((chunks + 3) / 4), 256>>>(dp, ds, c, d, lb, (chunks + 3) / 4, NP, fail); });
     int hf; CHK(hipMemcpy(&hf, fail, 4, hipMemcpyDeviceToHost)); printf("fails %d\n", hf);
