@@ -658,7 +658,10 @@ struct Batch {
       int* redo_count = fb_count + 1;
       int2* redo_list = (int2*)ctx->knn_redo.p;
       s3d_knn3_moments_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), sorted(), cells(), mom, mom_plane, nb_head, d_list, NL, normals(), fb_count, fb_list, redo_count, redo_list);
-      s3d_knn_moments_redo_kernel<20, true><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list);
+      if ((long long)NL * max_n <= 2000000ll)   // a few clouds: the redo list's latency counts (see the kernel)
+        s3d_knn_moments_redo_kernel<20, true, true><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list);
+      else
+        s3d_knn_moments_redo_kernel<20, true, false><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list);
     } else if (k <= 8)
       s3d_knn_moments_kernel<8><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
     else if (k <= 16)

@@ -1054,8 +1054,12 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN3_WAVES) s3d_knn3_moments_kerne
   fallback_list[atomicAdd(fallback_count, 1)] = s.off + i;
 }
 
-// the queries s3d_knn3_moments_kernel listed, through the exact search; a fixed grid strides over the list
-template <int KMAX, bool FULL>
+// the queries s3d_knn3_moments_kernel listed, through the exact search; a fixed grid strides over the list.
+// THIN (the host asks for it when the batch is small): the list is dealt one entry per wave while the waves last, then
+// eight - an exact search is a long chain of dependent steps and the lanes of a wave serialise their different paths,
+// so the list's LATENCY is what a lone registration waits for (600 entries of one pair: 161 -> 40 us).  A large
+// batch's list (150 k entries) is a throughput matter: full waves.
+template <int KMAX, bool FULL, bool THIN>
 __global__ void __launch_bounds__(kBlock) s3d_knn_moments_redo_kernel(const SlotDev* __restrict__ slots,
                                                                        const float4* __restrict__ filt,
                                                                        const float4* __restrict__ sorted,
@@ -1066,16 +1070,16 @@ __global__ void __launch_bounds__(kBlock) s3d_knn_moments_redo_kernel(const Slot
                                                                        int* __restrict__ fallback_list,
                                                                        const int* __restrict__ redo_count,
                                                                        const int2* __restrict__ redo_list) {
-  // a short list is dealt thinly - one entry per wave while the waves last: an exact search is a long chain of
-  // dependent steps and the lanes of a wave serialise their different paths, so the list's LATENCY is what a lone
-  // registration waits for (600 entries of one pair: 161 -> 40 us); a long list: full waves, throughput counts
   const int count = *redo_count;
-  const int waves = (int)gridDim.x * (kBlock / kWave);
-  const int per = count <= waves ? 1 : count <= 8 * waves ? 8 : kWave;
-  const int wave = (int)blockIdx.x * (kBlock / kWave) + wave_id();
-  for (int j0 = wave * per; j0 < count; j0 += waves * per) {
-    const int j = j0 + lane_id();
-    if (lane_id() >= per || j >= count) continue;
+  int first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
+  if (THIN) {
+    const int waves = (int)gridDim.x * (kBlock / kWave);
+    const int per = count <= waves ? 1 : count <= 8 * waves ? 8 : kWave;
+    const int wave = (int)blockIdx.x * (kBlock / kWave) + wave_id();
+    first = lane_id() < per ? wave * per + lane_id() : count;
+    stride = waves * per;
+  }
+  for (int j = first; j < count; j += stride) {
     const int2 e = redo_list[j];
     knn_moments_point<KMAX, FULL>(slots[e.x], e.y, filt, sorted, cell_start, moments, plane, k, normals, fallback_count,
                                   fallback_list);
