@@ -1187,13 +1187,40 @@ S3D_HD uint32_t knn3_position(uint32_t key, const uint32_t* tab, int tstride) {
 // transform, read from the copy that travels with the correspondence, no gather.  The nine rows are then cut to the
 // ball of that radius (+ the re-validation shell, as grid_nn1_box does): a slab test per row, the x-range of its
 // chord - a stale neighbour half a cell away leaves ~8 of the 27 cells.
-template <typename F4T>
+// PRESCAN (no seed known - the second pass): the query's own ROW (three cells, a third of the candidates on the
+// surfaces a scan consists of) is scanned first, and its best point is the seed that cuts the other eight rows.
+template <int PRESCAN = 0, typename F4T>
 S3D_HD bool grid_nn1_scan27(const GridParams& g, const uint32_t* __restrict__ cell_start, const F4T* __restrict__ pts,
                             float qx, float qy, float qz, uint32_t* tab, int tstride, NNResult& r,
                             float seed_d2 = 3.0e38f) {
   r.idx = -1; r.d2 = 3.0e38f; r.pos = -1; r.second_d2 = 3.0e38f; r.radius = 0.f;
   const int ix = grid_coord(g, 0, qx), iy = grid_coord(g, 1, qy), iz = grid_coord(g, 2, qz);
   if (ix < 0 || ix >= g.dim[0] || iy < 0 || iy >= g.dim[1] || iz < 0 || iz >= g.dim[2]) return false;
+  const double kInf = __builtin_bit_cast(double, 0x7FDFFFFFFFFFFFFFull);
+  double best = kInf, second = kInf;
+#define S3D_NN27_USE(P_, K_, V_)                                                                       \
+  {                                                                                                    \
+    const float d2_ = dist2_xy(qx, qy, qz, P_);                                                        \
+    const unsigned long long kb_ = ((unsigned long long)(__builtin_bit_cast(uint32_t, d2_) + 0x00800000u) << 32) | \
+                                   (unsigned long long)K_;                                             \
+    const double c_ = V_ ? __builtin_bit_cast(double, kb_) : kInf;                                     \
+    second = f64_min_raw(second, f64_max_raw(c_, best));                                               \
+    best = f64_min_raw(best, c_);                                                                      \
+  }
+  bool prescanned = false;
+  if (PRESCAN == 2 || (PRESCAN == 1 && seed_d2 >= 1.0e30f)) {   // (2: also next to a seed, whichever is nearer)
+    const int rowbase = g.dim[0] * (iy + g.dim[1] * iz);
+    const uint32_t a = cell_start[rowbase + imax(ix - 1, 0)], b = cell_start[rowbase + imin(ix + 1, g.dim[0] - 1) + 1];
+    for (uint32_t k = a; k < b; k += 2) {          // two loads in flight
+      const bool v1 = k + 1 < b;
+      const F4T p0 = pts[k], p1 = pts[v1 ? k + 1 : k];
+      const uint32_t k1 = k + 1;
+      S3D_NN27_USE(p0, k, true)
+      S3D_NN27_USE(p1, k1, v1)
+    }
+    prescanned = true;
+    if (best != kInf) seed_d2 = fminf(seed_d2, knn_key_d2(best));
+  }
   int nseg = 0;
   uint32_t total = 0;
   float reach = 3.0e38f;            // every point nearer than this lies in an examined cell (if it lies in the 27 at all)
@@ -1220,6 +1247,7 @@ S3D_HD bool grid_nn1_scan27(const GridParams& g, const uint32_t* __restrict__ ce
         xb = imin(xb, grid_coord(g, 0, qx + rx));
       }
       in = in && xa <= xb;
+      if (PRESCAN && k == 4) in = in && !prescanned;          // (the own row is done)
       const int rowbase = in ? g.dim[0] * (cy + g.dim[1] * cz) : 0;
       const uint32_t a = cell_start[rowbase + (in ? xa : 0)], b = cell_start[rowbase + (in ? xb + 1 : 0)];
       rs[k] = a; re[k] = in ? b : a;
@@ -1230,10 +1258,8 @@ S3D_HD bool grid_nn1_scan27(const GridParams& g, const uint32_t* __restrict__ ce
       ok = knn3_push(tab, tstride, nseg, rs[k], re[k]) && ok;
       total += re[k] - rs[k];
     }
-    if (!ok || total == 0) return false;
+    if (!ok || (total == 0 && best == kInf)) return false;
   }
-  const double kInf = __builtin_bit_cast(double, 0x7FDFFFFFFFFFFFFFull);
-  double best = kInf, second = kInf;
   // the iterator of knn3_scan without ids: [pos, end) = what is left of the current entry
   int e = 0;
   uint32_t pos = 0, end = 0;
@@ -1248,15 +1274,6 @@ S3D_HD bool grid_nn1_scan27(const GridParams& g, const uint32_t* __restrict__ ce
     K_ = V_ ? pos : 0u;                                                                                \
     P_ = pts[K_];                                                                                      \
     pos += V_ ? 1u : 0u;                                                                               \
-  }
-#define S3D_NN27_USE(P_, K_, V_)                                                                       \
-  {                                                                                                    \
-    const float d2_ = dist2_xy(qx, qy, qz, P_);                                                        \
-    const unsigned long long kb_ = ((unsigned long long)(__builtin_bit_cast(uint32_t, d2_) + 0x00800000u) << 32) | \
-                                   (unsigned long long)K_;                                             \
-    const double c_ = V_ ? __builtin_bit_cast(double, kb_) : kInf;                                     \
-    second = f64_min_raw(second, f64_max_raw(c_, best));                                               \
-    best = f64_min_raw(best, c_);                                                                      \
   }
   F4T pa, pb;
   uint32_t ka, kb;

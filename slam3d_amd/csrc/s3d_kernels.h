@@ -1411,6 +1411,12 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
 #ifndef S3D_NN27_WAVES
 #define S3D_NN27_WAVES 8    // s3d_nn_scan27_kernel
 #endif
+#ifndef S3D_NN27_PRESCAN
+#define S3D_NN27_PRESCAN 1  // pass 2 (no seed): the own row first, its best point cuts the other eight (grid_nn1_scan27<PRESCAN>)
+#endif
+#ifndef S3D_NN27_PRESCAN_REVAL
+#define S3D_NN27_PRESCAN_REVAL 0
+#endif
 #ifndef S3D_NN27_SEED
 #define S3D_NN27_SEED 1     // s3d_nn_scan27_kernel cuts the 27 cells to the ball of the previous neighbour's new distance
 #endif
@@ -1577,7 +1583,7 @@ __global__ void __launch_bounds__(kBlock, S3D_NN27_WAVES) s3d_nn_scan27_kernel(c
   if (prof_counts && lane_id() == 0) atomicAdd(&prof_counts[0], (int)__popcll(nmask));
   NNResult r;
   bool ok = false;
-  if (need) ok = grid_nn1_scan27(Ss.g, A.cell_start + Ss.cell_off, A.sorted + Ss.off, q.x, q.y, q.z, tab + threadIdx.x, kBlock, r, seed_d2);
+  if (need) ok = grid_nn1_scan27<REVAL ? S3D_NN27_PRESCAN_REVAL : S3D_NN27_PRESCAN>(Ss.g, A.cell_start + Ss.cell_off, A.sorted + Ss.off, q.x, q.y, q.z, tab + threadIdx.x, kBlock, r, seed_d2);
   if (need && ok) {                 // (the stores of nn_query; a scan27 answer always has a neighbour)
     A.corr_idx[ci] = r.pos;
     A.corr_d2[ci] = r.d2;

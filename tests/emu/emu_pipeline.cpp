@@ -175,7 +175,7 @@ void emu_normals(const float* xyz, int n, int k, float h0, int cpp, float* out) 
 // round-3 1-NN by a flat scan of the 27 cells (grid_nn1_scan27): idx / d2 of the answered queries (flag 1), -1 / 0 flag 0
 // seed (may be null): per query the index of a target point whose distance is handed in as the known upper bound
 void emu_nn_scan27(const float* tgt, int n, const float* qry, int m, float h0, int cpp, int* idx, float* d2, int* answered,
-                   float* lower_bound, const int* seed) {
+                   float* lower_bound, const int* seed, int prescan) {
   Cloud c = voxel(tgt, n, 3, 0.0);
   Grid G = build_grid(c, h0, cpp);
   for (int i = 0; i < m; ++i) {
@@ -183,7 +183,8 @@ void emu_nn_scan27(const float* tgt, int n, const float* qry, int m, float h0, i
     NNResult r;
     float sd2 = 3.0e38f;
     if (seed && seed[i] >= 0) sd2 = dist2(qry[i * 3], qry[i * 3 + 1], qry[i * 3 + 2], tgt[seed[i] * 3], tgt[seed[i] * 3 + 1], tgt[seed[i] * 3 + 2]);
-    const bool ok = grid_nn1_scan27(G.g, G.cell_start.data(), G.sorted.data(), qry[i * 3], qry[i * 3 + 1], qry[i * 3 + 2], tab, 1, r, sd2);
+    const bool ok = prescan ? grid_nn1_scan27<1>(G.g, G.cell_start.data(), G.sorted.data(), qry[i * 3], qry[i * 3 + 1], qry[i * 3 + 2], tab, 1, r, sd2)
+                            : grid_nn1_scan27(G.g, G.cell_start.data(), G.sorted.data(), qry[i * 3], qry[i * 3 + 1], qry[i * 3 + 2], tab, 1, r, sd2);
     answered[i] = ok ? 1 : 0;
     idx[i] = ok ? r.idx : -1; d2[i] = ok ? r.d2 : 0.f;
     lower_bound[i] = ok ? nn_lower_bound_others(r) : 0.f;

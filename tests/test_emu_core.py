@@ -96,10 +96,11 @@ def test_device_scan27_nn_is_exact_when_it_answers(emu, oracle_mod, fixture_clou
     _, nb5 = tree.query(q.astype(np.float64), 5)
     seeds = {"none": None, "exact": oi.astype(np.int32), "stale": nb5[:, 4].astype(np.int32),
              "random": rng.integers(0, len(tgt), len(q)).astype(np.int32)}
+    seeds["prescan"] = None      # no seed, the query's own row first (grid_nn1_scan27<PRESCAN>, the second pass)
     for kind, sd in seeds.items():
         emu.emu_nn_scan27(tgt.ctypes.data_as(fp), len(tgt), q.ctypes.data_as(fp), len(q), C.c_float(h0), cpp,
                           idx.ctypes.data_as(ip), d2.ctypes.data_as(fp), ans.ctypes.data_as(ip), lb.ctypes.data_as(fp),
-                          sd.ctypes.data_as(ip) if sd is not None else None)
+                          sd.ctypes.data_as(ip) if sd is not None else None, 1 if kind == "prescan" else 0)
         a = ans == 1
         assert a.mean() > (0.2 if shift > 0.2 or h0 > 0.9 else 0.5), (kind, a.mean())
         assert np.array_equal(idx[a], oi[a]) and np.array_equal(d2[a], od[a]), kind
