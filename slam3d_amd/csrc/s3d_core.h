@@ -340,7 +340,7 @@ S3D_HD void nn1_fast_sync(NNResult& best, double bkey) {
 }
 template <bool FAST = false, typename F4T>
 S3D_HD void nn1_consider(NNResult& best, double& bkey, const F4T& p, uint32_t k, float qx, float qy, float qz) {
-  const float d2 = dist2(qx, qy, qz, p.x, p.y, p.z);
+  const float d2 = FAST ? dist2_xy(qx, qy, qz, p) : dist2(qx, qy, qz, p.x, p.y, p.z);   // (the same value, see dist2_xy)
   if (FAST) {
     const unsigned long long kb = ((unsigned long long)(__builtin_bit_cast(uint32_t, d2) + 0x00800000u) << 32) |
                                   (unsigned long long)__builtin_bit_cast(uint32_t, p.w);
