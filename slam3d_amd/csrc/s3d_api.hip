@@ -303,8 +303,8 @@ struct Batch {
     std::memset(&s, 0, sizeof s);
     s.raw = c->d;
     s.n_raw = c->n;
-    s.off = (int)total_pts;
-    total_pts += (size_t)((c->n + 3) & ~3);
+    s.off = (int)total_pts;   // slots start on multiples of 64 points: a wave's 12-byte and 4-byte records begin on a cache line
+    total_pts += (size_t)((c->n + 63) & ~63);
     const long long cap =
         std::min<long long>(std::max<long long>((long long)opts.grid_cells_per_point * c->n, 64), cell_cap_max);
     s.cell_cap = (int)cap;
@@ -327,7 +327,7 @@ struct Batch {
       P.slot_s = add_slot(sources[p], index);
       P.slot_t = add_slot(targets[p], index);
       P.corr_off = (int)total_corr;
-      total_corr += (size_t)((targets[p]->n + 3) & ~3);
+      total_corr += (size_t)((targets[p]->n + 63) & ~63);
       max_n_t = std::max(max_n_t, targets[p]->n);
       for (int i = 0; i < 16; ++i) P.guess.m[i] = (float)guesses[(size_t)p * 16 + i];  // :70 cast<float>()
       h_pairs.push_back(P);
@@ -375,7 +375,7 @@ struct Batch {
       sc[j] = slot_clouds[(size_t)i];
       slot_entry[j] = ent[i];
       hs[j].off = (int)total_pts;
-      total_pts += (size_t)((hs[j].n_raw + 3) & ~3);
+      total_pts += (size_t)((hs[j].n_raw + 63) & ~63);
       hs[j].cell_off = (int)total_cells;
       total_cells += (size_t)hs[j].cell_cap + 1;
     }

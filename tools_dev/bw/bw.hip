@@ -151,6 +151,14 @@ int main() {
       printf("%-34s %8.3f ms  %6.2f TB/s\n", "settled pass after 1.4 GB of reads", tot / 10, n * 32.0 / (tot / 10 * 1e-3) / 1e12);
       CHK(hipFree(fl));
     }
+    {  // sustained: 3000 launches back to back (0.5 s), the mean of the last 1000
+      for (int i = 0; i < 2000; ++i) k_reval_pairs<1><<<NP * chunks, 256>>>(dp, ds, c, d, lb, chunks, NP, fail);
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 1000; ++i) k_reval_pairs<1><<<NP * chunks, 256>>>(dp, ds, c, d, lb, chunks, NP, fail);
+      hipEventRecord(e1, 0); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      printf("%-34s %8.3f ms  %6.2f TB/s\n", "settled pass, sustained 0.5 s", ms / 1000, n * 32.0 / (ms / 1000 * 1e-3) / 1e12);
+    }
     run("settled pass, pairs, 2 chunk/blk", n * 32.0, [&] { k_reval_pairs<2><<<NP * ((chunks + 1) / 2), 256>>>(dp, ds, c, d, lb, (chunks + 1) / 2, NP, fail); });
     run("settled pass, pairs, 4 chunk/blk", n * 32.0, [&] { k_reval_pairs<4><<<NP * ((chunks + 3) / 4), 256>>>(dp, ds, c, d, lb, (chunks + 3) / 4, NP, fail); });
     int hf; CHK(hipMemcpy(&hf, fail, 4, hipMemcpyDeviceToHost)); printf("fails %d\n", hf);
