@@ -1059,8 +1059,11 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN3_WAVES) s3d_knn3_moments_kerne
 // eight - an exact search is a long chain of dependent steps and the lanes of a wave serialise their different paths,
 // so the list's LATENCY is what a lone registration waits for (600 entries of one pair: 161 -> 40 us).  A large
 // batch's list (150 k entries) is a throughput matter: full waves.
+#ifndef S3D_KNN_REDO_WAVES
+#define S3D_KNN_REDO_WAVES 3
+#endif
 template <int KMAX, bool FULL, bool THIN>
-__global__ void __launch_bounds__(kBlock) s3d_knn_moments_redo_kernel(const SlotDev* __restrict__ slots,
+__global__ void __launch_bounds__(kBlock, S3D_KNN_REDO_WAVES) s3d_knn_moments_redo_kernel(const SlotDev* __restrict__ slots,
                                                                        const float4* __restrict__ filt,
                                                                        const float4* __restrict__ sorted,
                                                                        const uint32_t* __restrict__ cell_start,
