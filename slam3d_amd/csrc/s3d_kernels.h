@@ -211,11 +211,17 @@ __global__ void __launch_bounds__(kBlock) k_bbox(SlotDev* slots, const float4* _
   const int base = blockIdx.x * (kBlock * 4);
   if (base >= n) return;
   unsigned int mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
+  float4 pv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {           // four independent loads in flight (a tail lane re-reads the last point)
+    const int i = base + r * kBlock + threadIdx.x;
+    pv[r] = p[i < n ? i : n - 1];
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = base + r * kBlock + threadIdx.x;
     if (i < n) {
-      const float4 v = p[i];
+      const float4 v = pv[r];
       if (finite3(v.x, v.y, v.z)) {
         const unsigned int a = f2ord(v.x), b = f2ord(v.y), c = f2ord(v.z);
         mn[0] = min(mn[0], a); mn[1] = min(mn[1], b); mn[2] = min(mn[2], c);
@@ -731,9 +737,11 @@ __global__ void __launch_bounds__(kBlock) k_heads_count(const SlotDev* __restric
   if (base >= s.n_raw) return;
   const int i = base + threadIdx.x;
   const bool head = i < s.n_raw && voxel_head(keys + s.off, i);
-  int total;
-  block_excl_flag(head, &total, lds4);
-  if (threadIdx.x == 0) blockcnt[(size_t)blockIdx.y * nb_max + blockIdx.x] = (uint32_t)total;
+  const unsigned long long m = __ballot(head);            // (only the block's total is wanted here: one barrier)
+  if (lane_id() == 0) lds4[wave_id()] = (int)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    blockcnt[(size_t)blockIdx.y * nb_max + blockIdx.x] = (uint32_t)(lds4[0] + lds4[1] + lds4[2] + lds4[3]);
 }
 
 __global__ void __launch_bounds__(kBlock) k_heads_scan(SlotDev* slots, uint32_t* __restrict__ blockcnt, int nb_max) {
