@@ -591,6 +591,29 @@ def test_nn_revalidation_shortcut_is_bitwise_neutral(gpu_ctx, fixture_clouds, mo
             assert st0 == st1 == 0 and np.array_equal(T0, T1) and i0 == i1, flags
 
 
+def test_round3_fast_paths_are_bitwise_neutral(gpu_ctx, fixture_clouds, monkeypatch):
+    """The round-3 kernels are alternative routes to the same results: the first-pass kernel and the flat 27-cell scans
+    (S3D_DBG_NN 262144 / 524288 switch them off), the 32-bit k-NN pre-pass (S3D_KNN_EXACT64=1: the 64-bit search for
+    every point) and the two forms of the radix sort (S3D_SORT_CLASSIC=1 / 0).  Not a bit may change - on the real
+    scans and on a synthetic pair of the benchmark's size."""
+    import slam3d_amd as s3d
+    opts = s3d.ExecOptions(force_iterations=1)
+    a, b, _ = s3d.make_pair(100000, 3)
+    cases = [(fixture_clouds[1], fixture_clouds[2], s3d.default_params(maximum_iterations=12)),
+             (a, b, s3d.default_params(point_cloud_density=0.02, maximum_iterations=8))]
+    for src, tgt, p in cases:
+        for k in ("S3D_DBG_NN", "S3D_KNN_EXACT64", "S3D_SORT_CLASSIC"):
+            monkeypatch.delenv(k, raising=False)
+        st0, T0, i0 = gpu_ctx.align(src, tgt, np.eye(4), p, opts)
+        assert st0 == 0
+        for key, val in (("S3D_DBG_NN", "262144"), ("S3D_DBG_NN", "524288"), ("S3D_DBG_NN", str(262144 + 524288)),
+                         ("S3D_KNN_EXACT64", "1"), ("S3D_SORT_CLASSIC", "1"), ("S3D_SORT_CLASSIC", "0")):
+            monkeypatch.setenv(key, val)
+            st1, T1, i1 = gpu_ctx.align(src, tgt, np.eye(4), p, opts)
+            monkeypatch.delenv(key, raising=False)
+            assert st1 == 0 and np.array_equal(T0, T1) and i0 == i1, (key, val)
+
+
 def test_million_point_pair(gpu_ctx, oracle_mod):
     """BASELINE.json configs[4] scale (1M-point scans): exact NN against the kd-tree oracle on a sample of
     the queries, and a 50-iteration registration that recovers the ground truth and is deterministic."""
