@@ -43,7 +43,8 @@ s3d_context* shared_context_for_static_calls() {
 }
 }  // namespace
 
-PointCloudSensor::PointCloudSensor(const std::string& n, Logger* l, int device) : ScanSensor(n, l), mContext(nullptr) {
+PointCloudSensor::PointCloudSensor(const std::string& n, Logger* l, int device, int reserved_cus)
+    : ScanSensor(n, l), mContext(nullptr) {
   mScanResolution = 0.1;      // PointCloudSensor.cpp:179-182
   mMapResolution = 0.1;
   mMapOutlierRadius = 0.2;
@@ -53,7 +54,17 @@ PointCloudSensor::PointCloudSensor(const std::string& n, Logger* l, int device) 
   // createConstraint - the application thread's blocking call per new scan (ScanSensor.cpp:113) - runs on a HIGH-priority
   // context: the detached linkToNeighbors thread (:209-210) sweeps its candidates on the sweep's own contexts
   // (createConstraints), and the dispatcher takes this context's kernels before their queued blocks
-  if (s3d_context_create_priority(device, 1, &mContext) != S3D_STATUS_OK)
+  int st;
+  if (reserved_cus > 0) {
+    uint32_t mine[32], rest[32];
+    const int words = s3d_cu_masks(device, reserved_cus, mine, rest, 32);
+    if (words <= 0) throw std::invalid_argument("PointCloudSensor: reserved_cus must be below the device's compute units");
+    mSweepCuMask.assign(rest, rest + words);
+    st = s3d_context_create_cu_mask(device, mine, words, &mContext);
+  } else {
+    st = s3d_context_create_priority(device, 1, &mContext);
+  }
+  if (st != S3D_STATUS_OK)
     throw std::runtime_error("slam3d (MI355X build): no usable HIP device, and there is no CPU fallback");
   mContextHolder = std::make_shared<ContextHolder>(mContext);
 }
@@ -120,7 +131,11 @@ std::vector<Constraint::Ptr> PointCloudSensor::createConstraints(const std::vect
   std::lock_guard<std::mutex> lock(mSweepMutex);
   if (!mSweep || devices != mSweepDevices) {
     releaseSweep();
-    if (s3d_sweep_create((int)devices.size(), devices.empty() ? nullptr : devices.data(), &mSweep) != S3D_STATUS_OK)
+    const int sst = mSweepCuMask.empty()
+                        ? s3d_sweep_create((int)devices.size(), devices.empty() ? nullptr : devices.data(), &mSweep)
+                        : s3d_sweep_create_cu_mask((int)devices.size(), devices.empty() ? nullptr : devices.data(),
+                                                   mSweepCuMask.data(), (int)mSweepCuMask.size(), &mSweep);
+    if (sst != S3D_STATUS_OK)
       throw std::runtime_error("slam3d (MI355X build): no usable HIP devices / RCCL for the sweep, and there is no CPU fallback");
     mSweepDevices = devices;
   }

@@ -7,7 +7,8 @@ tests and by ``bench.py``; it never computes anything itself and it has no CPU f
 """
 from .api import (  # noqa: F401
     ALG_GICP, ALG_GICP_OMP, ALG_ICP, ALG_NDT, ALG_NDT_OMP, STATUS_NAMES, AlignInfo, BackendError, Cloud, Context,
-    EdgeRecord, ExecOptions, Profile, RegParams, Sweep, backend_info, build, default_params, lib_path, load_library,
+    EdgeRecord, ExecOptions, Profile, RegParams, Sweep, backend_info, build, cu_masks, default_params, lib_path,
+    load_library,
     EDGE_RECORD_DOUBLES)
 from .synthetic import make_pair, make_scene_cloud  # noqa: F401
 from . import posegraph  # noqa: F401

@@ -130,6 +130,7 @@ def load_library():
         "s3d_abi_version": (C.c_int, []),
         "s3d_context_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
         "s3d_context_create_priority": (C.c_int, [C.c_int, C.c_int, C.POINTER(vp)]),
+        "s3d_context_create_cu_mask": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_int, C.POINTER(vp)]),
         "s3d_context_destroy": (None, [vp]),
         "s3d_last_error": (C.c_char_p, [vp]),
         "s3d_backend_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
@@ -166,6 +167,8 @@ def load_library():
         "s3d_profile_nn_kernel": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, pp, C.c_int, dp,
                                             C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
         "s3d_sweep_create": (C.c_int, [C.c_int, ip, C.POINTER(vp)]),
+        "s3d_sweep_create_cu_mask": (C.c_int, [C.c_int, ip, C.POINTER(C.c_uint32), C.c_int, C.POINTER(vp)]),
+        "s3d_cu_masks": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int]),
         "s3d_sweep_destroy": (None, [vp]),
         "s3d_sweep_ranks": (C.c_int, [vp]),
         "s3d_sweep_collective": (C.c_char_p, [vp]),
@@ -256,15 +259,31 @@ class Cloud:
             pass
 
 
+def cu_masks(device=0, reserved_cus=32):
+    """(reserved, rest): two complementary CU masks (lists of 32-bit words) for Context(cu_mask=) / Sweep(cu_mask=)."""
+    L = load_library()
+    a = (C.c_uint32 * 32)()
+    b = (C.c_uint32 * 32)()
+    n = L.s3d_cu_masks(int(device), int(reserved_cus), a, b, 32)
+    if n <= 0:
+        raise BackendError("s3d_cu_masks failed: device %d, %d reserved compute units" % (device, reserved_cus))
+    return list(a[:n]), list(b[:n])
+
+
 class Context:
     """One HIP device + stream + workspace (s3d_context)."""
 
-    def __init__(self, device=0, stream=None, high_priority=False):
+    def __init__(self, device=0, stream=None, high_priority=False, cu_mask=None):
         """high_priority: a private stream of the device's highest priority (s3d_context_create_priority) - for the
-        latency-critical sequential registration while a loop-closure batch runs on another context."""
+        latency-critical sequential registration while a loop-closure batch runs on another context.
+        cu_mask: a sequence of 32-bit words, the compute units this context's stream may use
+        (s3d_context_create_cu_mask)."""
         self._L = load_library()
         h = C.c_void_p()
-        if high_priority and not stream:
+        if cu_mask is not None and not stream:
+            words = (C.c_uint32 * len(cu_mask))(*[int(w) & 0xFFFFFFFF for w in cu_mask])
+            st = self._L.s3d_context_create_cu_mask(int(device), words, len(cu_mask), C.byref(h))
+        elif high_priority and not stream:
             st = self._L.s3d_context_create_priority(int(device), 1, C.byref(h))
         else:
             st = self._L.s3d_context_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
@@ -591,13 +610,18 @@ class Sweep:
     """s3d_sweep: one rank (context + host thread) per device, pair list sharded in contiguous blocks, one
     all-gather of the edge records (include/slam3d_hip.h, C1)."""
 
-    def __init__(self, devices=None):
+    def __init__(self, devices=None, cu_mask=None):
+        """cu_mask: 32-bit words, the compute units every rank's stream may use (s3d_sweep_create_cu_mask)."""
         self._L = load_library()
         h = C.c_void_p()
-        if devices is None:
+        arr = (C.c_int * len(devices))(*devices) if devices is not None else None
+        nd = len(devices) if devices is not None else 0
+        if cu_mask is not None:
+            words = (C.c_uint32 * len(cu_mask))(*[int(w) & 0xFFFFFFFF for w in cu_mask])
+            st = self._L.s3d_sweep_create_cu_mask(nd, arr, words, len(cu_mask), C.byref(h))
+        elif devices is None:
             st = self._L.s3d_sweep_create(0, None, C.byref(h))
         else:
-            arr = (C.c_int * len(devices))(*devices)
             st = self._L.s3d_sweep_create(len(devices), arr, C.byref(h))
         if st != 0 or not h:
             raise BackendError("s3d_sweep_create failed (status %d): no usable HIP devices / RCCL (no CPU fallback)" % st)

@@ -1362,13 +1362,33 @@ int s3d_backend_info(int device, char* buf, int len) {
   return S3D_STATUS_OK;
 }
 
-static int context_create(int device, void* hip_stream, int priority_class, s3d_context** out);
+static int context_create(int device, void* hip_stream, int priority_class, s3d_context** out,
+                          const uint32_t* cu_mask = nullptr, int cu_words = 0);
 int s3d_context_create(int device, void* hip_stream, s3d_context** out) { return context_create(device, hip_stream, 0, out); }
+int s3d_cu_masks(int device, int reserved_cus, uint32_t* reserved_mask, uint32_t* rest_mask, int max_words) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return -1;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -1;
+  const int cus = prop.multiProcessorCount, words = (cus + 31) / 32;
+  if (!reserved_mask || !rest_mask || words > max_words || reserved_cus <= 0 || reserved_cus >= cus) return -1;
+  for (int w = 0; w < words; ++w) { reserved_mask[w] = 0u; rest_mask[w] = 0u; }
+  for (int c = 0; c < cus; ++c) (c < reserved_cus ? reserved_mask : rest_mask)[c / 32] |= 1u << (c % 32);
+  return words;
+}
+int s3d_context_create_cu_mask(int device, const uint32_t* cu_mask, int n_words, s3d_context** out) {
+  if (!cu_mask || n_words <= 0 || n_words > 32) return S3D_STATUS_INVALID_ARGUMENT;
+  bool any = false;
+  for (int i = 0; i < n_words; ++i) any = any || cu_mask[i] != 0u;
+  if (!any) return S3D_STATUS_INVALID_ARGUMENT;
+  return context_create(device, nullptr, 0, out, cu_mask, n_words);
+}
 int s3d_context_create_priority(int device, int priority_class, s3d_context** out) {
   if (priority_class < 0 || priority_class > 1) return S3D_STATUS_INVALID_ARGUMENT;
   return context_create(device, nullptr, priority_class, out);
 }
-static int context_create(int device, void* hip_stream, int priority_class, s3d_context** out) {
+static int context_create(int device, void* hip_stream, int priority_class, s3d_context** out, const uint32_t* cu_mask,
+                          int cu_words) {
   if (!out) return S3D_STATUS_INVALID_ARGUMENT;
   *out = nullptr;
   int count = 0;
@@ -1381,7 +1401,9 @@ static int context_create(int device, void* hip_stream, int priority_class, s3d_
     if (hip_stream) {
       ctx->stream = (hipStream_t)hip_stream;
     } else {
-      if (priority_class > 0) {
+      if (cu_mask) {
+        HIPCHK(hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)cu_words, cu_mask));
+      } else if (priority_class > 0) {
         int least = 0, greatest = 0;     // (numerically lower = higher priority)
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPCHK(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest));

@@ -139,7 +139,15 @@ void s3d_sweep_destroy(s3d_sweep* sw) {
   delete sw;
 }
 
+static int sweep_create(int n_devices, const int* devices, const uint32_t* cu_mask, int cu_words, s3d_sweep** out);
 int s3d_sweep_create(int n_devices, const int* devices, s3d_sweep** out) {
+  return sweep_create(n_devices, devices, nullptr, 0, out);
+}
+int s3d_sweep_create_cu_mask(int n_devices, const int* devices, const uint32_t* cu_mask, int n_words, s3d_sweep** out) {
+  if (!cu_mask || n_words <= 0 || n_words > 32) return S3D_STATUS_INVALID_ARGUMENT;
+  return sweep_create(n_devices, devices, cu_mask, n_words, out);
+}
+static int sweep_create(int n_devices, const int* devices, const uint32_t* cu_mask, int cu_words, s3d_sweep** out) {
   if (!out || n_devices < 0) return S3D_STATUS_INVALID_ARGUMENT;
   *out = nullptr;
   int count = 0;
@@ -164,7 +172,8 @@ int s3d_sweep_create(int n_devices, const int* devices, s3d_sweep** out) {
   if (R > 1)
     for (int r = 0; r < R; ++r) { sw->workers.emplace_back(new RankWorker()); sw->workers.back()->start(); }
   for (int r = 0; r < R; ++r) {
-    if (s3d_context_create(sw->devices[r], nullptr, &sw->ctx[r]) != S3D_STATUS_OK ||
+    if ((cu_mask ? s3d_context_create_cu_mask(sw->devices[r], cu_mask, cu_words, &sw->ctx[r])
+                 : s3d_context_create(sw->devices[r], nullptr, &sw->ctx[r])) != S3D_STATUS_OK ||
         hipSetDevice(sw->devices[r]) != hipSuccess ||
         hipStreamCreateWithFlags(&sw->coll[r], hipStreamNonBlocking) != hipSuccess) {
       s3d_sweep_destroy(sw);
