@@ -53,12 +53,39 @@ typedef struct s3d_exec_options {
                                0 (default): the pclomp build - both are served by the GICP / NDT device code.
                                1: the build without pclomp - S3D_STATUS_OMP_UNAVAILABLE after the voxel filter and
                                the 100-point gate (the reference's order), which the C++ mirror re-raises.           */
+  unsigned int debug_flags; /* S3D_DBG_* bits below; 0 = the product's behaviour.  Every bit switches ONE fast path off
+                               (or forces one of two equivalent forms) and must not change a bit of any result - that is
+                               what the tests use them for.  Read once per call from this struct: the library reads no
+                               environment variable on any registration path.                                         */
+  int debug_accum_blocks;   /* 0 = automatic; 1, 2, 4 ... 64: REAL blocks per pair in the accumulate kernels (the sums
+                               are defined over 64 virtual blocks whatever this is: the invariance test sets it)        */
 } s3d_exec_options;
+
+/* s3d_exec_options.debug_flags */
+#define S3D_DBG_NN_RING            0x00000004u /* 1-NN by ring expansion (round-1 A/B; only with S3D_NN_AB builds)       */
+#define S3D_DBG_NN_PLAIN_MAP       0x00000010u /* no XCD-aware block map in the NN kernel (round-1 A/B)                  */
+#define S3D_DBG_NN_NO_SEED         0x00000020u /* searches ignore the previous neighbour (round-1 A/B)                   */
+#define S3D_DBG_NN_NO_REVALIDATE   0x00000040u /* every pass searches every query (no triangle-inequality shortcut)      */
+#define S3D_DBG_NN_NO_FAR_SEED     0x00000080u /* far previous neighbours are never trusted seeds                        */
+#define S3D_DBG_NN_FIRST_BOX_1     0x00000100u /* first-pass box of 1 / 1.5 / 2 cells instead of 3 (round-1 A/B)         */
+#define S3D_DBG_NN_FIRST_BOX_15    0x00000200u
+#define S3D_DBG_NN_FIRST_BOX_2     0x00000400u
+#define S3D_DBG_NN_NO_COOP         0x00000800u /* no wave-cooperative wide search                                        */
+#define S3D_DBG_NN_NO_COMPACT      0x00010000u /* passes 4-5 without the block compaction                                */
+#define S3D_DBG_NN_NO_FIRST_KERNEL 0x00040000u /* pass 1 through the general kernel (implies the next one)               */
+#define S3D_DBG_NN_NO_SCAN27       0x00080000u /* passes 2-3 through the general kernel                                  */
+#define S3D_DBG_NN_NO_SETTLED      0x00100000u /* settled passes query by query (no record-level re-validation)          */
+#define S3D_DBG_KNN_EXACT64        0x00200000u /* k-NN pre-pass: the exact 64-bit search for every point                 */
+#define S3D_DBG_SORT_CLASSIC       0x00400000u /* radix sort: three kernels per pass, whatever the batch size            */
+#define S3D_DBG_SORT_ONESWEEP      0x00800000u /* radix sort: one sweep per pass (decoupled look-back), whatever ...      */
+#define S3D_DBG_SCAN27_NO_COMPACT  0x01000000u /* pass 3 without the block compaction                                    */
+#define S3D_DBG_PRINT_KNN          0x02000000u /* stderr: how many points took the eigen fallback / the exact-search redo */
+#define S3D_DBG_SORT_FULL_KEYS     0x04000000u /* radix sort: fixed pass counts (4 voxel + 3 grid), not the key range's   */
 
 /* The structs above grow at the END only.  A binding compiled against another revision of this header must not be
  * used: compare S3D_ABI_VERSION with s3d_abi_version() once after loading the library (the Python binding and the
  * C++ mirror do). */
-#define S3D_ABI_VERSION 3
+#define S3D_ABI_VERSION 4
 int  s3d_abi_version(void);
 
 typedef struct s3d_align_info {   /* diagnostics of one align() */
@@ -76,6 +103,8 @@ typedef struct s3d_profile {      /* milliseconds, HIP events on the context's s
   float  nn_launch_ms[64];          /* duration of the first 64 NN launches of the ICP loop, in order */
   int    nn_searched[64];           /* profile >= 2: queries of launch i that needed a grid search (not re-validated) */
   int    nn_unseeded[64];           /* ... of which without a usable previous neighbour (wide search)            */
+  int    nn_records[64];            /* profile >= 2, settled passes: 64-query records tested by launch i ...         */
+  int    nn_records_searched[64];   /* ... of which failed the record-level proof and ran query by query             */
 } s3d_profile;
 
 /* ---- context ------------------------------------------------------------------ */

@@ -11,4 +11,4 @@ from .api import (  # noqa: F401
     load_library,
     EDGE_RECORD_DOUBLES)
 from .synthetic import make_pair, make_scene_cloud  # noqa: F401
-from . import posegraph  # noqa: F401
+from . import api, posegraph  # noqa: F401

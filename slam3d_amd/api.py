@@ -12,7 +12,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 ALG_ICP, ALG_GICP, ALG_GICP_OMP, ALG_NDT, ALG_NDT_OMP = range(5)
 STATUS_NAMES = ["OK", "TOO_FEW_POINTS", "NOT_CONVERGED", "FITNESS_EXCEEDED", "TOO_FAR_FROM_GUESS",
                 "UNKNOWN_ALGORITHM", "UNSUPPORTED_ALGORITHM", "INVALID_ARGUMENT", "BACKEND_ERROR", "OMP_UNAVAILABLE"]
-ABI_VERSION = 3          # include/slam3d_hip.h S3D_ABI_VERSION (struct layouts of this binding)
+ABI_VERSION = 4          # include/slam3d_hip.h S3D_ABI_VERSION (struct layouts of this binding)
 EDGE_RECORD_DOUBLES = 16
 
 
@@ -33,7 +33,15 @@ class RegParams(C.Structure):
 
 class ExecOptions(C.Structure):
     _fields_ = [("force_iterations", C.c_int), ("check_interval", C.c_int), ("grid_cells_per_point", C.c_int),
-                ("profile", C.c_int), ("cache_prepass", C.c_int), ("omp_unavailable", C.c_int)]
+                ("profile", C.c_int), ("cache_prepass", C.c_int), ("omp_unavailable", C.c_int),
+                ("debug_flags", C.c_uint), ("debug_accum_blocks", C.c_int)]
+
+
+# s3d_exec_options.debug_flags (include/slam3d_hip.h S3D_DBG_*): each switches one fast path off, none may change a bit
+DBG_NN_NO_REVALIDATE, DBG_NN_NO_FAR_SEED, DBG_NN_NO_COOP = 0x40, 0x80, 0x800
+DBG_NN_NO_COMPACT, DBG_NN_NO_FIRST_KERNEL, DBG_NN_NO_SCAN27, DBG_NN_NO_SETTLED = 0x10000, 0x40000, 0x80000, 0x100000
+DBG_KNN_EXACT64, DBG_SORT_CLASSIC, DBG_SORT_ONESWEEP, DBG_SCAN27_NO_COMPACT = 0x200000, 0x400000, 0x800000, 0x1000000
+DBG_PRINT_KNN, DBG_SORT_FULL_KEYS = 0x2000000, 0x4000000
 
 
 class CacheStats(C.Structure):
@@ -58,12 +66,14 @@ class Profile(C.Structure):
     _fields_ = [("voxel_ms", C.c_double), ("grid_ms", C.c_double), ("normals_ms", C.c_double), ("icp_ms", C.c_double),
                 ("fitness_ms", C.c_double), ("total_ms", C.c_double), ("nn_ms", C.c_double), ("nn_launches", C.c_int),
                 ("nn_queries", C.c_longlong), ("nn_targets", C.c_longlong), ("nn_launch_ms", C.c_float * 64),
-                ("nn_searched", C.c_int * 64), ("nn_unseeded", C.c_int * 64)]
+                ("nn_searched", C.c_int * 64), ("nn_unseeded", C.c_int * 64), ("nn_records", C.c_int * 64),
+                ("nn_records_searched", C.c_int * 64)]
 
     def asdict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("nn_launch_ms", "nn_searched", "nn_unseeded")}
-        d["nn_searched"] = list(self.nn_searched[:max(min(self.nn_launches, 64), 0)])
-        d["nn_unseeded"] = list(self.nn_unseeded[:max(min(self.nn_launches, 64), 0)])
+        arrays = ("nn_launch_ms", "nn_searched", "nn_unseeded", "nn_records", "nn_records_searched")
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in arrays}
+        for k in arrays[1:]:
+            d[k] = list(getattr(self, k)[:max(min(self.nn_launches, 64), 0)])
         d["nn_launch_ms"] = [round(float(x), 4) for x in self.nn_launch_ms[:max(self.nn_launch_ms and self.nn_launches, 0)]][:64]
         return d
 

@@ -155,7 +155,7 @@ struct s3d_context {
   s3d_map_profile map_prof{};
   // workspace (grown on demand, reused across calls)
   DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, sorted3, normals, moments, cell_start, counts, digit_tot, blockcnt, blockbb,
-      corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active, knn_list, knn_fallback, knn_redo;
+      corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active, knn_list, knn_fallback, knn_redo, wave_recs, t_hist, worklist, rec_list, rec_counts;
   int* h_active = nullptr;  // pinned
   // pinned staging of the slot / pair records (up and down): a copy from or to pageable memory stalls the stream for
   // tens of microseconds, which a single-pair registration of ~1.5 ms notices
@@ -215,7 +215,8 @@ struct s3d_context {
       const size_t want = total + total / 8;
       HIPCHK(hipMalloc(&arena.p, want));
       arena.cap = want;
-      if (getenv("S3D_DBG_ARENA")) std::fprintf(stderr, "[s3d] arena %p + %zu MiB\n", arena.p, want >> 20);
+      static const bool print_arena = getenv("S3D_DBG_ARENA") != nullptr;   // (the library's only environment variable: a debug print, read once)
+      if (print_arena) std::fprintf(stderr, "[s3d] arena %p + %zu MiB\n", arena.p, want >> 20);
     }
     size_t off = 0;
     for (auto& r : reqs) {
@@ -279,6 +280,7 @@ struct Batch {
 
   void set_params(const s3d_reg_params* p, const s3d_exec_options* o) {
     if (o) opts = *o;
+    dbg_nn = (int)(opts.debug_flags & 0x001FFFFFu);
     if (opts.check_interval <= 0) opts.check_interval = 4;
     if (opts.grid_cells_per_point <= 0) opts.grid_cells_per_point = 2;
     rp.algorithm = p->registration_algorithm == S3D_ALG_ICP ? 0 : 1;
@@ -474,8 +476,8 @@ struct Batch {
     accum_blocks = kAccumVB;
     while (accum_blocks > 4 && (long long)accum_blocks * std::max(1, P()) > 1024) accum_blocks >>= 1;
     while (accum_blocks > 1 && accum_blocks * kBlock * 2 > std::max(max_n_t, 1)) accum_blocks >>= 1;
-    if (const char* e = getenv("S3D_ACCUM_BLOCKS")) {   // A/B and the invariance test: any divisor of kAccumVB
-      const int v = atoi(e);
+    {   // A/B and the invariance test (s3d_exec_options.debug_accum_blocks): any divisor of kAccumVB
+      const int v = opts.debug_accum_blocks;
       if (v >= 1 && v <= kAccumVB && kAccumVB % v == 0) accum_blocks = v;
     }
     const size_t np = std::max<size_t>(total_pts, 4);
@@ -494,7 +496,14 @@ struct Batch {
                 {&ctx->corr_idx, 4 * nc}, {&ctx->corr_d2, 4 * nc}, {&ctx->corr_lb, 4 * nc},
                 {&ctx->corr_q, 16 * nc}, {&ctx->corr_n, 16 * nc},
                 {&ctx->partials, 8 * (size_t)std::max(1, P()) * kAccumVB * GQ_NACC},
-                {&ctx->n_active, 64 + 2 * 64 * sizeof(int)},
+                {&ctx->n_active, 64 + 4 * 64 * sizeof(int)},
+                // the queries a scan27 pass declines (pair, index): up to every query of every pair - NOT bounded by the
+                // point count of the batch, whose clouds are shared by the pairs of a sweep
+                {&ctx->worklist, icp_buffers ? 8 * nc : 8},
+                {&ctx->wave_recs, sizeof(WaveRec) * (icp_buffers ? nc / kWave + 1 : 1)},
+                {&ctx->rec_list, sizeof(uint4) * (icp_buffers ? rec_list_entries() : 1)},
+                {&ctx->rec_counts, sizeof(int) * 2 * kNNRecSublists + sizeof(NNArrays)},
+                {&ctx->t_hist, sizeof(Mat4f) * (icp_buffers ? (size_t)std::max(1, P()) * (size_t)hist_stride() : 1)},
                 {&ctx->knn_list, sizeof(int) * (size_t)std::max(1, C())},
                 {&ctx->knn_fallback, sizeof(int) * npi}, {&ctx->knn_redo, sizeof(int2) * npi}});
     if (!ctx->h_active) HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
@@ -522,9 +531,14 @@ struct Batch {
     }
     {
       const size_t bs = sizeof(SlotDev) * (size_t)C(), bp = sizeof(PairDev) * (size_t)P();
-      char* stage = ctx->stage_host(bs + bp + 16);
+      char* stage = ctx->stage_host(bs + bp + 16 + sizeof(NNArrays));
       if (bs) { std::memcpy(stage, h_slots.data(), bs); HIPCHK(hipMemcpyAsync(ctx->slots.p, stage, bs, hipMemcpyHostToDevice, st)); }
       if (bp) { std::memcpy(stage + bs, h_pairs.data(), bp); HIPCHK(hipMemcpyAsync(ctx->pairs.p, stage + bs, bp, hipMemcpyHostToDevice, st)); }
+      if (icp_buffers) {   // the array table in device memory: the out-of-line search of the touch kernels takes it by pointer
+        const NNArrays A = nn_arrays();
+        std::memcpy(stage + bs + bp + 16, &A, sizeof A);
+        HIPCHK(hipMemcpyAsync(nn_arrays_dev(), stage + bs + bp + 16, sizeof A, hipMemcpyHostToDevice, st));
+      }
     }
     restore_from_cache();
   }
@@ -539,8 +553,8 @@ struct Batch {
   // batch and a lone pair (-25 us).  S3D_SORT_CLASSIC=1 / 0 forces one or the other (A/B).
   bool sort_classic = false;
   void sort_choose() {
-    const char* e = getenv("S3D_SORT_CLASSIC");
-    sort_classic = e ? atoi(e) != 0 : (long long)Cu * (long long)max_n >= 40000000ll;
+    sort_classic = (opts.debug_flags & S3D_DBG_SORT_CLASSIC) ? true : (opts.debug_flags & S3D_DBG_SORT_ONESWEEP) ? false
+                   : (long long)Cu * (long long)max_n >= 40000000ll;
   }
   bool sort_used = false;
   void sort_prepare(int nslots) {   // before the kernel that counts the digit totals
@@ -652,8 +666,8 @@ struct Batch {
     int* fb_list = (int*)ctx->knn_fallback.p;
     HIPCHK(hipMemsetAsync(fb_count, 0, 2 * sizeof(int), st));
     // k = 20 (the reference default): 32-bit keys + med3 insertion; what it does not answer goes through the exact
-    // 64-bit search (redo list, counted in n_active[5]).  S3D_KNN_EXACT64=1: the 64-bit search for every point.
-    const bool exact64 = getenv("S3D_KNN_EXACT64") && atoi(getenv("S3D_KNN_EXACT64")) != 0;
+    // 64-bit search (redo list, counted in n_active[5]).  S3D_DBG_KNN_EXACT64: the 64-bit search for every point.
+    const bool exact64 = (opts.debug_flags & S3D_DBG_KNN_EXACT64) != 0;
     if (k == 20 && !exact64 && max_n < kKnn3MaxPoints) {
       int* redo_count = fb_count + 1;
       int2* redo_list = (int2*)ctx->knn_redo.p;
@@ -673,7 +687,7 @@ struct Batch {
     else
       s3d_knn_moments_kernel<32><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
     s3d_normals_fallback_kernel<<<256, kBlock, 0, st>>>(fb_count, fb_list, mom, mom_plane, normals(), k);
-    if (getenv("S3D_DBG_KNN")) {   // dev aid: how many points took the eigen fallback / the exact-search redo
+    if (opts.debug_flags & S3D_DBG_PRINT_KNN) {   // dev aid: how many points took the eigen fallback / the exact-search redo
       int cnt[2];
       HIPCHK(hipMemcpyAsync(cnt, fb_count, sizeof cnt, hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
@@ -681,7 +695,13 @@ struct Batch {
     }
   }
 
-  int dbg_nn = getenv("S3D_DBG_NN") ? atoi(getenv("S3D_DBG_NN")) : 0;
+  // per pair and outer iteration: the transformation_ that iteration's correspondence pass ran with (written by the
+  // controller, read by the record-level re-validation of the settled passes and by the fitness pass)
+  int hist_stride() const { return std::max(1, std::min(rp.max_iterations, 4096)); }
+  WaveRec* wave_recs() { return (WaveRec*)ctx->wave_recs.p; }
+  NNArrays* nn_arrays_dev() { return (NNArrays*)((char*)ctx->rec_counts.p + sizeof(int) * 2 * kNNRecSublists); }
+  Mat4f* t_hist() { return (Mat4f*)ctx->t_hist.p; }
+  int dbg_nn = 0;   // the S3D_DBG_NN_* bits of s3d_exec_options.debug_flags (set_params)
   // prof_slot >= 0: count searched / unseeded queries of this launch into the profile counters.
   // compact: the block-compacting mode of the kernel (see s3d_nn_search_kernel).
   NNArrays nn_arrays() {
@@ -700,7 +720,7 @@ struct Batch {
     const int pairs8 = P() >= 8 ? cdiv(P(), 8) * 8 : P();
     dim3 grid((unsigned)(pairs8 * chunks));
     NNArrays A = nn_arrays();
-    int* pc = (prof_slot >= 0 && prof_slot < 64) ? (int*)ctx->n_active.p + 16 + 2 * prof_slot : nullptr;
+    int* pc = (prof_slot >= 0 && prof_slot < 64) ? (int*)ctx->n_active.p + 16 + 4 * prof_slot : nullptr;
     const bool family = mode == 0 && it >= 0 && !(dbg_nn & (262144 | 64 | 32 | 4));
     if (family && it == 0) {
       s3d_nn_first_kernel<<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc);
@@ -710,25 +730,78 @@ struct Batch {
     // that switch the re-validation off imply it)
     // (measured per 128 pairs: pass 2 1.47 -> 0.99 ms, pass 3 0.90 -> 0.80 ms with the compacting form; passes 4 and 5,
     // where 2 % and 0.1 % of the queries search, are slower this way: 0.39 -> 0.55, 0.15 -> 0.19 ms)
-    static const int scan27_passes = getenv("S3D_SCAN27_PASSES") ? atoi(getenv("S3D_SCAN27_PASSES")) : 2;
+    constexpr int scan27_passes = 2;
     if (family && it >= 1 && it <= scan27_passes && !(dbg_nn & (524288 | 128 | 2048)) && max_n < kKnn3MaxPoints) {
       int* wc = (int*)ctx->n_active.p + 8;              // eight counters, used in turn (zeroed by stage_icp / the drain)
-      static const bool compact27 = !(getenv("S3D_SCAN27_COMPACT") && atoi(getenv("S3D_SCAN27_COMPACT")) == 0);
+      const bool compact27 = !(opts.debug_flags & S3D_DBG_SCAN27_NO_COMPACT);
+      uint32_t* wl_pair = (uint32_t*)ctx->worklist.p;
+      uint32_t* wl_index = wl_pair + std::max<size_t>(total_corr, 4);
       if (it == 1)
-        s3d_nn_scan27_kernel<false, false><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), wc + (it & 7), kA(), kB(), pc);
+        s3d_nn_scan27_kernel<false, false><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), wc + (it & 7), wl_pair, wl_index, pc);
       else if (compact27)
-        s3d_nn_scan27_kernel<true, true><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), wc + (it & 7), kA(), kB(), pc);
+        s3d_nn_scan27_kernel<true, true><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), wc + (it & 7), wl_pair, wl_index, pc);
       else
-        s3d_nn_scan27_kernel<true, false><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), wc + (it & 7), kA(), kB(), pc);
-      s3d_nn_worklist_kernel<<<4096, kWave, 0, st>>>(d_pairs(), d_slots(), A, max_d, dbg_nn, wc + (it & 7), kA(), kB(),
+        s3d_nn_scan27_kernel<true, false><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), wc + (it & 7), wl_pair, wl_index, pc);
+      s3d_nn_worklist_kernel<<<4096, kWave, 0, st>>>(d_pairs(), d_slots(), A, max_d, dbg_nn, wc + (it & 7), wl_pair, wl_index,
                                                       wc + ((it + 1) & 7));
+      return;
+    }
+    // passes 6 ...: record-level re-validation (s3d_nn_settled_kernel); S3D_DBG_NN_NO_SETTLED = query by query
+    if (settled_on() && mode == 0 && it >= kSettledFrom) {
+      if (it == kSettledFrom) {                     // every record is evaluated (and gets its box): no test, no list
+        s3d_nn_record_touch_kernel<false><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc,
+                                                                   wave_recs(), t_hist(), hist_stride(), nullptr, 1, 0, nullptr,
+                                                                   nullptr, nn_arrays_dev());
+        return;
+      }
+      // two sets of list counters, used in turn (zeroed by stage_icp / by the touch kernel of the pass before)
+      int* sc = (int*)ctx->rec_counts.p;
+      uint4* rl = (uint4*)ctx->rec_list.p;
+      const int nrec = cdiv(std::max(max_n_t, 1), kWave);
+      const int rpt = rec_per_thread();
+      const int bpp = cdiv(nrec, kBlock * rpt);
+      const int nblocks = pairs8 * bpp;
+      const int nsub = std::min(kNNRecSublists, nblocks);
+      const int sub_cap = cdiv(nblocks, nsub) * kBlock * rpt;          // (every record of every block of a list failing)
+      int* cnt = sc + (it & 1) * kNNRecSublists;
+      int* cnt_next = sc + ((it + 1) & 1) * kNNRecSublists;
+      if (rpt == kNNRecPerThread)
+        s3d_nn_record_test_kernel<kNNRecPerThread><<<(unsigned)nblocks, kBlock, 0, st>>>(
+            d_pairs(), d_slots(), bpp, P(), wave_recs(), t_hist(), hist_stride(), cnt, nsub, sub_cap, rl, pc);
+      else
+        s3d_nn_record_test_kernel<1><<<(unsigned)nblocks, kBlock, 0, st>>>(
+            d_pairs(), d_slots(), bpp, P(), wave_recs(), t_hist(), hist_stride(), cnt, nsub, sub_cap, rl, pc);
+      // a fixed grid walks the lists: one record per wave and trip (at most as many waves as there are records)
+      // one wave per failing record while at most a quarter of the records fail (the waves without an entry leave after
+      // one load); beyond that the waves loop
+      const long long waves = std::max<long long>(std::min<long long>((long long)P() * nrec, 7168), (long long)P() * nrec / 4);
+      const int tblocks = std::max(cdiv(cdiv((int)waves, kBlock / kWave), nsub), 1) * nsub;   // a multiple of nsub blocks
+      s3d_nn_record_touch_kernel<true><<<(unsigned)tblocks, kBlock, 0, st>>>(
+          d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc, wave_recs(), t_hist(), hist_stride(), cnt, nsub, sub_cap, rl,
+          cnt_next, nn_arrays_dev());
       return;
     }
     const int cmp = (compact && mode == 0 && !(dbg_nn & 65536)) ? 1 : 0;
     if (mode == 0)
-      s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc, cmp);
+      s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc, cmp, nullptr,
+                                                       nullptr, 0);
     else
-      s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc, 0);
+      s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc, 0,
+                                                       settled_used ? wave_recs() : nullptr, t_hist(), hist_stride());
+  }
+  static constexpr int kSettledFrom = 5;   // first outer iteration (0-based) that runs record-wise
+  // records per thread of the test kernel: four for a large batch (few blocks, one list append each), one for a small one
+  int rec_per_thread() const { return (long long)P() * cdiv(std::max(max_n_t, 1), kWave) >= 65536 ? kNNRecPerThread : 1; }
+  size_t rec_list_entries() const {
+    const int nrec = cdiv(std::max(max_n_t, 1), kWave), rpt = rec_per_thread();
+    const int pairs8 = P() >= 8 ? cdiv(P(), 8) * 8 : std::max(P(), 1);
+    const int nblocks = pairs8 * cdiv(nrec, kBlock * rpt);
+    const int nsub = std::min(kNNRecSublists, nblocks);
+    return (size_t)nsub * (size_t)(cdiv(nblocks, nsub) * kBlock * rpt);
+  }
+  bool settled_used = false;               // stage_icp: this batch's records / transform history are initialised
+  bool settled_on() const {
+    return settled_used && !(dbg_nn & (S3D_DBG_NN_NO_SETTLED | 262144 | 64 | 32 | 4));
   }
 
   // one outer iteration: correspondences (K5), accumulate (K6), controller (K7)
@@ -746,7 +819,7 @@ struct Batch {
     if (!rp.algorithm)
       s3d_p2plane_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
           d_pairs(), d_slots(), sorted3(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp);
-    s3d_icp_control_kernel<<<P(), kCtrlThreads, 0, st>>>(d_pairs(), part, rp, (int*)ctx->n_active.p);
+    s3d_icp_control_kernel<<<P(), kCtrlThreads, 0, st>>>(d_pairs(), part, rp, (int*)ctx->n_active.p, t_hist(), hist_stride());
   }
 
   // K5-K7 loop.  The host only polls the active-pair counter every check_interval iterations.
@@ -759,9 +832,14 @@ struct Batch {
     HIPCHK(hipMemsetAsync(ctx->corr_d2.p, 0xFF, 4 * std::max<size_t>(total_corr, 4), st));
     HIPCHK(hipMemsetAsync(ctx->corr_lb.p, 0, 4 * std::max<size_t>(total_corr, 4), st));
     HIPCHK(hipMemsetAsync((int*)ctx->n_active.p + 8, 0, 8 * sizeof(int), st));   // worklist counters of the scan27 passes
+    // the 64-query records of the settled passes: touch = -1 ("never evaluated record-wise")
+    HIPCHK(hipMemsetAsync(ctx->wave_recs.p, 0xFF, sizeof(WaveRec) * (std::max<size_t>(total_corr, 4) / kWave + 1), st));
+    HIPCHK(hipMemsetAsync(ctx->rec_counts.p, 0, sizeof(int) * 2 * kNNRecSublists, st));   // the record-list counters
+
+    settled_used = true;
     const float max_d = (float)(rp.max_corr * 1.0001);
     const bool prof = opts.profile != 0;
-    if (prof) HIPCHK(hipMemsetAsync((int*)ctx->n_active.p + 16, 0, 2 * 64 * sizeof(int), st));
+    if (prof) HIPCHK(hipMemsetAsync((int*)ctx->n_active.p + 16, 0, 4 * 64 * sizeof(int), st));
     // segments of iterations between two polls of the active-pair counter (all of them when the count is forced)
     const int seg = rp.force_iterations ? std::max(rp.max_iterations, 1) : opts.check_interval;
     for (int it0 = 0; it0 < rp.max_iterations; it0 += seg) {
@@ -853,9 +931,12 @@ struct Batch {
         ctx->prof.nn_ms += ms;
         if (i < 64) ctx->prof.nn_launch_ms[i] = ms;
       }
-      int counts[128];
+      int counts[256];
       HIPCHK(hipMemcpy(counts, (int*)ctx->n_active.p + 16, sizeof counts, hipMemcpyDeviceToHost));
-      for (int i = 0; i < 64; ++i) { ctx->prof.nn_searched[i] = counts[2 * i]; ctx->prof.nn_unseeded[i] = counts[2 * i + 1]; }
+      for (int i = 0; i < 64; ++i) {
+        ctx->prof.nn_searched[i] = counts[4 * i]; ctx->prof.nn_unseeded[i] = counts[4 * i + 1];
+        ctx->prof.nn_records[i] = counts[4 * i + 2]; ctx->prof.nn_records_searched[i] = counts[4 * i + 3];
+      }
       ctx->prof.nn_queries = nq * ctx->prof.nn_launches;
       ctx->prof.nn_targets = nt * ctx->prof.nn_launches;
     }
@@ -1415,12 +1496,6 @@ static int context_create(int device, void* hip_stream, int priority_class, s3d_
     {
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 4 < ctx->cache_limit) ctx->cache_limit = free_b / 4;
-    }
-    if (const char* pre = getenv("S3D_ARENA_PREALLOC_MB")) {   // experiment: reserve the workspace before any cloud upload
-      const size_t want = (size_t)atoll(pre) << 20;
-      HIPCHK(hipMalloc(&ctx->arena.p, want));
-      ctx->arena.cap = want;
-      if (getenv("S3D_DBG_ARENA")) std::fprintf(stderr, "[s3d] arena (prealloc) %p + %zu MiB\n", ctx->arena.p, want >> 20);
     }
   } catch (const HipError& e) {
     fail(ctx, e);

@@ -528,6 +528,61 @@ S3D_HD bool nn_still_nearest(float d_new, float move, float lb_others) {
   return d_new + move < lb_others * 0.99999f - 1.0e-6f;
 }
 
+// ---- the same proof for 64 queries at once (round 4: the settled passes of a registration) ----
+// A RECORD of 64 consecutive queries of a pair (cell order: spatial neighbours) keeps the box of their positions
+// (centre c, half extents e: the guess-transformed points, which do not change during a registration), the pass of
+// its last full evaluation (`touch`: the bounds corr_lb of its queries are relative to the positions under THAT
+// pass's transformation_) and the smallest MARGIN of its queries at that pass,
+//     margin_i = (lb_i (1 - 1e-5) - 1e-6 - d_i) / 2      (a neighbour at distance d_i, every other point beyond lb_i)
+//     margin_i =  lb_i (1 - 1e-5) - 1e-6 - max_d         (no point within lb_i > max_d).
+// Under the current transformation_ T a query has moved by |fl(T p) - fl(T_touch p)| <= nn_record_move_bound(...)
+// =: b from where it stood at the touch, so its neighbour is now at most d_i + b away and every other point still
+// farther than lb_i - b: with b < margin_i the inequality of nn_still_nearest holds for the query (with room to
+// spare), and with b < min_i margin_i the WHOLE record is re-validated without loading a single query.  Nothing is
+// rewritten then: the bounds stay relative to the touch pass, which is why the displacement is taken from the touch
+// transform itself and not summed over the passes in between.  A record that fails runs the per-query test against
+// T_touch, searches what fails that, and is touched anew.
+struct WaveRec { float c[3]; float e[3]; float margin; int touch; };   // 32 bytes
+
+S3D_HD float nn_margin(bool has_neighbour, float lb_others, float d, float max_d) {
+  const float room = lb_others * 0.99999f - 1.0e-6f;
+  return has_neighbour ? 0.5f * (room - d) : room - max_d;
+}
+
+// upper bound of |fl(T p) - fl(Tt p)| (xf_eigen, float) over the points p of the box (c, e); double arithmetic on
+// the exact float entries.  |(T - Tt)(c, 1)| + sum_j |(T - Tt) column j| e_j bounds the exact displacement.  The
+// rounding of a float transform is bounded per coordinate r by gamma_4 (|T_r0 x| + |T_r1 y| + |T_r2 z| + |t_r|),
+// gamma_4 <= 4.0000008 u, u = 2^-24 (((a x + b y) + c z) + t: no term passes more than four roundings); both
+// transforms together, per coordinate, then as a vector.  It dominates once a registration has settled - at 40 m
+// from the origin a float coordinate is quantised to 3.8e-6 m and the bound is 1.9e-5 m - so it is taken per
+// coordinate from the box's own largest |x|, |y|, |z|, not from one norm for all three.
+// sqrt rounded UP, through the float unit (a double sqrt is ~50 instructions on the device): (float) s is within 2^-24
+// of s, sqrtf within an ulp; an argument below the float range (< 1e-38: a displacement < 1e-19 m) may come out as 0,
+// which the constant term of the bound absorbs
+S3D_HD double sqrt_up(double s) { return (double)sqrtf((float)s) * 1.000001; }
+S3D_HD double nn_record_move_bound(const Mat4f& T, const Mat4f& Tt, const float c[3], const float e[3]) {
+  double d[3][4];
+  for (int r = 0; r < 3; ++r)
+    for (int a = 0; a < 4; ++a) d[r][a] = (double)S3D_M(T, r, a) - (double)S3D_M(Tt, r, a);
+  double v2 = 0.0;
+  for (int r = 0; r < 3; ++r) {
+    const double v = fma(d[r][0], (double)c[0], fma(d[r][1], (double)c[1], fma(d[r][2], (double)c[2], d[r][3])));
+    v2 = fma(v, v, v2);
+  }
+  double b = sqrt_up(v2);
+  for (int a = 0; a < 3; ++a)
+    b += sqrt_up(fma(d[0][a], d[0][a], fma(d[1][a], d[1][a], d[2][a] * d[2][a]))) * (double)e[a];
+  const double pmax[3] = {fabs((double)c[0]) + (double)e[0], fabs((double)c[1]) + (double)e[1],
+                          fabs((double)c[2]) + (double)e[2]};
+  double g2 = 0.0;
+  for (int r = 0; r < 3; ++r) {
+    double g = fabs((double)S3D_M(T, r, 3)) + fabs((double)S3D_M(Tt, r, 3));
+    for (int a = 0; a < 3; ++a) g = fma(fabs((double)S3D_M(T, r, a)) + fabs((double)S3D_M(Tt, r, a)), pmax[a], g);
+    g2 = fma(g, g, g2);
+  }
+  return b * 1.000001 + 2.385e-7 * sqrt_up(g2) + 1.0e-9;   // 4 u = 2.3842e-7
+}
+
 // Exact k-NN of a point among its own cloud by ring expansion.  The k best are
 // kept in caller-provided storage addressed as d2s[j*stride], idxs[j*stride]
 // (LDS columns on the GPU).  Order of the result is unspecified.

@@ -1282,9 +1282,20 @@ struct NNArrays {
 };
 
 template <int MODE, int PHASE>
+__device__ __forceinline__ void nn_query_search(const PairDev& P, const SlotDev& Ss, int ci, bool need, const F3& q,
+                                                float move, const NNArrays& A, float max_d, int dbg,
+                                                int* __restrict__ prof_counts, int* out_class, float* out_margin);
+
+// PHASE 6 (the record-wise settled passes, round 4): PHASE 0 for one RECORD of 64 queries that failed the record-level proof -
+// the previous positions are those under Tref (the transformation_ of the record's last full evaluation, not of the
+// previous pass), *out_margin receives the query's margin for the next record-level proof (nn_margin; +inf for a lane
+// without a query), and the round-1 A/B switches are compiled out.
+template <int MODE, int PHASE>
 __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, const SlotDev& Ss, int pair, int i,
                                          bool need, const NNArrays& A, float max_d, int dbg,
-                                         int* __restrict__ prof_counts, int* out_class = nullptr) {
+                                         int* __restrict__ prof_counts, int* out_class, const Mat4f& Tref,
+                                         float* out_margin = nullptr) {
+  if (PHASE == 6) *out_margin = 3.0e38f;
   const int ci = P.corr_off + (need ? i : 0);
   // queries are taken in the CELL-SORTED order of their own cloud (spatially coherent waves)
   const CorrVec p0 = A.sorted3[St.off + (need ? i : 0)];
@@ -1302,26 +1313,38 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   float move = 3.0e38f;                          // how far this query moved since the previous pass (if known)
   if (need && lbs != 0.f && !(dbg & 64)) {
     // re-validate the previous result by the triangle inequality (s3d_core.h nn_still_nearest)
-    const F3 qo = xf_eigen(P.T_nn, pg.x, pg.y, pg.z);   // where this query stood in the previous pass
+    const F3 qo = xf_eigen(Tref, pg.x, pg.y, pg.z);     // where this query stood in the previous pass
     move = sqrtf(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
     if (PHASE != 2) {                                    // (a PHASE 2 query has failed this test already)
       if (lbs > 0.f) {
         const CorrVec ps = A.corr_q[ci];                  // the neighbour itself travels with the correspondence
         const float d2n = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z);
-        if (nn_still_nearest(sqrtf(d2n), move, lb)) {
+        const float dn = sqrtf(d2n);
+        if (nn_still_nearest(dn, move, lb)) {
           // same point, its exact new distance: the accumulate kernels recompute it from the copy of the neighbour
           // (bit for bit: the same float operations), only the fitness kernel reads the stored value
           if (MODE != 0) A.corr_d2[ci] = d2n;
           A.corr_lb[ci] = lb - move;                     // still a lower bound for the others (> 0: the test above)
+          if (PHASE == 6) *out_margin = nn_margin(true, lb - move, dn, max_d);
           need = false;
         }
       } else if (nn_still_nearest(max_d, move, lb)) {
         // no point at all within lb of the previous position, lb > max_d: still none within max_d
         A.corr_lb[ci] = move - lb;                       // (< 0)
+        if (PHASE == 6) *out_margin = nn_margin(false, lb - move, 0.f, max_d);
         need = false;
       }
     }
   }
+  nn_query_search<MODE, PHASE>(P, Ss, ci, need, q, move, A, max_d, dbg, prof_counts, out_class, out_margin);
+}
+
+// the second half of nn_query: the search of a query that was not re-validated, and the stores of its result
+template <int MODE, int PHASE>
+__device__ __forceinline__ void nn_query_search(const PairDev& P, const SlotDev& Ss, int ci, bool need, const F3& q,
+                                                float move, const NNArrays& A, float max_d, int dbg,
+                                                int* __restrict__ prof_counts, int* out_class, float* out_margin) {
+  constexpr bool kAB = S3D_NN_AB && PHASE != 6;
   // radius hint: this query's distance in the previous pass (NaN-filled before the first one)
   const float prev = PHASE == 5 ? __int_as_float(0x7FC00000) : (need ? A.corr_d2[ci] : 0.f);
   if (PHASE == 3) {   // classify only: 0 = near seed, 1 = wide, 2 = nothing to do (block-level compaction follows)
@@ -1338,10 +1361,10 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   const bool has_prev = prev >= 0.f && prev < 1.0e30f;
   const bool near_seed = has_prev && prev < Ss.g.h * Ss.g.h;
   const bool far_seed = has_prev && !near_seed && move < kNNRevalSlack * Ss.g.h && !(dbg & 128);
-  const int seed = ((near_seed || far_seed) && !(S3D_NN_AB && (dbg & 32))) ? A.corr_idx[ci] : -1;
+  const int seed = ((near_seed || far_seed) && !(kAB && (dbg & 32))) ? A.corr_idx[ci] : -1;
   // first pass (nothing known yet): a generous three-cell box — the shrinking-ball scan makes a large
   // initial radius cheap, while a small one costs a second scan for every badly aligned query
-  const float first = (!S3D_NN_AB ? 3.0f : (dbg & 256) ? 1.0f : (dbg & 512) ? 1.5f : (dbg & 1024) ? 2.0f : 3.0f) * Ss.g.h;
+  const float first = (!kAB ? 3.0f : (dbg & 256) ? 1.0f : (dbg & 512) ? 1.5f : (dbg & 1024) ? 2.0f : 3.0f) * Ss.g.h;
   const float hint = has_prev ? fminf(sqrtf(prev) * 1.25f + 0.05f * Ss.g.h, Ss.g.h) : first;
   if (prof_counts) {   // profile >= 2 only: how many queries search, how many of them without a near seed
     const unsigned long long all = __ballot(need), un = __ballot(need && !near_seed);
@@ -1354,7 +1377,7 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   r.idx = -1; r.d2 = 3.0e38f; r.pos = -1; r.second_d2 = 3.0e38f; r.radius = 0.f;
   const uint32_t* __restrict__ cs = A.cell_start + Ss.cell_off;
   const float4* __restrict__ tp = A.sorted + Ss.off;
-  if (S3D_NN_AB && (dbg & 4)) {
+  if (kAB && (dbg & 4)) {
     if (need) r = grid_nn1(Ss.g, cs, tp, q.x, q.y, q.z, max_d);
   } else {
     // served by the whole wave, one query after the other: the queries that will walk a wide box when they are
@@ -1383,10 +1406,11 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   // the target's cell-sorted array: every later access (K6, fitness) is then coalesced or a local gather
   A.corr_idx[ci] = r.pos;
   A.corr_d2[ci] = r.d2;
-  const float lbv = !(S3D_NN_AB && (dbg & 4)) ? nn_lower_bound_others(r) : 0.f;   // no neighbour at all: the scanned radius
+  const float lbv = !(kAB && (dbg & 4)) ? nn_lower_bound_others(r) : 0.f;   // no neighbour at all: the scanned radius
   // (first pass: the runner-up is not tracked - "nothing known" about the others; the second pass searches every
   // query again anyway, the first transform update has moved them all)
   A.corr_lb[ci] = r.pos >= 0 ? (PHASE == 5 ? 0.f : lbv) : -lbv;
+  if (PHASE == 6) *out_margin = nn_margin(r.pos >= 0, lbv, r.pos >= 0 ? sqrtf(r.d2) : 0.f, max_d);
   if (r.pos >= 0) {
     // a copy of the matched point and of its normal is kept with the correspondence: the re-validation
     // above and the accumulate kernel then stream them instead of gathering by index
@@ -1436,7 +1460,9 @@ template <int MODE>
 __global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_search_kernel(const PairDev* __restrict__ pairs,
                                                                 const SlotDev* __restrict__ slots, NNArrays A,
                                                                 float max_d, int chunks_per_pair, int npairs, int dbg,
-                                                                int* __restrict__ prof_counts, int compact) {
+                                                                int* __restrict__ prof_counts, int compact,
+                                                                const WaveRec* __restrict__ recs,
+                                                                const Mat4f* __restrict__ T_hist, int hist_stride) {
   __shared__ int order[kBlock];
   __shared__ int lds4[4];
   int pair, chunk;
@@ -1449,13 +1475,25 @@ __global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_search_kernel(con
   const int i = chunk * kBlock + threadIdx.x;
   if (chunk * kBlock >= St.n) return;
   const SlotDev& Ss = slots[P.slot_s];
+  // the positions the stored bounds refer to: the previous pass in the ICP loop; in the fitness pass (MODE 1) those of
+  // the record's last full evaluation, when the settled passes ran record-wise (s3d_nn_settled_kernel)
+  Mat4f Tloc;
+  if (MODE == 1) {
+    Tloc = P.T_nn;
+    const int rec = chunk * (kBlock / kWave) + wave_id();
+    if (recs && rec * kWave < St.n) {   // (a wave past the end of the cloud owns no record: what lies there is stale)
+      const int touch = __builtin_amdgcn_readfirstlane(recs[(P.corr_off >> 6) + rec].touch);
+      if (touch >= 0 && touch < hist_stride) Tloc = T_hist[(size_t)pair * hist_stride + touch];
+    }
+  }
+  const Mat4f& Tref = MODE == 1 ? Tloc : P.T_nn;
   // lanes past the end of the cloud stay in the wave (the cooperative search needs all of them) but own no query
   if (!compact) {
-    nn_query<MODE, 0>(P, St, Ss, pair, i, i < St.n, A, max_d, dbg, prof_counts);
+    nn_query<MODE, 0>(P, St, Ss, pair, i, i < St.n, A, max_d, dbg, prof_counts, nullptr, Tref);
     return;
   }
   int cls = 2;
-  nn_query<MODE, 3>(P, St, Ss, pair, i, i < St.n, A, max_d, dbg, nullptr, &cls);
+  nn_query<MODE, 3>(P, St, Ss, pair, i, i < St.n, A, max_d, dbg, nullptr, &cls, Tref);
   int n0, n1;
   const int p0 = block_excl_flag(cls == 0, &n0, lds4);
   const int p1 = block_excl_flag(cls == 1, &n1, lds4);
@@ -1466,7 +1504,248 @@ __global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_search_kernel(con
   if ((int)(threadIdx.x & ~(kWave - 1)) >= n0 + n1) return;        // whole wave without work
   const bool need = (int)threadIdx.x < n0 + n1;
   const int j = chunk * kBlock + (need ? order[threadIdx.x] : 0);
-  nn_query<MODE, 2>(P, St, Ss, pair, j, need, A, max_d, dbg, prof_counts);
+  nn_query<MODE, 2>(P, St, Ss, pair, j, need, A, max_d, dbg, prof_counts, nullptr, Tref);
+}
+
+// ---- the SETTLED passes of a registration, record-wise (round 4; nn_record_move_bound, s3d_core.h).
+// Once a registration has settled, >= 99.9 % of its queries do nothing in a correspondence pass but prove "unchanged":
+// 28 bytes read and 4 written per query, fifteen times per registration of the benchmark.  Here a pass is two
+// launches.  s3d_nn_record_test_kernel: one THREAD per record of 64 consecutive queries (32 bytes: the box of their
+// positions, their smallest margin, the pass of their last full evaluation) tests the record against the displacement
+// between the current transformation_ and that pass's - kept per pair and pass by the controller (T_hist) - and a
+// record that passes is left alone: nothing of its queries is read or written.  The records that fail are appended
+// to a list (one atomic per wave that has any).  s3d_nn_record_touch_kernel<true>: a fixed grid of waves walks the
+// list, one record per wave and trip, through the per-query path (nn_query PHASE 6: re-validation against the touch
+// pass, search of what fails it), which re-establishes margin and touch pass.  The first record-wise pass of a
+// registration evaluates every record: s3d_nn_record_touch_kernel<false>, the per-query kernel's launch geometry, no
+// list.  (One kernel that tests, packs the failing records in LDS and serves them was built first: 0.064 ms per
+// settled pass of 128 pairs against 0.098 query by query, with 88 % of the records skipped - every block pays the
+// chain pair record -> record -> touch transform -> test -> barrier before its first failing record, and its waves
+// then take their records one after the other.)
+// The neighbours, distances and copies left in corr_* are those of the per-query kernel bit for bit - every skipped
+// query is proven unchanged, by a weaker inequality than nn_still_nearest's - and so are the registrations
+// (S3D_DBG_NN_NO_SETTLED in s3d_exec_options.debug_flags switches the record test off; tests/test_gpu_parity.py).
+// A record that was never evaluated record-wise (touch < 0) always fails the test; it is evaluated against the
+// previous pass and gets its box.
+// The list is kNNRecSublists lists: block b of the test kernel appends to list b % nsub (ONE atomic per block and
+// list counter - 3 000 wave-level appends to a single counter made the test kernel 45 us long, all of it waiting on
+// that address), wave w of the touch kernel walks list w % nsub.  An entry carries the record's touch pass, so that
+// the touch kernel fetches the pair record and the touch transform side by side.
+// An entry also carries where the record's queries and correspondences start and how many of its 64 lanes hold a
+// query: the touch kernel issues the loads of a record's data as soon as it has the entry, next to - not after - the
+// loads of the pair record.
+__device__ __forceinline__ uint4 nn_record_entry(int pair, int rec, int touch, int corr_off, int query_off, int n) {
+  const int valid = imin(kWave, n - rec * kWave);
+  return make_uint4((unsigned)pair, (unsigned)(corr_off + rec * kWave), ((unsigned)touch & 0xFFFFu) | ((unsigned)valid << 16),
+                    (unsigned)(query_off + rec * kWave));
+}
+constexpr int kNNRecSublists = 64;
+constexpr int kNNRecPerThread = 4;     // records per thread of the test kernel (large batches; 1 for small ones)
+template <int RPT>
+__global__ void __launch_bounds__(kBlock) s3d_nn_record_test_kernel(const PairDev* __restrict__ pairs,
+                                                                     const SlotDev* __restrict__ slots, int blocks_per_pair,
+                                                                     int npairs, const WaveRec* __restrict__ recs,
+                                                                     const Mat4f* __restrict__ T_hist, int hist_stride,
+                                                                     int* __restrict__ list_counts, int nsub, int sub_cap,
+                                                                     uint4* __restrict__ list, int* __restrict__ prof_counts) {
+  __shared__ int wave_cnt[kBlock / kWave][RPT];
+  __shared__ int block_base;
+  int pair, chunk;
+  nn_block_map(blocks_per_pair, npairs, &pair, &chunk);
+  if (pair >= npairs) return;
+  const PairDev& P = pairs[pair];
+  if (!P.active) return;
+  const SlotDev& St = slots[P.slot_t];
+  const int nrec = (St.n + kWave - 1) / kWave;
+  if (chunk * (kBlock * RPT) >= nrec) return;
+  const WaveRec* __restrict__ prec = recs + (P.corr_off >> 6);
+  const Mat4f* __restrict__ hist = T_hist + (size_t)pair * hist_stride;
+  const int lane = lane_id(), w = wave_id();
+  WaveRec W[RPT];
+  int rec[RPT];
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {       // (all record loads first, then all touch transforms: two round trips per thread)
+    rec[j] = chunk * (kBlock * RPT) + j * kBlock + (int)threadIdx.x;
+    W[j] = prec[rec[j] < nrec ? rec[j] : nrec - 1];
+  }
+  bool fail[RPT];
+  int at[RPT];
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const bool ok = rec[j] < nrec && W[j].touch >= 0 && W[j].touch < hist_stride && W[j].margin > 0.f;
+    fail[j] = rec[j] < nrec;
+    if (ok) fail[j] = !(nn_record_move_bound(P.T, hist[W[j].touch], W[j].c, W[j].e) < (double)W[j].margin);
+    const unsigned long long m = __ballot(fail[j]);
+    at[j] = (int)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[w][j] = (int)__popcll(m);
+  }
+  __syncthreads();
+  // this thread's entries start at: the block's base + the failing records of (j', wave') before (j, wave)
+  int before[RPT], total = 0;
+#pragma unroll
+  for (int j = 0; j < RPT; ++j)
+#pragma unroll
+    for (int ww = 0; ww < kBlock / kWave; ++ww) {
+      if (ww == w) before[j] = total;
+      total += wave_cnt[ww][j];
+    }
+  if (total == 0) return;
+  const int sub = (int)(blockIdx.x % (unsigned)nsub);
+  if (threadIdx.x == 0) {
+    block_base = atomicAdd(&list_counts[sub], total);
+    if (prof_counts) {   // profile >= 2: records tested / records that go through the per-query path
+      atomicAdd(&prof_counts[2], imin(kBlock * RPT, nrec - chunk * (kBlock * RPT)));
+      atomicAdd(&prof_counts[3], total);
+    }
+  }
+  __syncthreads();
+  uint4* __restrict__ out = list + (size_t)sub * sub_cap + block_base;
+#pragma unroll
+  for (int j = 0; j < RPT; ++j)
+    if (fail[j]) out[before[j] + at[j]] = nn_record_entry(pair, rec[j], W[j].touch, P.corr_off, St.off, St.n);
+}
+
+// The search of the lanes of a record that failed their own re-validation, OUT OF LINE: inlined, its registers are the
+// touch kernel's, the 72-register cap spills, and the spills land in the re-validation stream that every lane runs
+// (measured: the first record-wise pass 0.185 ms per 128 pairs against 0.110 for the per-query kernel).  A call costs
+// nothing where it is not taken, and in a settled pass one query in 5 000 searches.  Returns the lane's margin.
+__device__ __noinline__ float nn_record_search(const PairDev* Pp, const SlotDev* Ssp, int ci, int need, float qx, float qy,
+                                               float qz, float move, const NNArrays* Ap, float max_d, int dbg,
+                                               int* prof_counts) {
+  // (the pointers are wave-uniform but arrive in vector registers: back to scalar ones, so that the records load as
+  // scalars again)
+  auto uni = [](const void* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+  };
+  const PairDev& P = *(const PairDev*)uni(Pp);
+  const SlotDev& Ss = *(const SlotDev*)uni(Ssp);
+  const NNArrays A = *(const NNArrays*)uni(Ap);
+  F3 q; q.x = qx; q.y = qy; q.z = qz;
+  float margin = 3.0e38f;
+  nn_query_search<0, 6>(P, Ss, ci, need != 0, q, move, A, max_d, __builtin_amdgcn_readfirstlane(dbg),
+                        (int*)uni(prof_counts), nullptr, &margin);
+  return margin;
+}
+
+template <bool LISTED>
+__global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_record_touch_kernel(const PairDev* __restrict__ pairs,
+                                                                      const SlotDev* __restrict__ slots, NNArrays A,
+                                                                      float max_d, int chunks_per_pair, int npairs,
+                                                                      int dbg, int* __restrict__ prof_counts,
+                                                                      WaveRec* __restrict__ recs,
+                                                                      const Mat4f* __restrict__ T_hist, int hist_stride,
+                                                                      const int* __restrict__ list_counts, int nsub,
+                                                                      int sub_cap, const uint4* __restrict__ list,
+                                                                      int* __restrict__ list_counts_next,
+                                                                      const NNArrays* __restrict__ A_dev) {
+  const int lane = lane_id();
+  // LISTED: the four waves of a block take four consecutive entries of ONE list - the records a block of the test
+  // kernel appended together belong to one pair, whose records then come through the scalar cache once per block
+  const int sub = LISTED ? (int)(blockIdx.x % (unsigned)nsub) : 0;
+  const int step = LISTED ? ((int)gridDim.x / nsub) * (kBlock / kWave) : 1;   // (the grid is a multiple of nsub blocks)
+  const int count = LISTED ? list_counts[sub] : 1;
+  if (LISTED && (int)blockIdx.x == 0 && (int)threadIdx.x < nsub) list_counts_next[threadIdx.x] = 0;   // the next pass's test appends here
+  const uint4* __restrict__ mylist = list + (size_t)sub * sub_cap;
+  const int entry0 = LISTED ? ((int)blockIdx.x / nsub) * (kBlock / kWave) + wave_id() : 0;
+  // (the first entry is fetched next to the count, not after it: a position beyond the count holds stale data, which is
+  // not used; sub_cap covers every position a wave of this grid can name, see Batch::launch_nn)
+  uint4 e_first = make_uint4(0u, 0u, 0u, 0u);
+  if (LISTED && entry0 < sub_cap) e_first = mylist[entry0];
+  for (int entry = entry0; entry < count; entry += step) {
+    int pair, cbase, qbase, nvalid, touch = -1;
+    if (LISTED) {
+      const uint4 e = entry == entry0 ? e_first : mylist[entry];
+      pair = __builtin_amdgcn_readfirstlane((int)e.x);
+      cbase = __builtin_amdgcn_readfirstlane((int)e.y);
+      touch = __builtin_amdgcn_readfirstlane((int)(e.z & 0xFFFFu));
+      touch = touch == 0xFFFF ? -1 : touch;
+      nvalid = __builtin_amdgcn_readfirstlane((int)(e.z >> 16));
+      qbase = __builtin_amdgcn_readfirstlane((int)e.w);
+    } else {
+      int chunk;
+      nn_block_map(chunks_per_pair, npairs, &pair, &chunk);
+      if (pair >= npairs) return;
+      const PairDev& P0 = pairs[pair];
+      if (!P0.active) return;
+      const SlotDev& St = slots[P0.slot_t];
+      const int rec = chunk * (kBlock / kWave) + wave_id();
+      if (rec * kWave >= St.n) return;
+      cbase = P0.corr_off + rec * kWave;
+      qbase = St.off + rec * kWave;
+      nvalid = imin(kWave, St.n - rec * kWave);
+    }
+    // the record's data: nothing here depends on the pair record, whose loads run next to these
+    const bool valid = lane < nvalid;
+    const int ci = cbase + (valid ? lane : 0);
+    const CorrVec p0 = A.sorted3[qbase + (valid ? lane : 0)];
+    const float lbs = A.corr_lb[ci];
+    const CorrVec ps = A.corr_q[ci];
+    const PairDev& P = pairs[pair];
+    // LISTED = false is the first record-wise pass of a registration: no record has been evaluated yet
+    const bool have = LISTED && touch >= 0 && touch < hist_stride;
+    const Mat4f& Tref = have ? T_hist[(size_t)pair * hist_stride + touch] : P.T_nn;   // (never evaluated record-wise: the previous pass)
+    // nn_query's re-validation, the same float operations
+    const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
+    const F3 q = xf_eigen(P.T, pg.x, pg.y, pg.z);
+    const float lb = fabsf(lbs);
+    bool need = valid;
+    float move = 3.0e38f, margin = 3.0e38f;
+    if (valid && lbs != 0.f) {
+      const F3 qo = xf_eigen(Tref, pg.x, pg.y, pg.z);
+      move = sqrtf(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
+      if (lbs > 0.f) {
+        const float dn = sqrtf(dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z));
+        if (nn_still_nearest(dn, move, lb)) {
+          A.corr_lb[ci] = lb - move;
+          margin = nn_margin(true, lb - move, dn, max_d);
+          need = false;
+        }
+      } else if (nn_still_nearest(max_d, move, lb)) {
+        A.corr_lb[ci] = move - lb;
+        margin = nn_margin(false, lb - move, 0.f, max_d);
+        need = false;
+      }
+    }
+    if (__ballot(need) != 0ull) {
+      const float m = nn_record_search(&P, &slots[P.slot_s], ci, need ? 1 : 0, q.x, q.y, q.z, move, A_dev, max_d, dbg,
+                                       prof_counts);
+      if (need) margin = m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) margin = fminf(margin, __shfl_xor(margin, o, kWave));
+    WaveRec* __restrict__ W = recs + (cbase >> 6);
+    if (!have) {
+      // first evaluation of this registration: the box of the record's positions (guess * p: fixed from here on)
+      float mn[3] = {valid ? pg.x : 3.0e38f, valid ? pg.y : 3.0e38f, valid ? pg.z : 3.0e38f};
+      float mx[3] = {valid ? pg.x : -3.0e38f, valid ? pg.y : -3.0e38f, valid ? pg.z : -3.0e38f};
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, kWave));
+          mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, kWave));
+        }
+      }
+      if (lane == 0) {
+        WaveRec w;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          w.c[a] = 0.5f * mn[a] + 0.5f * mx[a];
+          w.e[a] = fmaxf(mx[a] - w.c[a], w.c[a] - mn[a]) * 1.000001f + 1.0e-30f;   // (float rounding of the two differences)
+        }
+        w.margin = margin;
+        w.touch = P.iterations;
+        *W = w;
+      }
+    } else if (lane == 0) {
+      W->margin = margin;
+      W->touch = P.iterations;
+    }
+    if (!LISTED) return;
+  }
 }
 
 // ---- the FIRST pass of a registration has a kernel of its own (round 3): no history to load, no re-validation, no
@@ -1493,7 +1772,7 @@ __global__ void __launch_bounds__(kBlock, S3D_NN_FIRST_WAVES) s3d_nn_first_kerne
   const SlotDev& St = slots[P.slot_t];
   const int i = chunk * kBlock + threadIdx.x;
   if (chunk * kBlock >= St.n) return;
-  nn_query<0, 5>(P, St, slots[P.slot_s], pair, i, i < St.n, A, max_d, dbg, prof_counts);
+  nn_query<0, 5>(P, St, slots[P.slot_s], pair, i, i < St.n, A, max_d, dbg, prof_counts, nullptr, P.T_nn);
 }
 
 // ---- passes 2 and 3 of the ICP loop: the flat 27-cell scan (grid_nn1_scan27, s3d_core.h "K5, round 3").
@@ -1634,7 +1913,7 @@ __global__ void __launch_bounds__(kWave) s3d_nn_worklist_kernel(const PairDev* _
     const int pair = (int)work_pair[need ? j : 0];
     const int i = (int)work_index[need ? j : 0];
     const PairDev& P = pairs[pair];
-    nn_query<0, 2>(P, slots[P.slot_t], slots[P.slot_s], pair, i, need, A, max_d, dbg | 2048, nullptr);
+    nn_query<0, 2>(P, slots[P.slot_t], slots[P.slot_s], pair, i, need, A, max_d, dbg | 2048, nullptr, nullptr, P.T_nn);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) *work_count_next = 0;   // the counter the next scan27 pass appends to
 }
@@ -1792,7 +2071,7 @@ constexpr int kCtrlGroups = 8;      // the root of the fixed summation tree: 8 g
 constexpr int kCtrlThreads = 128;   // threads that load the tree root (the stand-alone kernel's block size: more
                                     // would cap the optimiser's registers below the 256 it uses)
 __device__ __forceinline__ void icp_control_pair(PairDev& P, const double* __restrict__ pair_partials, const RunParams& rp,
-                                                 int* n_active) {
+                                                 int* n_active, Mat4f* __restrict__ pair_hist, int hist_stride) {
   __shared__ double grp[kCtrlGroups][GQ_NACC];
   __shared__ double acc[GQ_NACC];
   const bool gicp = rp.algorithm != 0;
@@ -1854,6 +2133,9 @@ __device__ __forceinline__ void icp_control_pair(PairDev& P, const double* __res
   P.correspondences = corr;
   P.prev = prev;
   P.T_nn = prev;
+  // the transformation_ this iteration's correspondence pass ran with, by pass index: what the record-level
+  // re-validation of the settled passes measures displacements from (s3d_nn_settled_kernel)
+  if (pair_hist && it - 1 < hist_stride) pair_hist[it - 1] = prev;
   if (rc) {  // PCLException path: loop breaks, converged_ stays false
     P.active = 0; P.converged = 0;
     atomicSub(n_active, 1);
@@ -1872,10 +2154,12 @@ __device__ __forceinline__ void icp_control_pair(PairDev& P, const double* __res
 // block of a pair to finish, a counter per pair - saves the launch, but the optimiser's 308 registers become the
 // accumulate kernel's: 240 -> 328, one wave per SIMD instead of two, which costs more than the launch.)
 __global__ void __launch_bounds__(kCtrlThreads) s3d_icp_control_kernel(PairDev* pairs, const double* __restrict__ partials,
-                                                                        RunParams rp, int* n_active) {
+                                                                        RunParams rp, int* n_active,
+                                                                        Mat4f* __restrict__ T_hist, int hist_stride) {
   PairDev& P = pairs[blockIdx.x];
   if (!P.active) return;
-  icp_control_pair(P, partials + (size_t)blockIdx.x * kAccumVB * GQ_NACC, rp, n_active);
+  icp_control_pair(P, partials + (size_t)blockIdx.x * kAccumVB * GQ_NACC, rp, n_active,
+                   T_hist ? T_hist + (size_t)blockIdx.x * hist_stride : nullptr, hist_stride);
 }
 
 // GICP: Mahalanobis matrix + 73-term quadratic form (s3d_core.h "GICP quadratic form")

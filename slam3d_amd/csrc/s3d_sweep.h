@@ -181,8 +181,7 @@ static int sweep_create(int n_devices, const int* devices, const uint32_t* cu_ma
     }
   }
   // RCCL communicators: one rank per DISTINCT device (RCCL refuses a device named twice)
-  const char* force = getenv("S3D_SWEEP_COLLECTIVE");   // "copy": skip RCCL (A/B, hosts without librccl)
-  if (distinct && !(force && std::string(force) == "copy")) {
+  if (distinct) {
     std::string why;
     if (sw->rccl.load(&why)) {
       sw->comms.assign(R, nullptr);

@@ -26,6 +26,12 @@ static double g_emu_perturb = 0.0;
 static long long g_reval_hits = 0, g_reval_misses = 0, g_reval_mismatch = 0, g_far_seeded = 0;
 extern "C" void emu_reval_stats(long long* out) { out[0] = g_reval_hits; out[1] = g_reval_misses; out[2] = g_reval_mismatch; out[3] = g_far_seeded; }
 extern "C" void emu_set_perturb(double e) { g_emu_perturb = e; }
+// record-level re-validation of the settled passes (s3d_nn_settled_kernel): from which outer iteration on (-1: off)
+static int g_emu_records_from = -1;
+static long long g_rec_tested = 0, g_rec_skipped = 0, g_rec_queries_skipped = 0, g_rec_pass[64][2];
+extern "C" void emu_record_pass_stats(long long* out) { std::memcpy(out, g_rec_pass, sizeof g_rec_pass); std::memset(g_rec_pass, 0, sizeof g_rec_pass); }
+extern "C" void emu_set_records_from(int it) { g_emu_records_from = it; g_rec_tested = g_rec_skipped = g_rec_queries_skipped = 0; }
+extern "C" void emu_record_stats(long long* out) { out[0] = g_rec_tested; out[1] = g_rec_skipped; out[2] = g_rec_queries_skipped; }
 namespace {
 
 struct Cloud {
@@ -279,16 +285,38 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
   std::vector<float> hints(T.pts.size(), -1.f), lbs(T.pts.size(), 0.f);
   std::vector<int> seeds(T.pts.size(), -1);
   Mat4f T_nn = mat4f_identity();
+  // 64-query records of the settled passes (s3d_nn_settled_kernel): box, margin, touch pass; transformation_ per pass
+  const size_t nrec = (T.pts.size() + 63) / 64;
+  std::vector<WaveRec> recs(nrec);
+  for (WaveRec& w : recs) { w.touch = -1; w.margin = -1.f; }
+  std::vector<Mat4f> T_hist;
+  std::vector<char> rec_pass(nrec, 0);
   while (!converged) {
     double R[9], SS[6], Th0[12];
     gicp_rotation(Tr, guess, R, SS);
     for (int c = 0; c < 3; ++c)
       for (int a = 0; a < 4; ++a) Th0[c * 4 + a] = (double)S3D_M(Tr, c, a);
     double acc[GQ_NACC] = {0};
+    const bool records_on = g_emu_records_from >= 0 && nr >= g_emu_records_from;
     for (size_t i = 0; i < T.pts.size(); ++i) {
       const F4& p0 = T.pts[i];
       const F3 p = xf_pcl(guess, p0.x, p0.y, p0.z);
       const F3 q = xf_eigen(Tr, p.x, p.y, p.z);
+      WaveRec& W = recs[i / 64];
+      bool rec_skip = false;
+      if (records_on) {
+        if (i % 64 == 0) {   // the record-level proof, once per record
+          ++g_rec_tested;
+          rec_pass[i / 64] = W.touch >= 0 && W.margin > 0.f &&
+                             nn_record_move_bound(Tr, T_hist[(size_t)W.touch], W.c, W.e) < (double)W.margin;
+          if (getenv("EMU_REC_DEBUG") && nr == atoi(getenv("EMU_REC_DEBUG")))
+            fprintf(stderr, "rec %zu touch %d margin %.3e bound %.3e e %.2f %.2f %.2f\n", i / 64, W.touch, W.margin,
+                    W.touch >= 0 ? nn_record_move_bound(Tr, T_hist[(size_t)W.touch], W.c, W.e) : -1.0, W.e[0], W.e[1], W.e[2]);
+          if (rec_pass[i / 64]) ++g_rec_skipped;
+          if (nr < 64) { ++g_rec_pass[nr][0]; g_rec_pass[nr][1] += rec_pass[i / 64] ? 1 : 0; }
+        }
+        rec_skip = rec_pass[i / 64] != 0;
+      }
       // the same decisions as s3d_nn_search_kernel<0> (hints[i]: previous d2, 3e38 = searched but none, -1 = never)
       const float prevd = hints[i];
       const bool has_prev = prevd >= 0.f && prevd < 1.0e30f;
@@ -296,8 +324,22 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
       r.idx = -1; r.d2 = 3.0e38f; r.pos = -1;
       bool revalidated = false;
       float move = 3.0e38f;
-      if (lbs[i] > 0.f && prevd >= 0.f) {   // the kernel's triangle-inequality shortcut
-        const F3 qo = xf_eigen(T_nn, p.x, p.y, p.z);
+      if (rec_skip) {
+        // nothing of this query is read by the kernel: the stored correspondence stands.  Check it against a full search.
+        ++g_rec_queries_skipped;
+        if (has_prev) {
+          const F4& ps = GS.sorted[seeds[i]];
+          r.idx = __builtin_bit_cast(int, ps.w); r.d2 = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z); r.pos = seeds[i];
+        }
+        NNResult full = grid_nn1_box(GS.g, GS.cell_start.data(), GS.sorted.data(), q.x, q.y, q.z, max_d_search, GS.g.h);
+        const bool full_in = full.idx >= 0 && full.d2 <= max_d_search * max_d_search;
+        const bool r_in = r.idx >= 0 && r.d2 <= max_d_search * max_d_search;
+        if (full_in != r_in || (full_in && (full.idx != r.idx || full.d2 != r.d2))) ++g_reval_mismatch;
+        revalidated = true;
+      }
+      const Mat4f& Tref = (records_on && W.touch >= 0) ? T_hist[(size_t)W.touch] : T_nn;
+      if (!rec_skip && lbs[i] > 0.f && prevd >= 0.f) {   // the kernel's triangle-inequality shortcut
+        const F3 qo = xf_eigen(Tref, p.x, p.y, p.z);
         move = std::sqrt(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
         if (has_prev) {
           const F4& ps = GS.sorted[seeds[i]];
@@ -335,8 +377,30 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
           if (full_in != r_in || (full_in && (full.idx != r.idx || full.d2 != r.d2))) ++g_reval_mismatch;
         }
       }
-      hints[i] = r.d2;
-      seeds[i] = r.pos;
+      if (!rec_skip) {
+        hints[i] = r.d2;
+        seeds[i] = r.pos;
+      }
+      if (records_on && !rec_skip) {
+        // the record is being evaluated in full: its queries' margins for the next record-level proof, its box at
+        // the first evaluation, the touch pass when its last query is through
+        const bool has = r.idx >= 0 && r.d2 < 1.0e30f;
+        const float m = nn_margin(has, lbs[i], has ? std::sqrt(r.d2) : 0.f, max_d_search);
+        const size_t first = (i / 64) * 64, last = std::min(first + 64, T.pts.size()) - 1;
+        static float run_min, mn[3], mx[3];
+        if (i == first) { run_min = 3.0e38f; for (int a = 0; a < 3; ++a) { mn[a] = 3.0e38f; mx[a] = -3.0e38f; } }
+        run_min = std::fmin(run_min, m);
+        const float pv[3] = {p.x, p.y, p.z};
+        for (int a = 0; a < 3; ++a) { mn[a] = std::fmin(mn[a], pv[a]); mx[a] = std::fmax(mx[a], pv[a]); }
+        if (i == last) {
+          for (int a = 0; a < 3; ++a) {
+            W.c[a] = 0.5f * mn[a] + 0.5f * mx[a];
+            W.e[a] = std::fmax(mx[a] - W.c[a], W.c[a] - mn[a]) * 1.000001f + 1.0e-30f;
+          }
+          W.margin = run_min;
+          W.touch = nr;
+        }
+      }
       if (r.idx < 0 || !((double)r.d2 < thr)) continue;
       const F4& t = S.pts[r.idx];
       const double td[3] = {t.x, t.y, t.z};
@@ -358,6 +422,7 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
     }
     prev = Tr;
     T_nn = Tr;
+    T_hist.push_back(Tr);   // (pass index nr: what the controller stores)
     int rc;
     if (gicp) {
       cnt = (int)acc[GQ_CNT];
@@ -408,6 +473,22 @@ int emu_bfgs(const double* acc, int max_inner, float* T16, int* inner, int* eval
   int rc = gicp_estimate_bfgs(acc, max_inner, T, inner, evals);
   for (int i = 0; i < 16; ++i) T16[i] = T.m[i];
   return rc;
+}
+// the largest |fl(T p) - fl(Tt p)| over m points of the box (c, e) against nn_record_move_bound (must not exceed it)
+double emu_record_move_bound(const float* T16, const float* Tt16, const float* c, const float* e, const float* pts, int m,
+                             double* worst_ratio) {
+  Mat4f T, Tt;
+  for (int i = 0; i < 16; ++i) { T.m[i] = T16[i]; Tt.m[i] = Tt16[i]; }
+  const double bound = nn_record_move_bound(T, Tt, c, e);
+  double worst = 0.0;
+  for (int i = 0; i < m; ++i) {
+    const F3 a = xf_eigen(T, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    const F3 b = xf_eigen(Tt, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    const double dx = (double)a.x - b.x, dy = (double)a.y - b.y, dz = (double)a.z - b.z;
+    worst = std::fmax(worst, std::sqrt(dx * dx + dy * dy + dz * dz));
+  }
+  *worst_ratio = bound > 0 ? worst / bound : 0.0;
+  return bound;
 }
 void emu_mahalanobis(const double* S6, const double* n1r, const double* n2, double eps, double* M6) { gicp_mahalanobis(S6, n1r, n2, eps, M6); }
 void emu_normal_roundtrip(const double* n, double* out, float* fpart) {

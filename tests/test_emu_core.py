@@ -275,6 +275,69 @@ def test_correspondence_revalidation_is_exact(emu, oracle_mod, fixture_clouds):
     assert hits > 2 * misses, (hits, misses)   # once ICP has converged nearly every correspondence is re-validated
 
 
+def test_record_level_revalidation_is_exact(emu, oracle_mod, fixture_clouds):
+    """Round 4: the settled passes re-validate 64 queries at once (s3d_core.h nn_record_move_bound / nn_margin,
+    s3d_nn_settled_kernel).  The emulation runs the same record logic from the third outer iteration on and checks
+    EVERY query of every skipped record against a full search; the registration must come out bit-identical to the
+    run without records, and most records must be skipped once the registration has settled."""
+    emu.emu_set_records_from.argtypes = [C.c_int]
+    before = (C.c_longlong * 4)()
+    emu.emu_reval_stats(before)
+    for alg, pair in ((oracle_mod.ALG_ICP, (0, 1)), (oracle_mod.ALG_GICP, (2, 3))):
+        p = oracle_mod.default_params(registration_algorithm=alg, maximum_iterations=30)
+        emu.emu_set_records_from(-1)
+        st0, T0, i0 = emu_align(emu, oracle_mod, fixture_clouds[pair[0]], fixture_clouds[pair[1]], params=p, force=1)
+        emu.emu_set_records_from(2)
+        st1, T1, i1 = emu_align(emu, oracle_mod, fixture_clouds[pair[0]], fixture_clouds[pair[1]], params=p, force=1)
+        rs = (C.c_longlong * 3)()
+        emu.emu_record_stats(rs)
+        emu.emu_set_records_from(-1)
+        assert st0 == st1 and np.array_equal(T0, T1) and i0 == i1
+        tested, skipped, queries = rs[0], rs[1], rs[2]
+        assert skipped > 0.5 * tested, (tested, skipped)     # 28 passes x ~500 records
+        assert queries > 100000
+    after = (C.c_longlong * 4)()
+    emu.emu_reval_stats(after)
+    assert after[2] == before[2] == 0       # no skipped query ever disagreed with a full search
+
+
+def test_record_move_bound_covers_the_float_transforms(emu):
+    """nn_record_move_bound must bound |fl(T p) - fl(Tt p)| for every float point of the box, including the rounding
+    of the two float transforms: random boxes up to 150 m from the origin, transforms a few micrometres to centimetres
+    apart, 4096 points per box (corners included)."""
+    emu.emu_record_move_bound.restype = C.c_double
+    rng = np.random.default_rng(5)
+
+    def rot(r):
+        cx, cy, cz = np.cos(r)
+        sx, sy, sz = np.sin(r)
+        return (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @
+                np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+
+    worst_all, tight = 0.0, []
+    for trial in range(300):
+        scale = 10.0 ** rng.uniform(-7, -2)
+        r0, t0 = rng.uniform(-0.05, 0.05, 3), rng.uniform(-1, 1, 3)
+        T = np.eye(4); T[:3, :3] = rot(r0); T[:3, 3] = t0
+        Tt = np.eye(4); Tt[:3, :3] = rot(r0 + rng.normal(0, scale, 3)); Tt[:3, 3] = t0 + rng.normal(0, 10 * scale, 3)
+        Tf = np.ascontiguousarray(T.T.reshape(-1), np.float32)       # column-major floats (Mat4f)
+        Ttf = np.ascontiguousarray(Tt.T.reshape(-1), np.float32)
+        c = rng.uniform(-150, 150, 3).astype(np.float32)
+        c[2] = np.float32(rng.uniform(-5, 5))
+        e = (10.0 ** rng.uniform(-2, 1, 3)).astype(np.float32)
+        u = rng.uniform(-1, 1, (4096, 3))
+        u[:8] = np.array([[i, j, k] for i in (-1, 1) for j in (-1, 1) for k in (-1, 1)], np.float64)
+        pts = np.clip((c + u * e).astype(np.float32), c - e, c + e)
+        ratio = C.c_double()
+        b = emu.emu_record_move_bound(Tf.ctypes.data_as(fp), Ttf.ctypes.data_as(fp), c.ctypes.data_as(fp),
+                                      e.ctypes.data_as(fp), np.ascontiguousarray(pts).ctypes.data_as(fp), len(pts), C.byref(ratio))
+        assert ratio.value <= 1.0, (trial, b, ratio.value)
+        worst_all = max(worst_all, ratio.value)
+        tight.append(ratio.value)
+    assert worst_all > 0.5     # the bound is not vacuous: some box comes within a factor two of it
+    assert np.median(tight) > 0.2
+
+
 def test_normal_record_round_trip(emu):
     """The 16-byte stored form of a unit normal (s3d_core.h NormalRec: float xyz + three 10-bit remainders in units
     of 2^-34): restored to 2^-34 = 6e-11 per component (half of that except at the +2^-25 tie), the float part is the plain float rounding."""

@@ -573,45 +573,42 @@ def test_cpp_point_cloud_sensor_create_constraint(gpu_ctx, fixture_clouds, tmp_p
     assert out[0] == "OK SE(3)" and abs(float(out[1].split()[3]) - 0.68) < 0.05
 
 
-def test_nn_revalidation_shortcut_is_bitwise_neutral(gpu_ctx, fixture_clouds, monkeypatch):
-    """The NN kernel's shortcuts (triangle-inequality re-validation, trusted far seeds, wave-cooperative wide
-    search) can be switched off one by one with S3D_DBG_NN: results must not change by a bit."""
+def test_nn_revalidation_shortcut_is_bitwise_neutral(gpu_ctx, fixture_clouds):
+    """The NN kernel's shortcuts (triangle-inequality re-validation per query and per 64-query record, trusted far
+    seeds, wave-cooperative wide search, block compaction) can be switched off one by one with
+    s3d_exec_options.debug_flags: results must not change by a bit."""
     import slam3d_amd as s3d
-    opts = s3d.ExecOptions(force_iterations=1)
+    A = s3d.api
     for alg in (s3d.ALG_ICP, s3d.ALG_GICP):
         p = s3d.default_params(registration_algorithm=alg, maximum_iterations=25)
-        monkeypatch.delenv("S3D_DBG_NN", raising=False)
-        st0, T0, i0 = gpu_ctx.align(fixture_clouds[1], fixture_clouds[2], np.eye(4), p, opts)
-        # 64: no re-validation; 128: no trusted far seeds; 2048: no wave-cooperative wide search;
-        # 65536: no block-compacting kernel in passes 3-5
-        for flags in ("64", "128", "2048", "65536", str(64 + 128 + 2048 + 65536)):
-            monkeypatch.setenv("S3D_DBG_NN", flags)
-            st1, T1, i1 = gpu_ctx.align(fixture_clouds[1], fixture_clouds[2], np.eye(4), p, opts)
-            monkeypatch.delenv("S3D_DBG_NN", raising=False)
-            assert st0 == st1 == 0 and np.array_equal(T0, T1) and i0 == i1, flags
+        st0, T0, i0 = gpu_ctx.align(fixture_clouds[1], fixture_clouds[2], np.eye(4), p, s3d.ExecOptions(force_iterations=1))
+        everything = A.DBG_NN_NO_REVALIDATE | A.DBG_NN_NO_FAR_SEED | A.DBG_NN_NO_COOP | A.DBG_NN_NO_COMPACT
+        for flags in (A.DBG_NN_NO_REVALIDATE, A.DBG_NN_NO_FAR_SEED, A.DBG_NN_NO_COOP, A.DBG_NN_NO_COMPACT, A.DBG_NN_NO_SETTLED,
+                      A.DBG_NN_NO_SETTLED | A.DBG_NN_NO_FAR_SEED, everything):
+            st1, T1, i1 = gpu_ctx.align(fixture_clouds[1], fixture_clouds[2], np.eye(4), p,
+                                         s3d.ExecOptions(force_iterations=1, debug_flags=flags))
+            assert st0 == st1 == 0 and np.array_equal(T0, T1) and i0 == i1, hex(flags)
 
 
-def test_round3_fast_paths_are_bitwise_neutral(gpu_ctx, fixture_clouds, monkeypatch):
-    """The round-3 kernels are alternative routes to the same results: the first-pass kernel and the flat 27-cell scans
-    (S3D_DBG_NN 262144 / 524288 switch them off), the 32-bit k-NN pre-pass (S3D_KNN_EXACT64=1: the 64-bit search for
-    every point) and the two forms of the radix sort (S3D_SORT_CLASSIC=1 / 0).  Not a bit may change - on the real
-    scans and on a synthetic pair of the benchmark's size."""
+def test_fast_paths_are_bitwise_neutral(gpu_ctx, fixture_clouds):
+    """The round-3 and round-4 kernels are alternative routes to the same results: the first-pass kernel, the flat
+    27-cell scans, the record-wise settled passes, the 32-bit k-NN pre-pass (DBG_KNN_EXACT64: the 64-bit search for
+    every point), the two forms of the radix sort and its range-derived pass counts.  Not a bit may change - on the
+    real scans (with and without early exit) and on a synthetic pair of the benchmark's size."""
     import slam3d_amd as s3d
-    opts = s3d.ExecOptions(force_iterations=1)
+    A = s3d.api
     a, b, _ = s3d.make_pair(100000, 3)
-    cases = [(fixture_clouds[1], fixture_clouds[2], s3d.default_params(maximum_iterations=12)),
-             (a, b, s3d.default_params(point_cloud_density=0.02, maximum_iterations=8))]
-    for src, tgt, p in cases:
-        for k in ("S3D_DBG_NN", "S3D_KNN_EXACT64", "S3D_SORT_CLASSIC"):
-            monkeypatch.delenv(k, raising=False)
-        st0, T0, i0 = gpu_ctx.align(src, tgt, np.eye(4), p, opts)
+    cases = [(fixture_clouds[1], fixture_clouds[2], s3d.default_params(maximum_iterations=12), 1),
+             (fixture_clouds[0], fixture_clouds[1], s3d.default_params(), 0),
+             (a, b, s3d.default_params(point_cloud_density=0.02, maximum_iterations=20), 1)]
+    for src, tgt, p, force in cases:
+        st0, T0, i0 = gpu_ctx.align(src, tgt, np.eye(4), p, s3d.ExecOptions(force_iterations=force))
         assert st0 == 0
-        for key, val in (("S3D_DBG_NN", "262144"), ("S3D_DBG_NN", "524288"), ("S3D_DBG_NN", str(262144 + 524288)),
-                         ("S3D_KNN_EXACT64", "1"), ("S3D_SORT_CLASSIC", "1"), ("S3D_SORT_CLASSIC", "0")):
-            monkeypatch.setenv(key, val)
-            st1, T1, i1 = gpu_ctx.align(src, tgt, np.eye(4), p, opts)
-            monkeypatch.delenv(key, raising=False)
-            assert st1 == 0 and np.array_equal(T0, T1) and i0 == i1, (key, val)
+        for flags in (A.DBG_NN_NO_FIRST_KERNEL, A.DBG_NN_NO_SCAN27, A.DBG_NN_NO_FIRST_KERNEL | A.DBG_NN_NO_SCAN27,
+                      A.DBG_NN_NO_SETTLED, A.DBG_SCAN27_NO_COMPACT, A.DBG_KNN_EXACT64, A.DBG_SORT_CLASSIC,
+                      A.DBG_SORT_ONESWEEP, A.DBG_SORT_FULL_KEYS, A.DBG_SORT_FULL_KEYS | A.DBG_SORT_CLASSIC):
+            st1, T1, i1 = gpu_ctx.align(src, tgt, np.eye(4), p, s3d.ExecOptions(force_iterations=force, debug_flags=flags))
+            assert st1 == 0 and np.array_equal(T0, T1) and i0 == i1, hex(flags)
 
 
 def test_million_point_pair(gpu_ctx, oracle_mod):

@@ -24,7 +24,7 @@ def _pairs(n_pairs, points, first=0):
 
 
 @pytest.mark.parametrize("alg_name", ["gicp", "icp"])
-def test_result_does_not_depend_on_the_batch(gpu_ctx, alg_name, monkeypatch):
+def test_result_does_not_depend_on_the_batch(gpu_ctx, alg_name):
     """The same pair alone, in batches of 8 / 32 / 128 / 256 and with 1 ... 64 real accumulate blocks: identical
     records, bit for bit (the sums are defined over 64 virtual blocks per pair, s3d_kernels.h
     block_reduce_store_fixed).  Early exit enabled: iteration counts are part of the comparison."""
@@ -36,18 +36,18 @@ def test_result_does_not_depend_on_the_batch(gpu_ctx, alg_name, monkeypatch):
     tgt = [gpu_ctx.upload(p[1]) for p in pairs]
     try:
         p = s3d.default_params(registration_algorithm=alg, point_cloud_density=0.05, maximum_iterations=30)
-        monkeypatch.delenv("S3D_ACCUM_BLOCKS", raising=False)
         full = gpu_ctx.align_batch(src, tgt, None, p)
         assert (full[:, 15] == 0).all()
         for bs in (1, 8, 32, 128):
             for lo in (0, n - bs):
                 part = gpu_ctx.align_batch(src[lo:lo + bs], tgt[lo:lo + bs], None, p)
                 assert np.array_equal(part, full[lo:lo + bs]), (bs, lo)
-        for blocks in ("1", "2", "16", "64"):
-            monkeypatch.setenv("S3D_ACCUM_BLOCKS", blocks)
-            part = gpu_ctx.align_batch(src[:8], tgt[:8], None, p)
-            monkeypatch.delenv("S3D_ACCUM_BLOCKS", raising=False)
+        for blocks in (1, 2, 16, 64):
+            part = gpu_ctx.align_batch(src[:8], tgt[:8], None, p, s3d.ExecOptions(debug_accum_blocks=blocks))
             assert np.array_equal(part, full[:8]), blocks
+        # ... nor on whether the settled passes run record-wise or query by query
+        part = gpu_ctx.align_batch(src[:32], tgt[:32], None, p, s3d.ExecOptions(debug_flags=s3d.api.DBG_NN_NO_SETTLED))
+        assert np.array_equal(part, full[:32])
         # the host-buffer entry point on one pair
         st, T, info = gpu_ctx.align(pairs[3][0], pairs[3][1], np.eye(4), p)
         assert st == 0 and np.array_equal(s3d.api.record_transform(full[3])[:3], T[:3])
@@ -83,6 +83,40 @@ def _sweep_case(gpu_ctx, devices, n_pairs, points, alg):
         return sw.collective, sw.ranks
     finally:
         sw.close()
+
+
+def test_every_ordered_pair_of_partly_overlapping_clouds(gpu_ctx):
+    """A loop-closure sweep reuses its clouds: every ordered pair of 14 windows of one scene (182 pairs, 14 clouds), no
+    voxel filter, neighbouring windows half overlapping, far ones not at all.  The pairs' correspondences then outnumber
+    the batch's points 13 to 1 and most queries of most pairs have no near neighbour - what the flat 27-cell scans of
+    passes 2-3 decline goes to their worklist, which must hold up to every query of every pair (round-3 advisor finding:
+    it lived in a buffer sized by the POINT count).  Same records with the scans, the first-pass kernel and the
+    record-wise settled passes switched off."""
+    import slam3d_amd as s3d
+    A = s3d.api
+    scene = s3d.make_scene_cloud(120000, 4242)
+    clouds = []
+    for w in range(14):
+        x0 = -38.0 + 5.0 * w
+        sel = scene[(scene[:, 0] >= x0) & (scene[:, 0] < x0 + 10.0)]
+        clouds.append(np.ascontiguousarray(sel[:6000]))
+    assert min(len(c) for c in clouds) >= 3000
+    dev = [gpu_ctx.upload(c) for c in clouds]
+    try:
+        idx = [(i, j) for i in range(14) for j in range(14) if i != j]
+        src = [dev[i] for i, _ in idx]
+        tgt = [dev[j] for _, j in idx]
+        p = s3d.default_params(point_cloud_density=0.0, maximum_iterations=6, max_correspondence_distance=2.5)
+        base = gpu_ctx.align_batch(src, tgt, None, p, s3d.ExecOptions(force_iterations=1))
+        for flags in (A.DBG_NN_NO_SCAN27, A.DBG_NN_NO_FIRST_KERNEL, A.DBG_NN_NO_SETTLED):
+            other = gpu_ctx.align_batch(src, tgt, None, p, s3d.ExecOptions(force_iterations=1, debug_flags=flags))
+            assert np.array_equal(base, other), hex(flags)
+        # neighbouring windows register (status OK), the result is deterministic
+        again = gpu_ctx.align_batch(src, tgt, None, p, s3d.ExecOptions(force_iterations=1))
+        assert np.array_equal(base, again)
+    finally:
+        for c in dev:
+            c.release()
 
 
 def test_sweep_two_and_three_contexts_on_one_device_equal_the_single_context(gpu_ctx):
