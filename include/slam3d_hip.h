@@ -318,7 +318,8 @@ int  s3d_sweep_gathered_records(s3d_sweep* sw, int rank, int n_pairs, s3d_edge_r
  *          removeEdge drops one), BoostGraph::calculateGraphDistance (:301-324: Dijkstra over all stored edges, weight 1
  *          for an SE(3) edge and 10000 for any other, float; an unreachable vertex keeps FLT_MAX), "skip when
  *          dist <= 2 * patch_building_range or dist < min_loop_length", stop after max_neighbor_links candidates.
- *          The candidates are the calls link(neighbour, vertex) of :198 in their order: out_sources[k] -> vertex.
+ *          The candidates are the calls link(neighbour, vertex) of :198 in their order: out_sources[k] -> vertex,
+ *          under the assumption that every listed registration succeeds (s3d_link_policy.static_graph = 0).
  *          Vertices are named by their insertion index 0 .. n_vertices-1 (boost vecS descriptors). */
 typedef struct s3d_graph_edge {
   int source, target;       /* an out-edge as stored (both directions of an edge are two entries) */
@@ -330,6 +331,12 @@ typedef struct s3d_link_policy {   /* ScanSensor's knobs, constructor defaults S
   int      max_neighbor_links;     /* mMaxNeighorLinks      (1)   */
   unsigned min_loop_length;        /* mMinLoopLength        (10)  */
   unsigned patch_building_range;   /* mPatchBuildingRange   (0)   */
+  int      static_graph;           /* 0: link(neighbour, vertex) of :198 adds its SE(3) edge before the next neighbour is
+                                      examined, as in the reference when the registration succeeds (:143, :157-158) - with
+                                      max_neighbor_links > 1 the next neighbour of the same cluster is then a hop or two
+                                      away and fails min_loop_length: about one link per cluster.  != 0: every neighbour
+                                      is judged on the graph as given (more candidates than the reference links; for a
+                                      caller that re-filters after each registration).  Same result at the default of 1. */
 } s3d_link_policy;
 /* positions: 3 doubles per vertex (translation of correctedPose); linkable: per vertex != 0 when its sensor is one of
  * mLinkSensors (NULL: every vertex).  Writes at most `capacity` sources, *n_out = how many there are.

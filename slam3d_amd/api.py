@@ -119,7 +119,7 @@ class GraphEdge(C.Structure):       # include/slam3d_hip.h s3d_graph_edge
 
 class LinkPolicyC(C.Structure):     # include/slam3d_hip.h s3d_link_policy
     _fields_ = [("neighbor_radius", C.c_float), ("max_neighbor_links", C.c_int), ("min_loop_length", C.c_uint),
-                ("patch_building_range", C.c_uint)]
+                ("patch_building_range", C.c_uint), ("static_graph", C.c_int)]
 
 
 _lib = None
@@ -290,6 +290,10 @@ class Context:
         (s3d_context_create_cu_mask)."""
         self._L = load_library()
         h = C.c_void_p()
+        if stream and (cu_mask is not None or high_priority):
+            raise ValueError("cu_mask / high_priority create a private stream: they cannot be combined with stream=")
+        if cu_mask is not None and len(cu_mask) == 0:
+            raise ValueError("cu_mask must name at least one 32-bit word")
         if cu_mask is not None and not stream:
             words = (C.c_uint32 * len(cu_mask))(*[int(w) & 0xFFFFFFFF for w in cu_mask])
             st = self._L.s3d_context_create_cu_mask(int(device), words, len(cu_mask), C.byref(h))
@@ -298,7 +302,8 @@ class Context:
         else:
             st = self._L.s3d_context_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
         if st != 0 or not h:
-            raise BackendError("s3d_context_create failed: no usable HIP device %d (no CPU fallback)" % device)
+            raise BackendError("s3d_context_create failed with %s on HIP device %d (no CPU fallback)" %
+                               (STATUS_NAMES[st] if 0 <= st < len(STATUS_NAMES) else st, device))
         self._h = h
         self.device = device
 
@@ -587,7 +592,7 @@ class Context:
 
 
 def link_candidates(positions, edges, vertex, neighbor_radius=1.0, max_neighbor_links=1, min_loop_length=10,
-                    patch_building_range=0, linkable=None):
+                    patch_building_range=0, linkable=None, static_graph=False):
     """s3d_link_candidates (host only): the sources of ScanSensor::linkToNeighbors' link(source, vertex) calls.
     positions: (n, 3) translations of the corrected poses in vertex insertion order; edges: (source, target, se3,
     own_sensor) out-edges as stored."""
@@ -596,7 +601,8 @@ def link_candidates(positions, edges, vertex, neighbor_radius=1.0, max_neighbor_
     E = (GraphEdge * max(len(edges), 1))()
     for k, e in enumerate(edges):
         E[k] = GraphEdge(int(e[0]), int(e[1]), int(e[2]), int(e[3]))
-    pol = LinkPolicyC(float(neighbor_radius), int(max_neighbor_links), int(min_loop_length), int(patch_building_range))
+    pol = LinkPolicyC(float(neighbor_radius), int(max_neighbor_links), int(min_loop_length), int(patch_building_range),
+                      1 if static_graph else 0)
     lk = None
     if linkable is not None:
         lk = np.ascontiguousarray(np.asarray(linkable, np.uint8)).ctypes.data_as(C.POINTER(C.c_ubyte))

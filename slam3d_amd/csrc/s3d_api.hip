@@ -242,6 +242,11 @@ int fail(s3d_context* ctx, const HipError& e) {
   return S3D_STATUS_BACKEND_ERROR;
 }
 
+// device -> host copy ON THE CONTEXT'S STREAM, then a wait for that stream: a plain hipMemcpy runs on the legacy null
+// stream, which every blocking stream of the process (a CU-masked context's, an application's default stream) waits
+// for and is waited for by - a 'reserved' context would serialise with the sweep it is meant to run beside
+static void copy_to_host(s3d_context* ctx, void* dst, const void* src, size_t bytes);
+
 // ------------------------------------------------------------------ one batch of align() jobs
 
 struct Batch {
@@ -555,18 +560,23 @@ struct Batch {
   void sort_choose() {
     sort_classic = (opts.debug_flags & S3D_DBG_SORT_CLASSIC) ? true : (opts.debug_flags & S3D_DBG_SORT_ONESWEEP) ? false
                    : (long long)Cu * (long long)max_n >= 40000000ll;
+    if (max_n >= (1 << 28)) sort_classic = true;   // the one-sweep state words hold a 28-bit count next to their tag
   }
   bool sort_used = false;
   void sort_prepare(int nslots) {   // before the kernel that counts the digit totals
     if (!sort_classic && nslots > 0)
       HIPCHK(hipMemsetAsync(ctx->digit_tot.p, 0, sizeof(uint32_t) * (size_t)nslots * kSortPlaces * 256, ctx->stream));
   }
+  // (measured, round 4: the clouds of a batch sorted in GROUPS of 16 ... 128, all passes of a group back to back so
+  // that its 1.6 MB per cloud stay in the 256 MB memory-side cache between passes - voxel + grid 4.0 -> 7.3 / 5.7 / 4.7 /
+  // 4.2 ms for groups of 16 / 32 / 64 / 128 of the 512 clouds: the smaller launches lose more than the cache gives)
   void sort(int passes, int nslots, bool hist_done = false) {
     hipStream_t st = ctx->stream;
     if (nslots <= 0) return;
     uint32_t *ki = kA(), *vi = vA(), *ko = kB(), *vo = vB();
     uint32_t* cnt = (uint32_t*)ctx->counts.p;
     uint32_t* dtot = (uint32_t*)ctx->digit_tot.p;
+    SlotDev* gslots = d_slots();
     const unsigned blocks = (unsigned)((nslots >= 8 ? cdiv(nslots, 8) * 8 : nslots) * nb_sort);
     if (!sort_classic) {
       if (!sort_used) {     // the first sort of this batch clears the error word (stream order: before any look-back)
@@ -575,11 +585,11 @@ struct Batch {
       }
       if (!hist_done) {
         sort_prepare(nslots);
-        k_sort_hist_all<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(d_slots(), ki, dtot, cnt, passes, nb_sort);
+        k_sort_hist_all<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(gslots, ki, dtot, cnt, passes, nb_sort);
       }
       int* err = (int*)ctx->n_active.p + 6;
       for (int p = 0; p < passes; ++p) {
-        k_sort_onesweep<<<blocks, kBlock, 0, st>>>(d_slots(), ki, vi, ko, vo, cnt, dtot, p, nb_sort, nslots, err);
+        k_sort_onesweep<<<blocks, kBlock, 0, st>>>(gslots, ki, vi, ko, vo, cnt, dtot, p, nb_sort, nslots, err);
         std::swap(ki, ko);
         std::swap(vi, vo);
       }
@@ -587,10 +597,10 @@ struct Batch {
     }
     for (int p = 0; p < passes; ++p) {
       const int shift = 8 * p;
-      if (p > 0 || !hist_done) k_sort_hist<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(d_slots(), ki, cnt, shift, nb_sort);
-      if (nb_sort <= kSortTileMajor) k_sort_scan_tiles<<<nslots, 256, 0, st>>>(d_slots(), cnt, dtot, nb_sort);
-      else k_sort_scan_rows<<<dim3(256 / (kBlock / kWave), nslots), kBlock, 0, st>>>(d_slots(), cnt, dtot, nb_sort);
-      k_sort_scatter<<<blocks, kBlock, 0, st>>>(d_slots(), ki, vi, ko, vo, cnt, dtot, shift, nb_sort, nslots);
+      if (p > 0 || !hist_done) k_sort_hist<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(gslots, ki, cnt, shift, nb_sort);
+      if (nb_sort <= kSortTileMajor) k_sort_scan_tiles<<<nslots, 256, 0, st>>>(gslots, cnt, dtot, nb_sort);
+      else k_sort_scan_rows<<<dim3(256 / (kBlock / kWave), nslots), kBlock, 0, st>>>(gslots, cnt, dtot, nb_sort);
+      k_sort_scatter<<<blocks, kBlock, 0, st>>>(gslots, ki, vi, ko, vo, cnt, dtot, shift, nb_sort, nslots);
       std::swap(ki, ko);
       std::swap(vi, vo);
     }
@@ -932,7 +942,7 @@ struct Batch {
         if (i < 64) ctx->prof.nn_launch_ms[i] = ms;
       }
       int counts[256];
-      HIPCHK(hipMemcpy(counts, (int*)ctx->n_active.p + 16, sizeof counts, hipMemcpyDeviceToHost));
+      copy_to_host(ctx, counts, (int*)ctx->n_active.p + 16, sizeof counts);
       for (int i = 0; i < 64; ++i) {
         ctx->prof.nn_searched[i] = counts[4 * i]; ctx->prof.nn_unseeded[i] = counts[4 * i + 1];
         ctx->prof.nn_records[i] = counts[4 * i + 2]; ctx->prof.nn_records_searched[i] = counts[4 * i + 3];
@@ -974,6 +984,11 @@ struct Batch {
     return S3D_STATUS_OK;
   }
 };
+
+static void copy_to_host(s3d_context* ctx, void* dst, const void* src, size_t bytes) {
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+}
 
 int check_algorithm(const s3d_reg_params* p, const s3d_exec_options* o) {
   switch (p->registration_algorithm) {  // PointCloudSensor.cpp:139-165
@@ -1483,6 +1498,9 @@ static int context_create(int device, void* hip_stream, int priority_class, s3d_
       ctx->stream = (hipStream_t)hip_stream;
     } else {
       if (cu_mask) {
+        // (HIP has no flag argument here: a CU-masked stream is a BLOCKING stream, i.e. it synchronises with the legacy
+        // null stream of the process.  The library itself issues nothing on the null stream - copy_to_host - but an
+        // application that does, e.g. through plain hipMemcpy, serialises such a context with that work.)
         HIPCHK(hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)cu_words, cu_mask));
       } else if (priority_class > 0) {
         int least = 0, greatest = 0;     // (numerically lower = higher priority)
@@ -1917,7 +1935,7 @@ int s3d_voxel_downsample(s3d_context* ctx, const float* xyz, int n, int stride, 
     b.download();
     const int m = b.h_slots[0].n;
     std::vector<float4> tmp((size_t)std::max(m, 1));
-    if (m > 0) HIPCHK(hipMemcpy(tmp.data(), b.filt() + b.h_slots[0].off, sizeof(float4) * (size_t)m, hipMemcpyDeviceToHost));
+    if (m > 0) copy_to_host(ctx, tmp.data(), b.filt() + b.h_slots[0].off, sizeof(float4) * (size_t)m);
     for (int i = 0; i < m; ++i) {
       out_xyz[(size_t)i * 3 + 0] = tmp[i].x; out_xyz[(size_t)i * 3 + 1] = tmp[i].y; out_xyz[(size_t)i * 3 + 2] = tmp[i].z;
     }
@@ -1962,8 +1980,8 @@ int s3d_nn_search(s3d_context* ctx, const float* target_xyz, int n, int stride_t
         b.d_pairs(), b.d_slots(), b.sorted(), (int*)ctx->corr_idx.p, (float*)ctx->corr_d2.p, (int*)b.kA(), (float*)b.kB());
     b.download();
     if (m > 0) {
-      HIPCHK(hipMemcpy(idx, (int*)b.kA() + b.h_pairs[0].corr_off, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(d2, (float*)b.kB() + b.h_pairs[0].corr_off, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost));
+      copy_to_host(ctx, idx, (int*)b.kA() + b.h_pairs[0].corr_off, sizeof(int) * (size_t)m);
+      copy_to_host(ctx, d2, (float*)b.kB() + b.h_pairs[0].corr_off, sizeof(float) * (size_t)m);
     }
     free_cloud(&ct);
     free_cloud(&cq);
@@ -2000,7 +2018,7 @@ int s3d_knn_normals(s3d_context* ctx, const float* xyz, int n, int stride, int k
                                                                                          b.filt());  // filt is free now
     b.download();
     std::vector<float4> tmp((size_t)std::max(n, 1));
-    HIPCHK(hipMemcpy(tmp.data(), b.filt() + b.h_slots[0].off, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost));
+    copy_to_host(ctx, tmp.data(), b.filt() + b.h_slots[0].off, sizeof(float4) * (size_t)n);
     for (int i = 0; i < n; ++i) {
       normals_xyz[(size_t)i * 3 + 0] = tmp[i].x; normals_xyz[(size_t)i * 3 + 1] = tmp[i].y;
       normals_xyz[(size_t)i * 3 + 2] = tmp[i].z;

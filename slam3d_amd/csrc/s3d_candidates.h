@@ -70,6 +70,15 @@ extern "C" int s3d_link_candidates(int n_vertices, const double* positions, cons
     ++count;
     if (written < capacity) out_sources[written] = index;
     ++written;
+    // link(index, vertex) changes the graph before the next neighbour is examined (ScanSensor.cpp:137-166): a
+    // tentative edge while it registers, and on success an SE(3) edge index <-> vertex of weight 1 in its place - the
+    // next neighbour of the same cluster is then only a hop or two from `vertex` and fails min_loop_length.  The
+    // candidates of a sweep are listed BEFORE anything is registered: every accepted link is assumed to succeed (a
+    // NoMatch would have removed the tentative edge again and let a later neighbour of that cluster through).
+    if (!policy->static_graph) {
+      out[(size_t)index].push_back(std::make_pair(vertex, 1.0f));
+      out[(size_t)vertex].push_back(std::make_pair(index, 1.0f));
+    }
   }
   *n_out = written;
   return S3D_STATUS_OK;

@@ -672,6 +672,8 @@ __global__ void __launch_bounds__(kBlock) k_sort_onesweep(const SlotDev* __restr
           if (++spins > (1u << 22)) { if (error_flag) atomicOr(error_flag, 1); break; }   // (never hang the device)
         }
       }
+      // (a tile that gave up publishes its prefix all the same - its successors must not wait for it - and the host
+      // fails the call in Batch::download(); what this sort leaves in the output is not used)
     }
     if (tile_i != 0)
       __hip_atomic_store(row + (size_t)tile_i * 256, tag_inc | (excl + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1284,7 +1286,8 @@ struct NNArrays {
 template <int MODE, int PHASE>
 __device__ __forceinline__ void nn_query_search(const PairDev& P, const SlotDev& Ss, int ci, bool need, const F3& q,
                                                 float move, const NNArrays& A, float max_d, int dbg,
-                                                int* __restrict__ prof_counts, int* out_class, float* out_margin);
+                                                int* __restrict__ prof_counts, int* out_class, float* out_margin,
+                                                float pre_prev = 0.f, int pre_seed = -1);
 
 // PHASE 6 (the record-wise settled passes, round 4): PHASE 0 for one RECORD of 64 queries that failed the record-level proof -
 // the previous positions are those under Tref (the transformation_ of the record's last full evaluation, not of the
@@ -1343,10 +1346,13 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
 template <int MODE, int PHASE>
 __device__ __forceinline__ void nn_query_search(const PairDev& P, const SlotDev& Ss, int ci, bool need, const F3& q,
                                                 float move, const NNArrays& A, float max_d, int dbg,
-                                                int* __restrict__ prof_counts, int* out_class, float* out_margin) {
+                                                int* __restrict__ prof_counts, int* out_class, float* out_margin,
+                                                float pre_prev, int pre_seed) {
   constexpr bool kAB = S3D_NN_AB && PHASE != 6;
-  // radius hint: this query's distance in the previous pass (NaN-filled before the first one)
-  const float prev = PHASE == 5 ? __int_as_float(0x7FC00000) : (need ? A.corr_d2[ci] : 0.f);
+  // radius hint: this query's distance in the previous pass (NaN-filled before the first one).  PHASE 6: the touch
+  // kernel has fetched it, and the previous neighbour's position, with the record's other data (a search there is a
+  // chain of dependent loads with nothing to hide behind: two links less)
+  const float prev = PHASE == 5 ? __int_as_float(0x7FC00000) : PHASE == 6 ? (need ? pre_prev : 0.f) : (need ? A.corr_d2[ci] : 0.f);
   if (PHASE == 3) {   // classify only: 0 = near seed, 1 = wide, 2 = nothing to do (block-level compaction follows)
     const bool near_c = need && prev >= 0.f && prev < 1.0e30f && prev < Ss.g.h * Ss.g.h;
     *out_class = need ? (near_c ? 0 : 1) : 2;
@@ -1361,7 +1367,7 @@ __device__ __forceinline__ void nn_query_search(const PairDev& P, const SlotDev&
   const bool has_prev = prev >= 0.f && prev < 1.0e30f;
   const bool near_seed = has_prev && prev < Ss.g.h * Ss.g.h;
   const bool far_seed = has_prev && !near_seed && move < kNNRevalSlack * Ss.g.h && !(dbg & 128);
-  const int seed = ((near_seed || far_seed) && !(kAB && (dbg & 32))) ? A.corr_idx[ci] : -1;
+  const int seed = ((near_seed || far_seed) && !(kAB && (dbg & 32))) ? (PHASE == 6 ? pre_seed : A.corr_idx[ci]) : -1;
   // first pass (nothing known yet): a generous three-cell box — the shrinking-ball scan makes a large
   // initial radius cheap, while a small one costs a second scan for every badly aligned query
   const float first = (!kAB ? 3.0f : (dbg & 256) ? 1.0f : (dbg & 512) ? 1.5f : (dbg & 1024) ? 2.0f : 3.0f) * Ss.g.h;
@@ -1414,8 +1420,11 @@ __device__ __forceinline__ void nn_query_search(const PairDev& P, const SlotDev&
   if (r.pos >= 0) {
     // a copy of the matched point and of its normal is kept with the correspondence: the re-validation
     // above and the accumulate kernel then stream them instead of gathering by index
-    A.corr_q[ci] = corr_vec(A.sorted[Ss.off + r.pos]);
-    A.corr_n[ci] = A.normals[Ss.off + r.pos];
+    // (PHASE 6: the search of a settled registration usually confirms the neighbour - its copies are in place)
+    if (!(PHASE == 6 && r.pos == pre_seed)) {
+      A.corr_q[ci] = corr_vec(A.sorted[Ss.off + r.pos]);
+      A.corr_n[ci] = A.normals[Ss.off + r.pos];
+    }
   } else if (MODE == 0) {
     // no neighbour within max_d: a neighbour at infinity, so that the distance the accumulate kernels compute from
     // this copy fails their threshold like the stored 3e38 did
@@ -1610,8 +1619,8 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_record_test_kernel(const PairDe
 // (measured: the first record-wise pass 0.185 ms per 128 pairs against 0.110 for the per-query kernel).  A call costs
 // nothing where it is not taken, and in a settled pass one query in 5 000 searches.  Returns the lane's margin.
 __device__ __noinline__ float nn_record_search(const PairDev* Pp, const SlotDev* Ssp, int ci, int need, float qx, float qy,
-                                               float qz, float move, const NNArrays* Ap, float max_d, int dbg,
-                                               int* prof_counts) {
+                                               float qz, float move, float prev, int seed, const NNArrays* Ap,
+                                               float max_d, int dbg, int* prof_counts) {
   // (the pointers are wave-uniform but arrive in vector registers: back to scalar ones, so that the records load as
   // scalars again)
   auto uni = [](const void* p) {
@@ -1626,12 +1635,14 @@ __device__ __noinline__ float nn_record_search(const PairDev* Pp, const SlotDev*
   F3 q; q.x = qx; q.y = qy; q.z = qz;
   float margin = 3.0e38f;
   nn_query_search<0, 6>(P, Ss, ci, need != 0, q, move, A, max_d, __builtin_amdgcn_readfirstlane(dbg),
-                        (int*)uni(prof_counts), nullptr, &margin);
+                        (int*)uni(prof_counts), nullptr, &margin, prev, seed);
   return margin;
 }
 
+// (waves per SIMD: the listed form is bound by the latency of its few searches - 5 waves, 96 registers: 0.055 ->
+// 0.050 ms per settled pass of 128 pairs; the first record-wise pass streams every query - 7 waves: 0.161 ms, 0.188 at 5)
 template <bool LISTED>
-__global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_record_touch_kernel(const PairDev* __restrict__ pairs,
+__global__ void __launch_bounds__(kBlock, LISTED ? 5 : S3D_NN_WAVES) s3d_nn_record_touch_kernel(const PairDev* __restrict__ pairs,
                                                                       const SlotDev* __restrict__ slots, NNArrays A,
                                                                       float max_d, int chunks_per_pair, int npairs,
                                                                       int dbg, int* __restrict__ prof_counts,
@@ -1683,6 +1694,8 @@ __global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_record_touch_kern
     const CorrVec p0 = A.sorted3[qbase + (valid ? lane : 0)];
     const float lbs = A.corr_lb[ci];
     const CorrVec ps = A.corr_q[ci];
+    const float prev_d2 = A.corr_d2[ci];      // (the radius hint and the seed of a search: see nn_query_search)
+    const int prev_pos = A.corr_idx[ci];
     const PairDev& P = pairs[pair];
     // LISTED = false is the first record-wise pass of a registration: no record has been evaluated yet
     const bool have = LISTED && touch >= 0 && touch < hist_stride;
@@ -1710,8 +1723,8 @@ __global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_record_touch_kern
       }
     }
     if (__ballot(need) != 0ull) {
-      const float m = nn_record_search(&P, &slots[P.slot_s], ci, need ? 1 : 0, q.x, q.y, q.z, move, A_dev, max_d, dbg,
-                                       prof_counts);
+      const float m = nn_record_search(&P, &slots[P.slot_s], ci, need ? 1 : 0, q.x, q.y, q.z, move, prev_d2, prev_pos, A_dev,
+                                       max_d, dbg, prof_counts);
       if (need) margin = m;
     }
 #pragma unroll

@@ -348,8 +348,10 @@ int s3d_align_batch_multi(s3d_sweep* sw, int n_pairs, s3d_sweep_cloud* const* so
   }
   // ---- host result: rank 0's gathered buffer, padding of short blocks dropped
   std::vector<s3d_edge_record> all((size_t)per * R);
+  // (on the rank's collective stream, not the null stream: see copy_to_host in s3d_api.hip)
   if (hipSetDevice(sw->devices[0]) != hipSuccess ||
-      hipMemcpy(all.data(), sw->recvbuf[0], all.size() * rec_bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+      hipMemcpyAsync(all.data(), sw->recvbuf[0], all.size() * rec_bytes, hipMemcpyDeviceToHost, sw->coll[0]) != hipSuccess ||
+      hipStreamSynchronize(sw->coll[0]) != hipSuccess) {
     sw->err = "download of the gathered records failed";
     return S3D_STATUS_BACKEND_ERROR;
   }
@@ -373,7 +375,8 @@ int s3d_sweep_gathered_records(s3d_sweep* sw, int rank, int n_pairs, s3d_edge_re
   if (sw->recv_cap[rank] < (size_t)per * R * rec_bytes) return S3D_STATUS_INVALID_ARGUMENT;
   std::vector<s3d_edge_record> all((size_t)per * R);
   if (hipSetDevice(sw->devices[rank]) != hipSuccess ||
-      hipMemcpy(all.data(), sw->recvbuf[rank], all.size() * rec_bytes, hipMemcpyDeviceToHost) != hipSuccess)
+      hipMemcpyAsync(all.data(), sw->recvbuf[rank], all.size() * rec_bytes, hipMemcpyDeviceToHost, sw->coll[rank]) != hipSuccess ||
+      hipStreamSynchronize(sw->coll[rank]) != hipSuccess)
     return S3D_STATUS_BACKEND_ERROR;
   for (int r = 0; r < R; ++r) {
     int lo, hi;

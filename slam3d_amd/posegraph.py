@@ -115,19 +115,28 @@ class LinkPolicy:
     """ScanSensor's scalar knobs with the constructor defaults (ScanSensor.cpp:34-41)."""
 
     def __init__(self, name="velodyne", neighbor_radius=1.0, max_neighbor_links=1, min_loop_length=10,
-                 patch_building_range=0, link_sensors=None):
+                 patch_building_range=0, link_sensors=None, static_graph=False):
         self.name = name
         self.neighbor_radius = neighbor_radius
         self.max_neighbor_links = max_neighbor_links
         self.min_loop_length = min_loop_length
         self.patch_building_range = patch_building_range
         self.link_sensors = set(link_sensors) if link_sensors is not None else {name}
+        self.static_graph = static_graph      # see link_candidates
 
 
 def link_candidates(graph, vertex, policy):
     """ScanSensor::linkToNeighbors (ScanSensor.cpp:170-202) up to, not including, the registration:
-    the (source, target) pairs it would hand to link(), in its order."""
+    the (source, target) pairs it would hand to link(), in its order.
+
+    link() changes the graph before the next neighbour is examined (ScanSensor.cpp:143, :157-158: a tentative edge,
+    replaced by an SE(3) edge when the registration succeeds), so with max_neighbor_links > 1 the next neighbour of the
+    same cluster is only a hop or two from `vertex` and fails min_loop_length.  The candidates of a sweep are listed
+    before anything is registered: every accepted link is assumed to succeed (policy.static_graph = False) - a working
+    copy of the adjacency gets its SE(3) edge.  policy.static_graph = True judges every neighbour on the graph as
+    given (more candidates than the reference links)."""
     out = []
+    saved = {}
     if policy.max_neighbor_links == 0:
         return out
     neighbors = graph.get_nearby_vertices(graph.pose[vertex], policy.neighbor_radius, policy.link_sensors)
@@ -144,6 +153,12 @@ def link_candidates(graph, vertex, policy):
             continue
         count += 1
         out.append((index, vertex))                          # link(index, vertex)
+        if not policy.static_graph:
+            for v in (index, vertex):
+                saved.setdefault(v, list(graph.out[v]))
+            graph.add_edge(index, vertex, policy.name, SE3)
+    for v, edges in saved.items():                           # (the caller's graph is left as it was)
+        graph.out[v] = edges
     return out
 
 

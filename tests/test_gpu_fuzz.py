@@ -102,3 +102,49 @@ def test_gicp_and_ndt_on_random_synthetic_pairs_match_oracle(gpu_ctx, oracle_mod
                 worst[name] = [max(worst[name][0], dt), max(worst[name][1], dr)]
                 assert dt < 1e-4 and dr < 1e-4, (name, len(a), dens, dt, dr, io["iterations"], ig["iterations"])
     print("registration fuzz, worst |dt| m / |dr| rad vs oracle:", worst)
+
+
+def test_registration_soak_72_random_pairs(gpu_ctx, oracle_mod):
+    """72 random registrations (round 3's tools_dev/parity_soak.py, now a test): scene clouds of 3 / 20 / 60 k points,
+    the second one an independent resample (30 %) or a noisy copy, a random planar motion, GICP (70 %) or
+    point-to-plane, voxel 0.02 / 0.1 / 0.3 m, 5 / 12 / 20 outer iterations with early exit.  GPU against the oracle's
+    smooth-objective variant: identical status and outer-iteration count, <= 1e-4 m and <= 1e-4 rad."""
+    import slam3d_amd as s3d
+    from multiprocessing.pool import ThreadPool
+    cases = []
+    for seed in (5, 6, 7):
+        rng = np.random.default_rng(seed)
+        for case in range(24):
+            n = int(rng.choice([3000, 20000, 60000]))
+            a = s3d.make_scene_cloud(n, int(rng.integers(1 << 30)))
+            b = s3d.make_scene_cloud(n, int(rng.integers(1 << 30))) if rng.random() < 0.3 else \
+                a + rng.normal(0, 0.005, a.shape).astype(np.float32)
+            T = np.eye(4); T[:3, 3] = rng.uniform(-0.4, 0.4, 3)
+            ang = rng.uniform(-0.03, 0.03)
+            T[:2, :2] = [[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]]
+            bl = ((b.astype(np.float64) - T[:3, 3]) @ T[:3, :3]).astype(np.float32)
+            alg = oracle_mod.ALG_GICP if rng.random() < 0.7 else oracle_mod.ALG_ICP
+            cases.append((a, bl, alg, float(rng.choice([0.02, 0.1, 0.3])), int(rng.choice([5, 12, 20]))))
+
+    def ref(c):
+        a, bl, alg, dens, its = c
+        return oracle_mod.align(a, bl, np.eye(4), oracle_mod.default_params(registration_algorithm=alg,
+                                                                              point_cloud_density=dens, maximum_iterations=its))
+    oracle_mod.set_eval_precision(2)
+    try:
+        with ThreadPool(16) as pool:
+            refs = pool.map(ref, cases)
+    finally:
+        oracle_mod.set_eval_precision(0)
+    worst = [0.0, 0.0]
+    for k, ((a, bl, alg, dens, its), (so, To, io)) in enumerate(zip(cases, refs)):
+        sg, Tg, ig = gpu_ctx.align(a, bl, np.eye(4), s3d.default_params(registration_algorithm=alg, point_cloud_density=dens,
+                                                                     maximum_iterations=its))
+        assert sg == so, (k, sg, so)
+        if so != 0:
+            continue
+        dt, dr = transform_delta(To, Tg)
+        worst = [max(worst[0], dt), max(worst[1], dr)]
+        assert dt < 1e-4 and dr < 1e-4 and io["iterations"] == ig["iterations"], (k, len(a), alg, dens, its, dt, dr,
+                                                                              io["iterations"], ig["iterations"])
+    print("soak, worst |dt| m / |dr| rad vs oracle:", worst)

@@ -390,16 +390,21 @@ def test_align_gicp_parity_median_within_north_star_tolerance():
     assert np.median([d[0] for d in _gicp_deltas]) < TOL_T and np.median([d[1] for d in _gicp_deltas]) < TOL_R
 
 
-@pytest.mark.parametrize("a,b", PAIRS[:2])
-def test_align_gicp_vs_pcl_literal_same_basin(gpu_ctx, oracle_mod, fixture_clouds, a, b):
+@pytest.mark.parametrize("a,b,gx", [(0, 1, 0.0), (1, 2, 0.0), (2, 3, 0.0), (0, 3, 2.0)])
+def test_align_gicp_vs_pcl_literal_same_basin(gpu_ctx, oracle_mod, fixture_clouds, a, b, gx):
+    """Against the PCL-LITERAL restatement (float transform inside the objective): all three consecutive
+    fixture pairs and cloud1 -> cloud4 from a 2 m guess.  Its result is not defined to 1e-4 m (1e-15
+    perturbations of its Mahalanobis matrices move it by millimetres, tests/test_conditioning.py), so: same basin, and
+    the device result is an equally good minimiser of the reference's own objective."""
     import slam3d_amd as s3d
-    st_o, T_o, _ = oracle_mod.align(fixture_clouds[a], fixture_clouds[b])
-    st, T, _ = gpu_ctx.align(fixture_clouds[a], fixture_clouds[b], np.eye(4), s3d.default_params())
+    g = np.eye(4); g[0, 3] = gx
+    st_o, T_o, _ = oracle_mod.align(fixture_clouds[a], fixture_clouds[b], g)
+    st, T, _ = gpu_ctx.align(fixture_clouds[a], fixture_clouds[b], g, s3d.default_params())
     dt, dr = transform_delta(T_o, T)
-    assert st == st_o == 0 and dt < 6e-3 and dr < 1e-3
+    assert st == st_o == 0 and dt < 2.5e-2 and dr < 1e-3, (dt, dr)
     c_ref, n_ref = oracle_mod.gicp_cost(fixture_clouds[a], fixture_clouds[b], T_o)
     c_gpu, n_gpu = oracle_mod.gicp_cost(fixture_clouds[a], fixture_clouds[b], T)
-    assert c_gpu < c_ref * 1.01 and abs(n_gpu - n_ref) < 50
+    assert c_gpu < c_ref * 1.01 and abs(n_gpu - n_ref) < 80, (c_gpu, c_ref, n_gpu, n_ref)
 
 
 def test_align_with_guess_and_gates(gpu_ctx, oracle_mod, fixture_clouds):
@@ -652,6 +657,13 @@ def test_bench_contract_line(tmp_path):
     assert line["accuracy"]["status_ok"] == 4
     sp = line["single_pair"]                       # --extras: configs[1] latency and the other algorithm of the path
     assert sp["latency_ms"] > 0 and sp["other_algorithm"]["registrations_per_s"] > 0
+    # round 4: the reference's own scans and defaults, the host -> HBM hand-over, the pair-parallel CPU figure
+    rs = line["real_scans"]
+    assert rs["status_ok"] == 96 and rs["registrations_per_s"] > 0 and 2 <= rs["median_outer_iterations"] <= 50
+    assert rs["vs_oracle"]["max_dt_m"] < 1e-4 and rs["vs_oracle"]["max_dr_rad"] < 1e-4
+    assert all(a == b and c == d == 0 for a, b, c, d in rs["vs_oracle"]["iterations_status_gpu_oracle"])
+    assert line["upload_ms"] > 0 and 0 < line["value_incl_upload"] < line["value"]
+    assert line["cpu_baseline_parallel"]["cores"] == 2
 
 
 def test_ndt_batch_mixed_inputs(gpu_ctx, fixture_clouds):

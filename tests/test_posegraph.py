@@ -80,7 +80,7 @@ def test_link_candidates_follow_the_reference_policy():
     passing = [v for v in near if v != n - 1 and g.calculate_graph_distance(v, n - 1) >= 10]
     assert c == [(passing[-1], n - 1)]
     # more links allowed: reverse graph order, capped
-    pol3 = LinkPolicy(neighbor_radius=3.5, max_neighbor_links=3, min_loop_length=10)
+    pol3 = LinkPolicy(neighbor_radius=3.5, max_neighbor_links=3, min_loop_length=10, static_graph=True)
     assert link_candidates(g, n - 1, pol3) == [(v, n - 1) for v in reversed(passing)][:3]
     # max_neighbor_links = 0 -> nothing; a vertex in the middle of the open loop has only close-by neighbours
     assert link_candidates(g, n - 1, LinkPolicy(neighbor_radius=3.5, max_neighbor_links=0)) == []
@@ -95,6 +95,64 @@ def test_link_candidates_follow_the_reference_policy():
     polp = LinkPolicy(neighbor_radius=3.5, max_neighbor_links=5, min_loop_length=0, patch_building_range=1)
     for s, t in link_candidates(g, 20, polp):
         assert g.calculate_graph_distance(s, t) > 2
+
+
+def _reference_link_to_neighbors(g, vertex, pol):
+    """A model of ScanSensor::linkToNeighbors (ScanSensor.cpp:170-202) that MUTATES the graph as link() does
+    (:137-166) when every registration succeeds: tentative edge in both directions, removed again (removeConstraint
+    drops both directions, Graph.cpp), SE(3) edge in both directions - before the next neighbour is examined."""
+    calls = []
+    if pol.max_neighbor_links == 0:
+        return calls
+    count = 0
+    for index in reversed(g.get_nearby_vertices(g.pose[vertex], pol.neighbor_radius, pol.link_sensors)):
+        if count >= pol.max_neighbor_links:
+            break
+        if index == vertex or g.has_edge(vertex, index, pol.name):
+            continue
+        dist = g.calculate_graph_distance(index, vertex)
+        if dist <= pol.patch_building_range * 2 or dist < pol.min_loop_length:
+            continue
+        count += 1
+        calls.append((index, vertex))
+        g.add_edge(index, vertex, pol.name, TENTATIVE)       # addTentativeConstraint
+        g.remove_edge(index, vertex, pol.name)               # removeConstraint
+        g.remove_edge(vertex, index, pol.name)
+        g.add_edge(index, vertex, pol.name, SE3)             # addConstraint(se3)
+    return calls
+
+
+def test_link_candidates_with_several_links_follow_the_mutating_reference():
+    """max_neighbor_links > 1 (round-3 advisor finding): link() inserts its SE(3) edge before the next neighbour is
+    examined, so the neighbours of one spatial cluster are a hop or two from the vertex after the first link and fail
+    min_loop_length - about one link per cluster, not max_neighbor_links of them.  Python restatement and C ABI
+    against a model that mutates a copy of the graph; the caller's graph is left untouched."""
+    import copy
+    n = 40
+    g = loop_graph(n)
+    pol = LinkPolicy(neighbor_radius=3.5, max_neighbor_links=3, min_loop_length=10)
+    before = copy.deepcopy(g.out)
+    want = _reference_link_to_neighbors(copy.deepcopy(g), n - 1, pol)
+    got = link_candidates(g, n - 1, pol)
+    assert got == want and g.out == before
+    static = link_candidates(g, n - 1, LinkPolicy(neighbor_radius=3.5, max_neighbor_links=3, min_loop_length=10,
+                                                   static_graph=True))
+    assert len(want) == 1 and len(static) > 1 and static[0] == want[0]      # one cluster at the loop's start: one link
+    assert _c_abi_candidates(g, n - 1, pol) == want
+    rng = np.random.default_rng(9)
+    for trial in range(30):
+        m = int(rng.integers(10, 70))
+        r = PoseGraph()
+        for i in range(m):
+            r.add_vertex(i, pose(*rng.uniform(-5, 5, 2)))
+        for i in range(m - 1):
+            r.add_edge(i, i + 1, "velodyne", SE3)
+        p2 = LinkPolicy(neighbor_radius=float(rng.uniform(2, 6)), max_neighbor_links=int(rng.integers(2, 8)),
+                        min_loop_length=int(rng.integers(2, 12)), patch_building_range=int(rng.integers(0, 2)))
+        for v in rng.integers(0, m, 5):
+            want = _reference_link_to_neighbors(copy.deepcopy(r), int(v), p2)
+            assert link_candidates(r, int(v), p2) == want, (trial, int(v))
+            assert _c_abi_candidates(r, int(v), p2) == want, (trial, int(v))
 
 
 def test_sweep_candidates_deduplicates_both_directions():
@@ -115,7 +173,7 @@ def _c_abi_candidates(g, vertex, pol):
     edges = [(idx[u], idx[t], int(ty == SE3), int(s == pol.name)) for u in g.ids for t, s, ty in g.out[u]]
     linkable = [int(g.sensor[v] in pol.link_sensors) for v in g.ids]
     src = api.link_candidates(pos, edges, idx[vertex], pol.neighbor_radius, pol.max_neighbor_links, pol.min_loop_length,
-                              pol.patch_building_range, linkable)
+                              pol.patch_building_range, linkable, pol.static_graph)
     return [(g.ids[s], vertex) for s in src]
 
 
@@ -147,7 +205,8 @@ def test_c_abi_link_candidates_equal_the_python_restatement():
             if a != b:
                 r.add_edge(int(a), int(b), ["velodyne", "gps"][int(rng.integers(0, 2))], [SE3, "GPS", TENTATIVE][int(rng.integers(0, 3))])
         pol = LinkPolicy(neighbor_radius=float(rng.uniform(1, 8)), max_neighbor_links=int(rng.integers(1, 6)),
-                         min_loop_length=int(rng.integers(0, 8)), patch_building_range=int(rng.integers(0, 3)))
+                         min_loop_length=int(rng.integers(0, 8)), patch_building_range=int(rng.integers(0, 3)),
+                         static_graph=bool(trial % 2))
         for v in rng.integers(0, m, 6):
             assert _c_abi_candidates(r, int(v), pol) == link_candidates(r, int(v), pol), (trial, int(v))
     with pytest.raises(ValueError):

@@ -1,4 +1,6 @@
-for v in default exp_NOSEARCH; do
-  if [ $v = default ]; then unset S3D_LIB_PATH; else export S3D_LIB_PATH=$PWD/slam3d_amd/lib/$v.so; fi
-  echo "== $v"; timeout 300 python tools_dev/r4.py 0 2>&1 | grep -A1 "^flags" | tail -2
+for v in 0 16 32 64 128; do
+  export S3D_SORT_GROUP=$v
+  for f in 0 0x800000; do
+  echo "== group $v flags $f"; NPAIRS=256 timeout 300 python tools_dev/r4.py $f 2>&1 | grep "^flags" | tail -1
+  done
 done
