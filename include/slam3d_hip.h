@@ -80,6 +80,8 @@ typedef struct s3d_exec_options {
 #define S3D_DBG_SORT_ONESWEEP      0x00800000u /* radix sort: one sweep per pass (decoupled look-back), whatever ...      */
 #define S3D_DBG_SCAN27_NO_COMPACT  0x01000000u /* pass 3 without the block compaction                                    */
 #define S3D_DBG_PRINT_KNN          0x02000000u /* stderr: how many points took the eigen fallback / the exact-search redo */
+#define S3D_DBG_NN_FORCE_SETTLED   0x08000000u /* record-level re-validation for a small batch too (the host takes it from
+                                                  65 536 records = 42 pairs of 100 k points: below that it is slower)   */
 #define S3D_DBG_SORT_FULL_KEYS     0x04000000u /* radix sort: fixed pass counts (4 voxel + 3 grid), not the key range's   */
 
 /* The structs above grow at the END only.  A binding compiled against another revision of this header must not be

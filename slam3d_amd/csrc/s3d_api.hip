@@ -494,8 +494,8 @@ struct Batch {
                 {&ctx->keysA, 4 * np}, {&ctx->keysB, 4 * np}, {&ctx->valsA, 4 * np}, {&ctx->valsB, 4 * np},
                 {&ctx->filt, 16 * np}, {&ctx->sorted, 16 * np}, {&ctx->sorted3, 12 * npi}, {&ctx->normals, sizeof(NormalRec) * npi}, {&ctx->moments, 72 * npi},
                 {&ctx->cell_start, 4 * std::max<size_t>(total_cells, 4)},
-                {&ctx->counts, 4 * (size_t)std::max(1, C()) * 256 * nb_sort},
-                {&ctx->digit_tot, 4 * (size_t)std::max(1, C()) * 256 * kSortPlaces},
+                {&ctx->counts, 4 * (size_t)std::max(1, C()) * (1 << kSortMaxBits) * nb_sort},
+                {&ctx->digit_tot, 4 * (size_t)std::max(1, C()) * (1 << kSortMaxBits) * kSortPlaces},
                 {&ctx->blockcnt, 4 * (size_t)std::max(1, C()) * nb_head},
                 {&ctx->blockbb, 24 * (size_t)std::max(1, C()) * nb_head},
                 {&ctx->corr_idx, 4 * nc}, {&ctx->corr_d2, 4 * nc}, {&ctx->corr_lb, 4 * nc},
@@ -548,14 +548,14 @@ struct Batch {
     restore_from_cache();
   }
 
-  // segmented LSD radix sort of (keys, vals) of every slot; `passes` 8-bit digits.
+  // segmented LSD radix sort of (keys, vals) of every slot: `passes` digits of `bits` bits (8, 9 or 10).
   // input in A; result in A for even `passes`, in B for odd.
   // One sweep per pass (k_sort_onesweep, decoupled look-back); hist_done: the kernel that produced the keys has
   // counted the digit totals of all passes (k_keys_hist with sweep_passes) and zeroed the look-back rows.
   // The three-kernels-per-pass form (k_sort_hist / scan / scatter) reads the keys twice but never waits for another
   // tile: it is the faster one once the batch is large (256 pairs of 100 k points: voxel + grid 4.22 -> 4.07 ms,
   // equal at 128 pairs, 0.03 ms slower at 32), the one-sweep form - 5 launches instead of 11 per sort - for a small
-  // batch and a lone pair (-25 us).  S3D_SORT_CLASSIC=1 / 0 forces one or the other (A/B).
+  // batch and a lone pair (-25 us).  S3D_DBG_SORT_CLASSIC / _ONESWEEP force one or the other (A/B).
   bool sort_classic = false;
   void sort_choose() {
     sort_classic = (opts.debug_flags & S3D_DBG_SORT_CLASSIC) ? true : (opts.debug_flags & S3D_DBG_SORT_ONESWEEP) ? false
@@ -565,14 +565,35 @@ struct Batch {
   bool sort_used = false;
   void sort_prepare(int nslots) {   // before the kernel that counts the digit totals
     if (!sort_classic && nslots > 0)
-      HIPCHK(hipMemsetAsync(ctx->digit_tot.p, 0, sizeof(uint32_t) * (size_t)nslots * kSortPlaces * 256, ctx->stream));
+      HIPCHK(hipMemsetAsync(ctx->digit_tot.p, 0, sizeof(uint32_t) * (size_t)nslots * kSortPlaces * (1 << kSortMaxBits), ctx->stream));
   }
+  // the digits of a sort from the number of key bits: 8-bit digits unless a ninth (then a tenth) bit per digit removes
+  // a pass (18 bits: 2 x 9 instead of 3 x 8; 24: 3 x 8; 30: 4 x 8 - wider digits cost more per pass than they save,
+  // see s3d_kernels.h K2a); S3D_DBG_SORT_FULL_KEYS: always 8-bit digits
+  struct SortPlan { int passes, bits; };
+  SortPlan sort_plan(int key_bits) const {
+    const int p8 = std::max(1, cdiv(key_bits, 8));
+    if (opts.debug_flags & S3D_DBG_SORT_FULL_KEYS) return {p8, 8};
+    if (cdiv(key_bits, 9) < p8) return {cdiv(key_bits, 9), 9};
+    if (cdiv(key_bits, 10) < p8) return {cdiv(key_bits, 10), 10};
+    return {p8, 8};
+  }
+  static int bits_for(long long max_value) { int b = 1; while (b < 32 && (max_value >> b) != 0) ++b; return b; }
   // (measured, round 4: the clouds of a batch sorted in GROUPS of 16 ... 128, all passes of a group back to back so
   // that its 1.6 MB per cloud stay in the 256 MB memory-side cache between passes - voxel + grid 4.0 -> 7.3 / 5.7 / 4.7 /
   // 4.2 ms for groups of 16 / 32 / 64 / 128 of the 512 clouds: the smaller launches lose more than the cache gives)
-  void sort(int passes, int nslots, bool hist_done = false) {
+  void sort(SortPlan plan, int nslots, bool hist_done = false) {
+    switch (plan.bits) {
+      case 8: sort_bits<8>(plan.passes, nslots, hist_done); break;
+      case 9: sort_bits<9>(plan.passes, nslots, hist_done); break;
+      default: sort_bits<10>(plan.passes, nslots, hist_done); break;
+    }
+  }
+  template <int BITS>
+  void sort_bits(int passes, int nslots, bool hist_done) {
     hipStream_t st = ctx->stream;
     if (nslots <= 0) return;
+    constexpr int NB = 1 << BITS;
     uint32_t *ki = kA(), *vi = vA(), *ko = kB(), *vo = vB();
     uint32_t* cnt = (uint32_t*)ctx->counts.p;
     uint32_t* dtot = (uint32_t*)ctx->digit_tot.p;
@@ -585,22 +606,22 @@ struct Batch {
       }
       if (!hist_done) {
         sort_prepare(nslots);
-        k_sort_hist_all<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(gslots, ki, dtot, cnt, passes, nb_sort);
+        k_sort_hist_all<BITS><<<dim3(nb_sort, nslots), kBlock, 0, st>>>(gslots, ki, dtot, cnt, passes, nb_sort);
       }
       int* err = (int*)ctx->n_active.p + 6;
       for (int p = 0; p < passes; ++p) {
-        k_sort_onesweep<<<blocks, kBlock, 0, st>>>(gslots, ki, vi, ko, vo, cnt, dtot, p, nb_sort, nslots, err);
+        k_sort_onesweep<BITS><<<blocks, kBlock, 0, st>>>(gslots, ki, vi, ko, vo, cnt, dtot, p, nb_sort, nslots, err);
         std::swap(ki, ko);
         std::swap(vi, vo);
       }
       return;
     }
     for (int p = 0; p < passes; ++p) {
-      const int shift = 8 * p;
-      if (p > 0 || !hist_done) k_sort_hist<<<dim3(nb_sort, nslots), kBlock, 0, st>>>(gslots, ki, cnt, shift, nb_sort);
-      if (nb_sort <= kSortTileMajor) k_sort_scan_tiles<<<nslots, 256, 0, st>>>(gslots, cnt, dtot, nb_sort);
-      else k_sort_scan_rows<<<dim3(256 / (kBlock / kWave), nslots), kBlock, 0, st>>>(gslots, cnt, dtot, nb_sort);
-      k_sort_scatter<<<blocks, kBlock, 0, st>>>(gslots, ki, vi, ko, vo, cnt, dtot, shift, nb_sort, nslots);
+      const int shift = BITS * p;
+      if (p > 0 || !hist_done) k_sort_hist<BITS><<<dim3(nb_sort, nslots), kBlock, 0, st>>>(gslots, ki, cnt, shift, nb_sort);
+      if (nb_sort <= kSortTileMajor) k_sort_scan_tiles<BITS><<<nslots, 256, 0, st>>>(gslots, cnt, dtot, nb_sort);
+      else k_sort_scan_rows<BITS><<<dim3(NB / (kBlock / kWave), nslots), kBlock, 0, st>>>(gslots, cnt, dtot, nb_sort);
+      k_sort_scatter<BITS><<<blocks, kBlock, 0, st>>>(gslots, ki, vi, ko, vo, cnt, dtot, shift, nb_sort, nslots);
       std::swap(ki, ko);
       std::swap(vi, vo);
     }
@@ -613,12 +634,13 @@ struct Batch {
     if (NS == 0) return;
     sort_choose();
     if (rp.leaf > 0.f) {
+      // voxel keys are up to 31 bits wide and the host does not know how wide (the bounding boxes live on the device)
       k_bbox<0><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), NS), kBlock, 0, st>>>(d_slots(), filt());
       k_voxel_params<<<cdiv(NS, 64), 64, 0, st>>>(d_slots(), rp, NS);
       sort_prepare(NS);
-      k_keys_hist<0><<<dim3(nb_sort, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA(), (uint32_t*)ctx->counts.p, nb_sort,
-                                                             sort_classic ? 0 : 4, (uint32_t*)ctx->digit_tot.p);
-      sort(4, NS, true);
+      k_keys_hist<0, 8><<<dim3(nb_sort, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA(), (uint32_t*)ctx->counts.p, nb_sort,
+                                                                sort_classic ? 0 : 4, (uint32_t*)ctx->digit_tot.p);
+      sort(SortPlan{4, 8}, NS, true);
       uint32_t* bc = (uint32_t*)ctx->blockcnt.p;
       k_heads_count<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), kA(), bc, nb_head);
       k_heads_scan<<<NS, kBlock, 0, st>>>(d_slots(), bc, nb_head);
@@ -640,14 +662,22 @@ struct Batch {
       k_bbox<1><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), NS), kBlock, 0, st>>>(d_slots(), filt());
     }
     k_grid_params<<<NS, kWave, 0, st>>>(d_slots(), rp, from_centroids ? (const unsigned int*)ctx->blockbb.p : nullptr, nb_head);
-    const bool wide = max_cell_cap > (1ll << 24);
+    // cell ids are below the largest cell budget of the batch, which the host knows
+    const SortPlan plan = sort_plan(bits_for(std::max<long long>(max_cell_cap, 2) - 1));
     sort_prepare(NS);
-    k_keys_hist<1><<<dim3(nb_sort, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA(), (uint32_t*)ctx->counts.p, nb_sort,
-                                                           sort_classic ? 0 : (wide ? 4 : 3), (uint32_t*)ctx->digit_tot.p);
-    sort(wide ? 4 : 3, NS, true);  // cell ids < 2^24 unless a map job raised the cap
+    uint32_t* cnt = (uint32_t*)ctx->counts.p;
+    uint32_t* dtot = (uint32_t*)ctx->digit_tot.p;
+    const int sweep = sort_classic ? 0 : plan.passes;
+    switch (plan.bits) {
+      case 8: k_keys_hist<1, 8><<<dim3(nb_sort, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA(), cnt, nb_sort, sweep, dtot); break;
+      case 9: k_keys_hist<1, 9><<<dim3(nb_sort, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA(), cnt, nb_sort, sweep, dtot); break;
+      default: k_keys_hist<1, 10><<<dim3(nb_sort, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA(), cnt, nb_sort, sweep, dtot); break;
+    }
+    sort(plan, NS, true);
+    const bool in_a = plan.passes % 2 == 0;
     // (a slot -> XCD block map as in k_centroids gains nothing here: vals[] runs nearly in step with the cell order)
-    k_grid_finalize<<<dim3(cdiv(max_n + 1, kBlock), NS), kBlock, 0, st>>>(d_slots(), filt(), wide ? kA() : kB(),
-                                                                          wide ? vA() : vB(), sorted(), sorted3(), cells());
+    k_grid_finalize<<<dim3(cdiv(max_n + 1, kBlock), NS), kBlock, 0, st>>>(d_slots(), filt(), in_a ? kA() : kB(),
+                                                                          in_a ? vA() : vB(), sorted(), sorted3(), cells());
   }
 
   // K4
@@ -810,8 +840,12 @@ struct Batch {
     return (size_t)nsub * (size_t)(cdiv(nblocks, nsub) * kBlock * rpt);
   }
   bool settled_used = false;               // stage_icp: this batch's records / transform history are initialised
+  // (a small batch keeps the per-query kernel: a record-wise pass is two launches whose second one ends with the few
+  // searches of the pass, which the per-query kernel hides among its 1 500 waves per pair.  Measured, settled pass per
+  // query / per record: 1 pair 11 / 16 us, 32 pairs equal, 128 pairs 0.100 / 0.055 ms, 256 pairs 0.196 / 0.089 ms)
   bool settled_on() const {
-    return settled_used && !(dbg_nn & (S3D_DBG_NN_NO_SETTLED | 262144 | 64 | 32 | 4));
+    return settled_used && !(dbg_nn & (S3D_DBG_NN_NO_SETTLED | 262144 | 64 | 32 | 4)) &&
+           ((long long)P() * cdiv(std::max(max_n_t, 1), kWave) >= 65536 || (opts.debug_flags & S3D_DBG_NN_FORCE_SETTLED));
   }
 
   // one outer iteration: correspondences (K5), accumulate (K6), controller (K7)
@@ -1265,7 +1299,7 @@ void align_ndt_pairs(Batch& b, const s3d_reg_params* params, const double* guess
     for (const NdtGrid& G : grids) max_n = std::max(max_n, G.n);
     k_ndt_keys<<<dim3(cdiv(max_n, kBlock), NG), kBlock, 0, st>>>(b.d_slots(), d_grids, b.filt(), b.kA(), b.vA());
     k_ndt_select_slots<<<cdiv(b.C(), 64), 64, 0, st>>>(b.d_slots(), b.C(), d_grids, NG);
-    b.sort(4, b.C());   // result back in A
+    b.sort(Batch::SortPlan{4, 8}, b.C());   // result back in A
     k_ndt_cells<<<dim3(cdiv(max_n, kBlock), NG), kBlock, 0, st>>>(b.d_slots(), d_grids, b.filt(), b.kA(), b.vA());
     for (int g = 0; g < NG; ++g)
       HIPCHK(hipMemcpyAsync(&n_cells[g], grids[g].counter, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -22,8 +22,16 @@ constexpr int kBlock = 256;        // 4 waves
 constexpr int kWave = 64;
 constexpr int kSortTile = 4096;    // elements per block and pass in the radix sort (16 per thread: digit runs of a
                                    // tile are then ~64 B long; 1024 -> 4096 took 1.3 ms off the 256-pair step)
-constexpr int kAccumVB = 64;       // VIRTUAL blocks per pair in the accumulate / fitness kernels: the unit of the
-                                   // fixed summation tree (block_reduce_store_fixed); a launch runs them on 1..64 real blocks
+#ifndef S3D_ACCUM_VB
+#define S3D_ACCUM_VB 32
+#endif
+constexpr int kAccumVB = S3D_ACCUM_VB;   // VIRTUAL blocks per pair in the accumulate / fitness kernels: the unit of the
+                                   // fixed summation tree (block_reduce_store_fixed); a launch runs them on 1..32 real blocks.
+                                   // Round 4: 64 -> 32.  Every virtual block ends in a 73-value butterfly over its 256
+                                   // virtual threads, and at 100 k points a virtual block of 64 folds only six
+                                   // correspondences per thread before it: a quarter of the kernel's instructions.
+                                   // 256 pairs: 6.3 -> 5.65 ms per step (16: 5.3); the price is the lone pair, whose
+                                   // accumulate launch has 32 blocks instead of 64: 1.43 -> 1.48 ms (16: 1.59)
 constexpr uint32_t kInvalidKey = 0xFFFFFFFFu;
 
 #ifndef S3D_NN_AB
@@ -273,56 +281,93 @@ __global__ void __launch_bounds__(kBlock) k_copy_many(const CopyDesc* __restrict
 }
 
 // ------------------------------------------------------------------ K2a: segmented stable LSD radix sort
-// 8-bit digits, (key, value) pairs, one segment per slot.  The tile histograms `counts` come in two layouts:
-//   nb_max <= kSortTileMajor (clouds up to 262 k points): counts[(slot * nb_max + tile) * 256 + digit] - the 256
-//     counters a histogram kernel writes and a scatter tile reads are ONE contiguous kilobyte, and the scan over the
-//     tiles of a digit is a loop of a thread per digit (k_sort_scan_tiles);
-//   larger slots (map building: ~10^4 tiles): counts[(slot * 256 + digit) * nb_max + tile], a row per digit that a
+// (key, value) pairs, one segment per slot, BITS-bit digits (round 4: 8, 9 or 10 - the pass count follows the key
+// range instead of being 4 + 3 passes of 8 bits whatever the keys are: the voxel keys of the benchmark are 30 bits =
+// 3 x 10, its grid-cell ids 18 bits = 2 x 9).  NB = 2^BITS bins.  The tile histograms `counts` come in two layouts:
+//   nb_max <= kSortTileMajor (clouds up to 262 k points): counts[(slot * nb_max + tile) * NB + digit] - the NB
+//     counters a histogram kernel writes and a scatter tile reads are contiguous, and the scan over the tiles of a
+//     digit is a loop of a thread per digit (k_sort_scan_tiles);
+//   larger slots (map building: ~10^4 tiles): counts[(slot * NB + digit) * nb_max + tile], a row per digit that a
 //     wave scans 256 tiles at a time (k_sort_scan_rows).
+// Measured (256 pairs x 100 k points, scatter kernel per pass): 8 bits 0.208 ms, 9 bits 0.224 ms, 10 bits 0.380 ms - a
+// tile of 4096 elements leaves digit runs of 16 / 8 / 4 elements, and below 32 bytes a run no longer fills the sectors
+// it is written to (and the kernel's LDS allows three blocks per compute unit instead of four).  So a digit gets a
+// ninth bit where that removes a pass (grid-cell ids of up to 18 bits: 2 x 9 instead of 3 x 8) and a tenth only where
+// 9 bits do not (19-20 bits); the 30-bit voxel keys of the benchmark stay at 4 x 8 (3 x 10 + a gated fourth pass for
+// wider keys was built: voxel stage 2.35 -> 2.71 ms).
 constexpr int kSortTileMajor = 64;
+constexpr int kSortMaxBits = 10;
+template <int NB>
 __device__ __forceinline__ size_t sort_count_index(int slot, int digit, int tile, int nb_max) {
-  return nb_max <= kSortTileMajor ? ((size_t)slot * nb_max + tile) * 256 + digit
-                                  : ((size_t)slot * 256 + digit) * nb_max + tile;
+  return nb_max <= kSortTileMajor ? ((size_t)slot * nb_max + tile) * NB + digit
+                                  : ((size_t)slot * NB + digit) * nb_max + tile;
+}
+// exclusive scan over the NB = D * 256 digits of a block, thread t holding the values of digits t * D ... t * D + D - 1
+// (ex[k]: sum of all digits before t * D + k).  Two independent scans share the barrier.  wave_tot: [2][kBlock / kWave].
+template <int D>
+__device__ __forceinline__ void block_excl_scan2(const unsigned int (&a)[D], const unsigned int (&b)[D], unsigned int (&exa)[D],
+                                                 unsigned int (&exb)[D], unsigned int (*wave_tot)[kBlock / kWave]) {
+  const int lane = lane_id(), w = wave_id();
+  unsigned int sa = 0, sb = 0;
+#pragma unroll
+  for (int k = 0; k < D; ++k) { sa += a[k]; sb += b[k]; }
+  unsigned int ia = sa, ib = sb;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const unsigned int ta = __shfl_up(ia, o, kWave), tb = __shfl_up(ib, o, kWave);
+    if (lane >= o) { ia += ta; ib += tb; }
+  }
+  if (lane == kWave - 1) { wave_tot[0][w] = ia; wave_tot[1][w] = ib; }
+  __syncthreads();
+  unsigned int ba = ia - sa, bb = ib - sb;
+#pragma unroll
+  for (int ww = 0; ww < kBlock / kWave; ++ww) { ba += ww < w ? wave_tot[0][ww] : 0u; bb += ww < w ? wave_tot[1][ww] : 0u; }
+#pragma unroll
+  for (int k = 0; k < D; ++k) { exa[k] = ba; exb[k] = bb; ba += a[k]; bb += b[k]; }
 }
 
+template <int BITS>
 __global__ void __launch_bounds__(kBlock) k_sort_hist(const SlotDev* __restrict__ slots, const uint32_t* __restrict__ keys,
                                                        uint32_t* __restrict__ counts, int shift, int nb_max) {
-  __shared__ unsigned int hist[256];
+  constexpr int NB = 1 << BITS;
+  __shared__ unsigned int hist[NB];
   const SlotDev& s = slots[blockIdx.y];
   const int n = s.n_sort;
   const int nb = (n + kSortTile - 1) / kSortTile;
   if ((int)blockIdx.x >= nb) return;
-  hist[threadIdx.x] = 0;
+  for (int d = threadIdx.x; d < NB; d += kBlock) hist[d] = 0;
   __syncthreads();
   const int base = blockIdx.x * kSortTile;
 #pragma unroll
   for (int r = 0; r < kSortTile / kBlock; ++r) {
     const int i = base + r * kBlock + threadIdx.x;
-    if (i < n) atomicAdd(&hist[(keys[s.off + i] >> shift) & 255u], 1u);
+    if (i < n) atomicAdd(&hist[(keys[s.off + i] >> shift) & (uint32_t)(NB - 1)], 1u);
   }
   __syncthreads();
-  counts[sort_count_index(blockIdx.y, threadIdx.x, blockIdx.x, nb_max)] = hist[threadIdx.x];
+  for (int d = threadIdx.x; d < NB; d += kBlock) counts[sort_count_index<NB>(blockIdx.y, d, blockIdx.x, nb_max)] = hist[d];
 }
 
 // The keys of a sort and the tile histogram of its FIRST pass in one kernel (WHICH = 0: PCL voxel keys of the raw
 // points, 1: grid-cell ids of the filtered points): the keys are produced a 4096-element tile at a time and counted
 // as they are written, instead of being read back by k_sort_hist (one pass over the keys and one launch less per
 // sort: 0.2 ms of the 256-pair step).
-// sweep_passes > 0 (the one-sweep sort below): the digit totals of that many 8-bit places go to digit_tot_all instead,
+// sweep_passes > 0 (the one-sweep sort below): the digit totals of that many BITS-bit places go to digit_tot_all instead,
 // and `counts` is the look-back state, whose row of this tile is zeroed.
-constexpr int kSortPlacesFwd = 4;
-template <int WHICH>
+constexpr int kSortPlaces = 4;
+template <int WHICH, int BITS>
 __global__ void __launch_bounds__(kBlock) k_keys_hist(const SlotDev* __restrict__ slots, const float4* __restrict__ filt,
                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                                                        uint32_t* __restrict__ counts, int nb_max, int sweep_passes,
                                                        uint32_t* __restrict__ digit_tot_all) {
-  __shared__ unsigned int hist[kSortPlacesFwd][256];
+  constexpr int NB = 1 << BITS;
+  __shared__ unsigned int hist[kSortPlaces][NB];
   const SlotDev& s = slots[blockIdx.y];
   const int n = WHICH == 0 ? s.n_raw : s.n;
   const int nb = (n + kSortTile - 1) / kSortTile;
   if ((int)blockIdx.x >= nb) return;
-#pragma unroll
-  for (int p = 0; p < kSortPlacesFwd; ++p) hist[p][threadIdx.x] = 0;
+  const int places = sweep_passes > 0 ? sweep_passes : 1;
+  for (int p = 0; p < places; ++p)
+    for (int d = threadIdx.x; d < NB; d += kBlock) hist[p][d] = 0;
   __syncthreads();
   const int base = blockIdx.x * kSortTile;
 #pragma unroll 4
@@ -340,34 +385,37 @@ __global__ void __launch_bounds__(kBlock) k_keys_hist(const SlotDev* __restrict_
       }
       keys[s.off + i] = key;
       vals[s.off + i] = (uint32_t)i;
-      atomicAdd(&hist[0][key & 255u], 1u);
-      for (int p = 1; p < sweep_passes; ++p) atomicAdd(&hist[p][(key >> (8 * p)) & 255u], 1u);
+      atomicAdd(&hist[0][key & (uint32_t)(NB - 1)], 1u);
+      for (int p = 1; p < sweep_passes; ++p) atomicAdd(&hist[p][(key >> (BITS * p)) & (uint32_t)(NB - 1)], 1u);
     }
   }
   __syncthreads();
   if (sweep_passes > 0) {
-    for (int p = 0; p < sweep_passes; ++p) {
-      const unsigned int v = hist[p][threadIdx.x];
-      if (v) atomicAdd(&digit_tot_all[((size_t)blockIdx.y * kSortPlacesFwd + p) * 256 + threadIdx.x], v);
-    }
-    counts[((size_t)blockIdx.y * nb_max + blockIdx.x) * 256 + threadIdx.x] = 0u;
+    for (int p = 0; p < sweep_passes; ++p)
+      for (int d = threadIdx.x; d < NB; d += kBlock) {
+        const unsigned int v = hist[p][d];
+        if (v) atomicAdd(&digit_tot_all[((size_t)blockIdx.y * kSortPlaces + p) * NB + d], v);
+      }
+    for (int d = threadIdx.x; d < NB; d += kBlock) counts[((size_t)blockIdx.y * nb_max + blockIdx.x) * NB + d] = 0u;
     return;
   }
-  counts[sort_count_index(blockIdx.y, threadIdx.x, blockIdx.x, nb_max)] = hist[0][threadIdx.x];
+  for (int d = threadIdx.x; d < NB; d += kBlock) counts[sort_count_index<NB>(blockIdx.y, d, blockIdx.x, nb_max)] = hist[0][d];
 }
 
 // Offsets of one pass in two steps.  (1) one WAVE per (slot, digit) row of tile counts: exclusive scan of the row
 // in place, 64 tiles per step (four steps' loads in flight), row total -> digit_tot.  (2) the exclusive scan of the
-// slot's 256 row totals is redone by every scatter tile (k_sort_scatter), which adds it to its tile's row offset.  A lone 10^7-point
+// slot's NB row totals is redone by every scatter tile (k_sort_scatter), which adds it to its tile's row offset.  A lone 10^7-point
 // slot (map building) has ~10^4 tiles per row: the first version walked each row with one thread and took 5 ms
 // per pass there.
+template <int BITS>
 __global__ void __launch_bounds__(kBlock) k_sort_scan_rows(const SlotDev* __restrict__ slots, uint32_t* __restrict__ counts,
                                                             uint32_t* __restrict__ digit_tot, int nb_max) {
+  constexpr int NB = 1 << BITS;
   const SlotDev& s = slots[blockIdx.y];
   const int nb = (s.n_sort + kSortTile - 1) / kSortTile;
   const int digit = blockIdx.x * (kBlock / kWave) + wave_id();
   const int lane = lane_id();
-  uint32_t* __restrict__ c = counts + ((size_t)blockIdx.y * 256 + digit) * nb_max;
+  uint32_t* __restrict__ c = counts + ((size_t)blockIdx.y * NB + digit) * nb_max;
   unsigned int carry = 0;
   for (int b0 = 0; b0 < nb; b0 += 4 * kWave) {
     unsigned int v[4];
@@ -389,35 +437,70 @@ __global__ void __launch_bounds__(kBlock) k_sort_scan_rows(const SlotDev* __rest
       carry += __shfl(incl, kWave - 1, kWave);
     }
   }
-  if (lane == 0) digit_tot[(size_t)blockIdx.y * 256 + digit] = carry;
+  if (lane == 0) digit_tot[(size_t)blockIdx.y * NB + digit] = carry;
 }
 
 // nb_max <= kSortTileMajor: one block per slot, a thread per digit walks the tiles (coalesced over the digits); all
 // loads of a chunk of 16 tiles are issued before the first addition
+template <int BITS>
 __global__ void __launch_bounds__(256) k_sort_scan_tiles(const SlotDev* __restrict__ slots, uint32_t* __restrict__ counts,
                                                          uint32_t* __restrict__ digit_tot, int nb_max) {
+  constexpr int NB = 1 << BITS;
   const SlotDev& s = slots[blockIdx.x];
   const int nb = (s.n_sort + kSortTile - 1) / kSortTile;
-  uint32_t* __restrict__ c = counts + (size_t)blockIdx.x * nb_max * 256 + threadIdx.x;
-  unsigned int carry = 0;
-  for (int t0 = 0; t0 < nb; t0 += 16) {
-    unsigned int v[16];
+  for (int d = threadIdx.x; d < NB; d += 256) {
+    uint32_t* __restrict__ c = counts + (size_t)blockIdx.x * nb_max * NB + d;
+    unsigned int carry = 0;
+    for (int t0 = 0; t0 < nb; t0 += 16) {
+      unsigned int v[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = t0 + j < nb ? c[(size_t)(t0 + j) * 256] : 0u;
+      for (int j = 0; j < 16; ++j) v[j] = t0 + j < nb ? c[(size_t)(t0 + j) * NB] : 0u;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      if (t0 + j < nb) c[(size_t)(t0 + j) * 256] = carry;
-      carry += v[j];
+      for (int j = 0; j < 16; ++j) {
+        if (t0 + j < nb) c[(size_t)(t0 + j) * NB] = carry;
+        carry += v[j];
+      }
     }
+    digit_tot[(size_t)blockIdx.x * NB + d] = carry;
   }
-  digit_tot[(size_t)blockIdx.x * 256 + threadIdx.x] = carry;
 }
 
-// Stable scatter of one 1024-element tile.  Every wave owns a CONTIGUOUS quarter of the tile (4 rounds
-// of 64 elements), so the output order (wave, round, lane) is the input order and the per-digit ranks
-// can be accumulated per wave without a block barrier per round: lanes holding the same digit find
-// each other with 8 ballots, the first of them bumps the wave's private LDS counter.  Two block
-// barriers in all (the first version needed twelve).
+// the ranks of a wave's 16 rounds of 64 elements among the elements of the same digit in the wave's quarter of the
+// tile (a wave owns a CONTIGUOUS quarter, so the output order (wave, round, lane) is the input order and no block
+// barrier is needed per round): lanes holding the same digit find each other with BITS ballots, the first of them
+// bumps the wave's private LDS counter.
+template <int BITS, int ROUNDS>
+__device__ __forceinline__ void sort_rank_rounds(const uint32_t (&key)[ROUNDS], unsigned int (&rank)[ROUNDS], int base, int n,
+                                                 int shift, unsigned short* __restrict__ my_cnt /* [NB] of this wave */) {
+  constexpr uint32_t kMask = (1u << BITS) - 1u;
+  const int lane = lane_id();
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int i = base + r * kWave + lane;
+    const bool act = i < n;
+    const unsigned int d = (key[r] >> shift) & kMask;
+    unsigned long long peers = __ballot(act);
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+      const unsigned long long m = __ballot(act && ((d >> b) & 1u));
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    const int in_round = __popcll(peers & ((1ull << lane) - 1ull));
+    unsigned int before = 0;
+    if (act) before = my_cnt[d];                            // same value for all peers
+    __builtin_amdgcn_wave_barrier();
+    if (act && in_round == 0) my_cnt[d] = (unsigned short)(before + (unsigned int)__popcll(peers));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    rank[r] = before + (unsigned int)in_round;
+  }
+}
+
+// Stable scatter of one 4096-element tile.  Two block barriers around the digit scans, two around the LDS staging:
+// the tile is first put in digit order in LDS, then written out with consecutive threads on consecutive addresses of
+// each digit run (a direct scatter issues 64 unrelated 4-byte stores per wave and array).
+template <int BITS>
 __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restrict__ slots,
                                                           const uint32_t* __restrict__ keys_in,
                                                           const uint32_t* __restrict__ vals_in,
@@ -425,7 +508,12 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
                                                           const uint32_t* __restrict__ counts,
                                                           const uint32_t* __restrict__ digit_tot, int shift, int nb_max,
                                                           int nslots) {
-  __shared__ unsigned int wave_cnt[kBlock / kWave][256];   // per wave: elements of each digit seen so far
+  constexpr int NB = 1 << BITS, D = NB / kBlock;
+  constexpr uint32_t kMask = (uint32_t)(NB - 1);
+  __shared__ unsigned short wave_cnt[kBlock / kWave][NB];   // per wave: elements of each digit seen so far
+  __shared__ unsigned short dig_local[NB];
+  __shared__ unsigned int dig_global[NB], wave_tot[2][kBlock / kWave];
+  __shared__ uint32_t lkey[kSortTile], lval[kSortTile];
   // 1-D grid, slot -> XCD affinity (nn_block_map): the digit runs that the tiles of one cloud write next to each other
   // meet in ONE L2
   int slot_i, tile_i;
@@ -437,8 +525,10 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
   if (tile_i >= nb) return;
   const int lane = lane_id(), w = wave_id();
   constexpr int kRounds = kSortTile / kBlock;               // 16
+  for (int d = threadIdx.x; d < NB; d += kBlock) {
 #pragma unroll
-  for (int ww = 0; ww < kBlock / kWave; ++ww) wave_cnt[ww][threadIdx.x] = 0;
+    for (int ww = 0; ww < kBlock / kWave; ++ww) wave_cnt[ww][d] = 0;
+  }
   __syncthreads();
   const int base = tile_i * kSortTile + w * (kSortTile / (kBlock / kWave));
   uint32_t key[kRounds], val[kRounds];
@@ -449,74 +539,42 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
     key[r] = 0; val[r] = 0;
     if (i < n) { key[r] = keys_in[s.off + i]; val[r] = vals_in[s.off + i]; }
   }
-#pragma unroll
-  for (int r = 0; r < kRounds; ++r) {
-    const int i = base + r * kWave + lane;
-    const bool act = i < n;
-    const unsigned int d = (key[r] >> shift) & 255u;
-    unsigned long long peers = __ballot(act);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const unsigned long long m = __ballot(act && ((d >> b) & 1u));
-      peers &= ((d >> b) & 1u) ? m : ~m;
-    }
-    const int in_round = __popcll(peers & ((1ull << lane) - 1ull));
-    unsigned int before = 0;
-    if (act) before = wave_cnt[w][d];                       // same value for all peers
-    __builtin_amdgcn_wave_barrier();
-    if (act && in_round == 0) wave_cnt[w][d] = before + (unsigned int)__popcll(peers);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    rank[r] = before + (unsigned int)in_round;
-  }
+  sort_rank_rounds<BITS, kRounds>(key, rank, base, n, shift, wave_cnt[w]);
   __syncthreads();
-  // digit = threadIdx.x: exclusive prefix over the waves (tile-local), the digit's first position inside the
-  // tile (exclusive scan of the tile histogram over the 256 digits) and in the output (this tile's row offset
-  // + the digit base of the pass)
-  __shared__ unsigned int dig_local[256], dig_global[256], wave_tot[kBlock / kWave], wave_tot2[kBlock / kWave];
-  __shared__ uint32_t lkey[kSortTile], lval[kSortTile];
   {
-    unsigned int run = 0;
+    // digits threadIdx.x * D ... + D - 1: exclusive prefix over the waves (tile-local), the digit's first position
+    // inside the tile (exclusive scan of the tile histogram over the digits) and in the output (this tile's row
+    // offset + the digit base of the pass = the exclusive scan of the slot's digit totals, redone by every tile
+    // instead of a kernel of its own between the row scan and the scatter)
+    unsigned int run[D], dtot[D], ex_run[D], ex_tot[D];
 #pragma unroll
-    for (int ww = 0; ww < kBlock / kWave; ++ww) {
-      const unsigned int c = wave_cnt[ww][threadIdx.x];
-      wave_cnt[ww][threadIdx.x] = run;      // elements of this digit in earlier waves of the tile
-      run += c;
+    for (int k = 0; k < D; ++k) {
+      const int d = (int)threadIdx.x * D + k;
+      unsigned int acc = 0;
+#pragma unroll
+      for (int ww = 0; ww < kBlock / kWave; ++ww) {
+        const unsigned int c = wave_cnt[ww][d];
+        wave_cnt[ww][d] = (unsigned short)acc;      // elements of this digit in earlier waves of the tile
+        acc += c;
+      }
+      run[k] = acc;
+      dtot[k] = digit_tot[(size_t)slot_i * NB + d];
     }
-    unsigned int incl = run;                // tile histogram -> inclusive scan over the digits
+    block_excl_scan2<D>(run, dtot, ex_run, ex_tot, wave_tot);
 #pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const unsigned int t = __shfl_up(incl, o, kWave);
-      if (lane >= o) incl += t;
+    for (int k = 0; k < D; ++k) {
+      const int d = (int)threadIdx.x * D + k;
+      dig_local[d] = (unsigned short)ex_run[k];
+      dig_global[d] = counts[sort_count_index<NB>(slot_i, d, tile_i, nb_max)] + ex_tot[k];
     }
-    if (lane == kWave - 1) wave_tot[w] = incl;
-    // the digit's base in the output = exclusive scan of the slot's 256 digit totals: every tile redoes that small
-    // scan here instead of a kernel of its own between the row scan and the scatter (seven launches per step less)
-    const unsigned int dtot = digit_tot[(size_t)slot_i * 256 + threadIdx.x];
-    unsigned int incl2 = dtot;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const unsigned int t = __shfl_up(incl2, o, kWave);
-      if (lane >= o) incl2 += t;
-    }
-    if (lane == kWave - 1) wave_tot2[w] = incl2;
-    __syncthreads();
-    unsigned int before = 0, before2 = 0;
-#pragma unroll
-    for (int ww = 0; ww < kBlock / kWave; ++ww) { before += ww < w ? wave_tot[ww] : 0u; before2 += ww < w ? wave_tot2[ww] : 0u; }
-    dig_local[threadIdx.x] = before + incl - run;
-    dig_global[threadIdx.x] = counts[sort_count_index(slot_i, threadIdx.x, tile_i, nb_max)] + (before2 + incl2 - dtot);
   }
   __syncthreads();
-  // the tile is first put in digit order in LDS, then written out with consecutive threads on consecutive
-  // addresses of each digit run (a direct scatter issues 64 unrelated 4-byte stores per wave and array)
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const int i = base + r * kWave + lane;
     if (i < n) {
-      const unsigned int d = (key[r] >> shift) & 255u;
-      const unsigned int lp = dig_local[d] + wave_cnt[w][d] + rank[r];
+      const unsigned int d = (key[r] >> shift) & kMask;
+      const unsigned int lp = (unsigned int)dig_local[d] + wave_cnt[w][d] + rank[r];
       lkey[lp] = key[r];
       lval[lp] = val[r];
     }
@@ -525,7 +583,7 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
   const int tile_n = min(kSortTile, n - tile_i * kSortTile);
   for (int j = threadIdx.x; j < tile_n; j += kBlock) {
     const uint32_t kk = lkey[j];
-    const unsigned int d = (kk >> shift) & 255u;
+    const unsigned int d = (kk >> shift) & kMask;
     const unsigned int pos = dig_global[d] + ((unsigned int)j - dig_local[d]);
     keys_out[s.off + pos] = kk;
     vals_out[s.off + pos] = lval[j];
@@ -536,35 +594,27 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
 // (decoupled look-back: Merrill & Garland's chained scan, as in Adinets & Merrill's Onesweep).  Above, a pass is
 // three kernels - tile histograms, their scan over the tiles, the scatter - and the keys are read twice.  Here the
 // digit totals of ALL passes of a sort are counted once up front (k_sort_hist_all, or the kernel that produces the
-// keys), and a pass is one kernel: a tile ranks its elements, publishes its 256 digit counts (AGGREGATE), walks back
+// keys), and a pass is one kernel: a tile ranks its elements, publishes its NB digit counts (AGGREGATE), walks back
 // over the tiles before it adding their counts until it meets one that has published its INCLUSIVE prefix, publishes
-// its own, and scatters - one read and one write of keys and values per pass, 5 launches instead of 11 for the
-// four-pass voxel sort.  A state word is (tag << 28 | count): tag = 2 * pass + 1 (aggregate) / + 2 (inclusive), so a
+// its own, and scatters - one read and one write of keys and values per pass.  A state word is (tag << 28 | count):
+// tag = 2 * pass + 1 (aggregate) / + 2 (inclusive), so a
 // word left by an earlier pass reads as "not there yet"; the rows are zeroed once per sort by the histogram kernel.
 // Tiles wait only for tiles with a smaller block index of the same launch (nn_block_map keeps a cloud's tiles in
 // ascending block order), which the dispatcher has started before them.
-constexpr int kSortPlaces = kSortPlacesFwd;
 constexpr uint32_t kSweepValMask = 0x0FFFFFFFu;
 
-// digit totals of `passes` 8-bit places of every slot's keys, and zeroed look-back rows.  digit_tot_all must be zero.
-__device__ __forceinline__ void sort_hist_all_block(unsigned int (*hist)[256], int passes, uint32_t* __restrict__ digit_tot_all,
-                                                    uint32_t* __restrict__ state, int slot, int tile, int nb_max) {
-  __syncthreads();
-  for (int p = 0; p < passes; ++p) {
-    const unsigned int v = hist[p][threadIdx.x];
-    if (v) atomicAdd(&digit_tot_all[((size_t)slot * kSortPlaces + p) * 256 + threadIdx.x], v);
-  }
-  state[((size_t)slot * nb_max + tile) * 256 + threadIdx.x] = 0u;
-}
+template <int BITS>
 __global__ void __launch_bounds__(kBlock) k_sort_hist_all(const SlotDev* __restrict__ slots, const uint32_t* __restrict__ keys,
                                                            uint32_t* __restrict__ digit_tot_all, uint32_t* __restrict__ state,
                                                            int passes, int nb_max) {
-  __shared__ unsigned int hist[kSortPlaces][256];
+  constexpr int NB = 1 << BITS;
+  __shared__ unsigned int hist[kSortPlaces][NB];
   const SlotDev& s = slots[blockIdx.y];
   const int n = s.n_sort;
   const int nb = (n + kSortTile - 1) / kSortTile;
   if ((int)blockIdx.x >= nb) return;
-  for (int p = 0; p < kSortPlaces; ++p) hist[p][threadIdx.x] = 0;
+  for (int p = 0; p < passes; ++p)
+    for (int d = threadIdx.x; d < NB; d += kBlock) hist[p][d] = 0;
   __syncthreads();
   const int base = blockIdx.x * kSortTile;
 #pragma unroll 4
@@ -572,12 +622,19 @@ __global__ void __launch_bounds__(kBlock) k_sort_hist_all(const SlotDev* __restr
     const int i = base + r * kBlock + threadIdx.x;
     if (i < n) {
       const uint32_t key = keys[s.off + i];
-      for (int p = 0; p < passes; ++p) atomicAdd(&hist[p][(key >> (8 * p)) & 255u], 1u);
+      for (int p = 0; p < passes; ++p) atomicAdd(&hist[p][(key >> (BITS * p)) & (uint32_t)(NB - 1)], 1u);
     }
   }
-  sort_hist_all_block(hist, passes, digit_tot_all, state, blockIdx.y, blockIdx.x, nb_max);
+  __syncthreads();
+  for (int p = 0; p < passes; ++p)
+    for (int d = threadIdx.x; d < NB; d += kBlock) {
+      const unsigned int v = hist[p][d];
+      if (v) atomicAdd(&digit_tot_all[((size_t)blockIdx.y * kSortPlaces + p) * NB + d], v);
+    }
+  for (int d = threadIdx.x; d < NB; d += kBlock) state[((size_t)blockIdx.y * nb_max + blockIdx.x) * NB + d] = 0u;
 }
 
+template <int BITS>
 __global__ void __launch_bounds__(kBlock) k_sort_onesweep(const SlotDev* __restrict__ slots,
                                                            const uint32_t* __restrict__ keys_in,
                                                            const uint32_t* __restrict__ vals_in,
@@ -585,7 +642,12 @@ __global__ void __launch_bounds__(kBlock) k_sort_onesweep(const SlotDev* __restr
                                                            uint32_t* __restrict__ state,
                                                            const uint32_t* __restrict__ digit_tot_all, int pass, int nb_max,
                                                            int nslots, int* __restrict__ error_flag) {
-  __shared__ unsigned int wave_cnt[kBlock / kWave][256];   // per wave: elements of each digit seen so far
+  constexpr int NB = 1 << BITS, D = NB / kBlock;
+  constexpr uint32_t kMask = (uint32_t)(NB - 1);
+  __shared__ unsigned short wave_cnt[kBlock / kWave][NB];   // per wave: elements of each digit seen so far
+  __shared__ unsigned short dig_local[NB];
+  __shared__ unsigned int dig_global[NB], wave_tot[2][kBlock / kWave];
+  __shared__ uint32_t lkey[kSortTile], lval[kSortTile];
   int slot_i, tile_i;
   nn_block_map(nb_max, nslots, &slot_i, &tile_i);
   if (slot_i >= nslots) return;
@@ -593,11 +655,13 @@ __global__ void __launch_bounds__(kBlock) k_sort_onesweep(const SlotDev* __restr
   const int n = s.n_sort;
   const int nb = (n + kSortTile - 1) / kSortTile;
   if (tile_i >= nb) return;
-  const int shift = 8 * pass;
+  const int shift = BITS * pass;
   const int lane = lane_id(), w = wave_id();
   constexpr int kRounds = kSortTile / kBlock;               // 16
+  for (int d = threadIdx.x; d < NB; d += kBlock) {
 #pragma unroll
-  for (int ww = 0; ww < kBlock / kWave; ++ww) wave_cnt[ww][threadIdx.x] = 0;
+    for (int ww = 0; ww < kBlock / kWave; ++ww) wave_cnt[ww][d] = 0;
+  }
   __syncthreads();
   const int base = tile_i * kSortTile + w * (kSortTile / (kBlock / kWave));
   uint32_t key[kRounds], val[kRounds];
@@ -608,45 +672,32 @@ __global__ void __launch_bounds__(kBlock) k_sort_onesweep(const SlotDev* __restr
     key[r] = 0; val[r] = 0;
     if (i < n) { key[r] = keys_in[s.off + i]; val[r] = vals_in[s.off + i]; }
   }
-#pragma unroll
-  for (int r = 0; r < kRounds; ++r) {                       // ranks within the wave's quarter (see k_sort_scatter)
-    const int i = base + r * kWave + lane;
-    const bool act = i < n;
-    const unsigned int d = (key[r] >> shift) & 255u;
-    unsigned long long peers = __ballot(act);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const unsigned long long m = __ballot(act && ((d >> b) & 1u));
-      peers &= ((d >> b) & 1u) ? m : ~m;
-    }
-    const int in_round = __popcll(peers & ((1ull << lane) - 1ull));
-    unsigned int before = 0;
-    if (act) before = wave_cnt[w][d];
-    __builtin_amdgcn_wave_barrier();
-    if (act && in_round == 0) wave_cnt[w][d] = before + (unsigned int)__popcll(peers);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    rank[r] = before + (unsigned int)in_round;
-  }
+  sort_rank_rounds<BITS, kRounds>(key, rank, base, n, shift, wave_cnt[w]);
   __syncthreads();
-  __shared__ unsigned int dig_local[256], dig_global[256], wave_tot[kBlock / kWave], wave_tot2[kBlock / kWave];
-  __shared__ uint32_t lkey[kSortTile], lval[kSortTile];
   {
-    // digit = threadIdx.x: this tile's count, published at once; then the look-back over the earlier tiles
-    unsigned int run = 0;
-#pragma unroll
-    for (int ww = 0; ww < kBlock / kWave; ++ww) {
-      const unsigned int c = wave_cnt[ww][threadIdx.x];
-      wave_cnt[ww][threadIdx.x] = run;      // elements of this digit in earlier waves of the tile
-      run += c;
-    }
+    // digits threadIdx.x * D ...: this tile's counts, published at once; then the look-back over the earlier tiles
+    unsigned int run[D], dtot[D], excl[D], ex_run[D], ex_tot[D];
     const uint32_t tag_agg = (uint32_t)(2 * pass + 1) << 28, tag_inc = (uint32_t)(2 * pass + 2) << 28;
-    uint32_t* __restrict__ row = state + ((size_t)slot_i * nb_max) * 256 + threadIdx.x;     // [tile * 256]
-    __hip_atomic_store(row + (size_t)tile_i * 256, (tile_i == 0 ? tag_inc : tag_agg) | run, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-    unsigned int excl = 0;
-    {
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const int d = (int)threadIdx.x * D + k;
+      unsigned int acc = 0;
+#pragma unroll
+      for (int ww = 0; ww < kBlock / kWave; ++ww) {
+        const unsigned int c = wave_cnt[ww][d];
+        wave_cnt[ww][d] = (unsigned short)acc;      // elements of this digit in earlier waves of the tile
+        acc += c;
+      }
+      run[k] = acc;
+      uint32_t* __restrict__ row = state + ((size_t)slot_i * nb_max) * NB + d;     // [tile * NB]
+      __hip_atomic_store(row + (size_t)tile_i * NB, (tile_i == 0 ? tag_inc : tag_agg) | acc, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const int d = (int)threadIdx.x * D + k;
+      uint32_t* __restrict__ row = state + ((size_t)slot_i * nb_max) * NB + d;
+      unsigned int ex = 0;
       int t = tile_i - 1;                    // (tile 0 has published an inclusive prefix: the walk ends there at the latest)
       unsigned int spins = 0;
       bool found = t < 0;
@@ -655,15 +706,15 @@ __global__ void __launch_bounds__(kBlock) k_sort_onesweep(const SlotDev* __restr
         uint32_t wv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          wv[u] = __hip_atomic_load(row + (size_t)(t - u >= 0 ? t - u : 0) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          wv[u] = __hip_atomic_load(row + (size_t)(t - u >= 0 ? t - u : 0) * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int consumed = 0;
         bool stop = false;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (stop || t - u < 0) continue;
           const uint32_t tg = wv[u] & ~kSweepValMask;
-          if (tg == tag_inc) { excl += wv[u] & kSweepValMask; found = true; stop = true; }
-          else if (tg == tag_agg) { excl += wv[u] & kSweepValMask; ++consumed; }
+          if (tg == tag_inc) { ex += wv[u] & kSweepValMask; found = true; stop = true; }
+          else if (tg == tag_agg) { ex += wv[u] & kSweepValMask; ++consumed; }
           else stop = true;
         }
         t -= consumed;
@@ -674,38 +725,26 @@ __global__ void __launch_bounds__(kBlock) k_sort_onesweep(const SlotDev* __restr
       }
       // (a tile that gave up publishes its prefix all the same - its successors must not wait for it - and the host
       // fails the call in Batch::download(); what this sort leaves in the output is not used)
+      if (tile_i != 0)
+        __hip_atomic_store(row + (size_t)tile_i * NB, tag_inc | (ex + run[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      excl[k] = ex;
+      dtot[k] = digit_tot_all[((size_t)slot_i * kSortPlaces + pass) * NB + d];
     }
-    if (tile_i != 0)
-      __hip_atomic_store(row + (size_t)tile_i * 256, tag_inc | (excl + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned int incl = run;                // tile histogram -> inclusive scan over the digits
+    block_excl_scan2<D>(run, dtot, ex_run, ex_tot, wave_tot);
 #pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const unsigned int t2 = __shfl_up(incl, o, kWave);
-      if (lane >= o) incl += t2;
+    for (int k = 0; k < D; ++k) {
+      const int d = (int)threadIdx.x * D + k;
+      dig_local[d] = (unsigned short)ex_run[k];
+      dig_global[d] = excl[k] + ex_tot[k];
     }
-    if (lane == kWave - 1) wave_tot[w] = incl;
-    const unsigned int dtot = digit_tot_all[((size_t)slot_i * kSortPlaces + pass) * 256 + threadIdx.x];
-    unsigned int incl2 = dtot;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const unsigned int t2 = __shfl_up(incl2, o, kWave);
-      if (lane >= o) incl2 += t2;
-    }
-    if (lane == kWave - 1) wave_tot2[w] = incl2;
-    __syncthreads();
-    unsigned int before = 0, before2 = 0;
-#pragma unroll
-    for (int ww = 0; ww < kBlock / kWave; ++ww) { before += ww < w ? wave_tot[ww] : 0u; before2 += ww < w ? wave_tot2[ww] : 0u; }
-    dig_local[threadIdx.x] = before + incl - run;
-    dig_global[threadIdx.x] = excl + (before2 + incl2 - dtot);
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const int i = base + r * kWave + lane;
     if (i < n) {
-      const unsigned int d = (key[r] >> shift) & 255u;
-      const unsigned int lp = dig_local[d] + wave_cnt[w][d] + rank[r];
+      const unsigned int d = (key[r] >> shift) & kMask;
+      const unsigned int lp = (unsigned int)dig_local[d] + wave_cnt[w][d] + rank[r];
       lkey[lp] = key[r];
       lval[lp] = val[r];
     }
@@ -714,7 +753,7 @@ __global__ void __launch_bounds__(kBlock) k_sort_onesweep(const SlotDev* __restr
   const int tile_n = min(kSortTile, n - tile_i * kSortTile);
   for (int j = threadIdx.x; j < tile_n; j += kBlock) {
     const uint32_t kk = lkey[j];
-    const unsigned int d = (kk >> shift) & 255u;
+    const unsigned int d = (kk >> shift) & kMask;
     const unsigned int pos = dig_global[d] + ((unsigned int)j - dig_local[d]);
     keys_out[s.off + pos] = kk;
     vals_out[s.off + pos] = lval[j];

@@ -588,8 +588,10 @@ def test_nn_revalidation_shortcut_is_bitwise_neutral(gpu_ctx, fixture_clouds):
         p = s3d.default_params(registration_algorithm=alg, maximum_iterations=25)
         st0, T0, i0 = gpu_ctx.align(fixture_clouds[1], fixture_clouds[2], np.eye(4), p, s3d.ExecOptions(force_iterations=1))
         everything = A.DBG_NN_NO_REVALIDATE | A.DBG_NN_NO_FAR_SEED | A.DBG_NN_NO_COOP | A.DBG_NN_NO_COMPACT
-        for flags in (A.DBG_NN_NO_REVALIDATE, A.DBG_NN_NO_FAR_SEED, A.DBG_NN_NO_COOP, A.DBG_NN_NO_COMPACT, A.DBG_NN_NO_SETTLED,
-                      A.DBG_NN_NO_SETTLED | A.DBG_NN_NO_FAR_SEED, everything):
+        # (a single pair runs query by query unless DBG_NN_FORCE_SETTLED asks for the record-wise passes)
+        for flags in (A.DBG_NN_NO_REVALIDATE, A.DBG_NN_NO_FAR_SEED, A.DBG_NN_NO_COOP, A.DBG_NN_NO_COMPACT,
+                      A.DBG_NN_FORCE_SETTLED, A.DBG_NN_FORCE_SETTLED | A.DBG_NN_NO_FAR_SEED,
+                      A.DBG_NN_FORCE_SETTLED | A.DBG_NN_NO_COOP, everything):
             st1, T1, i1 = gpu_ctx.align(fixture_clouds[1], fixture_clouds[2], np.eye(4), p,
                                          s3d.ExecOptions(force_iterations=1, debug_flags=flags))
             assert st0 == st1 == 0 and np.array_equal(T0, T1) and i0 == i1, hex(flags)
@@ -610,7 +612,7 @@ def test_fast_paths_are_bitwise_neutral(gpu_ctx, fixture_clouds):
         st0, T0, i0 = gpu_ctx.align(src, tgt, np.eye(4), p, s3d.ExecOptions(force_iterations=force))
         assert st0 == 0
         for flags in (A.DBG_NN_NO_FIRST_KERNEL, A.DBG_NN_NO_SCAN27, A.DBG_NN_NO_FIRST_KERNEL | A.DBG_NN_NO_SCAN27,
-                      A.DBG_NN_NO_SETTLED, A.DBG_SCAN27_NO_COMPACT, A.DBG_KNN_EXACT64, A.DBG_SORT_CLASSIC,
+                      A.DBG_NN_FORCE_SETTLED, A.DBG_SCAN27_NO_COMPACT, A.DBG_KNN_EXACT64, A.DBG_SORT_CLASSIC,
                       A.DBG_SORT_ONESWEEP, A.DBG_SORT_FULL_KEYS, A.DBG_SORT_FULL_KEYS | A.DBG_SORT_CLASSIC):
             st1, T1, i1 = gpu_ctx.align(src, tgt, np.eye(4), p, s3d.ExecOptions(force_iterations=force, debug_flags=flags))
             assert st1 == 0 and np.array_equal(T0, T1) and i0 == i1, hex(flags)

@@ -42,12 +42,14 @@ def test_result_does_not_depend_on_the_batch(gpu_ctx, alg_name):
             for lo in (0, n - bs):
                 part = gpu_ctx.align_batch(src[lo:lo + bs], tgt[lo:lo + bs], None, p)
                 assert np.array_equal(part, full[lo:lo + bs]), (bs, lo)
-        for blocks in (1, 2, 16, 64):
+        for blocks in (1, 2, 16, 32):
             part = gpu_ctx.align_batch(src[:8], tgt[:8], None, p, s3d.ExecOptions(debug_accum_blocks=blocks))
             assert np.array_equal(part, full[:8]), blocks
-        # ... nor on whether the settled passes run record-wise or query by query
-        part = gpu_ctx.align_batch(src[:32], tgt[:32], None, p, s3d.ExecOptions(debug_flags=s3d.api.DBG_NN_NO_SETTLED))
+        # ... nor on whether the settled passes run record-wise (large batches) or query by query (small ones)
+        part = gpu_ctx.align_batch(src[:32], tgt[:32], None, p, s3d.ExecOptions(debug_flags=s3d.api.DBG_NN_FORCE_SETTLED))
         assert np.array_equal(part, full[:32])
+        part = gpu_ctx.align_batch(src, tgt, None, p, s3d.ExecOptions(debug_flags=s3d.api.DBG_NN_NO_SETTLED))
+        assert np.array_equal(part, full)
         # the host-buffer entry point on one pair
         st, T, info = gpu_ctx.align(pairs[3][0], pairs[3][1], np.eye(4), p)
         assert st == 0 and np.array_equal(s3d.api.record_transform(full[3])[:3], T[:3])
@@ -108,7 +110,7 @@ def test_every_ordered_pair_of_partly_overlapping_clouds(gpu_ctx):
         tgt = [dev[j] for _, j in idx]
         p = s3d.default_params(point_cloud_density=0.0, maximum_iterations=6, max_correspondence_distance=2.5)
         base = gpu_ctx.align_batch(src, tgt, None, p, s3d.ExecOptions(force_iterations=1))
-        for flags in (A.DBG_NN_NO_SCAN27, A.DBG_NN_NO_FIRST_KERNEL, A.DBG_NN_NO_SETTLED):
+        for flags in (A.DBG_NN_NO_SCAN27, A.DBG_NN_NO_FIRST_KERNEL, A.DBG_NN_FORCE_SETTLED):
             other = gpu_ctx.align_batch(src, tgt, None, p, s3d.ExecOptions(force_iterations=1, debug_flags=flags))
             assert np.array_equal(base, other), hex(flags)
         # neighbouring windows register (status OK), the result is deterministic
