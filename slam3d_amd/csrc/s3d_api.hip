@@ -155,7 +155,7 @@ struct s3d_context {
   s3d_map_profile map_prof{};
   // workspace (grown on demand, reused across calls)
   DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, sorted3, normals, moments, cell_start, counts, digit_tot, blockcnt, blockbb,
-      corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active, knn_list, knn_fallback, knn_redo, wave_recs, t_hist, worklist, rec_list, rec_counts;
+      corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active, knn_list, knn_fallback, knn_redo, wave_recs, t_hist, worklist, rec_list, rec_counts, search_list;
   int* h_active = nullptr;  // pinned
   // pinned staging of the slot / pair records (up and down): a copy from or to pageable memory stalls the stream for
   // tens of microseconds, which a single-pair registration of ~1.5 ms notices
@@ -507,7 +507,8 @@ struct Batch {
                 {&ctx->worklist, icp_buffers ? 8 * nc : 8},
                 {&ctx->wave_recs, sizeof(WaveRec) * (icp_buffers ? nc / kWave + 1 : 1)},
                 {&ctx->rec_list, sizeof(uint4) * (icp_buffers ? rec_list_entries() : 1)},
-                {&ctx->rec_counts, sizeof(int) * 2 * kNNRecSublists + sizeof(NNArrays)},
+                {&ctx->rec_counts, sizeof(int) * 4 * kNNRecSublists},
+                {&ctx->search_list, sizeof(uint2) * (icp_buffers && settled_wanted() ? (size_t)kNNRecSublists * (size_t)search_sub_cap() : 1)},
                 {&ctx->t_hist, sizeof(Mat4f) * (icp_buffers ? (size_t)std::max(1, P()) * (size_t)hist_stride() : 1)},
                 {&ctx->knn_list, sizeof(int) * (size_t)std::max(1, C())},
                 {&ctx->knn_fallback, sizeof(int) * npi}, {&ctx->knn_redo, sizeof(int2) * npi}});
@@ -536,14 +537,9 @@ struct Batch {
     }
     {
       const size_t bs = sizeof(SlotDev) * (size_t)C(), bp = sizeof(PairDev) * (size_t)P();
-      char* stage = ctx->stage_host(bs + bp + 16 + sizeof(NNArrays));
+      char* stage = ctx->stage_host(bs + bp + 16);
       if (bs) { std::memcpy(stage, h_slots.data(), bs); HIPCHK(hipMemcpyAsync(ctx->slots.p, stage, bs, hipMemcpyHostToDevice, st)); }
       if (bp) { std::memcpy(stage + bs, h_pairs.data(), bp); HIPCHK(hipMemcpyAsync(ctx->pairs.p, stage + bs, bp, hipMemcpyHostToDevice, st)); }
-      if (icp_buffers) {   // the array table in device memory: the out-of-line search of the touch kernels takes it by pointer
-        const NNArrays A = nn_arrays();
-        std::memcpy(stage + bs + bp + 16, &A, sizeof A);
-        HIPCHK(hipMemcpyAsync(nn_arrays_dev(), stage + bs + bp + 16, sizeof A, hipMemcpyHostToDevice, st));
-      }
     }
     restore_from_cache();
   }
@@ -739,7 +735,6 @@ struct Batch {
   // controller, read by the record-level re-validation of the settled passes and by the fitness pass)
   int hist_stride() const { return std::max(1, std::min(rp.max_iterations, 4096)); }
   WaveRec* wave_recs() { return (WaveRec*)ctx->wave_recs.p; }
-  NNArrays* nn_arrays_dev() { return (NNArrays*)((char*)ctx->rec_counts.p + sizeof(int) * 2 * kNNRecSublists); }
   Mat4f* t_hist() { return (Mat4f*)ctx->t_hist.p; }
   int dbg_nn = 0;   // the S3D_DBG_NN_* bits of s3d_exec_options.debug_flags (set_params)
   // prof_slot >= 0: count searched / unseeded queries of this launch into the profile counters.
@@ -786,39 +781,45 @@ struct Batch {
                                                       wc + ((it + 1) & 7));
       return;
     }
-    // passes 6 ...: record-level re-validation (s3d_nn_settled_kernel); S3D_DBG_NN_NO_SETTLED = query by query
+    // passes 6 ...: record-level re-validation (s3d_nn_record_*_kernel); S3D_DBG_NN_NO_SETTLED = query by query
     if (settled_on() && mode == 0 && it >= kSettledFrom) {
-      if (it == kSettledFrom) {                     // every record is evaluated (and gets its box): no test, no list
-        s3d_nn_record_touch_kernel<false><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc,
-                                                                   wave_recs(), t_hist(), hist_stride(), nullptr, 1, 0, nullptr,
-                                                                   nullptr, nn_arrays_dev());
-        return;
-      }
-      // two sets of list counters, used in turn (zeroed by stage_icp / by the touch kernel of the pass before)
+      // two sets of list counters, used in turn (zeroed by stage_icp / by the consuming kernel of the pass before):
+      // [set][0 .. 63] record lists, [set][64 .. 127] search lists
       int* sc = (int*)ctx->rec_counts.p;
+      int* cnt = sc + (it & 1) * 2 * kNNRecSublists;
+      int* cnt_next = sc + ((it + 1) & 1) * 2 * kNNRecSublists;
       uint4* rl = (uint4*)ctx->rec_list.p;
-      const int nrec = cdiv(std::max(max_n_t, 1), kWave);
-      const int rpt = rec_per_thread();
-      const int bpp = cdiv(nrec, kBlock * rpt);
-      const int nblocks = pairs8 * bpp;
-      const int nsub = std::min(kNNRecSublists, nblocks);
-      const int sub_cap = cdiv(nblocks, nsub) * kBlock * rpt;          // (every record of every block of a list failing)
-      int* cnt = sc + (it & 1) * kNNRecSublists;
-      int* cnt_next = sc + ((it + 1) & 1) * kNNRecSublists;
-      if (rpt == kNNRecPerThread)
-        s3d_nn_record_test_kernel<kNNRecPerThread><<<(unsigned)nblocks, kBlock, 0, st>>>(
-            d_pairs(), d_slots(), bpp, P(), wave_recs(), t_hist(), hist_stride(), cnt, nsub, sub_cap, rl, pc);
-      else
-        s3d_nn_record_test_kernel<1><<<(unsigned)nblocks, kBlock, 0, st>>>(
-            d_pairs(), d_slots(), bpp, P(), wave_recs(), t_hist(), hist_stride(), cnt, nsub, sub_cap, rl, pc);
-      // a fixed grid walks the lists: one record per wave and trip (at most as many waves as there are records)
-      // one wave per failing record while at most a quarter of the records fail (the waves without an entry leave after
-      // one load); beyond that the waves loop
-      const long long waves = std::max<long long>(std::min<long long>((long long)P() * nrec, 7168), (long long)P() * nrec / 4);
-      const int tblocks = std::max(cdiv(cdiv((int)waves, kBlock / kWave), nsub), 1) * nsub;   // a multiple of nsub blocks
-      s3d_nn_record_touch_kernel<true><<<(unsigned)tblocks, kBlock, 0, st>>>(
-          d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc, wave_recs(), t_hist(), hist_stride(), cnt, nsub, sub_cap, rl,
-          cnt_next, nn_arrays_dev());
+      uint2* sl = (uint2*)ctx->search_list.p;
+      const int scap = search_sub_cap();
+      if (it == kSettledFrom) {                     // every record is evaluated (and gets its box): no test, no list
+        s3d_nn_record_touch_kernel<false><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), wave_recs(),
+                                                                   t_hist(), hist_stride(), nullptr, 1, 0, nullptr, nullptr,
+                                                                   cnt + kNNRecSublists, scap, sl, pc);
+      } else {
+        const int nrec = cdiv(std::max(max_n_t, 1), kWave);
+        const int rpt = rec_per_thread();
+        const int bpp = cdiv(nrec, kBlock * rpt);
+        const int nblocks = pairs8 * bpp;
+        const int nsub = std::min(kNNRecSublists, nblocks);
+        const int sub_cap = cdiv(nblocks, nsub) * kBlock * rpt;          // (every record of every block of a list failing)
+        if (rpt == kNNRecPerThread)
+          s3d_nn_record_test_kernel<kNNRecPerThread><<<(unsigned)nblocks, kBlock, 0, st>>>(
+              d_pairs(), d_slots(), bpp, P(), wave_recs(), t_hist(), hist_stride(), cnt, nsub, sub_cap, rl, pc);
+        else
+          s3d_nn_record_test_kernel<1><<<(unsigned)nblocks, kBlock, 0, st>>>(
+              d_pairs(), d_slots(), bpp, P(), wave_recs(), t_hist(), hist_stride(), cnt, nsub, sub_cap, rl, pc);
+        // one wave per failing record while at most a quarter of the records fail (the waves without an entry leave
+        // after one load); beyond that the waves loop
+        const long long waves = std::max<long long>(std::min<long long>((long long)P() * nrec, 7168), (long long)P() * nrec / 4);
+        const int tblocks = std::max(cdiv(cdiv((int)waves, kBlock / kWave), nsub), 1) * nsub;   // a multiple of nsub blocks
+        s3d_nn_record_touch_kernel<true><<<(unsigned)tblocks, kBlock, 0, st>>>(
+            d_pairs(), d_slots(), A, max_d, chunks, P(), wave_recs(), t_hist(), hist_stride(), cnt, nsub, sub_cap, rl, cnt_next,
+            cnt + kNNRecSublists, scap, sl, pc);
+      }
+      // the queries that failed their re-validation: the general search, eight per wave (16 waves per list)
+      s3d_nn_record_search_kernel<<<16 * kNNRecSublists, kWave, 0, st>>>(d_pairs(), d_slots(), A, max_d, dbg_nn,
+                                                                         cnt + kNNRecSublists, scap, sl,
+                                                                         cnt_next + kNNRecSublists);
       return;
     }
     const int cmp = (compact && mode == 0 && !(dbg_nn & 65536)) ? 1 : 0;
@@ -832,6 +833,20 @@ struct Batch {
   static constexpr int kSettledFrom = 5;   // first outer iteration (0-based) that runs record-wise
   // records per thread of the test kernel: four for a large batch (few blocks, one list append each), one for a small one
   int rec_per_thread() const { return (long long)P() * cdiv(std::max(max_n_t, 1), kWave) >= 65536 ? kNNRecPerThread : 1; }
+  // capacity of one of the kNNRecSublists search lists: every query of the records the waves of a list can touch -
+  // the listed form (a list of failing records per sublist) and the first pass (block b -> list b % 64)
+  int search_sub_cap() const {
+    const int chunks = cdiv(std::max(max_n_t, 1), kBlock);
+    const int pairs8 = P() >= 8 ? cdiv(P(), 8) * 8 : std::max(P(), 1);
+    const long long a = (long long)(rec_list_entries() / (size_t)std::max(1, std::min(kNNRecSublists, rec_blocks()))) * kWave;
+    const long long b = (long long)cdiv(pairs8 * chunks, kNNRecSublists) * kBlock;
+    return (int)std::min<long long>(std::max(a, b), 0x7FFFFFF0);
+  }
+  int rec_blocks() const {
+    const int nrec = cdiv(std::max(max_n_t, 1), kWave), rpt = rec_per_thread();
+    const int pairs8 = P() >= 8 ? cdiv(P(), 8) * 8 : std::max(P(), 1);
+    return pairs8 * cdiv(nrec, kBlock * rpt);
+  }
   size_t rec_list_entries() const {
     const int nrec = cdiv(std::max(max_n_t, 1), kWave), rpt = rec_per_thread();
     const int pairs8 = P() >= 8 ? cdiv(P(), 8) * 8 : std::max(P(), 1);
@@ -843,10 +858,11 @@ struct Batch {
   // (a small batch keeps the per-query kernel: a record-wise pass is two launches whose second one ends with the few
   // searches of the pass, which the per-query kernel hides among its 1 500 waves per pair.  Measured, settled pass per
   // query / per record: 1 pair 11 / 16 us, 32 pairs equal, 128 pairs 0.100 / 0.055 ms, 256 pairs 0.196 / 0.089 ms)
-  bool settled_on() const {
-    return settled_used && !(dbg_nn & (S3D_DBG_NN_NO_SETTLED | 262144 | 64 | 32 | 4)) &&
+  bool settled_wanted() const {
+    return !(dbg_nn & (S3D_DBG_NN_NO_SETTLED | 262144 | 64 | 32 | 4)) &&
            ((long long)P() * cdiv(std::max(max_n_t, 1), kWave) >= 65536 || (opts.debug_flags & S3D_DBG_NN_FORCE_SETTLED));
   }
+  bool settled_on() const { return settled_used && settled_wanted(); }
 
   // one outer iteration: correspondences (K5), accumulate (K6), controller (K7)
   void launch_iteration(int it, float max_d, int prof_slot) {
@@ -878,7 +894,7 @@ struct Batch {
     HIPCHK(hipMemsetAsync((int*)ctx->n_active.p + 8, 0, 8 * sizeof(int), st));   // worklist counters of the scan27 passes
     // the 64-query records of the settled passes: touch = -1 ("never evaluated record-wise")
     HIPCHK(hipMemsetAsync(ctx->wave_recs.p, 0xFF, sizeof(WaveRec) * (std::max<size_t>(total_corr, 4) / kWave + 1), st));
-    HIPCHK(hipMemsetAsync(ctx->rec_counts.p, 0, sizeof(int) * 2 * kNNRecSublists, st));   // the record-list counters
+    HIPCHK(hipMemsetAsync(ctx->rec_counts.p, 0, sizeof(int) * 4 * kNNRecSublists, st));   // the record / search list counters
 
     settled_used = true;
     const float max_d = (float)(rp.max_corr * 1.0001);

@@ -1101,6 +1101,14 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN3_WAVES) s3d_knn3_moments_kerne
   fallback_list[atomicAdd(fallback_count, 1)] = s.off + i;
 }
 
+// (Round 4, measured and dropped: the SHELL stage compacted over the block.  Half of the benchmark's queries need the
+// 5x5x5 shell to prove their 20 neighbours and two thirds of those find nothing in it, yet every wave pays the stage -
+// 2 040 of its 5 920 instructions - because every wave has such a lane.  A kernel that lets the 256 queries of a block
+// change hands between the stages (key lists through LDS, 21 words per query; the shell queries packed into the first
+// waves, only those waves run the stage) returns the same normals bit for bit and takes 10.7 ms instead of 7.4: the
+// exchange buffer makes it 40 KB of LDS per block = 4 waves per SIMD, and THIS kernel needs its waves - 11.1 ms at 4
+// per SIMD, 7.7 at 6, 7.4 at 8.  At equal occupancy the compaction is worth 4 %, not the 14 % of the instruction
+// count: the two waves of a block that have no shell query finish early, but their LDS stays with the block.)
 // the queries s3d_knn3_moments_kernel listed, through the exact search; a fixed grid strides over the list.
 // THIN (the host asks for it when the batch is small): the list is dealt one entry per wave while the waves last, then
 // eight - an exact search is a long chain of dependent steps and the lanes of a wave serialise their different paths,
@@ -1322,22 +1330,12 @@ struct NNArrays {
   NormalRec* __restrict__ corr_n;
 };
 
-template <int MODE, int PHASE>
-__device__ __forceinline__ void nn_query_search(const PairDev& P, const SlotDev& Ss, int ci, bool need, const F3& q,
-                                                float move, const NNArrays& A, float max_d, int dbg,
-                                                int* __restrict__ prof_counts, int* out_class, float* out_margin,
-                                                float pre_prev = 0.f, int pre_seed = -1);
-
-// PHASE 6 (the record-wise settled passes, round 4): PHASE 0 for one RECORD of 64 queries that failed the record-level proof -
-// the previous positions are those under Tref (the transformation_ of the record's last full evaluation, not of the
-// previous pass), *out_margin receives the query's margin for the next record-level proof (nn_margin; +inf for a lane
-// without a query), and the round-1 A/B switches are compiled out.
+// Tref: the transformation_ of the pass the stored bounds corr_lb refer to - the previous pass in the ICP loop
+// (P.T_nn); in the fitness pass, after record-wise settled passes, that of the record's last full evaluation.
 template <int MODE, int PHASE>
 __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, const SlotDev& Ss, int pair, int i,
                                          bool need, const NNArrays& A, float max_d, int dbg,
-                                         int* __restrict__ prof_counts, int* out_class, const Mat4f& Tref,
-                                         float* out_margin = nullptr) {
-  if (PHASE == 6) *out_margin = 3.0e38f;
+                                         int* __restrict__ prof_counts, int* out_class, const Mat4f& Tref) {
   const int ci = P.corr_off + (need ? i : 0);
   // queries are taken in the CELL-SORTED order of their own cloud (spatially coherent waves)
   const CorrVec p0 = A.sorted3[St.off + (need ? i : 0)];
@@ -1355,43 +1353,28 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   float move = 3.0e38f;                          // how far this query moved since the previous pass (if known)
   if (need && lbs != 0.f && !(dbg & 64)) {
     // re-validate the previous result by the triangle inequality (s3d_core.h nn_still_nearest)
-    const F3 qo = xf_eigen(Tref, pg.x, pg.y, pg.z);     // where this query stood in the previous pass
+    const F3 qo = xf_eigen(Tref, pg.x, pg.y, pg.z);     // where this query stood at the pass the stored bounds refer to
     move = sqrtf(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
     if (PHASE != 2) {                                    // (a PHASE 2 query has failed this test already)
       if (lbs > 0.f) {
         const CorrVec ps = A.corr_q[ci];                  // the neighbour itself travels with the correspondence
         const float d2n = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z);
-        const float dn = sqrtf(d2n);
-        if (nn_still_nearest(dn, move, lb)) {
+        if (nn_still_nearest(sqrtf(d2n), move, lb)) {
           // same point, its exact new distance: the accumulate kernels recompute it from the copy of the neighbour
           // (bit for bit: the same float operations), only the fitness kernel reads the stored value
           if (MODE != 0) A.corr_d2[ci] = d2n;
           A.corr_lb[ci] = lb - move;                     // still a lower bound for the others (> 0: the test above)
-          if (PHASE == 6) *out_margin = nn_margin(true, lb - move, dn, max_d);
           need = false;
         }
       } else if (nn_still_nearest(max_d, move, lb)) {
         // no point at all within lb of the previous position, lb > max_d: still none within max_d
         A.corr_lb[ci] = move - lb;                       // (< 0)
-        if (PHASE == 6) *out_margin = nn_margin(false, lb - move, 0.f, max_d);
         need = false;
       }
     }
   }
-  nn_query_search<MODE, PHASE>(P, Ss, ci, need, q, move, A, max_d, dbg, prof_counts, out_class, out_margin);
-}
-
-// the second half of nn_query: the search of a query that was not re-validated, and the stores of its result
-template <int MODE, int PHASE>
-__device__ __forceinline__ void nn_query_search(const PairDev& P, const SlotDev& Ss, int ci, bool need, const F3& q,
-                                                float move, const NNArrays& A, float max_d, int dbg,
-                                                int* __restrict__ prof_counts, int* out_class, float* out_margin,
-                                                float pre_prev, int pre_seed) {
-  constexpr bool kAB = S3D_NN_AB && PHASE != 6;
-  // radius hint: this query's distance in the previous pass (NaN-filled before the first one).  PHASE 6: the touch
-  // kernel has fetched it, and the previous neighbour's position, with the record's other data (a search there is a
-  // chain of dependent loads with nothing to hide behind: two links less)
-  const float prev = PHASE == 5 ? __int_as_float(0x7FC00000) : PHASE == 6 ? (need ? pre_prev : 0.f) : (need ? A.corr_d2[ci] : 0.f);
+  // radius hint: this query's distance in the previous pass (NaN-filled before the first one)
+  const float prev = PHASE == 5 ? __int_as_float(0x7FC00000) : (need ? A.corr_d2[ci] : 0.f);
   if (PHASE == 3) {   // classify only: 0 = near seed, 1 = wide, 2 = nothing to do (block-level compaction follows)
     const bool near_c = need && prev >= 0.f && prev < 1.0e30f && prev < Ss.g.h * Ss.g.h;
     *out_class = need ? (near_c ? 0 : 1) : 2;
@@ -1406,10 +1389,10 @@ __device__ __forceinline__ void nn_query_search(const PairDev& P, const SlotDev&
   const bool has_prev = prev >= 0.f && prev < 1.0e30f;
   const bool near_seed = has_prev && prev < Ss.g.h * Ss.g.h;
   const bool far_seed = has_prev && !near_seed && move < kNNRevalSlack * Ss.g.h && !(dbg & 128);
-  const int seed = ((near_seed || far_seed) && !(kAB && (dbg & 32))) ? (PHASE == 6 ? pre_seed : A.corr_idx[ci]) : -1;
+  const int seed = ((near_seed || far_seed) && !(S3D_NN_AB && (dbg & 32))) ? A.corr_idx[ci] : -1;
   // first pass (nothing known yet): a generous three-cell box — the shrinking-ball scan makes a large
   // initial radius cheap, while a small one costs a second scan for every badly aligned query
-  const float first = (!kAB ? 3.0f : (dbg & 256) ? 1.0f : (dbg & 512) ? 1.5f : (dbg & 1024) ? 2.0f : 3.0f) * Ss.g.h;
+  const float first = (!S3D_NN_AB ? 3.0f : (dbg & 256) ? 1.0f : (dbg & 512) ? 1.5f : (dbg & 1024) ? 2.0f : 3.0f) * Ss.g.h;
   const float hint = has_prev ? fminf(sqrtf(prev) * 1.25f + 0.05f * Ss.g.h, Ss.g.h) : first;
   if (prof_counts) {   // profile >= 2 only: how many queries search, how many of them without a near seed
     const unsigned long long all = __ballot(need), un = __ballot(need && !near_seed);
@@ -1422,7 +1405,7 @@ __device__ __forceinline__ void nn_query_search(const PairDev& P, const SlotDev&
   r.idx = -1; r.d2 = 3.0e38f; r.pos = -1; r.second_d2 = 3.0e38f; r.radius = 0.f;
   const uint32_t* __restrict__ cs = A.cell_start + Ss.cell_off;
   const float4* __restrict__ tp = A.sorted + Ss.off;
-  if (kAB && (dbg & 4)) {
+  if (S3D_NN_AB && (dbg & 4)) {
     if (need) r = grid_nn1(Ss.g, cs, tp, q.x, q.y, q.z, max_d);
   } else {
     // served by the whole wave, one query after the other: the queries that will walk a wide box when they are
@@ -1451,19 +1434,15 @@ __device__ __forceinline__ void nn_query_search(const PairDev& P, const SlotDev&
   // the target's cell-sorted array: every later access (K6, fitness) is then coalesced or a local gather
   A.corr_idx[ci] = r.pos;
   A.corr_d2[ci] = r.d2;
-  const float lbv = !(kAB && (dbg & 4)) ? nn_lower_bound_others(r) : 0.f;   // no neighbour at all: the scanned radius
+  const float lbv = !(S3D_NN_AB && (dbg & 4)) ? nn_lower_bound_others(r) : 0.f;   // no neighbour at all: the scanned radius
   // (first pass: the runner-up is not tracked - "nothing known" about the others; the second pass searches every
   // query again anyway, the first transform update has moved them all)
   A.corr_lb[ci] = r.pos >= 0 ? (PHASE == 5 ? 0.f : lbv) : -lbv;
-  if (PHASE == 6) *out_margin = nn_margin(r.pos >= 0, lbv, r.pos >= 0 ? sqrtf(r.d2) : 0.f, max_d);
   if (r.pos >= 0) {
     // a copy of the matched point and of its normal is kept with the correspondence: the re-validation
     // above and the accumulate kernel then stream them instead of gathering by index
-    // (PHASE 6: the search of a settled registration usually confirms the neighbour - its copies are in place)
-    if (!(PHASE == 6 && r.pos == pre_seed)) {
-      A.corr_q[ci] = corr_vec(A.sorted[Ss.off + r.pos]);
-      A.corr_n[ci] = A.normals[Ss.off + r.pos];
-    }
+    A.corr_q[ci] = corr_vec(A.sorted[Ss.off + r.pos]);
+    A.corr_n[ci] = A.normals[Ss.off + r.pos];
   } else if (MODE == 0) {
     // no neighbour within max_d: a neighbour at infinity, so that the distance the accumulate kernels compute from
     // this copy fails their threshold like the stored 3e38 did
@@ -1562,14 +1541,14 @@ __global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_search_kernel(con
 // positions, their smallest margin, the pass of their last full evaluation) tests the record against the displacement
 // between the current transformation_ and that pass's - kept per pair and pass by the controller (T_hist) - and a
 // record that passes is left alone: nothing of its queries is read or written.  The records that fail are appended
-// to a list (one atomic per wave that has any).  s3d_nn_record_touch_kernel<true>: a fixed grid of waves walks the
-// list, one record per wave and trip, through the per-query path (nn_query PHASE 6: re-validation against the touch
-// pass, search of what fails it), which re-establishes margin and touch pass.  The first record-wise pass of a
-// registration evaluates every record: s3d_nn_record_touch_kernel<false>, the per-query kernel's launch geometry, no
-// list.  (One kernel that tests, packs the failing records in LDS and serves them was built first: 0.064 ms per
-// settled pass of 128 pairs against 0.098 query by query, with 88 % of the records skipped - every block pays the
-// chain pair record -> record -> touch transform -> test -> barrier before its first failing record, and its waves
-// then take their records one after the other.)
+// to a list.  s3d_nn_record_touch_kernel<true>: a fixed grid of waves walks the
+// list, one record per wave and trip, through nn_query's re-validation (against the transformation_ of the touch
+// pass; a query that fails it goes to a search list, see below), which re-establishes margin and touch pass.  The
+// first record-wise pass of a registration evaluates every record: s3d_nn_record_touch_kernel<false>, the per-query
+// kernel's launch geometry, no list.  (One kernel that tests, packs the failing records in LDS and serves them was
+// built first: 0.064 ms per settled pass of 128 pairs against 0.098 query by query, with 88 % of the records skipped -
+// every block pays the chain pair record -> record -> touch transform -> test -> barrier before its first failing
+// record, and its waves then take their records one after the other.)
 // The neighbours, distances and copies left in corr_* are those of the per-query kernel bit for bit - every skipped
 // query is proven unchanged, by a weaker inequality than nn_still_nearest's - and so are the registrations
 // (S3D_DBG_NN_NO_SETTLED in s3d_exec_options.debug_flags switches the record test off; tests/test_gpu_parity.py).
@@ -1653,48 +1632,28 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_record_test_kernel(const PairDe
     if (fail[j]) out[before[j] + at[j]] = nn_record_entry(pair, rec[j], W[j].touch, P.corr_off, St.off, St.n);
 }
 
-// The search of the lanes of a record that failed their own re-validation, OUT OF LINE: inlined, its registers are the
-// touch kernel's, the 72-register cap spills, and the spills land in the re-validation stream that every lane runs
-// (measured: the first record-wise pass 0.185 ms per 128 pairs against 0.110 for the per-query kernel).  A call costs
-// nothing where it is not taken, and in a settled pass one query in 5 000 searches.  Returns the lane's margin.
-__device__ __noinline__ float nn_record_search(const PairDev* Pp, const SlotDev* Ssp, int ci, int need, float qx, float qy,
-                                               float qz, float move, float prev, int seed, const NNArrays* Ap,
-                                               float max_d, int dbg, int* prof_counts) {
-  // (the pointers are wave-uniform but arrive in vector registers: back to scalar ones, so that the records load as
-  // scalars again)
-  auto uni = [](const void* p) {
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return (const void*)(((unsigned long long)hi << 32) | lo);
-  };
-  const PairDev& P = *(const PairDev*)uni(Pp);
-  const SlotDev& Ss = *(const SlotDev*)uni(Ssp);
-  const NNArrays A = *(const NNArrays*)uni(Ap);
-  F3 q; q.x = qx; q.y = qy; q.z = qz;
-  float margin = 3.0e38f;
-  nn_query_search<0, 6>(P, Ss, ci, need != 0, q, move, A, max_d, __builtin_amdgcn_readfirstlane(dbg),
-                        (int*)uni(prof_counts), nullptr, &margin, prev, seed);
-  return margin;
-}
-
-// (waves per SIMD: the listed form is bound by the latency of its few searches - 5 waves, 96 registers: 0.055 ->
-// 0.050 ms per settled pass of 128 pairs; the first record-wise pass streams every query - 7 waves: 0.161 ms, 0.188 at 5)
+// A query of a touched record that fails its own re-validation needs a search.  Not here: a search is a chain of a
+// dozen dependent loads, a settled pass has a few thousand of them among 25 million queries, and in a kernel that only
+// visits the failing records nothing hides them - the launch ended 30-60 us after its last re-validation, waiting
+// for the waves that searched (inlined, or out of line: the same; the per-query kernel hides the same searches among
+// its 400 000 waves).  The lanes are appended to kNNRecSublists search lists instead ((pair, index) as in the lists
+// of the scan27 passes; one atomic per wave that has any, on the counter of the wave's list) and
+// s3d_nn_record_search_kernel serves them right after, eight queries per wave.  The record's margin is then -1: it is
+// evaluated again in the next pass, when its searched queries carry fresh bounds.
 template <bool LISTED>
-__global__ void __launch_bounds__(kBlock, LISTED ? 5 : S3D_NN_WAVES) s3d_nn_record_touch_kernel(const PairDev* __restrict__ pairs,
-                                                                      const SlotDev* __restrict__ slots, NNArrays A,
-                                                                      float max_d, int chunks_per_pair, int npairs,
-                                                                      int dbg, int* __restrict__ prof_counts,
-                                                                      WaveRec* __restrict__ recs,
-                                                                      const Mat4f* __restrict__ T_hist, int hist_stride,
-                                                                      const int* __restrict__ list_counts, int nsub,
-                                                                      int sub_cap, const uint4* __restrict__ list,
-                                                                      int* __restrict__ list_counts_next,
-                                                                      const NNArrays* __restrict__ A_dev) {
+__global__ void __launch_bounds__(kBlock, 8) s3d_nn_record_touch_kernel(const PairDev* __restrict__ pairs,
+                                                           const SlotDev* __restrict__ slots, NNArrays A, float max_d,
+                                                           int chunks_per_pair, int npairs, WaveRec* __restrict__ recs,
+                                                           const Mat4f* __restrict__ T_hist, int hist_stride,
+                                                           const int* __restrict__ list_counts, int nsub, int sub_cap,
+                                                           const uint4* __restrict__ list,
+                                                           int* __restrict__ list_counts_next,
+                                                           int* __restrict__ search_counts, int search_cap,
+                                                           uint2* __restrict__ search_list, int* __restrict__ prof_counts) {
   const int lane = lane_id();
   // LISTED: the four waves of a block take four consecutive entries of ONE list - the records a block of the test
   // kernel appended together belong to one pair, whose records then come through the scalar cache once per block
-  const int sub = LISTED ? (int)(blockIdx.x % (unsigned)nsub) : 0;
+  const int sub = LISTED ? (int)(blockIdx.x % (unsigned)nsub) : (int)(blockIdx.x % (unsigned)kNNRecSublists);
   const int step = LISTED ? ((int)gridDim.x / nsub) * (kBlock / kWave) : 1;   // (the grid is a multiple of nsub blocks)
   const int count = LISTED ? list_counts[sub] : 1;
   if (LISTED && (int)blockIdx.x == 0 && (int)threadIdx.x < nsub) list_counts_next[threadIdx.x] = 0;   // the next pass's test appends here
@@ -1733,8 +1692,6 @@ __global__ void __launch_bounds__(kBlock, LISTED ? 5 : S3D_NN_WAVES) s3d_nn_reco
     const CorrVec p0 = A.sorted3[qbase + (valid ? lane : 0)];
     const float lbs = A.corr_lb[ci];
     const CorrVec ps = A.corr_q[ci];
-    const float prev_d2 = A.corr_d2[ci];      // (the radius hint and the seed of a search: see nn_query_search)
-    const int prev_pos = A.corr_idx[ci];
     const PairDev& P = pairs[pair];
     // LISTED = false is the first record-wise pass of a registration: no record has been evaluated yet
     const bool have = LISTED && touch >= 0 && touch < hist_stride;
@@ -1744,10 +1701,10 @@ __global__ void __launch_bounds__(kBlock, LISTED ? 5 : S3D_NN_WAVES) s3d_nn_reco
     const F3 q = xf_eigen(P.T, pg.x, pg.y, pg.z);
     const float lb = fabsf(lbs);
     bool need = valid;
-    float move = 3.0e38f, margin = 3.0e38f;
+    float margin = 3.0e38f;
     if (valid && lbs != 0.f) {
       const F3 qo = xf_eigen(Tref, pg.x, pg.y, pg.z);
-      move = sqrtf(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
+      const float move = sqrtf(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
       if (lbs > 0.f) {
         const float dn = sqrtf(dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z));
         if (nn_still_nearest(dn, move, lb)) {
@@ -1761,10 +1718,17 @@ __global__ void __launch_bounds__(kBlock, LISTED ? 5 : S3D_NN_WAVES) s3d_nn_reco
         need = false;
       }
     }
-    if (__ballot(need) != 0ull) {
-      const float m = nn_record_search(&P, &slots[P.slot_s], ci, need ? 1 : 0, q.x, q.y, q.z, move, prev_d2, prev_pos, A_dev,
-                                       max_d, dbg, prof_counts);
-      if (need) margin = m;
+    const unsigned long long nmask = __ballot(need);
+    if (nmask != 0ull) {      // its searches: to the list of this wave's sublist
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&search_counts[sub], (int)__popcll(nmask));
+      base = __shfl(base, 0, kWave);
+      if (need) {
+        const int k = base + (int)__popcll(nmask & ((1ull << lane) - 1ull));
+        if (k < search_cap)   // (cannot overflow: a list holds every query of the records its waves can touch)
+          search_list[(size_t)sub * search_cap + k] = make_uint2((unsigned)pair, (unsigned)(ci - P.corr_off));
+      }
+      margin = -1.0f;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) margin = fminf(margin, __shfl_xor(margin, o, kWave));
@@ -1796,7 +1760,34 @@ __global__ void __launch_bounds__(kBlock, LISTED ? 5 : S3D_NN_WAVES) s3d_nn_reco
       W->margin = margin;
       W->touch = P.iterations;
     }
+    if (prof_counts && nmask != 0ull && lane == 0) atomicAdd(&prof_counts[0], (int)__popcll(nmask));
     if (!LISTED) return;
+  }
+}
+
+// the queries the touch kernel listed, through the general search (nn_query PHASE 2: "has failed its re-validation
+// already"), kNNRecSublists lists: block b serves list b % kNNRecSublists.  One wave per block, eight queries per wave
+// while the waves last (their searches diverge, and a wave serialises its lanes' paths: the lists' latency is what
+// counts), 64 beyond.  The lanes of a wave serve different pairs: no wave-cooperative search.
+__global__ void __launch_bounds__(kWave) s3d_nn_record_search_kernel(const PairDev* __restrict__ pairs,
+                                                                      const SlotDev* __restrict__ slots, NNArrays A,
+                                                                      float max_d, int dbg,
+                                                                      const int* __restrict__ search_counts, int search_cap,
+                                                                      const uint2* __restrict__ search_list,
+                                                                      int* __restrict__ search_counts_next) {
+  const int sub = (int)(blockIdx.x % (unsigned)kNNRecSublists), part = (int)blockIdx.x / kNNRecSublists;
+  const int parts = (int)gridDim.x / kNNRecSublists;
+  const int count = imin(search_counts[sub], search_cap);
+  if ((int)blockIdx.x == 0 && (int)threadIdx.x < kNNRecSublists) search_counts_next[threadIdx.x] = 0;   // the next pass appends here
+  const uint2* __restrict__ mylist = search_list + (size_t)sub * search_cap;
+  const int per = count <= 8 * parts ? 8 : kWave;
+  for (int j0 = part * per; j0 < count; j0 += parts * per) {   // (whole waves stay: nn_query votes)
+    const int j = j0 + (int)threadIdx.x;
+    const bool need = (int)threadIdx.x < per && j < count;
+    const uint2 e = mylist[need ? j : 0];
+    const int pair = (int)e.x, i = (int)e.y;
+    const PairDev& P = pairs[pair];
+    nn_query<0, 2>(P, slots[P.slot_t], slots[P.slot_s], pair, i, need, A, max_d, dbg | 2048, nullptr, nullptr, P.T_nn);
   }
 }
 

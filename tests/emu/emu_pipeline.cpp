@@ -389,7 +389,9 @@ int emu_align(const float* source, int n_source, int stride_source, const float*
         const size_t first = (i / 64) * 64, last = std::min(first + 64, T.pts.size()) - 1;
         static float run_min, mn[3], mx[3];
         if (i == first) { run_min = 3.0e38f; for (int a = 0; a < 3; ++a) { mn[a] = 3.0e38f; mx[a] = -3.0e38f; } }
-        run_min = std::fmin(run_min, m);
+        // (a record with a searched query is evaluated again in the next pass: its searches run in a kernel of their own,
+        // after the record has been written - s3d_nn_record_touch_kernel)
+        run_min = std::fmin(run_min, revalidated ? m : -1.f);
         const float pv[3] = {p.x, p.y, p.z};
         for (int a = 0; a < 3; ++a) { mn[a] = std::fmin(mn[a], pv[a]); mx[a] = std::fmax(mx[a], pv[a]); }
         if (i == last) {
