@@ -508,7 +508,7 @@ struct Batch {
                 {&ctx->wave_recs, sizeof(WaveRec) * (icp_buffers ? nc / kWave + 1 : 1)},
                 {&ctx->rec_list, sizeof(uint4) * (icp_buffers ? rec_list_entries() : 1)},
                 {&ctx->rec_counts, sizeof(int) * 4 * kNNRecSublists},
-                {&ctx->search_list, sizeof(uint2) * (icp_buffers && settled_wanted() ? (size_t)kNNRecSublists * (size_t)search_sub_cap() : 1)},
+                {&ctx->search_list, sizeof(uint4) * (icp_buffers && settled_wanted() ? (size_t)kNNRecSublists * (size_t)search_sub_cap() : 1)},
                 {&ctx->t_hist, sizeof(Mat4f) * (icp_buffers ? (size_t)std::max(1, P()) * (size_t)hist_stride() : 1)},
                 {&ctx->knn_list, sizeof(int) * (size_t)std::max(1, C())},
                 {&ctx->knn_fallback, sizeof(int) * npi}, {&ctx->knn_redo, sizeof(int2) * npi}});
@@ -789,7 +789,7 @@ struct Batch {
       int* cnt = sc + (it & 1) * 2 * kNNRecSublists;
       int* cnt_next = sc + ((it + 1) & 1) * 2 * kNNRecSublists;
       uint4* rl = (uint4*)ctx->rec_list.p;
-      uint2* sl = (uint2*)ctx->search_list.p;
+      uint4* sl = (uint4*)ctx->search_list.p;
       const int scap = search_sub_cap();
       if (it == kSettledFrom) {                     // every record is evaluated (and gets its box): no test, no list
         s3d_nn_record_touch_kernel<false><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), wave_recs(),
@@ -816,8 +816,8 @@ struct Batch {
             d_pairs(), d_slots(), A, max_d, chunks, P(), wave_recs(), t_hist(), hist_stride(), cnt, nsub, sub_cap, rl, cnt_next,
             cnt + kNNRecSublists, scap, sl, pc);
       }
-      // the queries that failed their re-validation: the general search, eight per wave (16 waves per list)
-      s3d_nn_record_search_kernel<<<16 * kNNRecSublists, kWave, 0, st>>>(d_pairs(), d_slots(), A, max_d, dbg_nn,
+      // the queries that failed their re-validation: one per wave and trip (a settled pass of 256 pairs lists ~4 000)
+      s3d_nn_record_search_kernel<<<(unsigned)(search_parts() * kNNRecSublists), kWave, 0, st>>>(d_pairs(), d_slots(), A, max_d, dbg_nn,
                                                                          cnt + kNNRecSublists, scap, sl,
                                                                          cnt_next + kNNRecSublists);
       return;
@@ -841,6 +841,10 @@ struct Batch {
     const long long a = (long long)(rec_list_entries() / (size_t)std::max(1, std::min(kNNRecSublists, rec_blocks()))) * kWave;
     const long long b = (long long)cdiv(pairs8 * chunks, kNNRecSublists) * kBlock;
     return (int)std::min<long long>(std::max(a, b), 0x7FFFFFF0);
+  }
+  int search_parts() const {   // waves per search list: about one per 3 000 queries of the batch, 1 ... 256
+    const long long q = (long long)P() * std::max(max_n_t, 1);
+    return (int)std::max<long long>(1, std::min<long long>(256, q / (3000ll * kNNRecSublists)));
   }
   int rec_blocks() const {
     const int nrec = cdiv(std::max(max_n_t, 1), kWave), rpt = rec_per_thread();

@@ -410,7 +410,10 @@ constexpr float kNNRevalSlack = 0.25f;   // in cells
 template <bool FAST = false, typename F4T>
 S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ cell_start,
                              const F4T* __restrict__ pts, float qx, float qy, float qz, float max_d, float d_hint,
-                             int seed_pos = -1, bool seed_trusted = false) {
+                             int seed_pos = -1, bool seed_trusted = false, float seed_d2 = -1.f) {
+  // seed_d2 >= 0 (with seed_pos < 0): the squared distance of a point KNOWN to exist, e.g. the previous neighbour seen
+  // through the copy that travels with the correspondence - it sizes the first box exactly as a seed does, without
+  // the load of the seed itself (the scan meets the point anyway): one link less in a chain of dependent loads
   NNResult best;
   best.idx = -1; best.d2 = 3.0e38f; best.pos = -1; best.second_d2 = 3.0e38f; best.radius = 0.f;
   double bkey = __builtin_bit_cast(double, kNNFastNone);   // (FAST only)
@@ -426,6 +429,9 @@ S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ c
     // nn_still_nearest() prove the correspondence without a search (lower bound of the other points).
     // (an untrusted seed that ended up far away — the transform just moved — must not blow the box up)
     d = sqrtf(best.d2) * 1.0001f + 1.0e-6f + kNNRevalSlack * g.h;
+    d = fminf(seed_trusted ? d : fminf(d, g.h), cap);
+  } else if (seed_d2 >= 0.f) {
+    d = sqrtf(seed_d2) * 1.0001f + 1.0e-6f + kNNRevalSlack * g.h;
     d = fminf(seed_trusted ? d : fminf(d, g.h), cap);
   }
   for (int attempt = 0; attempt < 64; ++attempt) {

@@ -1195,19 +1195,24 @@ constexpr int kCoopAllLanes = 3;    // this few searching lanes in a wave: serve
 #endif
 __device__ S3D_COOP_INLINE NNResult wave_nn1_coop(const GridParams& g, const uint32_t* __restrict__ cell_start,
                                                   const float4* __restrict__ pts, float qx, float qy, float qz,
-                                                  float max_d, float d_hint, int seed_pos, bool seed_trusted) {
-  // all arguments are wave-uniform
+                                                  float max_d, float d_hint, int seed_pos, bool seed_trusted,
+                                                  float seed_d2 = -1.f) {
+  // all arguments are wave-uniform.  seed_d2 >= 0 (with seed_pos < 0): the squared distance of a point known to exist
+  // sizes the first box as a seed does, without the load of the seed (grid_nn1_box)
   const int lane = lane_id();
   NNResult best;
   best.idx = -1; best.d2 = 3.0e38f; best.pos = -1; best.second_d2 = 3.0e38f; best.radius = 0.f;
   const float cap = max_d + kNNRevalSlack * g.h;
   // every seeded search examines a shell beyond the neighbour: that is what the next pass re-validates against
-  const float shell = seed_pos >= 0 ? kNNRevalSlack * g.h : 0.f;
+  const float shell = (seed_pos >= 0 || seed_d2 >= 0.f) ? kNNRevalSlack * g.h : 0.f;
   float d = fminf(fmaxf(d_hint, 0.25f * g.h), cap);
   double unused_key = 0.0;   // (nn1_consider's packed key: the FAST variant only)
   if (seed_pos >= 0) {
     nn1_consider(best, unused_key, pts[seed_pos], (uint32_t)seed_pos, qx, qy, qz);
     d = sqrtf(best.d2) * 1.0001f + 1.0e-6f + kNNRevalSlack * g.h;
+    d = fminf(seed_trusted ? d : fminf(d, g.h), cap);
+  } else if (seed_d2 >= 0.f) {
+    d = sqrtf(seed_d2) * 1.0001f + 1.0e-6f + kNNRevalSlack * g.h;
     d = fminf(seed_trusted ? d : fminf(d, g.h), cap);
   }
   const float eps = 2.0e-3f * g.h;
@@ -1649,7 +1654,7 @@ __global__ void __launch_bounds__(kBlock, 8) s3d_nn_record_touch_kernel(const Pa
                                                            const uint4* __restrict__ list,
                                                            int* __restrict__ list_counts_next,
                                                            int* __restrict__ search_counts, int search_cap,
-                                                           uint2* __restrict__ search_list, int* __restrict__ prof_counts) {
+                                                           uint4* __restrict__ search_list, int* __restrict__ prof_counts) {
   const int lane = lane_id();
   // LISTED: the four waves of a block take four consecutive entries of ONE list - the records a block of the test
   // kernel appended together belong to one pair, whose records then come through the scalar cache once per block
@@ -1726,7 +1731,8 @@ __global__ void __launch_bounds__(kBlock, 8) s3d_nn_record_touch_kernel(const Pa
       if (need) {
         const int k = base + (int)__popcll(nmask & ((1ull << lane) - 1ull));
         if (k < search_cap)   // (cannot overflow: a list holds every query of the records its waves can touch)
-          search_list[(size_t)sub * search_cap + k] = make_uint2((unsigned)pair, (unsigned)(ci - P.corr_off));
+          search_list[(size_t)sub * search_cap + k] = make_uint4((unsigned)pair, (unsigned)(qbase + lane), (unsigned)ci,
+                                                                 (unsigned)P.slot_s);
       }
       margin = -1.0f;
     }
@@ -1765,29 +1771,78 @@ __global__ void __launch_bounds__(kBlock, 8) s3d_nn_record_touch_kernel(const Pa
   }
 }
 
-// the queries the touch kernel listed, through the general search (nn_query PHASE 2: "has failed its re-validation
-// already"), kNNRecSublists lists: block b serves list b % kNNRecSublists.  One wave per block, eight queries per wave
-// while the waves last (their searches diverge, and a wave serialises its lanes' paths: the lists' latency is what
-// counts), 64 beyond.  The lanes of a wave serve different pairs: no wave-cooperative search.
+// The queries the touch kernel listed: the general search of nn_query (PHASE 2: "has failed its re-validation
+// already"), laid out for LATENCY.  A settled pass has a few thousand of them and the launch lasts as long as one of
+// them does - a chain of dependent loads, each a cold miss somewhere in a 10 GB workspace: through nn_query 40 us.
+// Here an entry carries the query's place, its correspondence's place and the slot of the searched cloud, so that
+// everything known about the query (point, bound, previous distance, previous neighbour's position and copy) and both
+// records (pair, slot) are fetched in ONE round trip after the entry; a near previous neighbour sizes the box through
+// its copy instead of being fetched (grid_nn1_box seed_d2); and a search that confirms the previous neighbour - the
+// usual outcome once a registration has settled - leaves the copies of point and normal where they are.  Same
+// neighbours, same float d2 as nn_query (the box search is exact whatever sizes its first box); the lower bounds may
+// differ (they depend on what was examined), which moves later search decisions, not results.
+// kNNRecSublists lists: block b serves list b % kNNRecSublists.  One wave per block and ONE query per wave and trip, the
+// wave-cooperative search (wave_nn1_coop: the rows of the box one per lane, their points dealt over the lanes - two
+// round trips per attempt; eight queries per wave, each lane walking its own box row by row, took 38 us per launch).
 __global__ void __launch_bounds__(kWave) s3d_nn_record_search_kernel(const PairDev* __restrict__ pairs,
                                                                       const SlotDev* __restrict__ slots, NNArrays A,
                                                                       float max_d, int dbg,
                                                                       const int* __restrict__ search_counts, int search_cap,
-                                                                      const uint2* __restrict__ search_list,
+                                                                      const uint4* __restrict__ search_list,
                                                                       int* __restrict__ search_counts_next) {
   const int sub = (int)(blockIdx.x % (unsigned)kNNRecSublists), part = (int)blockIdx.x / kNNRecSublists;
   const int parts = (int)gridDim.x / kNNRecSublists;
   const int count = imin(search_counts[sub], search_cap);
   if ((int)blockIdx.x == 0 && (int)threadIdx.x < kNNRecSublists) search_counts_next[threadIdx.x] = 0;   // the next pass appends here
-  const uint2* __restrict__ mylist = search_list + (size_t)sub * search_cap;
-  const int per = count <= 8 * parts ? 8 : kWave;
-  for (int j0 = part * per; j0 < count; j0 += parts * per) {   // (whole waves stay: nn_query votes)
-    const int j = j0 + (int)threadIdx.x;
-    const bool need = (int)threadIdx.x < per && j < count;
-    const uint2 e = mylist[need ? j : 0];
-    const int pair = (int)e.x, i = (int)e.y;
+  const uint4* __restrict__ mylist = search_list + (size_t)sub * search_cap;
+  for (int j = part; j < count; j += parts) {
+    const uint4 e = mylist[j];
+    const int pair = __builtin_amdgcn_readfirstlane((int)e.x), qi = __builtin_amdgcn_readfirstlane((int)e.y);
+    const int ci = __builtin_amdgcn_readfirstlane((int)e.z), ss = __builtin_amdgcn_readfirstlane((int)e.w);
+    // one round trip: the query, what is known about it, the two records (every lane the same addresses)
+    const CorrVec p0 = A.sorted3[qi];
+    const float lbs = A.corr_lb[ci];
+    const float prev = A.corr_d2[ci];
+    const int prev_pos = A.corr_idx[ci];
+    const CorrVec ps = A.corr_q[ci];
     const PairDev& P = pairs[pair];
-    nn_query<0, 2>(P, slots[P.slot_t], slots[P.slot_s], pair, i, need, A, max_d, dbg | 2048, nullptr, nullptr, P.T_nn);
+    const SlotDev& Ss = slots[ss];
+    const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
+    const F3 q = xf_eigen(P.T, pg.x, pg.y, pg.z);
+    // nn_query's seed rules (speed only)
+    float move = 3.0e38f;
+    if (lbs != 0.f && !(dbg & 64)) {
+      const F3 qo = xf_eigen(P.T_nn, pg.x, pg.y, pg.z);
+      move = sqrtf(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
+    }
+    const float h = Ss.g.h;
+    const bool has_prev = prev >= 0.f && prev < 1.0e30f;
+    const bool near_seed = has_prev && prev < h * h;
+    const bool far_seed = has_prev && !near_seed && move < kNNRevalSlack * h && !(dbg & 128);
+    const float hint = has_prev ? fminf(sqrtf(prev) * 1.25f + 0.05f * h, h) : 3.0f * h;
+    const uint32_t* __restrict__ cs = A.cell_start + Ss.cell_off;
+    const float4* __restrict__ tp = A.sorted + Ss.off;
+    NNResult r;
+    if (near_seed && lbs > 0.f)     // (lbs > 0: the copy of the previous neighbour is a real point)
+      r = wave_nn1_coop(Ss.g, cs, tp, q.x, q.y, q.z, max_d, hint, -1, false, dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z));
+    else
+      r = wave_nn1_coop(Ss.g, cs, tp, q.x, q.y, q.z, max_d, hint, (near_seed || far_seed) ? prev_pos : -1, far_seed);
+    // the stores of nn_query, by one lane
+    if (lane_id() != 0) continue;
+    A.corr_idx[ci] = r.pos;
+    A.corr_d2[ci] = r.d2;
+    const float lbv = nn_lower_bound_others(r);
+    A.corr_lb[ci] = r.pos >= 0 ? lbv : -lbv;
+    if (r.pos >= 0) {
+      if (!(lbs > 0.f && r.pos == prev_pos)) {     // (the previous neighbour confirmed: its copies are in place)
+        A.corr_q[ci] = corr_vec(A.sorted[Ss.off + r.pos]);
+        A.corr_n[ci] = A.normals[Ss.off + r.pos];
+      }
+    } else {
+      CorrVec none;
+      none.x = none.y = none.z = __int_as_float(0x7F800000);
+      A.corr_q[ci] = none;
+    }
   }
 }
 

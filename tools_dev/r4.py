@@ -28,6 +28,7 @@ for rep in range(2):
             o2 = s3d.ExecOptions(force_iterations=1, profile=2, debug_flags=fl)
             ctx.align_batch(a, b, None, p, o2); pr = ctx.last_profile()
             print('   searched:', pr['nn_searched'][:IT])
+            print('   unseeded:', pr['nn_unseeded'][:IT])
             print('   records tested:', pr['nn_records'][:IT])
             print('   records failed:', pr['nn_records_searched'][:IT], flush=True)
             if os.environ.get('SINGLE') == '1':
