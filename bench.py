@@ -209,7 +209,7 @@ def main():
         popts = s3d.ExecOptions(force_iterations=1, check_interval=0, grid_cells_per_point=args.cells_per_point, profile=1)
         ctx.align_batch(src, tgt, guesses, params, popts)
         prof = ctx.last_profile()
-        # roofline of the dominant kernel (K5, s3d_nn_search_kernel<0>): algorithmic bytes per launch
+        # roofline of the dominant kernel family (K5, the correspondence pass): algorithmic bytes per launch
         # (20*M + 12*N per NN pass, summed over the batch) / average launch duration over
         # the ICP loop of one step, HIP events on the stream the kernel runs on.
         n_launch = max(prof["nn_launches"], 1)
@@ -229,16 +229,21 @@ def main():
         # "bound": the roofline the contract prices this path against (no dense contraction -> HBM).  What actually
         # limits the kernel is in "limiter" (PMC evidence in profiles/README.md): `achieved` is ALGORITHMIC bytes per
         # second, i.e. how far an exact grid search is from streaming its compulsory traffic.
-        # The correspondence pass is a kernel FAMILY since round 3: pass 1 of a registration runs s3d_nn_first_kernel,
-        # passes 2 and 3 s3d_nn_scan27_kernel (+ s3d_nn_worklist_kernel for the queries it declines), passes 4..I
-        # s3d_nn_search_kernel<0>; avg_launch_ms is (the time of all of them in one step) / I, HIP events around every
-        # pass (cross-check against rocprofv3: the TotalDurationNs of those five kernel names / (I x steps)).
+        # The correspondence pass is a kernel FAMILY: pass 1 of a registration runs s3d_nn_first_kernel, passes 2 and 3
+        # s3d_nn_scan27_kernel (+ s3d_nn_worklist_kernel for the queries it declines), pass 4 s3d_nn_search_kernel<0>, and
+        # from pass 5 on (round 4, batches of >= 65 536 records) the record-wise kernels: s3d_nn_record_touch_kernel<false>
+        # once, then s3d_nn_record_test_kernel + s3d_nn_record_touch_kernel<true> per pass, each followed by
+        # s3d_nn_record_search_kernel.  avg_launch_ms is (the time of all of them in one step) / I, HIP events around every
+        # pass (cross-check against rocprofv3: the TotalDurationNs of those kernel names / (I x steps)).  The ALGORITHMIC
+        # bytes stay 20 M + 12 N per pass whatever is actually moved: a record-wise pass reads 32 bytes per 64 queries for
+        # the records it proves unchanged, which is why its own `steady_frac` can exceed 1.
         roofline = {"kernel": "s3d_nn_first_kernel (pass 1) + s3d_nn_scan27_kernel<*> + s3d_nn_worklist_kernel (passes 2-3) "
-                              "+ s3d_nn_search_kernel<0> (passes 4-%d)" % n_launch,
+                              "+ s3d_nn_search_kernel<0> (pass 4) + s3d_nn_record_{test,touch,search}_kernel (passes 5-%d)"
+                              % n_launch,
                     "bound": "hbm", "achieved": round(achieved, 2),
                     "limiter": "VALU issue of divergent per-lane candidate walks in the first passes (82 % of the issue "
-                               "slots, 25 of 64 lanes active); HBM streaming (32 bytes per query actually moved, 4.2 TB/s "
-                               "incl. write-back) in the re-validated passes",
+                               "slots, 25 of 64 lanes active); in the settled passes the latency of three dependent "
+                               "launches (record test, touch of the ~10 % failing records, search of ~15 queries per pair)",
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n_launch,
                     "algorithmic_bytes_per_launch": int(alg_bytes),

@@ -830,7 +830,10 @@ struct Batch {
       s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc, 0,
                                                        settled_used ? wave_recs() : nullptr, t_hist(), hist_stride());
   }
-  static constexpr int kSettledFrom = 5;   // first outer iteration (0-based) that runs record-wise
+  // first outer iteration (0-based) that runs record-wise.  Measured at 256 pairs, passes 4 / 5 / 6 of the loop: from
+  // iteration 5 on 0.73 / 0.285 / 0.240 ms, from 4 on 0.73 / 0.255 / 0.133, from 3 on 2.1 / 0.27 / 0.13 (pass 4 still
+  // searches 2 % of its queries: 580 000 one-query waves)
+  static constexpr int kSettledFrom = 4;
   // records per thread of the test kernel: four for a large batch (few blocks, one list append each), one for a small one
   int rec_per_thread() const { return (long long)P() * cdiv(std::max(max_n_t, 1), kWave) >= 65536 ? kNNRecPerThread : 1; }
   // capacity of one of the kNNRecSublists search lists: every query of the records the waves of a list can touch -

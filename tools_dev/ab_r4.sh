@@ -1,2 +1,4 @@
-export S3D_LIB_PATH=$PWD/slam3d_amd/lib/exp_k4w4.so
-NPAIRS=256 timeout 300 python tools_dev/r4.py 0x10000000 2>&1 | grep "^flags" | tail -1
+for v in exp_sf4 exp_sf3; do
+  export S3D_LIB_PATH=$PWD/slam3d_amd/lib/$v.so
+  echo "== $v"; NPAIRS=256 timeout 300 python tools_dev/r4.py 0 2>&1 | grep -A1 "^flags" | tail -2
+done

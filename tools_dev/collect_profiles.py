@@ -20,14 +20,16 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             f.write('"%s",%.1f,%d\n' % (k, m, n))
     # the NN family of the ICP loop: s3d_nn_first_kernel + s3d_nn_search_kernel<0>, per launch over all their launches
     # per PASS of the ICP loop (a scan27 pass is two launches: the scan and its worklist)
-    fam = [x for x in summ if any(k in x[0] for k in ("nn_search_kernel<0>", "nn_first_kernel", "nn_scan27_kernel", "nn_worklist_kernel"))]
-    passes = sum(n for k, _, n in fam if "nn_worklist_kernel" not in k)
+    fam = [x for x in summ if any(k in x[0] for k in ("nn_search_kernel<0>", "nn_first_kernel", "nn_scan27_kernel", "nn_worklist_kernel",
+                                                        "nn_record_test_kernel", "nn_record_touch_kernel", "nn_record_search_kernel"))]
+    # launches that START a pass: the worklist / touch<true> / record search kernels follow another kernel of their pass
+    passes = sum(n for k, _, n in fam if not any(t in k for t in ("nn_worklist_kernel", "nn_record_touch_kernel<true>", "nn_record_search_kernel")))
     out[c] = sum(m * n for _, m, n in fam) / passes
 hbm = int(2 * out["FETCH_SIZE"] * 1024 + out["WRITE_SIZE"] * 1024)
-json.dump({"kernel": "s3d_nn_first_kernel + s3d_nn_scan27_kernel + s3d_nn_worklist_kernel + s3d_nn_search_kernel<0> (per pass of the ICP loop)", "fetch_size_kb_per_launch": round(out["FETCH_SIZE"], 1),
+json.dump({"kernel": "s3d_nn_first_kernel + s3d_nn_scan27_kernel + s3d_nn_worklist_kernel + s3d_nn_search_kernel<0> + s3d_nn_record_{test,touch,search}_kernel (per pass of the ICP loop)", "fetch_size_kb_per_launch": round(out["FETCH_SIZE"], 1),
            "write_size_kb_per_launch": round(out["WRITE_SIZE"], 1), "hbm_bytes_per_launch": hbm,
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is",
-           "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --no-cpu --no-single --steps 2 --warmup 1",
+           "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --no-cpu --no-single --no-real --steps 2 --warmup 1",
            "workload": "256 pairs x 100k points, 20 iterations (bench default)",
            "kernel_src_sha256": kernel_source_hash(), "round": ROUND},
           open(os.path.join(ROOT, "profiles/nn_traffic.json"), "w"), indent=1)
@@ -36,6 +38,9 @@ for f in os.listdir(F):
 shutil.copy(f"{R}/stats/b_kernel_stats.csv", f"{D}/rocprofv3_kernel_stats_bench_default.csv")
 shutil.copy(f"{R}/bench_under_rocprof.json", f"{D}/bench_under_rocprof.json")
 shutil.copy(f"{R}/map/m_kernel_stats.csv", f"{D}/rocprofv3_kernel_stats_bench_map.csv")
+if os.path.exists(f"{R}/stats1M/b_kernel_stats.csv"):
+    shutil.copy(f"{R}/stats1M/b_kernel_stats.csv", f"{D}/rocprofv3_kernel_stats_bench_1M_50it.csv")
+    shutil.copy(f"{R}/bench_1M_under_rocprof.json", f"{D}/bench_1M_under_rocprof.json")
 d = json.load(open(f"{D}/bench_default.json"))
 print("default", d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["avg_launch_ms"], d["roofline"]["achieved"],
       d["cpu_baseline"]["value"], d["cpu_baseline_parallel"]["value"], d["single_pair"], d["stage_ms"], d["nn_launch_ms"][:6])
