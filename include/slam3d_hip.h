@@ -62,16 +62,10 @@ typedef struct s3d_exec_options {
 } s3d_exec_options;
 
 /* s3d_exec_options.debug_flags */
-#define S3D_DBG_NN_RING            0x00000004u /* 1-NN by ring expansion (round-1 A/B; only with S3D_NN_AB builds)       */
-#define S3D_DBG_NN_PLAIN_MAP       0x00000010u /* no XCD-aware block map in the NN kernel (round-1 A/B)                  */
-#define S3D_DBG_NN_NO_SEED         0x00000020u /* searches ignore the previous neighbour (round-1 A/B)                   */
 #define S3D_DBG_NN_NO_REVALIDATE   0x00000040u /* every pass searches every query (no triangle-inequality shortcut)      */
 #define S3D_DBG_NN_NO_FAR_SEED     0x00000080u /* far previous neighbours are never trusted seeds                        */
-#define S3D_DBG_NN_FIRST_BOX_1     0x00000100u /* first-pass box of 1 / 1.5 / 2 cells instead of 3 (round-1 A/B)         */
-#define S3D_DBG_NN_FIRST_BOX_15    0x00000200u
-#define S3D_DBG_NN_FIRST_BOX_2     0x00000400u
 #define S3D_DBG_NN_NO_COOP         0x00000800u /* no wave-cooperative wide search                                        */
-#define S3D_DBG_NN_NO_COMPACT      0x00010000u /* passes 4-5 without the block compaction                                */
+#define S3D_DBG_NN_NO_COMPACT      0x00010000u /* pass 4 (small batches: passes 3-5) without the block compaction         */
 #define S3D_DBG_NN_NO_FIRST_KERNEL 0x00040000u /* pass 1 through the general kernel (implies the next one)               */
 #define S3D_DBG_NN_NO_SCAN27       0x00080000u /* passes 2-3 through the general kernel                                  */
 #define S3D_DBG_NN_NO_SETTLED      0x00100000u /* settled passes query by query (no record-level re-validation)          */
@@ -82,7 +76,7 @@ typedef struct s3d_exec_options {
 #define S3D_DBG_PRINT_KNN          0x02000000u /* stderr: how many points took the eigen fallback / the exact-search redo */
 #define S3D_DBG_NN_FORCE_SETTLED   0x08000000u /* record-level re-validation for a small batch too (the host takes it from
                                                   65 536 records = 42 pairs of 100 k points: below that it is slower)   */
-#define S3D_DBG_SORT_FULL_KEYS     0x04000000u /* radix sort: fixed pass counts (4 voxel + 3 grid), not the key range's   */
+#define S3D_DBG_SORT_FULL_KEYS     0x04000000u /* radix sort: 8-bit digits everywhere (grid: 3 passes instead of 2 x 9 bits) */
 
 /* The structs above grow at the END only.  A binding compiled against another revision of this header must not be
  * used: compare S3D_ABI_VERSION with s3d_abi_version() once after loading the library (the Python binding and the

@@ -507,8 +507,8 @@ struct Batch {
                 {&ctx->worklist, icp_buffers ? 8 * nc : 8},
                 {&ctx->wave_recs, sizeof(WaveRec) * (icp_buffers ? nc / kWave + 1 : 1)},
                 {&ctx->rec_list, sizeof(uint4) * (icp_buffers ? rec_list_entries() : 1)},
-                {&ctx->rec_counts, sizeof(int) * 4 * kNNRecSublists},
-                {&ctx->search_list, sizeof(uint4) * (icp_buffers && settled_wanted() ? (size_t)kNNRecSublists * (size_t)search_sub_cap() : 1)},
+                {&ctx->rec_counts, sizeof(int) * 2 * (kNNRecSublists + kNNSearchSublists)},
+                {&ctx->search_list, sizeof(uint4) * (icp_buffers && settled_wanted() ? (size_t)kNNSearchSublists * (size_t)search_sub_cap() : 1)},
                 {&ctx->t_hist, sizeof(Mat4f) * (icp_buffers ? (size_t)std::max(1, P()) * (size_t)hist_stride() : 1)},
                 {&ctx->knn_list, sizeof(int) * (size_t)std::max(1, C())},
                 {&ctx->knn_fallback, sizeof(int) * npi}, {&ctx->knn_redo, sizeof(int2) * npi}});
@@ -747,7 +747,7 @@ struct Batch {
     return A;
   }
   // it: outer iteration (0-based) of an ICP-loop pass, -1 otherwise.  The first pass has a kernel of its own
-  // (s3d_nn_first_kernel); S3D_DBG_NN bit 262144 = the one kernel for every pass (A/B; the bits that switch the
+  // (s3d_nn_first_kernel); S3D_DBG_NN_NO_FIRST_KERNEL = the one kernel for every pass (A/B; the bits that switch the
   // re-validation or the seeds off imply it).
   void launch_nn(int mode, float max_d, int prof_slot = -1, bool compact = false, int it = -1) {
     hipStream_t st = ctx->stream;
@@ -756,12 +756,12 @@ struct Batch {
     dim3 grid((unsigned)(pairs8 * chunks));
     NNArrays A = nn_arrays();
     int* pc = (prof_slot >= 0 && prof_slot < 64) ? (int*)ctx->n_active.p + 16 + 4 * prof_slot : nullptr;
-    const bool family = mode == 0 && it >= 0 && !(dbg_nn & (262144 | 64 | 32 | 4));
+    const bool family = mode == 0 && it >= 0 && !(dbg_nn & (262144 | 64));
     if (family && it == 0) {
       s3d_nn_first_kernel<<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc);
       return;
     }
-    // passes 2 and 3: the flat 27-cell scan + a worklist for what it declines (S3D_DBG_NN bit 524288 = off; the bits
+    // passes 2 and 3: the flat 27-cell scan + a worklist for what it declines (S3D_DBG_NN_NO_SCAN27 = off; the bits
     // that switch the re-validation off imply it)
     // (measured per 128 pairs: pass 2 1.47 -> 0.99 ms, pass 3 0.90 -> 0.80 ms with the compacting form; passes 4 and 5,
     // where 2 % and 0.1 % of the queries search, are slower this way: 0.39 -> 0.55, 0.15 -> 0.19 ms)
@@ -784,10 +784,11 @@ struct Batch {
     // passes 6 ...: record-level re-validation (s3d_nn_record_*_kernel); S3D_DBG_NN_NO_SETTLED = query by query
     if (settled_on() && mode == 0 && it >= kSettledFrom) {
       // two sets of list counters, used in turn (zeroed by stage_icp / by the consuming kernel of the pass before):
-      // [set][0 .. 63] record lists, [set][64 .. 127] search lists
+      // [set][0 .. 63] record lists, [set][64 .. 64 + 1023] search lists
+      constexpr int kSet = kNNRecSublists + kNNSearchSublists;
       int* sc = (int*)ctx->rec_counts.p;
-      int* cnt = sc + (it & 1) * 2 * kNNRecSublists;
-      int* cnt_next = sc + ((it + 1) & 1) * 2 * kNNRecSublists;
+      int* cnt = sc + (it & 1) * kSet;
+      int* cnt_next = sc + ((it + 1) & 1) * kSet;
       uint4* rl = (uint4*)ctx->rec_list.p;
       uint4* sl = (uint4*)ctx->search_list.p;
       const int scap = search_sub_cap();
@@ -817,7 +818,7 @@ struct Batch {
             cnt + kNNRecSublists, scap, sl, pc);
       }
       // the queries that failed their re-validation: one per wave and trip (a settled pass of 256 pairs lists ~4 000)
-      s3d_nn_record_search_kernel<<<(unsigned)(search_parts() * kNNRecSublists), kWave, 0, st>>>(d_pairs(), d_slots(), A, max_d, dbg_nn,
+      s3d_nn_record_search_kernel<<<(unsigned)(search_parts() * kNNSearchSublists), kWave, 0, st>>>(d_pairs(), d_slots(), A, max_d, dbg_nn,
                                                                          cnt + kNNRecSublists, scap, sl,
                                                                          cnt_next + kNNRecSublists);
       return;
@@ -836,18 +837,14 @@ struct Batch {
   static constexpr int kSettledFrom = 4;
   // records per thread of the test kernel: four for a large batch (few blocks, one list append each), one for a small one
   int rec_per_thread() const { return (long long)P() * cdiv(std::max(max_n_t, 1), kWave) >= 65536 ? kNNRecPerThread : 1; }
-  // capacity of one of the kNNRecSublists search lists: every query of the records the waves of a list can touch -
-  // the listed form (a list of failing records per sublist) and the first pass (block b -> list b % 64)
+  // capacity of one of the kNNSearchSublists search lists: every query of the records that map to it
   int search_sub_cap() const {
-    const int chunks = cdiv(std::max(max_n_t, 1), kBlock);
-    const int pairs8 = P() >= 8 ? cdiv(P(), 8) * 8 : std::max(P(), 1);
-    const long long a = (long long)(rec_list_entries() / (size_t)std::max(1, std::min(kNNRecSublists, rec_blocks()))) * kWave;
-    const long long b = (long long)cdiv(pairs8 * chunks, kNNRecSublists) * kBlock;
-    return (int)std::min<long long>(std::max(a, b), 0x7FFFFFF0);
+    const long long recs = (long long)(std::max<size_t>(total_corr, 4) / kWave + 1);
+    return (int)std::min<long long>((recs / kNNSearchSublists + 1) * kWave, 0x7FFFFFF0);
   }
-  int search_parts() const {   // waves per search list: about one per 3 000 queries of the batch, 1 ... 256
-    const long long q = (long long)P() * std::max(max_n_t, 1);
-    return (int)std::max<long long>(1, std::min<long long>(256, q / (3000ll * kNNRecSublists)));
+  int search_parts() const {   // waves per search list: about one per 3 000 queries of the batch (a settled pass searches
+    const long long q = (long long)P() * std::max(max_n_t, 1);   // one query in ~6 000), 1 ... 16
+    return (int)std::max<long long>(1, std::min<long long>(16, q / (3000ll * kNNSearchSublists) + 1));
   }
   int rec_blocks() const {
     const int nrec = cdiv(std::max(max_n_t, 1), kWave), rpt = rec_per_thread();
@@ -866,7 +863,7 @@ struct Batch {
   // searches of the pass, which the per-query kernel hides among its 1 500 waves per pair.  Measured, settled pass per
   // query / per record: 1 pair 11 / 16 us, 32 pairs equal, 128 pairs 0.100 / 0.055 ms, 256 pairs 0.196 / 0.089 ms)
   bool settled_wanted() const {
-    return !(dbg_nn & (S3D_DBG_NN_NO_SETTLED | 262144 | 64 | 32 | 4)) &&
+    return !(dbg_nn & (S3D_DBG_NN_NO_SETTLED | 262144 | 64)) &&
            ((long long)P() * cdiv(std::max(max_n_t, 1), kWave) >= 65536 || (opts.debug_flags & S3D_DBG_NN_FORCE_SETTLED));
   }
   bool settled_on() const { return settled_used && settled_wanted(); }
@@ -901,7 +898,7 @@ struct Batch {
     HIPCHK(hipMemsetAsync((int*)ctx->n_active.p + 8, 0, 8 * sizeof(int), st));   // worklist counters of the scan27 passes
     // the 64-query records of the settled passes: touch = -1 ("never evaluated record-wise")
     HIPCHK(hipMemsetAsync(ctx->wave_recs.p, 0xFF, sizeof(WaveRec) * (std::max<size_t>(total_corr, 4) / kWave + 1), st));
-    HIPCHK(hipMemsetAsync(ctx->rec_counts.p, 0, sizeof(int) * 4 * kNNRecSublists, st));   // the record / search list counters
+    HIPCHK(hipMemsetAsync(ctx->rec_counts.p, 0, sizeof(int) * 2 * (kNNRecSublists + kNNSearchSublists), st));   // the record / search list counters
 
     settled_used = true;
     const float max_d = (float)(rp.max_corr * 1.0001);

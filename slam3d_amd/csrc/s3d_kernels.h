@@ -34,10 +34,6 @@ constexpr int kAccumVB = S3D_ACCUM_VB;   // VIRTUAL blocks per pair in the accum
                                    // accumulate launch has 32 blocks instead of 64: 1.43 -> 1.48 ms (16: 1.59)
 constexpr uint32_t kInvalidKey = 0xFFFFFFFFu;
 
-#ifndef S3D_NN_AB
-#define S3D_NN_AB 1        // the round-1 A/B switches of the NN kernel (S3D_DBG_NN bits 4, 16, 32, 256, 512, 1024)
-#endif
-
 // ------------------------------------------------------------------ device-side records
 
 struct SlotDev {          // one cloud of the batch
@@ -1394,10 +1390,10 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   const bool has_prev = prev >= 0.f && prev < 1.0e30f;
   const bool near_seed = has_prev && prev < Ss.g.h * Ss.g.h;
   const bool far_seed = has_prev && !near_seed && move < kNNRevalSlack * Ss.g.h && !(dbg & 128);
-  const int seed = ((near_seed || far_seed) && !(S3D_NN_AB && (dbg & 32))) ? A.corr_idx[ci] : -1;
+  const int seed = (near_seed || far_seed) ? A.corr_idx[ci] : -1;
   // first pass (nothing known yet): a generous three-cell box — the shrinking-ball scan makes a large
   // initial radius cheap, while a small one costs a second scan for every badly aligned query
-  const float first = (!S3D_NN_AB ? 3.0f : (dbg & 256) ? 1.0f : (dbg & 512) ? 1.5f : (dbg & 1024) ? 2.0f : 3.0f) * Ss.g.h;
+  const float first = 3.0f * Ss.g.h;   // (1 / 1.5 / 2 / 4 / 6 cells were measured: DESIGN.md 6a)
   const float hint = has_prev ? fminf(sqrtf(prev) * 1.25f + 0.05f * Ss.g.h, Ss.g.h) : first;
   if (prof_counts) {   // profile >= 2 only: how many queries search, how many of them without a near seed
     const unsigned long long all = __ballot(need), un = __ballot(need && !near_seed);
@@ -1410,9 +1406,7 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   r.idx = -1; r.d2 = 3.0e38f; r.pos = -1; r.second_d2 = 3.0e38f; r.radius = 0.f;
   const uint32_t* __restrict__ cs = A.cell_start + Ss.cell_off;
   const float4* __restrict__ tp = A.sorted + Ss.off;
-  if (S3D_NN_AB && (dbg & 4)) {
-    if (need) r = grid_nn1(Ss.g, cs, tp, q.x, q.y, q.z, max_d);
-  } else {
+  {
     // served by the whole wave, one query after the other: the queries that will walk a wide box when they are
     // few, and every searching query when the wave has only a handful (a converging registration: most lanes
     // were re-validated, the wave would otherwise idle through the ~10 dependent loads of one lane's box scan)
@@ -1439,7 +1433,7 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
   // the target's cell-sorted array: every later access (K6, fitness) is then coalesced or a local gather
   A.corr_idx[ci] = r.pos;
   A.corr_d2[ci] = r.d2;
-  const float lbv = !(S3D_NN_AB && (dbg & 4)) ? nn_lower_bound_others(r) : 0.f;   // no neighbour at all: the scanned radius
+  const float lbv = nn_lower_bound_others(r);   // no neighbour at all: the scanned radius
   // (first pass: the runner-up is not tracked - "nothing known" about the others; the second pass searches every
   // query again anyway, the first transform update has moved them all)
   A.corr_lb[ci] = r.pos >= 0 ? (PHASE == 5 ? 0.f : lbv) : -lbv;
@@ -1467,12 +1461,11 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
 // 3.39 -> 3.49, 2.77 -> 2.17, 1.06 -> 0.94, then 0.25 -> 0.29 ms once nearly every query re-validates (five block
 // barriers on a streaming kernel): the host asks for it in passes 3 to 5 only.  A global worklist (atomics, second
 // kernel) loses the spatial order of the queries and was 2x slower.  Same results either way, bit for bit.
-// The `dbg` switches (S3D_DBG_NN: 64 no re-validation, 128 no trusted far seeds, 2048 no cooperative search, 65536 no
-// compaction - what test_nn_revalidation_shortcut_is_bitwise_neutral toggles - plus the A/B bits 4 / 16 / 32 / 256 /
-// 512 / 1024 of round 1) stay in the kernel on purpose: round 2 removed the A/B bits and the register allocation of
-// this 72-VGPR kernel re-rolled (scratch 76 -> 100 bytes per lane, spills moved into the streaming re-validation
-// path): 12.4 -> 13.5 ms of NN per step, same results.  Measured, reverted.  (6 waves / 80 VGPRs: 14.0 ms; the
-// cooperative search as a non-inlined call: 12.8 ms.)
+// The `dbg` switches (s3d_exec_options.debug_flags: S3D_DBG_NN_NO_REVALIDATE, _NO_FAR_SEED, _NO_COOP, _NO_COMPACT - what
+// test_nn_revalidation_shortcut_is_bitwise_neutral toggles) are read here.  The A/B switches of round 1 (ring search, plain
+// block map, no seeds, first-pass box size) stayed in this kernel until round 4 because compiling them out re-rolled its
+// register allocation (12.4 -> 13.5 ms of NN per step in round 2); since the settled passes have kernels of their own
+// this one serves pass 4 and small batches, and without the switches pass 4 takes 0.763 instead of 0.729 ms: removed.
 #ifndef S3D_NN27_WAVES
 #define S3D_NN27_WAVES 8    // s3d_nn_scan27_kernel
 #endif
@@ -1498,8 +1491,7 @@ __global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_search_kernel(con
   __shared__ int order[kBlock];
   __shared__ int lds4[4];
   int pair, chunk;
-  if (S3D_NN_AB && (dbg & 16)) { pair = blockIdx.x / chunks_per_pair; chunk = blockIdx.x % chunks_per_pair; }  // A/B: plain map
-  else nn_block_map(chunks_per_pair, npairs, &pair, &chunk);
+  nn_block_map(chunks_per_pair, npairs, &pair, &chunk);
   if (pair >= npairs) return;
   const PairDev& P = pairs[pair];
   if (MODE == 0 && !P.active) return;
@@ -1572,6 +1564,13 @@ __device__ __forceinline__ uint4 nn_record_entry(int pair, int rec, int touch, i
                     (unsigned)(query_off + rec * kWave));
 }
 constexpr int kNNRecSublists = 64;
+// The SEARCH lists (the queries of touched records that fail their own proof) are kNNSearchSublists lists, chosen by
+// the RECORD: record r (its index in the batch's record array) appends to list r % kNNSearchSublists, so a list can
+// hold at most every query of the records that map to it - a capacity that does not depend on which wave touches
+// what - and the one atomic per touching wave spreads over 1 024 counters.  (64 counters were enough for the settled
+// benchmark, ~4 000 searches per pass; on 32 pairs of 1 M points, whose passes 5-12 still search in nearly every record,
+// 500 000 appends to 64 counters made the touch kernel 0.18 ms long and the first record-wise pass 5.8 ms.)
+constexpr int kNNSearchSublists = 1024;
 constexpr int kNNRecPerThread = 4;     // records per thread of the test kernel (large batches; 1 for small ones)
 template <int RPT>
 __global__ void __launch_bounds__(kBlock) s3d_nn_record_test_kernel(const PairDev* __restrict__ pairs,
@@ -1641,7 +1640,7 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_record_test_kernel(const PairDe
 // dozen dependent loads, a settled pass has a few thousand of them among 25 million queries, and in a kernel that only
 // visits the failing records nothing hides them - the launch ended 30-60 us after its last re-validation, waiting
 // for the waves that searched (inlined, or out of line: the same; the per-query kernel hides the same searches among
-// its 400 000 waves).  The lanes are appended to kNNRecSublists search lists instead ((pair, index) as in the lists
+// its 400 000 waves).  The lanes are appended to kNNSearchSublists search lists instead ((pair, index) as in the lists
 // of the scan27 passes; one atomic per wave that has any, on the counter of the wave's list) and
 // s3d_nn_record_search_kernel serves them right after, eight queries per wave.  The record's margin is then -1: it is
 // evaluated again in the next pass, when its searched queries carry fresh bounds.
@@ -1658,7 +1657,7 @@ __global__ void __launch_bounds__(kBlock, 8) s3d_nn_record_touch_kernel(const Pa
   const int lane = lane_id();
   // LISTED: the four waves of a block take four consecutive entries of ONE list - the records a block of the test
   // kernel appended together belong to one pair, whose records then come through the scalar cache once per block
-  const int sub = LISTED ? (int)(blockIdx.x % (unsigned)nsub) : (int)(blockIdx.x % (unsigned)kNNRecSublists);
+  const int sub = LISTED ? (int)(blockIdx.x % (unsigned)nsub) : 0;
   const int step = LISTED ? ((int)gridDim.x / nsub) * (kBlock / kWave) : 1;   // (the grid is a multiple of nsub blocks)
   const int count = LISTED ? list_counts[sub] : 1;
   if (LISTED && (int)blockIdx.x == 0 && (int)threadIdx.x < nsub) list_counts_next[threadIdx.x] = 0;   // the next pass's test appends here
@@ -1724,15 +1723,16 @@ __global__ void __launch_bounds__(kBlock, 8) s3d_nn_record_touch_kernel(const Pa
       }
     }
     const unsigned long long nmask = __ballot(need);
-    if (nmask != 0ull) {      // its searches: to the list of this wave's sublist
+    if (nmask != 0ull) {      // its searches: to the search list of this RECORD
+      const int ssub = (cbase >> 6) % kNNSearchSublists;
       int base = 0;
-      if (lane == 0) base = atomicAdd(&search_counts[sub], (int)__popcll(nmask));
+      if (lane == 0) base = atomicAdd(&search_counts[ssub], (int)__popcll(nmask));
       base = __shfl(base, 0, kWave);
       if (need) {
         const int k = base + (int)__popcll(nmask & ((1ull << lane) - 1ull));
-        if (k < search_cap)   // (cannot overflow: a list holds every query of the records its waves can touch)
-          search_list[(size_t)sub * search_cap + k] = make_uint4((unsigned)pair, (unsigned)(qbase + lane), (unsigned)ci,
-                                                                 (unsigned)P.slot_s);
+        if (k < search_cap)   // (cannot overflow: a list holds every query of the records that map to it)
+          search_list[(size_t)ssub * search_cap + k] = make_uint4((unsigned)pair, (unsigned)(qbase + lane), (unsigned)ci,
+                                                                  (unsigned)P.slot_s);
       }
       margin = -1.0f;
     }
@@ -1781,20 +1781,34 @@ __global__ void __launch_bounds__(kBlock, 8) s3d_nn_record_touch_kernel(const Pa
 // usual outcome once a registration has settled - leaves the copies of point and normal where they are.  Same
 // neighbours, same float d2 as nn_query (the box search is exact whatever sizes its first box); the lower bounds may
 // differ (they depend on what was examined), which moves later search decisions, not results.
-// kNNRecSublists lists: block b serves list b % kNNRecSublists.  One wave per block and ONE query per wave and trip, the
-// wave-cooperative search (wave_nn1_coop: the rows of the box one per lane, their points dealt over the lanes - two
+// kNNSearchSublists lists: block b serves list b % kNNSearchSublists.  One wave per block and ONE query per wave and trip,
+// the wave-cooperative search (wave_nn1_coop: the rows of the box one per lane, their points dealt over the lanes - two
 // round trips per attempt; eight queries per wave, each lane walking its own box row by row, took 38 us per launch).
+// A LONG list - a registration that has not settled yet: every record has searching queries - is a matter of
+// throughput, not latency: 64 queries per wave and trip, each lane its own search (nn_query PHASE 2, as the lists of
+// the scan27 passes are served).
 __global__ void __launch_bounds__(kWave) s3d_nn_record_search_kernel(const PairDev* __restrict__ pairs,
                                                                       const SlotDev* __restrict__ slots, NNArrays A,
                                                                       float max_d, int dbg,
                                                                       const int* __restrict__ search_counts, int search_cap,
                                                                       const uint4* __restrict__ search_list,
                                                                       int* __restrict__ search_counts_next) {
-  const int sub = (int)(blockIdx.x % (unsigned)kNNRecSublists), part = (int)blockIdx.x / kNNRecSublists;
-  const int parts = (int)gridDim.x / kNNRecSublists;
+  const int sub = (int)(blockIdx.x % (unsigned)kNNSearchSublists), part = (int)blockIdx.x / kNNSearchSublists;
+  const int parts = (int)gridDim.x / kNNSearchSublists;
   const int count = imin(search_counts[sub], search_cap);
-  if ((int)blockIdx.x == 0 && (int)threadIdx.x < kNNRecSublists) search_counts_next[threadIdx.x] = 0;   // the next pass appends here
+  if ((int)blockIdx.x < kNNSearchSublists / kWave) search_counts_next[blockIdx.x * kWave + threadIdx.x] = 0;   // the next pass appends here
   const uint4* __restrict__ mylist = search_list + (size_t)sub * search_cap;
+  if (count > 4 * parts) {
+    for (int j0 = part * kWave; j0 < count; j0 += parts * kWave) {   // (whole waves stay: nn_query votes)
+      const int j = j0 + (int)threadIdx.x;
+      const bool need = j < count;
+      const uint4 e = mylist[need ? j : 0];
+      const PairDev& P = pairs[e.x];
+      nn_query<0, 2>(P, slots[P.slot_t], slots[P.slot_s], (int)e.x, (int)e.z - P.corr_off, need, A, max_d, dbg | 2048, nullptr,
+                     nullptr, P.T_nn);
+    }
+    return;
+  }
   for (int j = part; j < count; j += parts) {
     const uint4 e = mylist[j];
     const int pair = __builtin_amdgcn_readfirstlane((int)e.x), qi = __builtin_amdgcn_readfirstlane((int)e.y);
@@ -1849,7 +1863,7 @@ __global__ void __launch_bounds__(kWave) s3d_nn_record_search_kernel(const PairD
 // ---- the FIRST pass of a registration has a kernel of its own (round 3): no history to load, no re-validation, no
 // seeds - nn_query<0, 5>.  Inside the one kernel above the same path cost every other pass a register re-roll
 // (DESIGN.md 6a x); as a separate __global__ it takes 0.13 ms off the first pass of 128 pairs and touches nothing
-// else.  S3D_DBG_NN bit 262144 switches it off (A/B).
+// else.  S3D_DBG_NN_NO_FIRST_KERNEL switches it off (A/B).
 // Measured and dropped: (a) for a one-pair batch, 16 queries per wave with EVERY search served by the whole wave
 // (wave_nn1_coop: four times the waves, two latencies per query) - 35 us slower per registration than the per-lane
 // search; (b) the settled passes as a 24-VGPR stream kernel of the re-validation alone plus a worklist
@@ -1877,7 +1891,7 @@ __global__ void __launch_bounds__(kBlock, S3D_NN_FIRST_WAVES) s3d_nn_first_kerne
 // REVAL (pass 3): a query first tries the re-validation of nn_query - two thirds of them pass by then.  A query the
 // scan does not answer (its neighbour farther than the 27 cells reach, a query outside the target's grid, empty cells)
 // is appended to a worklist - one atomic per wave that has any - which s3d_nn_worklist_kernel serves right after with
-// the general search.  Same neighbours, same distances: bit-identical registrations (S3D_DBG_NN bit 524288 = off).
+// the general search.  Same neighbours, same distances: bit-identical registrations (S3D_DBG_NN_NO_SCAN27 = off).
 // COMPACT (pass 3, where a third of the queries still search, scattered over all waves): the queries of a block that
 // failed their re-validation are packed to the front of the block (one block scan, as in s3d_nn_search_kernel's
 // compact mode) and only the first waves scan - every lane of them busy.
