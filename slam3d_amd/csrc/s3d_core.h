@@ -1674,6 +1674,16 @@ S3D_HD void gq_sincos(double x, double* s, double* c) {
 // BFGS around it runs redundantly on every lane, so control flow stays uniform): the three sincos and
 // the twelve 12-term dot products of G are then spread over the lanes and exchanged by shuffles,
 // which makes one evaluation ~3x shorter than the scalar form the CPU emulation uses.
+#if defined(__HIP_DEVICE_COMPILE__)
+// the value of lane `LANE` (a compile-time constant) in every lane: two v_readlane_b32 - scalar moves, no trip through
+// the LDS crossbar and no wait for it, which is what a __shfl costs the one wave that evaluates the form
+template <int LANE>
+__device__ __forceinline__ double gq_bcast(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), LANE);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), LANE);
+  return __hiloint2double(hi, lo);
+}
+#endif
 S3D_HD void gq_eval(const double* acc, const double* Th0, const double x[6], double* f, double g[6]) {
   double cphi, sphi, cth, sth, cpsi, spsi;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1683,9 +1693,9 @@ S3D_HD void gq_eval(const double* acc, const double* Th0, const double x[6], dou
     const double ang = j == 0 ? x[3] : (j == 1 ? x[4] : x[5]);
     double sv, cv;
     gq_sincos(ang, &sv, &cv);
-    sphi = __shfl(sv, 0, 64); cphi = __shfl(cv, 0, 64);
-    sth = __shfl(sv, 1, 64);  cth = __shfl(cv, 1, 64);
-    spsi = __shfl(sv, 2, 64); cpsi = __shfl(cv, 2, 64);
+    sphi = gq_bcast<0>(sv); cphi = gq_bcast<0>(cv);
+    sth = gq_bcast<1>(sv);  cth = gq_bcast<1>(cv);
+    spsi = gq_bcast<2>(sv); cpsi = gq_bcast<2>(cv);
   }
 #else
   gq_sincos(x[3], &sphi, &cphi); gq_sincos(x[4], &sth, &cth); gq_sincos(x[5], &spsi, &cpsi);
@@ -1717,10 +1727,10 @@ S3D_HD void gq_eval(const double* acc, const double* Th0, const double x[6], dou
       }
     }
     sgc -= acc[GQ_B + c * 4 + a];
-#pragma unroll
-    for (int aa = 0; aa < 4; ++aa)
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc) G[aa][cc] = __shfl(sgc, aa * 3 + cc, 64);
+    G[0][0] = gq_bcast<0>(sgc); G[0][1] = gq_bcast<1>(sgc); G[0][2] = gq_bcast<2>(sgc);
+    G[1][0] = gq_bcast<3>(sgc); G[1][1] = gq_bcast<4>(sgc); G[1][2] = gq_bcast<5>(sgc);
+    G[2][0] = gq_bcast<6>(sgc); G[2][1] = gq_bcast<7>(sgc); G[2][2] = gq_bcast<8>(sgc);
+    G[3][0] = gq_bcast<9>(sgc); G[3][1] = gq_bcast<10>(sgc); G[3][2] = gq_bcast<11>(sgc);
   }
 #else
   for (int a = 0; a < 4; ++a)
@@ -1800,8 +1810,6 @@ S3D_HD void bfgs_eval(Bfgs& b, double alpha) {
   b.c_alpha = alpha;
   b.evals++;
 }
-S3D_HD double bfgs_f(Bfgs& b, double alpha) { bfgs_eval(b, alpha); return b.c_f; }
-S3D_HD double bfgs_df(Bfgs& b, double alpha) { bfgs_eval(b, alpha); return b.c_df; }
 
 S3D_HD double poly3(const double c[4], double z) { return c[0] + z * (c[1] + z * (c[2] + z * c[3])); }
 S3D_HD void check_extremum(const double c[4], double z, double* zmin, double* fmin) {
@@ -1860,59 +1868,66 @@ S3D_HD double bfgs_interpolate(double a, double fa, double fpa, double b, double
   return a + y * (b - a);
 }
 
+// Fletcher's line search (GSL / PCL bfgs.h: a bracketing loop, then a sectioning loop, at most 100 iterations between
+// them).  Written as ONE loop with ONE evaluation site: f and the gradient come out of the same gq_eval, so PCL's
+// applyF(alpha) followed by applyDF(alpha) is one evaluation here (its cache makes it one there), and the two phases
+// differ only in where alpha comes from and what is done with the result.  (Round 4: as two loops with bfgs_f / bfgs_df
+// calls the inlined controller held six copies of gq_eval - 9 200 instructions, more than the instruction cache of a
+// compute unit pair - and the one wave that runs it spent most of an evaluation's 1.8 us waiting for code.)
+// Same sequence of trial points, same decisions, same evaluation count as the two-loop form.
 S3D_HD int bfgs_line_search(Bfgs& B, double rho, double sigma, double tau1, double tau2, double tau3, int order,
                             double alpha1, double* alpha_new) {
   const int bracket_iters = 100, section_iters = 100;
-  double f0, fp0, falpha, falpha_prev, fpalpha, fpalpha_prev, delta, alpha_next;
+  const double f0 = B.f, fp0 = B.fp0;   // == applyFDF(0): position 0 is x0 with cached f, slope
+  double falpha_prev = f0, fpalpha_prev = fp0;
   double alpha = alpha1, alpha_prev = 0.0;
-  double a, b, fa, fb, fpa, fpb;
+  double a = 0.0, b = alpha, fa = f0, fb = 0.0, fpa = fp0, fpb = 0.0;
   int i = 0;
-  f0 = B.f; fp0 = B.fp0;  // == applyFDF(0): position 0 is x0 with cached f, slope
-  falpha_prev = f0; fpalpha_prev = fp0;
-  a = 0.0; b = alpha; fa = f0; fb = 0.0; fpa = fp0; fpb = 0.0;
-  while (i++ < bracket_iters) {
-    falpha = bfgs_f(B, alpha);
-    if (falpha > f0 + alpha * rho * fp0 || falpha >= falpha_prev) {
-      a = alpha_prev; fa = falpha_prev; fpa = fpalpha_prev;
-      b = alpha; fb = falpha; fpb = NAN;
-      break;
-    }
-    fpalpha = bfgs_df(B, alpha);
-    if (fabs(fpalpha) <= -sigma * fp0) { *alpha_new = alpha; return BFGS_SUCCESS; }
-    if (fpalpha >= 0) {
-      a = alpha; fa = falpha; fpa = fpalpha;
-      b = alpha_prev; fb = falpha_prev; fpb = fpalpha_prev;
-      break;
-    }
-    delta = alpha - alpha_prev;
-    {
-      double lower = alpha + delta, upper = alpha + tau1 * delta;
-      alpha_next = bfgs_interpolate(alpha_prev, falpha_prev, fpalpha_prev, alpha, falpha, fpalpha, lower, upper, order);
-    }
-    alpha_prev = alpha; falpha_prev = falpha; fpalpha_prev = fpalpha; alpha = alpha_next;
-  }
-  while (i++ < section_iters) {
-    delta = b - a;
-    {
-      double lower = a + tau2 * delta, upper = b - tau3 * delta;
+  bool section = false;
+  for (;;) {
+    if (!section) {
+      if (!(i++ < bracket_iters)) { section = true; continue; }
+    } else {
+      if (!(i++ < section_iters)) return BFGS_SUCCESS;
+      const double delta = b - a;
+      const double lower = a + tau2 * delta, upper = b - tau3 * delta;
       alpha = bfgs_interpolate(a, fa, fpa, b, fb, fpb, lower, upper, order);
     }
-    falpha = bfgs_f(B, alpha);
-    if ((a - alpha) * fpa <= 2.220446049250313e-16) return BFGS_NOPROGRESS;
-    if (falpha > f0 + rho * alpha * fp0 || falpha >= fa) {
-      b = alpha; fb = falpha; fpb = NAN;
-    } else {
-      fpalpha = bfgs_df(B, alpha);
+    bfgs_eval(B, alpha);                       // the one evaluation site
+    const double falpha = B.c_f, fpalpha = B.c_df;
+    if (!section) {
+      if (falpha > f0 + alpha * rho * fp0 || falpha >= falpha_prev) {
+        a = alpha_prev; fa = falpha_prev; fpa = fpalpha_prev;
+        b = alpha; fb = falpha; fpb = NAN;
+        section = true;
+        continue;
+      }
       if (fabs(fpalpha) <= -sigma * fp0) { *alpha_new = alpha; return BFGS_SUCCESS; }
-      if (((b - a) >= 0 && fpalpha >= 0) || ((b - a) <= 0 && fpalpha <= 0)) {
-        b = a; fb = fa; fpb = fpa;
+      if (fpalpha >= 0) {
         a = alpha; fa = falpha; fpa = fpalpha;
+        b = alpha_prev; fb = falpha_prev; fpb = fpalpha_prev;
+        section = true;
+        continue;
+      }
+      const double delta = alpha - alpha_prev;
+      const double lower = alpha + delta, upper = alpha + tau1 * delta;
+      const double alpha_next = bfgs_interpolate(alpha_prev, falpha_prev, fpalpha_prev, alpha, falpha, fpalpha, lower, upper, order);
+      alpha_prev = alpha; falpha_prev = falpha; fpalpha_prev = fpalpha; alpha = alpha_next;
+    } else {
+      if ((a - alpha) * fpa <= 2.220446049250313e-16) return BFGS_NOPROGRESS;
+      if (falpha > f0 + rho * alpha * fp0 || falpha >= fa) {
+        b = alpha; fb = falpha; fpb = NAN;
       } else {
-        a = alpha; fa = falpha; fpa = fpalpha;
+        if (fabs(fpalpha) <= -sigma * fp0) { *alpha_new = alpha; return BFGS_SUCCESS; }
+        if (((b - a) >= 0 && fpalpha >= 0) || ((b - a) <= 0 && fpalpha <= 0)) {
+          b = a; fb = fa; fpb = fpa;
+          a = alpha; fa = falpha; fpa = fpalpha;
+        } else {
+          a = alpha; fa = falpha; fpa = fpalpha;
+        }
       }
     }
   }
-  return BFGS_SUCCESS;
 }
 
 S3D_HD void bfgs_init(Bfgs& b, const double* acc, const double* th0, const double x[6]) {
@@ -1948,7 +1963,8 @@ S3D_HD int bfgs_one_step(Bfgs& b, double x[6]) {
   if (alpha == 0.0) {  // (section loop ran out without setting alpha: position unchanged)
     for (int i = 0; i < 6; ++i) { x[i] = b.x0[i]; b.gradient[i] = b.g0[i]; }
   } else {
-    bfgs_eval(b, alpha);
+    // (alpha is the trial point the line search evaluated last - it returns an alpha only right after evaluating it -
+    // so PCL's updatePosition(alpha) finds it in the cache: no evaluation site here)
     b.f = b.c_f;
     for (int i = 0; i < 6; ++i) { x[i] = b.c_x[i]; b.gradient[i] = b.c_g[i]; }
   }

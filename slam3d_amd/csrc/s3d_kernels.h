@@ -1501,16 +1501,15 @@ __global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_search_kernel(con
   const SlotDev& Ss = slots[P.slot_s];
   // the positions the stored bounds refer to: the previous pass in the ICP loop; in the fitness pass (MODE 1) those of
   // the record's last full evaluation, when the settled passes ran record-wise (s3d_nn_settled_kernel)
-  Mat4f Tloc;
-  if (MODE == 1) {
-    Tloc = P.T_nn;
+  const Mat4f* tref = &P.T_nn;       // (a wave-uniform pointer: the matrix comes through scalar loads either way)
+  if (MODE == 1 && recs) {
     const int rec = chunk * (kBlock / kWave) + wave_id();
-    if (recs && rec * kWave < St.n) {   // (a wave past the end of the cloud owns no record: what lies there is stale)
+    if (rec * kWave < St.n) {          // (a wave past the end of the cloud owns no record: what lies there is stale)
       const int touch = __builtin_amdgcn_readfirstlane(recs[(P.corr_off >> 6) + rec].touch);
-      if (touch >= 0 && touch < hist_stride) Tloc = T_hist[(size_t)pair * hist_stride + touch];
+      if (touch >= 0 && touch < hist_stride) tref = T_hist + (size_t)pair * hist_stride + touch;
     }
   }
-  const Mat4f& Tref = MODE == 1 ? Tloc : P.T_nn;
+  const Mat4f& Tref = *tref;
   // lanes past the end of the cloud stay in the wave (the cooperative search needs all of them) but own no query
   if (!compact) {
     nn_query<MODE, 0>(P, St, Ss, pair, i, i < St.n, A, max_d, dbg, prof_counts, nullptr, Tref);
