@@ -230,15 +230,15 @@ def main():
         # limits the kernel is in "limiter" (PMC evidence in profiles/README.md): `achieved` is ALGORITHMIC bytes per
         # second, i.e. how far an exact grid search is from streaming its compulsory traffic.
         # The correspondence pass is a kernel FAMILY: pass 1 of a registration runs s3d_nn_first_kernel, passes 2 and 3
-        # s3d_nn_scan27_kernel (+ s3d_nn_worklist_kernel for the queries it declines), pass 4 s3d_nn_search_kernel<0>, and
-        # from pass 5 on (round 4, batches of >= 65 536 records) the record-wise kernels: s3d_nn_record_touch_kernel<false>
+        # s3d_nn_scan27_kernel (+ s3d_nn_worklist_kernel for the queries it declines), and from pass 4 on (round 4, batches
+        # of >= 65 536 records; smaller ones keep s3d_nn_search_kernel<0>) the record-wise kernels: s3d_nn_record_touch_kernel<false>
         # once, then s3d_nn_record_test_kernel + s3d_nn_record_touch_kernel<true> per pass, each followed by
         # s3d_nn_record_search_kernel.  avg_launch_ms is (the time of all of them in one step) / I, HIP events around every
         # pass (cross-check against rocprofv3: the TotalDurationNs of those kernel names / (I x steps)).  The ALGORITHMIC
         # bytes stay 20 M + 12 N per pass whatever is actually moved: a record-wise pass reads 32 bytes per 64 queries for
         # the records it proves unchanged, which is why its own `steady_frac` can exceed 1.
         roofline = {"kernel": "s3d_nn_first_kernel (pass 1) + s3d_nn_scan27_kernel<*> + s3d_nn_worklist_kernel (passes 2-3) "
-                              "+ s3d_nn_search_kernel<0> (pass 4) + s3d_nn_record_{test,touch,search}_kernel (passes 5-%d)"
+                              "+ s3d_nn_record_{test,touch,search}_kernel (passes 4-%d)"
                               % n_launch,
                     "bound": "hbm", "achieved": round(achieved, 2),
                     "limiter": "VALU issue of divergent per-lane candidate walks in the first passes (82 % of the issue "

@@ -831,10 +831,11 @@ struct Batch {
       s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc, 0,
                                                        settled_used ? wave_recs() : nullptr, t_hist(), hist_stride());
   }
-  // first outer iteration (0-based) that runs record-wise.  Measured at 256 pairs, passes 4 / 5 / 6 of the loop: from
-  // iteration 5 on 0.73 / 0.285 / 0.240 ms, from 4 on 0.73 / 0.255 / 0.133, from 3 on 2.1 / 0.27 / 0.13 (pass 4 still
-  // searches 2 % of its queries: 580 000 one-query waves)
-  static constexpr int kSettledFrom = 4;
+  // first outer iteration (0-based) that runs record-wise: the pass after the two flat-scan passes.  Pass 4 still
+  // searches 2 % of its queries (580 000 at 256 pairs): the touch kernel streams all records and lists them, the search
+  // kernel serves the lists 64 queries per wave - 0.50 ms against 0.76 for the block-compacting per-query kernel (with
+  // one-query-per-wave searches only, before the throughput mode existed: 2.1 ms).  Passes 5 / 6: 0.247 / 0.098 ms.
+  static constexpr int kSettledFrom = 3;
   // records per thread of the test kernel: four for a large batch (few blocks, one list append each), one for a small one
   int rec_per_thread() const { return (long long)P() * cdiv(std::max(max_n_t, 1), kWave) >= 65536 ? kNNRecPerThread : 1; }
   // capacity of one of the kNNSearchSublists search lists: every query of the records that map to it

@@ -99,3 +99,19 @@ def test_product_does_not_reference_the_oracle():
                     if re.search(r"(import\s+oracle|from\s+oracle|s3d_oracle|libs3d_oracle|s3o_)", text):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_product_reads_no_environment_on_the_registration_path():
+    """Round 4: behaviour switches come through s3d_exec_options.debug_flags, never through getenv (the library is
+    entered from two threads of the host application, ScanSensor.cpp:209-210).  One read-once debug print may remain."""
+    import slam3d_amd
+    n = 0
+    for fn in os.listdir(os.path.join(ROOT, "slam3d_amd", "csrc")):
+        if fn.endswith((".h", ".hip")):
+            text = open(os.path.join(ROOT, "slam3d_amd", "csrc", fn)).read()
+            text = re.sub(r"//.*", "", text)
+            n += len(re.findall(r"\bgetenv\s*\(", text))
+    assert n <= 1, n
+    # the link policy and the options struct of the binding are the header's
+    src = 'int main(){return 0;}'
+    assert ctypes.sizeof(slam3d_amd.api.LinkPolicyC) == 20 and ctypes.sizeof(slam3d_amd.ExecOptions) == 32
