@@ -151,6 +151,12 @@ void s3d_default_params(s3d_reg_params* p);          /* RegistrationParameters.h
 
 /* ---- device-resident clouds ----------------------------------------------------- */
 int  s3d_cloud_upload(s3d_context* ctx, const float* xyz, int n, int stride, s3d_cloud** out);
+/* Bulk hand-over: n_clouds host arrays (xyz[i]: n[i] points of `stride` floats, x y z first) -> n_clouds clouds in ONE
+ * device allocation, which lives until the last of them is released (any order).  Host threads copy the arrays into
+ * pinned memory while the float4 expansion of the previous ones reads it over PCIe: the archive of a reloaded graph
+ * (GraphSerialization.cpp:68-135 rebuilds every measurement) or the scans of a loop-closure sweep are handed over at
+ * the link's rate instead of one allocation + staged copy + wait per scan.  out[i] are ordinary clouds. */
+int  s3d_cloud_upload_many(s3d_context* ctx, int n_clouds, const float* const* xyz, const int* n, int stride, s3d_cloud** out);
 /* wrap n float4 (x,y,z,*) already in HBM (e.g. a torch tensor); not copied, not freed */
 int  s3d_cloud_wrap_device(s3d_context* ctx, const void* device_float4, int n, s3d_cloud** out);
 int  s3d_cloud_size(const s3d_cloud* c);

@@ -150,6 +150,7 @@ def load_library():
         "s3d_cloud_cache_import": (C.c_int, [vp, vp, vp, C.c_longlong]),
         "s3d_default_params": (None, [pp]),
         "s3d_cloud_upload": (C.c_int, [vp, fp, C.c_int, C.c_int, C.POINTER(vp)]),
+        "s3d_cloud_upload_many": (C.c_int, [vp, C.c_int, C.POINTER(fp), C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]),
         "s3d_cloud_wrap_device": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp)]),
         "s3d_cloud_size": (C.c_int, [vp]),
         "s3d_cloud_release": (None, [vp, vp]),
@@ -388,6 +389,24 @@ class Context:
         if st:
             raise ValueError(STATUS_NAMES[st])
         return Cloud(self, h, n)
+
+    def upload_many(self, clouds):
+        """Bulk hand-over (s3d_cloud_upload_many): a list of (n_i, stride) float32 arrays of one stride -> Cloud handles
+        that share one device allocation."""
+        arrs = [_cloud(x) for x in clouds]
+        if not arrs:
+            return []
+        stride = arrs[0][2]
+        if any(a[2] != stride for a in arrs):
+            raise ValueError("upload_many: all clouds must have the same stride")
+        m = len(arrs)
+        ptrs = (C.POINTER(C.c_float) * m)(*[_fp(a[0]) for a in arrs])
+        ns = (C.c_int * m)(*[a[1] for a in arrs])
+        out = (C.c_void_p * m)()
+        st = self._check(self._L.s3d_cloud_upload_many(self._h, m, ptrs, ns, stride, out))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
+        return [Cloud(self, C.c_void_p(out[i]), arrs[i][1]) for i in range(m)]
 
     def wrap_device(self, device_ptr, n):
         h = C.c_void_p()

@@ -17,6 +17,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -28,11 +29,17 @@ using namespace s3d;
 
 // ------------------------------------------------------------------ host structs
 
+// one device allocation shared by the clouds of a bulk hand-over (s3d_cloud_upload_many): freed with the last of them
+struct S3dDevBlock {
+  void* p = nullptr;
+  ~S3dDevBlock() { if (p) (void)hipFree(p); }
+};
 struct s3d_cloud {
   float4* d = nullptr;
   int n = 0;
   bool owned = false;
   unsigned long long uid = 0;   // never reused: the key of the pre-pass cache (an address could be recycled)
+  std::shared_ptr<S3dDevBlock> block;   // set: d points into this block (owned = false)
 };
 
 namespace {
@@ -199,6 +206,24 @@ struct s3d_context {
   }
   hipEvent_t ev[8] = {};
   std::vector<hipEvent_t> nn_ev;
+  // s3d_cloud_upload_many: per worker thread a stream and two pinned slots (grown on demand, kept)
+  struct UploadLane {
+    hipStream_t st = nullptr;
+    char* pinned[2] = {nullptr, nullptr};
+    size_t cap = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+  };
+  std::vector<UploadLane> upload_lanes;
+  void release_upload_lanes() {
+    for (UploadLane& L : upload_lanes) {
+      if (L.st) { (void)hipStreamSynchronize(L.st); (void)hipStreamDestroy(L.st); }
+      for (int k = 0; k < 2; ++k) {
+        if (L.pinned[k]) (void)hipHostFree(L.pinned[k]);
+        if (L.ev[k]) (void)hipEventDestroy(L.ev[k]);
+      }
+    }
+    upload_lanes.clear();
+  }
 
   // ONE device allocation for the whole workspace, carved at 2 MiB boundaries: a few hundred MB per
   // array in separate hipMallocs left some processes with 3x slower streaming kernels on this pool
@@ -1089,6 +1114,87 @@ int upload_cloud(s3d_context* ctx, const float* xyz, int n, int stride, s3d_clou
 void free_cloud(s3d_cloud* c) {
   if (c->owned && c->d) (void)hipFree(c->d);
   c->d = nullptr;
+  c->block.reset();       // (a bulk hand-over's allocation goes with its last cloud)
+}
+
+// Bulk hand-over (s3d_cloud_upload_many).  One s3d_cloud_upload is a hipMalloc, a copy from pageable memory (which the
+// runtime stages in small pieces: ~12 GB/s) and a stream wait: ~100 us for a 100 k-point scan, 50 ms for the 512 clouds
+// of a sweep.  Here all clouds share ONE device allocation, and `lanes` host threads - each with a stream and two pinned
+// slots of its own - copy the callers' arrays into pinned memory (wide records packed to xyz on the way) while the
+// expansion kernels of the previous slots read that memory over PCIe and write the float4 layout straight into HBM: no
+// staging copy on the device, no per-cloud allocation, no per-cloud wait.
+void upload_many(s3d_context* ctx, int n_clouds, const float* const* xyz, const int* n, int stride, s3d_cloud** out) {
+  size_t total = 0, most = 0;
+  std::vector<size_t> off((size_t)n_clouds);
+  for (int i = 0; i < n_clouds; ++i) {
+    off[(size_t)i] = total;
+    total += ((size_t)std::max(n[i], 1) + 63) & ~(size_t)63;      // (clouds start on 1 KiB boundaries)
+    most = std::max(most, (size_t)std::max(n[i], 0));
+  }
+  auto block = std::make_shared<S3dDevBlock>();
+  HIPCHK(hipMalloc(&block->p, sizeof(float4) * std::max<size_t>(total, 64)));
+  const int hs = stride > 6 ? 3 : stride;                            // floats per point in the pinned slot
+  const size_t slot_bytes = std::max<size_t>(sizeof(float) * most * (size_t)hs, 256);
+  const int lanes = (int)std::max<size_t>(1, std::min<size_t>({(size_t)n_clouds, (size_t)8,
+                                                                 (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+  if ((int)ctx->upload_lanes.size() < lanes) ctx->upload_lanes.resize((size_t)lanes);
+  for (int t = 0; t < lanes; ++t) {
+    s3d_context::UploadLane& L = ctx->upload_lanes[(size_t)t];
+    if (!L.st) HIPCHK(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) if (!L.ev[k]) HIPCHK(hipEventCreateWithFlags(&L.ev[k], hipEventDisableTiming));
+    if (L.cap < slot_bytes) {
+      HIPCHK(hipStreamSynchronize(L.st));
+      for (int k = 0; k < 2; ++k) {
+        if (L.pinned[k]) HIPCHK(hipHostFree(L.pinned[k]));
+        L.pinned[k] = nullptr;
+        HIPCHK(hipHostMalloc((void**)&L.pinned[k], slot_bytes + slot_bytes / 4));
+      }
+      L.cap = slot_bytes + slot_bytes / 4;
+    }
+  }
+  std::atomic<int> next{0};
+  std::vector<HipError> errs;
+  std::mutex errs_mtx;
+  auto work = [&](int t) {
+    try {
+      HIPCHK(hipSetDevice(ctx->device));
+      s3d_context::UploadLane& L = ctx->upload_lanes[(size_t)t];
+      bool used[2] = {false, false};
+      int k = 0;
+      for (int i = next.fetch_add(1); i < n_clouds; i = next.fetch_add(1)) {
+        const int ni = n[i];
+        if (ni <= 0) continue;
+        if (used[k]) HIPCHK(hipEventSynchronize(L.ev[k]));          // the kernel that read this slot has finished
+        float* dst = (float*)L.pinned[k];
+        if (hs == stride) {
+          std::memcpy(dst, xyz[i], sizeof(float) * ((size_t)(ni - 1) * stride + 3));
+        } else {
+          const float* src = xyz[i];
+          for (int j = 0; j < ni; ++j) { dst[3 * j] = src[(size_t)j * stride]; dst[3 * j + 1] = src[(size_t)j * stride + 1]; dst[3 * j + 2] = src[(size_t)j * stride + 2]; }
+        }
+        k_expand_points<<<cdiv(ni, kBlock), kBlock, 0, L.st>>>(dst, ni, hs, (float4*)block->p + off[(size_t)i]);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(L.ev[k], L.st));
+        used[k] = true;
+        k ^= 1;
+      }
+      HIPCHK(hipStreamSynchronize(L.st));
+    } catch (const HipError& e) {
+      std::lock_guard<std::mutex> lock(errs_mtx);
+      errs.push_back(e);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < lanes; ++t) th.emplace_back(work, t);
+  work(0);
+  for (std::thread& x : th) x.join();
+  if (!errs.empty()) throw errs[0];
+  for (int i = 0; i < n_clouds; ++i) {
+    s3d_cloud* c = out[i];
+    c->n = std::max(n[i], 0); c->owned = false; c->uid = g_cloud_uid++;
+    c->d = (float4*)block->p + off[(size_t)i];
+    c->block = block;
+  }
 }
 
 // ---- device-resident helpers shared by the map / patch entry points --------------------------------
@@ -1590,6 +1696,7 @@ void s3d_context_destroy(s3d_context* ctx) {
   if (ctx->d_copy.p) (void)hipFree(ctx->d_copy.p);
   for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->nn_ev) (void)hipEventDestroy(e);
+  ctx->release_upload_lanes();
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1815,6 +1922,24 @@ int s3d_cloud_upload(s3d_context* ctx, const float* xyz, int n, int stride, s3d_
     return fail(ctx, e);
   }
   *out = c;
+  return S3D_STATUS_OK;
+}
+
+int s3d_cloud_upload_many(s3d_context* ctx, int n_clouds, const float* const* xyz, const int* n, int stride, s3d_cloud** out) {
+  if (!ctx || n_clouds < 0 || stride < 3 || (n_clouds > 0 && (!xyz || !n || !out))) return S3D_STATUS_INVALID_ARGUMENT;
+  for (int i = 0; i < n_clouds; ++i)
+    if (n[i] < 0 || (n[i] > 0 && !xyz[i])) return S3D_STATUS_INVALID_ARGUMENT;
+  if (n_clouds == 0) return S3D_STATUS_OK;
+  std::vector<s3d_cloud*> made((size_t)n_clouds, nullptr);
+  for (int i = 0; i < n_clouds; ++i) made[(size_t)i] = new s3d_cloud();
+  try {
+    ScopedDevice sd(ctx);
+    upload_many(ctx, n_clouds, xyz, n, stride, made.data());
+  } catch (const HipError& e) {
+    for (s3d_cloud* c : made) delete c;
+    return fail(ctx, e);
+  }
+  for (int i = 0; i < n_clouds; ++i) out[i] = made[(size_t)i];
   return S3D_STATUS_OK;
 }
 

@@ -751,3 +751,38 @@ def test_million_point_registration_matches_oracle(gpu_ctx, oracle_mod):
     assert st == so == 0 and info["iterations"] == io["iterations"] == 50
     assert info["n_source_filtered"] == io["n_source_filtered"] and info["n_target_filtered"] == io["n_target_filtered"]
     assert dt < TOL_T_GICP and dr < TOL_R_GICP, (dt, dr)
+
+
+def test_bulk_hand_over_equals_single_uploads(gpu_ctx, fixture_clouds):
+    """s3d_cloud_upload_many: the clouds of one call share a device allocation and are ordinary clouds - the same points
+    (download), the same registrations bit for bit as clouds handed over one by one, for packed xyz, xyzw and ragged
+    sizes including an empty cloud, released in any order."""
+    import slam3d_amd as s3d
+    rng = np.random.default_rng(3)
+    clouds = [np.ascontiguousarray(c[:, :3]) for c in fixture_clouds] + [fixture_clouds[0][:777, :3].copy(),
+                                                                          np.zeros((0, 3), np.float32)]
+    clouds += [s3d.make_pair(30000, s)[k] for s in range(6) for k in (0, 1)]          # more clouds than worker threads
+    many = gpu_ctx.upload_many(clouds)
+    assert [c.n for c in many] == [len(c) for c in clouds]
+    for c, h in zip(clouds, many):
+        assert np.array_equal(h.download(), c)
+    p = s3d.default_params()
+    one = [gpu_ctx.upload(c) for c in clouds[:4]]
+    a = gpu_ctx.align_batch(one[:3], one[1:4], None, p)
+    b = gpu_ctx.align_batch(many[:3], many[1:4], None, p)
+    assert (a[:, 15] == 0).all() and np.array_equal(a, b)
+    # xyzw records (the fourth float is ignored) give the same clouds
+    w4 = [np.concatenate([c, rng.normal(size=(len(c), 1)).astype(np.float32)], axis=1) for c in clouds[:5]]
+    many4 = gpu_ctx.upload_many(w4)
+    for c, h in zip(clouds[:5], many4):
+        assert np.array_equal(h.download(), c)
+    # released in any order; the survivors stay valid until the last one goes
+    for i in (3, 0, 7, 5):
+        many[i].release()
+    assert np.array_equal(many[1].download(), clouds[1]) and np.array_equal(many[-1].download(), clouds[-1])
+    b2 = gpu_ctx.align_batch([many[1]], [many[2]], None, p)
+    assert np.array_equal(b2[0], a[1])
+    with pytest.raises(ValueError):
+        gpu_ctx.upload_many([clouds[0], w4[1]])
+    for h in many + many4 + one:
+        h.release()
