@@ -48,9 +48,11 @@ typedef struct s3d_exec_options {
                                s3d_context_cache_control.  A cloud must not be modified while it is cached.       */
   int omp_unavailable;      /* GICP_OMP / NDT_OMP.  The reference has two behaviours, chosen when IT is built
                                (PointCloudSensor.cpp:149-162): with the external pclomp package the two enumerators
-                               run pclomp's multi-threaded GICP / NDT - the same objectives as GICP / NDT - and
+                               run pclomp's multi-threaded GICP / NDT - GICP_OMP the same objective as GICP, NDT_OMP
+                               the NDT objective over pclomp's DIRECT7 neighbourhood - and
                                without it align() throws std::runtime_error("OMP is not available, ...").
-                               0 (default): the pclomp build - both are served by the GICP / NDT device code.
+                               0 (default): the pclomp build - GICP_OMP is served by the GICP device code, NDT_OMP by the
+                               NDT code with the seven-voxel neighbourhood.
                                1: the build without pclomp - S3D_STATUS_OMP_UNAVAILABLE after the voxel filter and
                                the 100-point gate (the reference's order), which the C++ mirror re-raises.           */
   unsigned int debug_flags; /* S3D_DBG_* bits below; 0 = the product's behaviour.  Every bit switches ONE fast path off

@@ -25,7 +25,9 @@ enum s3d_registration_algorithm {
   S3D_ALG_GICP_OMP = 2, /* reference: pclomp variant, same arithmetic as GICP */
   S3D_ALG_NDT      = 3, /* doNDT (:84-117): voxel statistics + derivative passes on the device, Newton /
                            More-Thuente state machines on the host, batches advance in lock-step rounds */
-  S3D_ALG_NDT_OMP  = 4
+  S3D_ALG_NDT_OMP  = 4  /* reference: pclomp::NormalDistributionsTransform - the NDT optimiser over pclomp's default
+                           neighbour search DIRECT7 (the voxel holding the transformed point + its six face neighbours,
+                           VoxelGridCovariance::getNeighborhoodAtPoint7) instead of PCL's kd-tree radius query */
 };
 
 /* slam3d/sensor/pcl/RegistrationParameters.hpp:36-97 — field-for-field, same

@@ -1209,7 +1209,11 @@ done:
  *   - Eigen's Transform::rotation() (an SVD clean-up) is taken as the 3x3 block of the guess;
  *   - the angle-derivative vectors j_ang / h_ang are formed as products of the elementary rotation matrices and
  *     their derivatives (the same numbers as PCL's closed forms up to rounding);
- *   - NDT_OMP (pclomp, DIRECT7 neighbourhood) is served by the same code. */
+ *   - NDT_OMP is pclomp::NormalDistributionsTransform (koide3/ndt_omp, not in the image, pinned by nothing here): the
+ *     same objective and optimiser with its default neighbour search DIRECT7 - the voxel holding the transformed point,
+ *     floor(x / leaf), and its six face neighbours in the order 0 +x -x +y -y +z -z, every one with >= 6 points
+ *     (VoxelGridCovariance::getNeighborhoodAtPoint7) - instead of the kd-tree radius query; its float point
+ *     derivatives are NOT restated (double here as in PCL). */
 
 typedef struct {
   int n;            /* valid cells */
@@ -1217,10 +1221,13 @@ typedef struct {
   double* icov;     /* n * 9 */
   float* centroid;  /* n * 3 */
   s3o_kdtree* tree; /* over centroid */
+  unsigned* key;    /* n, ascending: the voxel index of a cell (DIRECT7 look-up) */
+  float leaf;
+  int min_b[3], div_b[3];
 } ndt_cells;
 
 static void ndt_cells_free(ndt_cells* c) {
-  free(c->mean); free(c->icov); free(c->centroid);
+  free(c->mean); free(c->icov); free(c->centroid); free(c->key);
   if (c->tree) s3o_kdtree_free(c->tree);
   memset(c, 0, sizeof *c);
 }
@@ -1256,9 +1263,13 @@ static void ndt_build_cells(const float* xyz, int n, double resolution, ndt_cell
   out->mean = (double*)malloc(sizeof(double) * 3 * (size_t)n);
   out->icov = (double*)malloc(sizeof(double) * 9 * (size_t)n);
   out->centroid = (float*)malloc(sizeof(float) * 3 * (size_t)n);
+  out->key = (unsigned*)malloc(sizeof(unsigned) * (size_t)n);
+  out->leaf = leaf;
+  for (int a = 0; a < 3; ++a) { out->min_b[a] = min_b[a]; out->div_b[a] = div_b[a]; }
   int m = 0;
   for (int i = 0; i < n;) {
     int j = i;
+    const unsigned cell_key = kv[i].key;
     double s[3] = {0, 0, 0}, c[3][3] = {{0}};
     while (j < n && kv[j].key == kv[i].key) {
       const float* p = xyz + (size_t)kv[j].idx * 3;
@@ -1301,6 +1312,7 @@ static void ndt_build_cells(const float* xyz, int n, double resolution, ndt_cell
       out->centroid[(size_t)m * 3 + a] = (float)mean[a];
       for (int b = 0; b < 3; ++b) out->icov[(size_t)m * 9 + a * 3 + b] = ci[a][b];
     }
+    out->key[m] = cell_key;
     ++m;
   }
   free(kv);
@@ -1314,7 +1326,27 @@ typedef struct {
   const ndt_cells* cells;
   double resolution, d1, d2;
   int evaluations;
+  int direct7;          /* NDT_OMP: pclomp's default neighbour search */
 } ndt_problem;
+
+/* VoxelGridCovariance::getNeighborhoodAtPoint7 (pclomp): cell ids of the voxel of xt and its six face neighbours */
+static int ndt_neighbourhood7(const ndt_cells* C, const float xt[3], int* out) {
+  static const int rel[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+  int ijk[3], k = 0;
+  for (int a = 0; a < 3; ++a) ijk[a] = (int)floorf(xt[a] / C->leaf) - C->min_b[a];
+  for (int r = 0; r < 7; ++r) {
+    const int v0 = ijk[0] + rel[r][0], v1 = ijk[1] + rel[r][1], v2 = ijk[2] + rel[r][2];
+    if (v0 < 0 || v1 < 0 || v2 < 0 || v0 >= C->div_b[0] || v1 >= C->div_b[1] || v2 >= C->div_b[2]) continue;
+    const unsigned key = (unsigned)(v0 + v1 * C->div_b[0] + v2 * C->div_b[0] * C->div_b[1]);
+    int lo = 0, hi = C->n - 1;
+    while (lo <= hi) {
+      const int mid = (lo + hi) / 2;
+      if (C->key[mid] == key) { out[k++] = mid; break; }
+      if (C->key[mid] < key) lo = mid + 1; else hi = mid - 1;
+    }
+  }
+  return k;
+}
 
 static void m3mul(const double a[3][3], const double b[3][3], double o[3][3]) {
   for (int i = 0; i < 3; ++i)
@@ -1389,12 +1421,12 @@ static double ndt_derivatives(ndt_problem* P, const float T[16], const double p[
     const float* xf = P->input + (size_t)i * 3;
     float xt[3];
     xf_pcl(T, xf, xt);
-    const int k = s3o_kdtree_knn(P->cells->tree, xt, 27, nn_i, nn_d);
+    const int k = P->direct7 ? ndt_neighbourhood7(P->cells, xt, nn_i) : s3o_kdtree_knn(P->cells->tree, xt, 27, nn_i, nn_d);
     const double x[3] = {xf[0], xf[1], xf[2]};
     double J[3][6];   /* point_gradient_ */
     int have_j = 0;
     for (int c = 0; c < k; ++c) {
-      if (!(nn_d[c] < r2)) break;                            /* sorted ascending; FLANN radius search is strict */
+      if (!P->direct7 && !(nn_d[c] < r2)) break;             /* sorted ascending; FLANN radius search is strict */
       if (!have_j) {
         for (int a = 0; a < 3; ++a) {
           for (int b = 0; b < 3; ++b) J[a][b] = a == b ? 1.0 : 0.0;
@@ -1586,6 +1618,7 @@ int s3o_ndt(const float* input, int m, const float* target, int n, const float g
   ndt_problem P;
   memset(&P, 0, sizeof P);
   P.input = input; P.m = m; P.cells = &cells; P.resolution = (double)cfg->resolution;
+  P.direct7 = cfg->registration_algorithm == S3D_ALG_NDT_OMP;
   {                                                          /* init(): Eq. 6.8 [Magnusson 2009] */
     const double c1 = 10 * (1 - cfg->outlier_ratio), c2 = cfg->outlier_ratio / pow(P.resolution, 3), d3 = -log(c2);
     P.d1 = -log(c1 + c2) - d3;

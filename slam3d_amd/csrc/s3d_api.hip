@@ -1368,8 +1368,8 @@ constexpr int kNdtBlocks = 64;   // blocks per derivative pass and pair (fixed: 
 // doNDT (PointCloudSensor.cpp:84-117) for every pair of `b` (voxel filter and grid already staged and
 // downloaded).  The voxel statistics and every derivative pass run on the device — one launch per ROUND over
 // all pairs that still iterate — and the Newton / More-Thuente state machines (s3d_ndt.h, one per pair) run on
-// the host between the rounds (one 224-byte result per pair and round comes back).  NDT_OMP is served by the
-// same code (pclomp differs in its neighbourhood search, not in the objective).
+// the host between the rounds (one 224-byte result per pair and round comes back).  NDT_OMP is the same optimiser over
+// pclomp's default neighbourhood (DIRECT7: the voxel of the point and its six face neighbours, s3d_ndt_derivatives_kernel<true>).
 // statuses / results / infos: one per pair.
 void align_ndt_pairs(Batch& b, const s3d_reg_params* params, const double* guesses, std::vector<int>& statuses,
                      std::vector<std::array<double, 16>>& results, std::vector<s3d_align_info>& infos) {
@@ -1436,6 +1436,9 @@ void align_ndt_pairs(Batch& b, const s3d_reg_params* params, const double* guess
   double d1, d2;
   ndt::gauss_constants(params->outlier_ratio, (double)params->resolution, &d1, &d2);
   const float r2 = params->resolution * params->resolution;
+  // NDT_OMP = pclomp's transform, whose default neighbour search is DIRECT7 (the voxel of the point + its six face
+  // neighbours) where PCL's NDT asks a kd-tree for the cells within `resolution`
+  const bool direct7 = params->registration_algorithm == S3D_ALG_NDT_OMP;
   std::vector<std::unique_ptr<ndt::Solver>> solver(NP);
   std::vector<ndt::Result> res(NP);
   for (int p = 0; p < NP; ++p) {
@@ -1471,8 +1474,12 @@ void align_ndt_pairs(Batch& b, const s3d_reg_params* params, const double* guess
     const int NJ = (int)jobs.size();
     if (NJ == 0) break;
     HIPCHK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(NdtJob) * NJ, hipMemcpyHostToDevice, st));
-    s3d_ndt_derivatives_kernel<<<dim3(kNdtBlocks, NJ), kBlock, 0, st>>>(b.d_slots(), d_grids, d_jobs, b.filt(), r2, d1, d2,
-                                                                        d_part);
+    if (direct7)
+      s3d_ndt_derivatives_kernel<true><<<dim3(kNdtBlocks, NJ), kBlock, 0, st>>>(b.d_slots(), d_grids, d_jobs, b.filt(), r2,
+                                                                                params->resolution, d1, d2, d_part);
+    else
+      s3d_ndt_derivatives_kernel<false><<<dim3(kNdtBlocks, NJ), kBlock, 0, st>>>(b.d_slots(), d_grids, d_jobs, b.filt(), r2,
+                                                                                 params->resolution, d1, d2, d_part);
     k_ndt_reduce<<<NJ, 64, 0, st>>>(d_part, kNdtBlocks, d_out);
     h_out.resize((size_t)NJ * NDT_NACC);
     HIPCHK(hipMemcpyAsync(h_out.data(), d_out, sizeof(double) * NDT_NACC * (size_t)NJ, hipMemcpyDeviceToHost, st));

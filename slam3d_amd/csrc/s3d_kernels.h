@@ -2680,10 +2680,14 @@ __global__ void __launch_bounds__(kBlock) k_ndt_cells(const SlotDev* __restrict_
 // score, gradient and Hessian of the NDT objective at the transform T (parameters enter through the angle
 // derivatives): every input point against the cells whose centroid lies within `resolution` of its image —
 // the kd-tree radius query of PCL, answered here by the 27 voxels around the point in the dense table.
+// DIRECT7 (NDT_OMP: pclomp::NormalDistributionsTransform with its default neighbour search,
+// VoxelGridCovariance::getNeighborhoodAtPoint7): the voxel that holds the image of the point - floor(x / leaf), the
+// division pclomp writes - and its six face neighbours, in pclomp's order, every one of them that is a cell; no radius.
+template <bool DIRECT7>
 __global__ void __launch_bounds__(kBlock) s3d_ndt_derivatives_kernel(const SlotDev* __restrict__ slots,
                                                                       const NdtGrid* __restrict__ grids,
                                                                       const NdtJob* __restrict__ jobs,
-                                                                      const float4* __restrict__ filt, float r2,
+                                                                      const float4* __restrict__ filt, float r2, float leaf,
                                                                       double d1, double d2,
                                                                       double* __restrict__ partials) {
   const NdtJob& Jb = jobs[blockIdx.y];
@@ -2702,16 +2706,19 @@ __global__ void __launch_bounds__(kBlock) s3d_ndt_derivatives_kernel(const SlotD
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < m; i += gridDim.x * kBlock) {
     const float4 pf = input[i];
     const F3 xt = xf_pcl(T, pf.x, pf.y, pf.z);
-    const int c0 = (int)(floorf(xt.x * vp.inv_leaf) - (float)vp.min_b[0]);
-    const int c1 = (int)(floorf(xt.y * vp.inv_leaf) - (float)vp.min_b[1]);
-    const int c2 = (int)(floorf(xt.z * vp.inv_leaf) - (float)vp.min_b[2]);
+    const int c0 = DIRECT7 ? (int)floorf(xt.x / leaf) - vp.min_b[0] : (int)(floorf(xt.x * vp.inv_leaf) - (float)vp.min_b[0]);
+    const int c1 = DIRECT7 ? (int)floorf(xt.y / leaf) - vp.min_b[1] : (int)(floorf(xt.y * vp.inv_leaf) - (float)vp.min_b[1]);
+    const int c2 = DIRECT7 ? (int)floorf(xt.z / leaf) - vp.min_b[2] : (int)(floorf(xt.z * vp.inv_leaf) - (float)vp.min_b[2]);
     const double x[3] = {pf.x, pf.y, pf.z};
     double J[3][3];                       // columns 3..5 of point_gradient_
     double Hx[6][3];                      // d2R[kl] x
     bool have = false;
-    for (int dz = -1; dz <= 1; ++dz)
-      for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
+    for (int nb = 0; nb < (DIRECT7 ? 7 : 27); ++nb) {
+        {
+          // 27: dz outermost, dx innermost; 7: (0,0,0) (+x) (-x) (+y) (-y) (+z) (-z)
+          const int dx = DIRECT7 ? (nb == 1 ? 1 : (nb == 2 ? -1 : 0)) : nb % 3 - 1;
+          const int dy = DIRECT7 ? (nb == 3 ? 1 : (nb == 4 ? -1 : 0)) : (nb / 3) % 3 - 1;
+          const int dz = DIRECT7 ? (nb == 5 ? 1 : (nb == 6 ? -1 : 0)) : nb / 9 - 1;
           const int v0 = c0 + dx, v1 = c1 + dy, v2 = c2 + dz;
           if (v0 < 0 || v1 < 0 || v2 < 0 || v0 >= vp.div_b[0] || v1 >= vp.div_b[1] || v2 >= vp.div_b[2]) continue;
           const int cid = table[v0 + v1 * vp.div_b[0] + v2 * vp.div_b[0] * vp.div_b[1]];
@@ -2719,7 +2726,7 @@ __global__ void __launch_bounds__(kBlock) s3d_ndt_derivatives_kernel(const SlotD
           const double* __restrict__ cell = cells + (size_t)cid * kNdtCellDoubles;
           const double mu0 = cell[0], mu1 = cell[1], mu2 = cell[2];
           // radius test on the float centroid, float arithmetic, strict (FLANN radius search)
-          if (!(dist2(xt.x, xt.y, xt.z, (float)mu0, (float)mu1, (float)mu2) < r2)) continue;
+          if (!DIRECT7 && !(dist2(xt.x, xt.y, xt.z, (float)mu0, (float)mu1, (float)mu2) < r2)) continue;
           if (!have) {
 #pragma unroll
             for (int k = 0; k < 3; ++k)
@@ -2780,6 +2787,7 @@ __global__ void __launch_bounds__(kBlock) s3d_ndt_derivatives_kernel(const SlotD
               acc[o++] += e * (-d2 * xCJ[ii] * xCJ[jj] + hx + jcj);
             }
         }
+    }
   }
   block_reduce_store<NDT_NACC>(acc, partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NDT_NACC);
 }

@@ -230,7 +230,9 @@ def test_omp_enumerators_follow_the_build_switch(gpu_ctx, oracle_mod):
         prm = dict(point_cloud_density=0.2, maximum_iterations=5)
         ref = gpu_ctx.align(src, tgt, np.eye(4), s3d.default_params(registration_algorithm=alg, **prm))
         got = gpu_ctx.align(src, tgt, np.eye(4), s3d.default_params(registration_algorithm=alg_omp, **prm))
-        assert got[0] == ref[0] and np.array_equal(got[1], ref[1])                     # served by the same code
+        assert got[0] == ref[0]
+        if alg == s3d.ALG_GICP:     # (NDT_OMP searches pclomp's DIRECT7 neighbourhood: test_ndt_omp_direct7_matches_oracle)
+            assert np.array_equal(got[1], ref[1])                                      # served by the same code
         off = s3d.ExecOptions(omp_unavailable=1)
         st, _, _ = gpu_ctx.align(src, tgt, np.eye(4), s3d.default_params(registration_algorithm=alg_omp, **prm), off)
         st_few, _, _ = gpu_ctx.align(src[:60], tgt[:60], np.eye(4), s3d.default_params(registration_algorithm=alg_omp, **prm), off)
@@ -286,7 +288,7 @@ def test_ndt_golden(gpu_ctx, fixture_clouds):
     for case in json.load(open(os.path.join(GOLDEN, "ndt_golden.json"))):
         g = np.eye(4)
         g[0, 3] = case["guess_x"]
-        p = s3d.default_params(registration_algorithm=s3d.ALG_NDT, **case["params"])
+        p = s3d.default_params(registration_algorithm=getattr(s3d, "ALG_" + case.get("algorithm", "NDT")), **case["params"])
         st, T, info = gpu_ctx.align(fixture_clouds[case["source"] - 1], fixture_clouds[case["target"] - 1], g, p)
         dt, dr = transform_delta(np.array(case["T"]), T)
         assert st == case["status"] and dt < TOL_T and dr < TOL_R and info["iterations"] == case["info"]["iterations"]
@@ -320,10 +322,35 @@ def test_ndt_batch_and_omp_enumerator(gpu_ctx, fixture_clouds):
     for k, (a, b) in enumerate(((0, 1), (1, 2))):
         st, T, info = gpu_ctx.align(fixture_clouds[a], fixture_clouds[b], np.eye(4), p)
         assert rec[k, 15] == st == 0 and np.array_equal(s3d.api.record_transform(rec[k]), T)
-    st2, T2, _ = gpu_ctx.align(fixture_clouds[0], fixture_clouds[1], np.eye(4),
-                               s3d.default_params(registration_algorithm=s3d.ALG_NDT_OMP))
-    st1, T1, _ = gpu_ctx.align(fixture_clouds[0], fixture_clouds[1], np.eye(4), p)
-    assert st1 == st2 == 0 and np.array_equal(T1, T2)
+    # NDT_OMP in a batch = NDT_OMP alone
+    po = s3d.default_params(registration_algorithm=s3d.ALG_NDT_OMP)
+    rec = gpu_ctx.align_batch([dev[0], dev[1]], [dev[1], dev[2]], None, po)
+    for k, (a, b) in enumerate(((0, 1), (1, 2))):
+        st, T, info = gpu_ctx.align(fixture_clouds[a], fixture_clouds[b], np.eye(4), po)
+        assert rec[k, 15] == st == 0 and np.array_equal(s3d.api.record_transform(rec[k]), T)
+
+
+@pytest.mark.parametrize("pair", [(0, 1), (1, 2), (2, 3)])
+def test_ndt_omp_direct7_matches_oracle(gpu_ctx, oracle_mod, fixture_clouds, pair):
+    """NDT_OMP (PointCloudSensor.cpp:155-157: pclomp::NormalDistributionsTransform, default neighbour search DIRECT7): the
+    voxel of the transformed point and its six face neighbours instead of PCL's kd-tree radius query.  GPU against the
+    oracle's restatement of getNeighborhoodAtPoint7: same status, iterations, cell hits and fitness; and the result is
+    NOT the plain NDT's (another neighbourhood, another objective value)."""
+    import slam3d_amd as s3d
+    a, b = pair
+    for kw in ({}, {"resolution": 2.0, "step_size": 0.1, "outlier_ratio": 0.55}):
+        po = oracle_mod.default_params(registration_algorithm=oracle_mod.ALG_NDT_OMP, **kw)
+        pg = s3d.default_params(registration_algorithm=s3d.ALG_NDT_OMP, **kw)
+        so, To, io = oracle_mod.align(fixture_clouds[a], fixture_clouds[b], np.eye(4), po)
+        sg, Tg, ig = gpu_ctx.align(fixture_clouds[a], fixture_clouds[b], np.eye(4), pg)
+        assert so == sg
+        dt, dr = transform_delta(To, Tg)
+        assert dt < TOL_T and dr < TOL_R
+        assert io["iterations"] == ig["iterations"] and io["correspondences"] == ig["correspondences"]
+        assert abs(io["fitness"] - ig["fitness"]) <= 1e-9 * max(1.0, io["fitness"])
+        sp, Tp, _ = gpu_ctx.align(fixture_clouds[a], fixture_clouds[b], np.eye(4),
+                                  s3d.default_params(registration_algorithm=s3d.ALG_NDT, **kw))
+        assert sp == sg and not np.array_equal(Tp, Tg)
 
 
 # ------------------------------------------------------------------ A2 align()

@@ -221,7 +221,7 @@ def test_ndt_golden_replay(oracle_mod, fixture_clouds):
     for case in json.load(open(os.path.join(GOLDEN, "ndt_golden.json"))):
         g = np.eye(4)
         g[0, 3] = case["guess_x"]
-        p = oracle_mod.default_params(registration_algorithm=oracle_mod.ALG_NDT, **case["params"])
+        p = oracle_mod.default_params(registration_algorithm=getattr(oracle_mod, "ALG_" + case.get("algorithm", "NDT")), **case["params"])
         st, T, info = oracle_mod.align(fixture_clouds[case["source"] - 1], fixture_clouds[case["target"] - 1], g, p)
         assert st == case["status"] and np.array_equal(T, np.array(case["T"]))
         assert info["iterations"] == case["info"]["iterations"] and info["fitness"] == case["info"]["fitness"]
@@ -334,6 +334,68 @@ def test_ndt_result_maximises_independent_ndt_score(oracle_mod, fixture_clouds):
         nb = tree.query_ball_point(X, res)
         ii = np.repeat(np.arange(len(X)), [len(b) for b in nb])
         jj = np.concatenate([np.array(b, dtype=int) for b in nb])
+        dd = X[ii] - mus[jj]
+        return float((-d1 * np.exp(-d2 / 2 * np.einsum("na,nab,nb->n", dd, icovs[jj], dd))).sum())
+
+    s0 = score(T)
+    assert s0 > 1.4 * score(np.eye(4))
+    for k in range(6):
+        for sign in (1.0, -1.0):
+            D = np.eye(4)
+            if k < 3:
+                D[k, 3] = sign * 1e-2
+            else:
+                a, b = [(1, 2), (0, 2), (0, 1)][k - 3]
+                c, s = np.cos(5e-3), np.sin(sign * 5e-3)
+                D[a, a], D[b, b], D[a, b], D[b, a] = c, c, -s, s
+            assert score(D @ T) < s0, (k, sign)
+
+
+def test_ndt_omp_result_maximises_independent_direct7_score(oracle_mod, fixture_clouds):
+    """NDT_OMP = pclomp's NDT with its default DIRECT7 neighbour search (PointCloudSensor.cpp:155-157).  The oracle's
+    restatement against an independent numpy statement of that objective: the same voxel Gaussians as PCL's NDT, but a
+    point is scored against the voxel that holds it and its six face neighbours (those that are cells) and nothing
+    else - no radius.  The oracle's NDT_OMP result scores far above the guess, every +-1 cm / +-5 mrad step away from
+    it lowers the score, and it is not the plain NDT's result."""
+    c1, c2 = fixture_clouds[0], fixture_clouds[1]
+    p = oracle_mod.default_params(registration_algorithm=oracle_mod.ALG_NDT_OMP)
+    st, T, info = oracle_mod.align(c1, c2, np.eye(4), p)
+    st_p, T_p, info_p = oracle_mod.align(c1, c2, np.eye(4), oracle_mod.default_params(registration_algorithm=oracle_mod.ALG_NDT))
+    assert st == 0 and st_p == 0 and not np.array_equal(T, T_p) and info["correspondences"] == info_p["correspondences"]
+    assert np.linalg.norm(T[:3, 3] - T_p[:3, 3]) < 0.01          # two objectives, the same scene
+    res, orat = p.resolution, p.outlier_ratio
+    S = oracle_mod.voxel_downsample(c1, p.point_cloud_density)[0].astype(np.float64)
+    Q = oracle_mod.voxel_downsample(c2, p.point_cloud_density)[0].astype(np.float64)
+    vox = np.floor(S / res).astype(np.int64)
+    keys, inv, cnt = np.unique(vox, axis=0, return_inverse=True, return_counts=True)
+    inv = inv.reshape(-1)
+    cell_of, mus, icovs = {}, [], []
+    for c in np.nonzero(cnt >= 6)[0]:
+        P = S[inv == c]
+        Cv = np.cov(P.T)
+        w, V = np.linalg.eigh(Cv)
+        if w[0] < 0.01 * w[2]:
+            Cv = V @ np.diag(np.maximum(w, 0.01 * w[2])) @ V.T
+        cell_of[tuple(keys[c])] = len(mus)
+        mus.append(P.mean(0))
+        icovs.append(np.linalg.inv(Cv))
+    mus, icovs = np.array(mus), np.array(icovs)
+    assert len(mus) == info["correspondences"]
+    g1, g2 = 10 * (1 - orat), orat / res ** 3
+    d3 = -np.log(g2)
+    d1 = -np.log(g1 + g2) - d3
+    d2 = -2 * np.log((-np.log(g1 * np.exp(-0.5) + g2) - d3) / d1)
+    rel = [(0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+
+    def score(A):
+        X = Q @ A[:3, :3].T + A[:3, 3]
+        V = np.floor(X / res).astype(np.int64)
+        ii, jj = [], []
+        for i, v in enumerate(map(tuple, V)):
+            for r in rel:
+                c = cell_of.get((v[0] + r[0], v[1] + r[1], v[2] + r[2]))
+                if c is not None:
+                    ii.append(i); jj.append(c)
         dd = X[ii] - mus[jj]
         return float((-d1 * np.exp(-d2 / 2 * np.einsum("na,nab,nb->n", dd, icovs[jj], dd))).sum())
 
