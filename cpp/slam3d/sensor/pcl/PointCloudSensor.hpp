@@ -193,7 +193,7 @@ class PointCloudSensor : public ScanSensor {
   size_t getSweepCloudLimit() const { return mSweepCloudLimit; }
   size_t getSweepCloudCount() const { return mSweepClouds.size(); }
   // GICP_OMP / NDT_OMP (PointCloudSensor.cpp:149-162).  true (default): like a reference built WITH pclomp, the two
-  // enumerators run (the GICP / NDT device code: same objectives).  false: like a reference built without it,
+  // enumerators run (GICP_OMP: the GICP device code; NDT_OMP: the NDT code over pclomp's DIRECT7 neighbourhood).  false: like a reference built without it,
   // align() throws std::runtime_error("OMP is not available, ...") (s3d_exec_options.omp_unavailable).
   void setOmpAvailable(bool on) { mOmpAvailable = on; }
 
