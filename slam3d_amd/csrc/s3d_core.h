@@ -123,6 +123,20 @@ S3D_HD F3 xf_pcl_d(const double* T, float xf, float yf, float zf) {
   return o;
 }
 
+// Square root for CONSERVATIVE bounds only - how far along x a ball still reaches into a row of cells - where the caller
+// widens the result by 1e-4 relative plus a rounding margin anyway: the bare v_sqrt_f32 (1 ulp) instead of the correctly
+// rounded library sequence, which is 18 instructions around that same instruction (scaling for denormals, two Newton
+// corrections, class fix-ups) and was a quarter of the per-row cost of every pruned scan.  A clipped x-range that
+// differs by one cell at a boundary changes what is examined, never what is found (the dropped cell lies beyond the
+// ball).  The host (emulation, oracle-side tests) keeps sqrtf.
+S3D_HD float sqrt_bound(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_sqrtf(x);
+#else
+  return sqrtf(x);
+#endif
+}
+
 S3D_HD bool lex_less(float d2a, int ia, float d2b, int ib) { return d2a < d2b || (d2a == d2b && ia < ib); }
 
 S3D_HD int imin(int a, int b) { return a < b ? a : b; }
@@ -482,7 +496,7 @@ S3D_HD NNResult grid_nn1_box(const GridParams& g, const uint32_t* __restrict__ c
             if (rowd2 > lim2) { yfar |= (oy & 1) ? 1 : 2; continue; }
             int xa = x0, xb = x1;
             if (best.idx >= 0) {   // only the cells within the remaining radius
-              const float rx = sqrtf(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
+              const float rx = sqrt_bound(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
               xa = imax(x0, grid_coord(g, 0, qx - rx));
               xb = imin(x1, grid_coord(g, 0, qx + rx));
               if (xa > xb) continue;
@@ -881,7 +895,7 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
           const float fy2 = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.h)) - eps, 0.f);
           const float rowd2 = fy2 * fy2 + fz2 * fz2;
           if (rowd2 > lim2) continue;
-          const float rx = sqrtf(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
+          const float rx = sqrt_bound(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
           const int xa = imax(imax(ix - 2, grid_coord(g, 0, qx - rx)), 0);
           const int xb = imin(imin(ix + 2, grid_coord(g, 0, qx + rx)), g.dim[0] - 1);
           const bool inner = dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
@@ -1172,7 +1186,7 @@ S3D_HD bool knn3_build_shell(const GridParams& g, const uint32_t* __restrict__ c
       const float fy2 = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.h)) - eps, 0.f);
       const float rowd2 = fy2 * fy2 + fz2 * fz2;
       if (rowd2 > lim2) continue;
-      const float rx = sqrtf(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
+      const float rx = sqrt_bound(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
       const int xa = imax(imax(ix - 2, grid_coord(g, 0, qx - rx)), 0);
       const int xb = imin(imin(ix + 2, grid_coord(g, 0, qx + rx)), g.dim[0] - 1);
       const bool inner = dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
@@ -1303,7 +1317,7 @@ S3D_HD bool grid_nn1_scan27(const GridParams& g, const uint32_t* __restrict__ ce
         const float fz = fmaxf(fmaxf(zlo - qz, qz - (zlo + g.h)) - eps, 0.f);
         const float rowd2 = fy * fy + fz * fz;
         in = in && rowd2 <= b2;
-        const float rx = sqrtf(fmaxf(b2 - rowd2, 0.f)) * 1.0001f + eps;
+        const float rx = sqrt_bound(fmaxf(b2 - rowd2, 0.f)) * 1.0001f + eps;
         xa = imax(xa, grid_coord(g, 0, qx - rx));
         xb = imin(xb, grid_coord(g, 0, qx + rx));
       }

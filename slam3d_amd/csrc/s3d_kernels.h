@@ -1241,7 +1241,7 @@ __device__ S3D_COOP_INLINE NNResult wave_nn1_coop(const GridParams& g, const uin
           if (rowd2 <= lim2) {
             int xa = x0, xb = x1;
             if (lim2 < 1.0e30f) {
-              const float rx = sqrtf(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
+              const float rx = sqrt_bound(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
               xa = imax(x0, grid_coord(g, 0, qx - rx));
               xb = imin(x1, grid_coord(g, 0, qx + rx));
             }
