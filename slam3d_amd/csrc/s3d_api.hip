@@ -1135,8 +1135,10 @@ void upload_many(s3d_context* ctx, int n_clouds, const float* const* xyz, const 
   HIPCHK(hipMalloc(&block->p, sizeof(float4) * std::max<size_t>(total, 64)));
   const int hs = stride > 6 ? 3 : stride;                            // floats per point in the pinned slot
   const size_t slot_bytes = std::max<size_t>(sizeof(float) * most * (size_t)hs, 256);
+  // up to eight worker threads, fewer for huge clouds: the pinned slots (two per thread) stay below 512 MiB
   const int lanes = (int)std::max<size_t>(1, std::min<size_t>({(size_t)n_clouds, (size_t)8,
-                                                                 (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+                                                                 (size_t)std::max(1u, std::thread::hardware_concurrency()),
+                                                                 ((size_t)512 << 20) / (2 * (slot_bytes + slot_bytes / 4))}));
   if ((int)ctx->upload_lanes.size() < lanes) ctx->upload_lanes.resize((size_t)lanes);
   for (int t = 0; t < lanes; ++t) {
     s3d_context::UploadLane& L = ctx->upload_lanes[(size_t)t];
