@@ -53,6 +53,10 @@ int main(int argc, char** argv) {
       r[i].reset(new PointCloudMeasurement(load_bin(argv[2 + i]), "robot", sensor.getName(), Transform::Identity(), id[i]));
       std::printf("uuid kept %d\n", (int)(r[i]->getUniqueId() == id[i]));
     }
+    // the reloaded measurements go to the device in one bulk hand-over; a second call finds nothing left to upload
+    const size_t pre1 = sensor.preloadDeviceClouds({r[0], r[1], r[0]});
+    const size_t pre2 = sensor.preloadDeviceClouds({r[0], r[1]});
+    std::printf("preload %d %d\n", (int)pre1, (int)pre2);
     std::printf("load wrong scan %d\n", (int)sensor.loadDeviceCache(r[0], folder + "/1.s3dc"));
     std::printf("load missing file %d\n", (int)sensor.loadDeviceCache(r[0], folder + "/7.s3dc"));
     for (int i = 0; i < 2; ++i)

@@ -257,6 +257,29 @@ std::shared_ptr<DeviceCloud> PointCloudSensor::deviceCloudOf(const PointCloudMea
   return d;
 }
 
+size_t PointCloudSensor::preloadDeviceClouds(const std::vector<PointCloudMeasurement::Ptr>& measurements) const {
+  std::vector<PointCloudMeasurement::Ptr> todo;
+  std::vector<const float*> ptrs;
+  std::vector<int> counts;
+  static const float dummy[4] = {0, 0, 0, 0};
+  for (const PointCloudMeasurement::Ptr& m : measurements) {
+    if (!m || m->getDeviceCloud()) continue;
+    bool seen = false;
+    for (const PointCloudMeasurement::Ptr& t : todo) seen = seen || t == m;
+    if (seen) continue;
+    const PointCloud::Ptr c = m->getPointCloud();
+    todo.push_back(m);
+    ptrs.push_back(c->size() ? &c->points[0].x : dummy);
+    counts.push_back((int)c->size());
+  }
+  if (todo.empty()) return 0;
+  std::vector<s3d_cloud*> out(todo.size(), nullptr);
+  if (s3d_cloud_upload_many(mContext, (int)todo.size(), ptrs.data(), counts.data(), 4, out.data()) != S3D_STATUS_OK)
+    throw std::runtime_error(std::string("HIP back-end error: ") + s3d_last_error(mContext));
+  for (size_t i = 0; i < todo.size(); ++i) todo[i]->setDeviceCloud(std::make_shared<DeviceCloud>(mContextHolder, out[i]));
+  return todo.size();
+}
+
 bool PointCloudSensor::saveDeviceCache(const PointCloudMeasurement::Ptr& m, const std::string& file) const {
   std::shared_ptr<DeviceCloud> d = m->getDeviceCloud();
   if (!d) return false;                                   // never registered on this device: nothing to keep

@@ -175,6 +175,7 @@ def test_cpp_mirror_device_cache_across_a_checkpoint(fixture_clouds, tmp_path):
     assert get("save 0") == ["1"] and get("save 1") == ["1"]
     assert get("entries after release") == ["0"]
     assert get("uuid kept") == ["1", "1"]
+    assert get("preload") == ["2 0"]      # PointCloudSensor::preloadDeviceClouds: one bulk hand-over, duplicates / repeats skipped
     assert get("load wrong scan") == ["0"] and get("load missing file") == ["0"]
     assert get("load 0") == ["1"] and get("load 1") == ["1"]
     assert len(get("first")) == 1 and get("first") == get("again")
