@@ -7,7 +7,8 @@ i=0
 QUICK=${1:-}
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  if [ -n "$QUICK" ] && [ $i -gt 2 ]; then break; fi
+  if [ "$QUICK" = quick ] && [ $i -gt 2 ]; then break; fi
+  if [ "$QUICK" = mem ] && [ $i -le 2 ]; then continue; fi
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $P/s$i -o p -- python3 bench.py --no-cpu --no-single --no-real --steps 2 --warmup 1 > $P/s$i.log 2>&1
   f=$(find $P/s$i -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python3 - "$f" "$P/set$i.csv" <<'PY'
