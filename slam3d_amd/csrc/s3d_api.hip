@@ -1190,7 +1190,11 @@ void upload_many(s3d_context* ctx, int n_clouds, const float* const* xyz, const 
   for (int t = 1; t < lanes; ++t) th.emplace_back(work, t);
   work(0);
   for (std::thread& x : th) x.join();
-  if (!errs.empty()) throw errs[0];
+  if (!errs.empty()) {
+    // (kernels of the lanes that did not fail may still be writing into the block the caller is about to drop)
+    for (int t = 0; t < lanes; ++t) (void)hipStreamSynchronize(ctx->upload_lanes[(size_t)t].st);
+    throw errs[0];
+  }
   for (int i = 0; i < n_clouds; ++i) {
     s3d_cloud* c = out[i];
     c->n = std::max(n[i], 0); c->owned = false; c->uid = g_cloud_uid++;
