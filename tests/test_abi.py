@@ -115,3 +115,26 @@ def test_product_reads_no_environment_on_the_registration_path():
     # the link policy and the options struct of the binding are the header's
     src = 'int main(){return 0;}'
     assert ctypes.sizeof(slam3d_amd.api.LinkPolicyC) == 20 and ctypes.sizeof(slam3d_amd.ExecOptions) == 32
+
+
+def test_bulk_hand_over_rejects_bad_arguments_before_touching_the_device():
+    """s3d_cloud_upload_many validates its arguments first (no context, a negative count, a stride below 3, a null
+    array for a non-empty cloud): S3D_STATUS_INVALID_ARGUMENT, nothing allocated - callable without a GPU."""
+    import numpy as np
+    import slam3d_amd
+    L = slam3d_amd.load_library()
+    C = ctypes
+    pts = np.zeros((4, 3), np.float32)
+    ptrs = (C.POINTER(C.c_float) * 1)(pts.ctypes.data_as(C.POINTER(C.c_float)))
+    ns = (C.c_int * 1)(4)
+    out = (C.c_void_p * 1)()
+    assert L.s3d_cloud_upload_many(None, 1, ptrs, ns, 3, out) == 7           # no context
+    fake = C.c_void_p(1)      # (never dereferenced: every check below fails before the context is used)
+    assert L.s3d_cloud_upload_many(fake, -1, ptrs, ns, 3, out) == 7
+    assert L.s3d_cloud_upload_many(fake, 1, ptrs, ns, 2, out) == 7           # stride < 3
+    assert L.s3d_cloud_upload_many(fake, 1, None, ns, 3, out) == 7
+    null = (C.POINTER(C.c_float) * 1)()
+    assert L.s3d_cloud_upload_many(fake, 1, null, ns, 3, out) == 7           # a null array for 4 points
+    neg = (C.c_int * 1)(-3)
+    assert L.s3d_cloud_upload_many(fake, 1, ptrs, neg, 3, out) == 7
+    assert L.s3d_cloud_upload_many(fake, 0, None, None, 3, None) == 0        # nothing to do
