@@ -59,26 +59,13 @@ typedef struct s3d_exec_options {
                                (or forces one of two equivalent forms) and must not change a bit of any result - that is
                                what the tests use them for.  Read once per call from this struct: the library reads no
                                environment variable on any registration path.                                         */
-  int debug_accum_blocks;   /* 0 = automatic; 1, 2, 4 ... 64: REAL blocks per pair in the accumulate kernels (the sums
-                               are defined over 64 virtual blocks whatever this is: the invariance test sets it)        */
+  int debug_accum_blocks;   /* 0 = automatic; 1, 2, 4 ... 32 (a divisor of the 32 VIRTUAL blocks the sums of a pair are
+                               defined over): REAL blocks per pair in the accumulate kernels - speed only, the
+                               invariance test sets it.  Any other value: S3D_STATUS_INVALID_ARGUMENT                   */
 } s3d_exec_options;
 
-/* s3d_exec_options.debug_flags */
-#define S3D_DBG_NN_NO_REVALIDATE   0x00000040u /* every pass searches every query (no triangle-inequality shortcut)      */
-#define S3D_DBG_NN_NO_FAR_SEED     0x00000080u /* far previous neighbours are never trusted seeds                        */
-#define S3D_DBG_NN_NO_COOP         0x00000800u /* no wave-cooperative wide search                                        */
-#define S3D_DBG_NN_NO_COMPACT      0x00010000u /* pass 4 (small batches: passes 3-5) without the block compaction         */
-#define S3D_DBG_NN_NO_FIRST_KERNEL 0x00040000u /* pass 1 through the general kernel (implies the next one)               */
-#define S3D_DBG_NN_NO_SCAN27       0x00080000u /* passes 2-3 through the general kernel                                  */
-#define S3D_DBG_NN_NO_SETTLED      0x00100000u /* settled passes query by query (no record-level re-validation)          */
-#define S3D_DBG_KNN_EXACT64        0x00200000u /* k-NN pre-pass: the exact 64-bit search for every point                 */
-#define S3D_DBG_SORT_CLASSIC       0x00400000u /* radix sort: three kernels per pass, whatever the batch size            */
-#define S3D_DBG_SORT_ONESWEEP      0x00800000u /* radix sort: one sweep per pass (decoupled look-back), whatever ...      */
-#define S3D_DBG_SCAN27_NO_COMPACT  0x01000000u /* pass 3 without the block compaction                                    */
-#define S3D_DBG_PRINT_KNN          0x02000000u /* stderr: how many points took the eigen fallback / the exact-search redo */
-#define S3D_DBG_NN_FORCE_SETTLED   0x08000000u /* record-level re-validation for a small batch too (the host takes it from
-                                                  65 536 records = 42 pairs of 100 k points: below that it is slower)   */
-#define S3D_DBG_SORT_FULL_KEYS     0x04000000u /* radix sort: 8-bit digits everywhere (grid: 3 passes instead of 2 x 9 bits) */
+/* The S3D_DBG_* bits of s3d_exec_options.debug_flags are test / measurement switches, not API: they live in
+ * slam3d_hip_debug.h, which this header does not include (the library and the tests do). */
 
 /* The structs above grow at the END only.  A binding compiled against another revision of this header must not be
  * used: compare S3D_ABI_VERSION with s3d_abi_version() once after loading the library (the Python binding and the

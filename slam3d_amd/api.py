@@ -37,7 +37,7 @@ class ExecOptions(C.Structure):
                 ("debug_flags", C.c_uint), ("debug_accum_blocks", C.c_int)]
 
 
-# s3d_exec_options.debug_flags (include/slam3d_hip.h S3D_DBG_*): each switches one fast path off, none may change a bit
+# s3d_exec_options.debug_flags (include/slam3d_hip_debug.h S3D_DBG_*): each switches one fast path off, none may change a bit
 DBG_NN_NO_REVALIDATE, DBG_NN_NO_FAR_SEED, DBG_NN_NO_COOP = 0x40, 0x80, 0x800
 DBG_NN_NO_COMPACT, DBG_NN_NO_FIRST_KERNEL, DBG_NN_NO_SCAN27, DBG_NN_NO_SETTLED = 0x10000, 0x40000, 0x80000, 0x100000
 DBG_KNN_EXACT64, DBG_SORT_CLASSIC, DBG_SORT_ONESWEEP, DBG_SCAN27_NO_COMPACT = 0x200000, 0x400000, 0x800000, 0x1000000
@@ -104,8 +104,10 @@ def lib_path():
 
 def build(force=False, verbose=False):
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("s3d_api.hip", "s3d_kernels.h", "s3d_core.h", "s3d_ndt.h", "s3d_sweep.h")]
-    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("slam3d_hip.h", "slam3d_registration_types.h")]
+    srcs = [os.path.join(_CSRC, f) for f in ("s3d_api.hip", "s3d_kernels.h", "s3d_core.h", "s3d_ndt.h", "s3d_sweep.h",
+                                              "s3d_candidates.h", "Makefile")]
+    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("slam3d_hip.h", "slam3d_hip_debug.h",
+                                                               "slam3d_registration_types.h")]
     stale = force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
     if stale:
         cmd = ["make", "-C", _CSRC] + (["-B"] if force else [])

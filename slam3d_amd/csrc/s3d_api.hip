@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/slam3d_hip.h"
+#include "../../include/slam3d_hip_debug.h"
 #include "s3d_kernels.h"
 #include "s3d_ndt.h"
 
@@ -53,6 +54,7 @@ struct HipError {
   hipError_t e;
   const char* what;
   int line;
+  int status = S3D_STATUS_BACKEND_ERROR;   // what the entry point returns (a bad option found late: INVALID_ARGUMENT)
 };
 #define HIPCHK(expr)                                            \
   do {                                                          \
@@ -264,7 +266,7 @@ int fail(s3d_context* ctx, const HipError& e) {
   std::snprintf(buf, sizeof buf, "HIP error %d (%s) at s3d_api.hip:%d: %s", (int)e.e, hipGetErrorString(e.e), e.line,
                 e.what);
   if (ctx) ctx->err = buf;
-  return S3D_STATUS_BACKEND_ERROR;
+  return e.status;
 }
 
 // device -> host copy ON THE CONTEXT'S STREAM, then a wait for that stream: a plain hipMemcpy runs on the legacy null
@@ -508,7 +510,10 @@ struct Batch {
     while (accum_blocks > 1 && accum_blocks * kBlock * 2 > std::max(max_n_t, 1)) accum_blocks >>= 1;
     {   // A/B and the invariance test (s3d_exec_options.debug_accum_blocks): any divisor of kAccumVB
       const int v = opts.debug_accum_blocks;
-      if (v >= 1 && v <= kAccumVB && kAccumVB % v == 0) accum_blocks = v;
+      if (v != 0 && !(v >= 1 && v <= kAccumVB && kAccumVB % v == 0))
+        throw HipError{hipErrorInvalidValue, "debug_accum_blocks must be 0 or a divisor of the 32 virtual blocks", __LINE__,
+                       S3D_STATUS_INVALID_ARGUMENT};
+      if (v != 0) accum_blocks = v;
     }
     const size_t np = std::max<size_t>(total_pts, 4);
     const size_t nc = std::max<size_t>(total_corr, 4);
@@ -1146,6 +1151,7 @@ void upload_many(s3d_context* ctx, int n_clouds, const float* const* xyz, const 
     for (int k = 0; k < 2; ++k) if (!L.ev[k]) HIPCHK(hipEventCreateWithFlags(&L.ev[k], hipEventDisableTiming));
     if (L.cap < slot_bytes) {
       HIPCHK(hipStreamSynchronize(L.st));
+      L.cap = 0;     // (a failed allocation below leaves the lane without slots: the next call must allocate again)
       for (int k = 0; k < 2; ++k) {
         if (L.pinned[k]) HIPCHK(hipHostFree(L.pinned[k]));
         L.pinned[k] = nullptr;
@@ -1187,9 +1193,16 @@ void upload_many(s3d_context* ctx, int n_clouds, const float* const* xyz, const 
     }
   };
   std::vector<std::thread> th;
-  for (int t = 1; t < lanes; ++t) th.emplace_back(work, t);
+  bool spawn_failed = false;
+  try {
+    th.reserve((size_t)lanes);
+    for (int t = 1; t < lanes; ++t) th.emplace_back(work, t);
+  } catch (const std::exception&) {   // std::system_error / bad_alloc: the lanes that did start (and lane 0) take all clouds
+    spawn_failed = true;
+  }
   work(0);
   for (std::thread& x : th) x.join();
+  (void)spawn_failed;                 // (not an error: the clouds are dealt by the shared counter `next`)
   if (!errs.empty()) {
     // (kernels of the lanes that did not fail may still be writing into the block the caller is about to drop)
     for (int t = 0; t < lanes; ++t) (void)hipStreamSynchronize(ctx->upload_lanes[(size_t)t].st);

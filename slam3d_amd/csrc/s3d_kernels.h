@@ -1557,9 +1557,13 @@ __global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_search_kernel(con
 // An entry also carries where the record's queries and correspondences start and how many of its 64 lanes hold a
 // query: the touch kernel issues the loads of a record's data as soon as it has the entry, next to - not after - the
 // loads of the pair record.
-__device__ __forceinline__ uint4 nn_record_entry(int pair, int rec, int touch, int corr_off, int query_off, int n) {
+__device__ __forceinline__ uint4 nn_record_entry(int pair, int rec, int touch, int hist_stride, int corr_off, int query_off,
+                                                 int n) {
   const int valid = imin(kWave, n - rec * kWave);
-  return make_uint4((unsigned)pair, (unsigned)(corr_off + rec * kWave), ((unsigned)touch & 0xFFFFu) | ((unsigned)valid << 16),
+  // the touch pass travels in 16 bits; 0xFFFF = "no usable touch transform" (never evaluated record-wise, or a pass
+  // beyond the transform history: hist_stride <= 4096 < 0xFFFF, so a pass the history holds always fits)
+  const unsigned t16 = (touch < 0 || touch >= hist_stride) ? 0xFFFFu : (unsigned)touch;
+  return make_uint4((unsigned)pair, (unsigned)(corr_off + rec * kWave), t16 | ((unsigned)valid << 16),
                     (unsigned)(query_off + rec * kWave));
 }
 constexpr int kNNRecSublists = 64;
@@ -1632,7 +1636,7 @@ __global__ void __launch_bounds__(kBlock) s3d_nn_record_test_kernel(const PairDe
   uint4* __restrict__ out = list + (size_t)sub * sub_cap + block_base;
 #pragma unroll
   for (int j = 0; j < RPT; ++j)
-    if (fail[j]) out[before[j] + at[j]] = nn_record_entry(pair, rec[j], W[j].touch, P.corr_off, St.off, St.n);
+    if (fail[j]) out[before[j] + at[j]] = nn_record_entry(pair, rec[j], W[j].touch, hist_stride, P.corr_off, St.off, St.n);
 }
 
 // A query of a touched record that fails its own re-validation needs a search.  Not here: a search is a chain of a
@@ -2060,8 +2064,9 @@ __global__ void __launch_bounds__(kBlock) k_export_normals(const SlotDev* __rest
 // tiles [v n / 64, (v + 1) n / 64) of the pair's n tiles (vb_tile_begin) and its virtual thread t folds element t of
 // each of them in ascending order; the 256 per-thread sums of a virtual
 // block are combined by the butterfly below (64 lanes) and then over its four waves in ascending order; the
-// controller adds the kAccumVB block sums in 8 groups of 8 (ascending inside a group, then the groups in ascending
-// order: icp_control_pair, k_fitness_final).  HOW MANY real blocks execute the virtual blocks (64 for
+// controller adds the kAccumVB = 32 block sums in kCtrlGroups = 8 groups of 4 (ascending inside a group, then the
+// groups in ascending order: icp_control_pair); k_fitness_final adds its two sums in 4 groups of 8 - a different, equally
+// fixed root.  HOW MANY real blocks execute the virtual blocks (64 for
 // a single pair, 4 for a 256-pair batch: few long-running blocks are faster there) is a launch parameter that
 // cannot change a bit of the result: a pair registers to the same edge alone, in any batch and in any shard of a
 // multi-GPU sweep.
@@ -2178,7 +2183,8 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
 // ------------------------------------------------------------------ K7: per-pair controller
 // fixed-order sum of the block partials, then the solver step and the PCL stopping rule.  Called by ALL threads of a
 // block (kCtrlThreads of them) for one pair; the scalar solver runs on wave 0 with the record in LDS.
-constexpr int kCtrlGroups = 8;      // the root of the fixed summation tree: 8 groups of 8 virtual blocks
+constexpr int kCtrlGroups = 8;      // the root of the fixed summation tree: 8 groups of kAccumVB / 8 = 4 virtual blocks
+static_assert(kAccumVB % kCtrlGroups == 0 && kAccumVB % 8 == 0, "the tree roots deal the virtual blocks in whole groups");
 constexpr int kCtrlThreads = 128;   // threads that load the tree root (the stand-alone kernel's block size: more
                                     // would cap the optimiser's registers below the 256 it uses)
 __device__ __forceinline__ void icp_control_pair(PairDev& P, const double* __restrict__ pair_partials, const RunParams& rp,
@@ -2187,12 +2193,12 @@ __device__ __forceinline__ void icp_control_pair(PairDev& P, const double* __res
   __shared__ double acc[GQ_NACC];
   const bool gicp = rp.algorithm != 0;
   const int nacc = gicp ? GQ_NACC : PP_NACC;
-  // root of the fixed tree: the kAccumVB virtual-block sums in 8 groups of 8 (ascending inside a group), then the
+  // root of the fixed tree: the kAccumVB virtual-block sums in 8 groups of 4 (ascending inside a group), then the
   // groups in ascending order.  Every thread takes up to five (group, accumulator) cells and issues all of their
   // loads before the first addition: one L2 round trip instead of eight on the critical path of every iteration.
   if (threadIdx.x < kCtrlThreads) {
     constexpr int kCells = (kCtrlGroups * GQ_NACC + kCtrlThreads - 1) / kCtrlThreads;   // 5
-    constexpr int kPer = kAccumVB / kCtrlGroups;                                        // 8
+    constexpr int kPer = kAccumVB / kCtrlGroups;                                        // 4
     double t[kCells][kPer];
 #pragma unroll
     for (int u = 0; u < kCells; ++u) {
@@ -2442,7 +2448,7 @@ __global__ void k_fitness_final(PairDev* pairs, const double* __restrict__ parti
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npairs) return;
   const double* in = partials + (size_t)p * kAccumVB * GQ_NACC;
-  double s = 0.0, c = 0.0;   // the same root as the controller's: 8 groups of 8, ascending
+  double s = 0.0, c = 0.0;   // fixed root: kAccumVB / 8 = 4 groups of 8, ascending (not the controller's 8 groups of 4)
   for (int g = 0; g < kAccumVB / 8; ++g) {
     const double* gi = in + (size_t)g * 8 * GQ_NACC;
     const double sg = ordered_partial_sum(gi, 8, GQ_NACC), cg = ordered_partial_sum(gi + 1, 8, GQ_NACC);

@@ -141,24 +141,26 @@ def link_candidates(graph, vertex, policy):
         return out
     neighbors = graph.get_nearby_vertices(graph.pose[vertex], policy.neighbor_radius, policy.link_sensors)
     count = 0
-    for index in reversed(neighbors):
-        if count >= policy.max_neighbor_links:
-            break
-        if index == vertex:
-            continue
-        if graph.has_edge(vertex, index, policy.name):       # getEdge(vertex, index, mName) did not throw
-            continue
-        dist = graph.calculate_graph_distance(index, vertex)
-        if dist <= policy.patch_building_range * 2 or dist < policy.min_loop_length:
-            continue
-        count += 1
-        out.append((index, vertex))                          # link(index, vertex)
-        if not policy.static_graph:
-            for v in (index, vertex):
-                saved.setdefault(v, list(graph.out[v]))
-            graph.add_edge(index, vertex, policy.name, SE3)
-    for v, edges in saved.items():                           # (the caller's graph is left as it was)
-        graph.out[v] = edges
+    try:
+        for index in reversed(neighbors):
+            if count >= policy.max_neighbor_links:
+                break
+            if index == vertex:
+                continue
+            if graph.has_edge(vertex, index, policy.name):       # getEdge(vertex, index, mName) did not throw
+                continue
+            dist = graph.calculate_graph_distance(index, vertex)
+            if dist <= policy.patch_building_range * 2 or dist < policy.min_loop_length:
+                continue
+            count += 1
+            out.append((index, vertex))                          # link(index, vertex)
+            if not policy.static_graph:
+                for v in (index, vertex):
+                    saved.setdefault(v, list(graph.out[v]))
+                graph.add_edge(index, vertex, policy.name, SE3)
+    finally:
+        for v, edges in saved.items():                           # (the caller's graph is left as it was, also when a
+            graph.out[v] = edges                                 # query above raises, e.g. KeyError on a bad vertex id)
     return out
 
 

@@ -8,8 +8,9 @@ Bars (DESIGN.md "parity"):
   * align(), point-to-plane mode and GICP on the smooth objective: 1e-4 m / 1e-4 rad
     (BASELINE.json north_star tolerance);
   * align(), GICP vs the PCL-literal functor: the reference result is itself only reproducible to
-    millimetres (tests/test_conditioning.py), so: same basin (6e-3 m / 1e-3 rad) AND the device
-    result must be an equally good minimiser of the reference objective.
+    millimetres (tests/test_conditioning.py), so: same basin (per case: 1.5 x the spread the conditioning experiment
+    records for that pair - 5 / 32 / 4 mm - and 1e-3 rad) AND the device result must be an equally good minimiser of
+    the reference objective.
 """
 import json
 import os
@@ -417,21 +418,44 @@ def test_align_gicp_parity_median_within_north_star_tolerance():
     assert np.median([d[0] for d in _gicp_deltas]) < TOL_T and np.median([d[1] for d in _gicp_deltas]) < TOL_R
 
 
-@pytest.mark.parametrize("a,b,gx", [(0, 1, 0.0), (1, 2, 0.0), (2, 3, 0.0), (0, 3, 2.0)])
-def test_align_gicp_vs_pcl_literal_same_basin(gpu_ctx, oracle_mod, fixture_clouds, a, b, gx):
+def _literal_spread(a, b):
+    """Largest displacement of the PCL-literal result of fixture pair (a, b) under 1e-15 ... 1e-9 perturbations of its
+    Mahalanobis matrices (tests/golden/conditioning_golden.json: how well the reference result itself is defined)."""
+    gold = json.load(open(os.path.join(GOLDEN, "conditioning_golden.json")))
+    for pr in gold["pairs"]:
+        if (pr["source"], pr["target"]) == (a + 1, b + 1):
+            return max(r["dt_m"] for r in pr["pcl_literal"]["runs"]), max(r["dr_rad"] for r in pr["pcl_literal"]["runs"])
+    return None
+
+
+# per case: (a, b, guess x, dt bound [m], |delta correspondences| bound).  The translation bound of a consecutive pair is
+# 1.5 x the spread the conditioning experiment records for THAT pair (3.3 / 21 / 2.6 mm), never one blanket number: pair
+# 2 -> 3 is the only one that needs centimetres.  cloud1 -> cloud4 from a 2 m guess has no conditioning record; its bound is
+# the round-4 one of the consecutive pairs (6 mm).  Measured values are printed (pytest -s / the GPU test log).
+_LITERAL_CASES = [(0, 1, 0.0, None, 50), (1, 2, 0.0, None, 80), (2, 3, 0.0, None, 50), (0, 3, 2.0, 6e-3, 50)]
+
+
+@pytest.mark.parametrize("a,b,gx,dt_bound,dn_bound", _LITERAL_CASES)
+def test_align_gicp_vs_pcl_literal_same_basin(gpu_ctx, oracle_mod, fixture_clouds, a, b, gx, dt_bound, dn_bound):
     """Against the PCL-LITERAL restatement (float transform inside the objective): all three consecutive
     fixture pairs and cloud1 -> cloud4 from a 2 m guess.  Its result is not defined to 1e-4 m (1e-15
-    perturbations of its Mahalanobis matrices move it by millimetres, tests/test_conditioning.py), so: same basin, and
-    the device result is an equally good minimiser of the reference's own objective."""
+    perturbations of its Mahalanobis matrices move it by millimetres, tests/test_conditioning.py), so: same basin - per
+    case, within 1.5 x the spread of the literal result of that very pair - and the device result is an equally good
+    minimiser of the reference's own objective."""
     import slam3d_amd as s3d
     g = np.eye(4); g[0, 3] = gx
+    if dt_bound is None:
+        spread_t, _ = _literal_spread(a, b)
+        dt_bound = 1.5 * spread_t
     st_o, T_o, _ = oracle_mod.align(fixture_clouds[a], fixture_clouds[b], g)
     st, T, _ = gpu_ctx.align(fixture_clouds[a], fixture_clouds[b], g, s3d.default_params())
     dt, dr = transform_delta(T_o, T)
-    assert st == st_o == 0 and dt < 2.5e-2 and dr < 1e-3, (dt, dr)
     c_ref, n_ref = oracle_mod.gicp_cost(fixture_clouds[a], fixture_clouds[b], T_o)
     c_gpu, n_gpu = oracle_mod.gicp_cost(fixture_clouds[a], fixture_clouds[b], T)
-    assert c_gpu < c_ref * 1.01 and abs(n_gpu - n_ref) < 80, (c_gpu, c_ref, n_gpu, n_ref)
+    print("pcl-literal case %d->%d guess %.1f m: dt %.3e m (bound %.3e)  dr %.3e rad  c_gpu/c_ref %.6f  dn %d" %
+          (a + 1, b + 1, gx, dt, dt_bound, dr, c_gpu / c_ref, n_gpu - n_ref))
+    assert st == st_o == 0 and dt < dt_bound and dr < 1e-3, (dt, dt_bound, dr)
+    assert c_gpu < c_ref * 1.01 and abs(n_gpu - n_ref) < dn_bound, (c_gpu, c_ref, n_gpu, n_ref)
 
 
 def test_align_with_guess_and_gates(gpu_ctx, oracle_mod, fixture_clouds):
@@ -778,6 +802,29 @@ def test_million_point_registration_matches_oracle(gpu_ctx, oracle_mod):
     assert st == so == 0 and info["iterations"] == io["iterations"] == 50
     assert info["n_source_filtered"] == io["n_source_filtered"] and info["n_target_filtered"] == io["n_target_filtered"]
     assert dt < TOL_T_GICP and dr < TOL_R_GICP, (dt, dr)
+    # round 5: the record-wise settled passes in the regime configs[4]'s per-GPU share runs them in.  ONE 1 M-point pair
+    # has 15 625 records - below the 65 536 from which the host takes the record-wise path - so the registration above
+    # went query by query.  FIVE such pairs in one batch are 78 125 records: test / touch / search kernels, and passes
+    # 5-12 (every record still has searching queries) through the throughput branch of the search lists.  The batch
+    # must equal the same batch with the path switched off bit for bit, and its pair 0 the lone registration above.
+    pairs = [(src, tgt)] + [s3d.make_pair(1_000_000, 7 + j)[:2] for j in range(1, 5)]
+    a = [gpu_ctx.upload(p_[0]) for p_ in pairs]
+    b = [gpu_ctx.upload(p_[1]) for p_ in pairs]
+    try:
+        r_on = gpu_ctx.align_batch(a, b, None, s3d.default_params(**prm), s3d.ExecOptions(force_iterations=1, profile=2))
+        prof = gpu_ctx.last_profile()
+        r_off = gpu_ctx.align_batch(a, b, None, s3d.default_params(**prm),
+                                    s3d.ExecOptions(force_iterations=1, debug_flags=s3d.api.DBG_NN_NO_SETTLED))
+    finally:
+        for h in a + b:
+            h.release()
+    assert (r_on[:, 15] == 0).all() and (r_on[:, 13] == 50).all()
+    assert np.array_equal(r_on, r_off)
+    # the record-wise path really ran: records were tested in the settled passes, and the early ones listed searches
+    assert sum(prof["nn_records"][4:50]) > 0 and max(prof["nn_searched"][4:12]) > 10000, (prof["nn_records"][:12],
+                                                                                           prof["nn_searched"][:12])
+    T0 = np.eye(4); T0[:3, :] = r_on[0, :12].reshape(4, 3).T
+    assert np.array_equal(T0, T), "pair 0 of the 5 x 1 M batch differs from the lone registration"
 
 
 def test_bulk_hand_over_equals_single_uploads(gpu_ctx, fixture_clouds):
