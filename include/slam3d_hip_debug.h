@@ -24,5 +24,24 @@
                                                   65 536 records = 42 pairs of 100 k points: below that it is slower)   */
 #define S3D_DBG_SORT_FULL_KEYS     0x04000000u /* radix sort: 8-bit digits everywhere (grid: 3 passes instead of 2 x 9 bits) */
 
+#define S3D_DBG_NO_FUSED_PREPASS   0x10000000u /* registration pre-pass as two sorts (voxel keys, then cell ids) instead of
+                                                  the one sort on (cell, voxel) keys                                     */
+
+/* ---- test hooks: exported by the library, used by tests/ only ---------------------------------------------------- */
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* batches of this context that the fused pre-pass could not serve and that ran again on the two-sort path */
+long long s3d_debug_fused_reruns(s3d_context* ctx);
+/* the registration's pre-pass (fused != 0: one sort; 0: two) of two device clouds at voxel size `leaf`, then one
+ * nearest-neighbour pass of the filtered target's points against the filtered source: the cell-sorted points of both
+ * (xyzw, w = the tie-breaking id as raw bits), and per target point the position of its neighbour in the source array
+ * (-1: none within max_distance) and the float squared distance.  capacity: points per output array. */
+int s3d_debug_filtered_nn(s3d_context* ctx, s3d_cloud* source, s3d_cloud* target, double leaf, int fused,
+                          double max_distance, int capacity, float* source_sorted_xyzw, int* n_source,
+                          float* target_sorted_xyzw, int* n_target, int* corr_pos, float* corr_d2, int* fused_ok);
+#ifdef __cplusplus
+}
+#endif
 
 #endif /* SLAM3D_HIP_DEBUG_H */

@@ -42,6 +42,7 @@ DBG_NN_NO_REVALIDATE, DBG_NN_NO_FAR_SEED, DBG_NN_NO_COOP = 0x40, 0x80, 0x800
 DBG_NN_NO_COMPACT, DBG_NN_NO_FIRST_KERNEL, DBG_NN_NO_SCAN27, DBG_NN_NO_SETTLED = 0x10000, 0x40000, 0x80000, 0x100000
 DBG_KNN_EXACT64, DBG_SORT_CLASSIC, DBG_SORT_ONESWEEP, DBG_SCAN27_NO_COMPACT = 0x200000, 0x400000, 0x800000, 0x1000000
 DBG_PRINT_KNN, DBG_SORT_FULL_KEYS, DBG_NN_FORCE_SETTLED = 0x2000000, 0x4000000, 0x8000000
+DBG_NO_FUSED_PREPASS = 0x10000000
 
 
 class CacheStats(C.Structure):
@@ -196,7 +197,11 @@ def load_library():
         "s3d_link_candidates": (C.c_int, [C.c_int, dp, C.POINTER(C.c_ubyte), C.c_int, C.POINTER(GraphEdge), C.c_int,
                                           C.POINTER(LinkPolicyC), ip, C.c_int, ip]),
     }
-    for name, (res, args) in sig.items():
+    debug_sig = {     # include/slam3d_hip_debug.h: test hooks, not part of the drop-in API
+        "s3d_debug_fused_reruns": (C.c_longlong, [vp]),
+        "s3d_debug_filtered_nn": (C.c_int, [vp, vp, vp, C.c_double, C.c_int, C.c_double, C.c_int, fp, ip, fp, ip, ip, fp, ip]),
+    }
+    for name, (res, args) in list(sig.items()) + list(debug_sig.items()):
         f = getattr(L, name)  # AttributeError if the symbol is not exported
         f.restype = res
         f.argtypes = args
@@ -346,6 +351,28 @@ class Context:
         if st:
             raise ValueError(STATUS_NAMES[st])
         return idx[:m], d2[:m]
+
+    # ---- test hooks (include/slam3d_hip_debug.h) ------------------------------------
+    def fused_reruns(self):
+        """batches of this context that the fused pre-pass could not serve and that ran again on the two-sort path"""
+        return int(self._L.s3d_debug_fused_reruns(self._h))
+
+    def debug_filtered_nn(self, source, target, leaf, fused, max_distance):
+        """The registration's pre-pass of two device clouds and one NN pass (s3d_debug_filtered_nn): cell-sorted points of
+        both clouds with their tie-breaking ids, the neighbour positions / squared distances of the target's points."""
+        cap = max(source.n, target.n, 1)
+        s4 = np.empty((cap, 4), np.float32); t4 = np.empty((cap, 4), np.float32)
+        pos = np.empty(cap, np.int32); d2 = np.empty(cap, np.float32)
+        ns, nt, ok = C.c_int(), C.c_int(), C.c_int()
+        st = self._check(self._L.s3d_debug_filtered_nn(self._h, source.handle, target.handle, float(leaf), int(fused),
+                                                       float(max_distance), cap, _fp(s4), C.byref(ns), _fp(t4), C.byref(nt),
+                                                       pos.ctypes.data_as(C.POINTER(C.c_int)), _fp(d2), C.byref(ok)))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
+        s4, t4 = s4[:ns.value], t4[:nt.value]
+        return dict(source_xyz=s4[:, :3].copy(), source_id=s4[:, 3].copy().view(np.uint32), target_xyz=t4[:, :3].copy(),
+                    target_id=t4[:, 3].copy().view(np.uint32), pos=pos[:nt.value].copy(), d2=d2[:nt.value].copy(),
+                    fused_ok=ok.value)
 
     def knn_normals(self, xyz, k=20):
         a, n, stride = _cloud(xyz)

@@ -146,6 +146,7 @@ struct s3d_context {
   size_t cache_bytes = 0, cache_limit = (size_t)16 << 30;   // (context_create lowers it to a quarter of the free HBM if that is less)
   unsigned long long cache_clock = 0;
   long long cache_hits = 0, cache_misses = 0;
+  long long fused_reruns = 0;   // batches the fused pre-pass could not serve and ran again on the two-sort path
   void cache_drop(std::map<CacheKey, CacheEntry>::iterator it) {
     if (it->second.block) (void)hipFree(it->second.block);
     cache_bytes -= it->second.bytes;
@@ -543,7 +544,7 @@ struct Batch {
                 {&ctx->knn_list, sizeof(int) * (size_t)std::max(1, C())},
                 {&ctx->knn_fallback, sizeof(int) * npi}, {&ctx->knn_redo, sizeof(int2) * npi}});
     if (!ctx->h_active) HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
-    hipStream_t st = ctx->stream;
+
     // which clouds need the k-NN pre-pass: GICP uses the covariances of both clouds of a pair, point-to-plane only
     // the normals of the searched one (PCL target = slam3d source); a batch without pairs is s3d_knn_normals
     for (SlotDev& sl : h_slots) {
@@ -565,13 +566,19 @@ struct Batch {
         sl.want_normals = 0;
       }
     }
-    {
-      const size_t bs = sizeof(SlotDev) * (size_t)C(), bp = sizeof(PairDev) * (size_t)P();
-      char* stage = ctx->stage_host(bs + bp + 16);
-      if (bs) { std::memcpy(stage, h_slots.data(), bs); HIPCHK(hipMemcpyAsync(ctx->slots.p, stage, bs, hipMemcpyHostToDevice, st)); }
-      if (bp) { std::memcpy(stage + bs, h_pairs.data(), bp); HIPCHK(hipMemcpyAsync(ctx->pairs.p, stage + bs, bp, hipMemcpyHostToDevice, st)); }
-    }
+    h_slots0 = h_slots;      // (what run_all() starts a second attempt from)
+    h_pairs0 = h_pairs;
+    upload_records();
     restore_from_cache();
+  }
+  std::vector<SlotDev> h_slots0;
+  std::vector<PairDev> h_pairs0;
+  void upload_records() {
+    hipStream_t st = ctx->stream;
+    const size_t bs = sizeof(SlotDev) * (size_t)C(), bp = sizeof(PairDev) * (size_t)P();
+    char* stage = ctx->stage_host(bs + bp + 16);
+    if (bs) { std::memcpy(stage, h_slots.data(), bs); HIPCHK(hipMemcpyAsync(ctx->slots.p, stage, bs, hipMemcpyHostToDevice, st)); }
+    if (bp) { std::memcpy(stage + bs, h_pairs.data(), bp); HIPCHK(hipMemcpyAsync(ctx->pairs.p, stage + bs, bp, hipMemcpyHostToDevice, st)); }
   }
 
   // segmented LSD radix sort of (keys, vals) of every slot: `passes` digits of `bits` bits (8, 9 or 10).
@@ -677,6 +684,35 @@ struct Batch {
     }
   }
 
+  // K1 + K2 + K3 of a registration batch in ONE sort (round 5; s3d_core.h "K2 + K3 in one sort", k_centroids_fused): the
+  // raw points sorted by (search cell, voxel) - the centroids then come out in cell order and the centroid kernel writes
+  // the cell-sorted arrays and the cell table itself.  Against stage_voxel + stage_grid: no k_keys_hist<1>, no second
+  // sort (two 9-bit passes at the benchmark), no k_grid_finalize, no `filt`.  Wanted by run_all() for GICP / point-to-plane
+  // with a voxel filter and k <= 32, without the pre-pass cache (whose entries hold `filt`); a slot it cannot serve
+  // reports so (FusedGrid::ok < 0) and run_all() runs the batch again on the two-sort path.
+  bool fused = false;
+  bool fused_wanted() const {
+    return rp.leaf > 0.f && !use_cache && rp.k <= 32 && has_sorted3 && !(opts.debug_flags & S3D_DBG_NO_FUSED_PREPASS);
+  }
+  void stage_prepass_fused() {
+    hipStream_t st = ctx->stream;
+    const int NS = Cu;
+    if (NS == 0) return;
+    sort_choose();
+    k_bbox<0><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), NS), kBlock, 0, st>>>(d_slots(), filt());
+    k_voxel_params<<<cdiv(NS, 64), 64, 0, st>>>(d_slots(), rp, NS);
+    k_fused_grid_params<<<cdiv(NS, 64), 64, 0, st>>>(d_slots(), NS);
+    sort_prepare(NS);
+    k_keys_hist<2, 8><<<dim3(nb_sort, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA(), (uint32_t*)ctx->counts.p, nb_sort,
+                                                              sort_classic ? 0 : 4, (uint32_t*)ctx->digit_tot.p);
+    sort(SortPlan{4, 8}, NS, true);      // (32-bit keys: the host does not know how many bits a slot's keys use)
+    uint32_t* bc = (uint32_t*)ctx->blockcnt.p;
+    k_heads_count<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), kA(), bc, nb_head);
+    k_heads_scan<<<NS, kBlock, 0, st>>>(d_slots(), bc, nb_head);
+    k_centroids_fused<<<(unsigned)((NS >= 8 ? cdiv(NS, 8) * 8 : NS) * nb_head), kBlock, 0, st>>>(
+        d_slots(), kA(), vA(), bc, sorted(), sorted3(), cells(), nb_head, NS);
+  }
+
   // K3: dense search grid + cell-sorted copy of every slot that is not restored from the cache
   void stage_grid() {
     hipStream_t st = ctx->stream;
@@ -738,10 +774,26 @@ struct Batch {
       int* redo_count = fb_count + 1;
       int2* redo_list = (int2*)ctx->knn_redo.p;
       s3d_knn3_moments_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), sorted(), cells(), mom, mom_plane, nb_head, d_list, NL, normals(), fb_count, fb_list, redo_count, redo_list);
-      if ((long long)NL * max_n <= 2000000ll)   // a few clouds: the redo list's latency counts (see the kernel)
+      const bool thin = (long long)NL * max_n <= 2000000ll;   // a few clouds: the redo list's latency counts (see the kernel)
+      if (thin && !fused)
         s3d_knn_moments_redo_kernel<20, true, true><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list);
-      else
+      else if (!fused)
         s3d_knn_moments_redo_kernel<20, true, false><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list);
+      else if (thin)
+        s3d_knn_moments_redo_kernel<20, true, true, true><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list);
+      else
+        s3d_knn_moments_redo_kernel<20, true, false, true><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list);
+    } else if (fused) {    // (the positions in `sorted` name the neighbours: BYPOS)
+      if (k <= 8)
+        s3d_knn_moments_kernel<8, false, true><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
+      else if (k <= 16)
+        s3d_knn_moments_kernel<16, false, true><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
+      else if (k == 20)
+        s3d_knn_moments_kernel<20, true, true><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
+      else if (k < 20)
+        s3d_knn_moments_kernel<20, false, true><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
+      else
+        s3d_knn_moments_kernel<32, false, true><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
     } else if (k <= 8)
       s3d_knn_moments_kernel<8><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
     else if (k <= 16)
@@ -1001,18 +1053,33 @@ struct Batch {
       HIPCHK(hipEventRecord(ctx->ev[i], st));
     };
     ctx->prof = s3d_profile{};
-    mark(0);
-    stage_voxel();
-    mark(1);
-    stage_grid();
-    mark(2);
-    stage_normals();
-    mark(3);
-    stage_icp();
-    mark(4);
-    stage_fitness();
-    mark(5);
-    download();
+    fused = fused_wanted();
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      mark(0);
+      if (fused) stage_prepass_fused(); else stage_voxel();
+      mark(1);
+      if (!fused) stage_grid();
+      mark(2);
+      stage_normals();
+      mark(3);
+      stage_icp();
+      mark(4);
+      stage_fitness();
+      mark(5);
+      download();
+      if (!fused) break;
+      bool served = true;
+      for (int j = 0; j < Cu; ++j) served = served && h_slots[(size_t)j].fz.ok > 0;
+      if (served) break;
+      // a slot the fused pre-pass cannot serve (PCL's own index overflow, a mixed key beyond 32 bits, a centroid outside
+      // its cell by more than the searches' margin): the whole batch again on the two-sort path, from the records as
+      // allocate() uploaded them
+      fused = false;
+      ++ctx->fused_reruns;
+      h_slots = h_slots0;
+      h_pairs = h_pairs0;
+      upload_records();
+    }
     store_to_cache(true);
     if (prof) {
       float ms = 0;
@@ -2232,6 +2299,57 @@ int s3d_knn_normals(s3d_context* ctx, const float* xyz, int n, int stride, int k
     free_cloud(&c);
   } catch (const HipError& e) {
     free_cloud(&c);
+    return fail(ctx, e);
+  }
+  return S3D_STATUS_OK;
+}
+
+// ---- test hooks (include/slam3d_hip_debug.h): not part of the drop-in API
+long long s3d_debug_fused_reruns(s3d_context* ctx) { return ctx ? ctx->fused_reruns : -1; }
+
+// The pre-pass of a registration (voxel filter + search grid, fused or as two sorts) and ONE nearest-neighbour pass of
+// the filtered target cloud's points against the filtered source cloud, everything as the registration lays it out:
+// the cell-sorted points of both clouds (w = the tie-breaking id: index in pcl::VoxelGrid's output order, or PCL's
+// voxel key on the fused path - the same order) and, per cell-sorted target point, the POSITION of its neighbour in
+// the source's array and the float d2.
+int s3d_debug_filtered_nn(s3d_context* ctx, s3d_cloud* source, s3d_cloud* target, double leaf, int fused,
+                          double max_distance, int capacity, float* source_sorted_xyzw, int* n_source,
+                          float* target_sorted_xyzw, int* n_target, int* corr_pos, float* corr_d2, int* fused_ok) {
+  if (!ctx || !source || !target || !(leaf > 0.0) || capacity < 0 || !n_source || !n_target || !fused_ok)
+    return S3D_STATUS_INVALID_ARGUMENT;
+  try {
+    ScopedDevice sd(ctx);
+    s3d_reg_params p;
+    s3d_default_params(&p);
+    p.point_cloud_density = leaf;
+    p.max_correspondence_distance = max_distance;
+    Batch b;
+    b.ctx = ctx;
+    b.set_params(&p, nullptr);
+    const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    b.add_pairs(1, &source, &target, ident);
+    b.allocate();
+    b.fused = fused != 0;
+    if (b.fused) b.stage_prepass_fused();
+    else { b.stage_voxel(); b.stage_grid(); }
+    k_pair_init<<<1, 64, 0, ctx->stream>>>(b.d_pairs(), 1, (int*)ctx->n_active.p);
+    HIPCHK(hipMemsetAsync(ctx->corr_d2.p, 0xFF, 4 * std::max<size_t>(b.total_corr, 4), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->corr_lb.p, 0, 4 * std::max<size_t>(b.total_corr, 4), ctx->stream));
+    b.launch_nn(1, (float)(max_distance * 1.0001));
+    b.download();
+    const PairDev& P = b.h_pairs[0];
+    const SlotDev& Ss = b.h_slots[P.slot_s];
+    const SlotDev& St = b.h_slots[P.slot_t];
+    *n_source = Ss.n; *n_target = St.n;
+    *fused_ok = b.fused ? std::min(Ss.fz.ok, St.fz.ok) : 0;
+    if (Ss.n > capacity || St.n > capacity) return S3D_STATUS_INVALID_ARGUMENT;
+    if (Ss.n > 0) copy_to_host(ctx, source_sorted_xyzw, b.sorted() + Ss.off, sizeof(float4) * (size_t)Ss.n);
+    if (St.n > 0) {
+      copy_to_host(ctx, target_sorted_xyzw, b.sorted() + St.off, sizeof(float4) * (size_t)St.n);
+      copy_to_host(ctx, corr_pos, (int*)ctx->corr_idx.p + P.corr_off, sizeof(int) * (size_t)St.n);
+      copy_to_host(ctx, corr_d2, (float*)ctx->corr_d2.p + P.corr_off, sizeof(float) * (size_t)St.n);
+    }
+  } catch (const HipError& e) {
     return fail(ctx, e);
   }
   return S3D_STATUS_OK;

@@ -217,6 +217,112 @@ S3D_HD int grid_cell_of_point(const GridParams& g, float x, float y, float z) {
   return ix + g.dim[0] * (iy + g.dim[1] * iz);
 }
 
+// ------------------------------------------------------------------ K2 + K3 in one sort (round 5): the fused pre-pass
+// pcl::VoxelGrid sorts the points by the voxel key (iz, iy, ix); the search grid then sorted the centroids again by the
+// cell id (cz, cy, cx).  Both orders are z-major / x-fastest: with the search cell an INTEGER number m of voxels per
+// edge and the grid's origin on the voxel lattice, a voxel lies in exactly one cell and ONE radix sort on the
+// mixed-radix key
+//     key = cell * msub + sub,   cell = cx + dim0 (cy + dim1 cz),   sub = sx + sub0 (sy + sub1 sz),
+//     (cx, sx) = (ix / m, ix mod m) ...,   sub_a = min(m, div_b[a]),   msub = sub0 sub1 sub2
+// leaves the raw points in cell order with voxel order inside a cell - the order the two sorts produced.  The centroid
+// kernel then writes the cell-sorted arrays and the cell table directly: no second key pass, no second sort, no gather
+// pass.  Tie-breaking id of a centroid (the `.w` of a cell-sorted point): PCL's voxel key, which orders the centroids as
+// their index in pcl::VoxelGrid's output does.
+// The grid is laid over the VOXEL lattice of the raw cloud's bounding box (known before the sort), not over the box of
+// the centroids: m is the smallest edge >= 2 voxels (the old h0 = 2 leaf) whose cell count fits the budget.
+// A slot the scheme cannot serve - PCL's own index overflow (passthrough), a mixed key beyond 32 bits, a centroid whose
+// float sums put it outside its cell by more than the searches' rounding margin - says so in FusedGrid::ok, and the
+// host runs the batch again on the two-sort path (s3d_api.hip Batch::run_all): never silently inexact.
+struct FusedGrid {
+  int m;            // cell edge in voxels
+  int sub[3];       // sub-voxel radix per axis
+  uint32_t msub;    // sub[0] * sub[1] * sub[2]
+  int ok;           // 1: served; 0: not attempted; < 0: this slot cannot use the fused path (see above)
+};
+constexpr float kFusedCellTol = 1.0e-3f;   // a stored point may lie this far (in cells) outside its cell's box: half of
+                                           // the 2e-3 margin every search adds for the rounding of cell assignments
+
+S3D_HD bool fused_grid_from_voxels(const VoxelParams& vp, int cap, GridParams& g, FusedGrid& f) {
+  f.m = 1; f.sub[0] = f.sub[1] = f.sub[2] = 1; f.msub = 1; f.ok = -1;
+  g.h = 1.f; g.inv_h = 1.f; g.ncells = 1;
+  for (int a = 0; a < 3; ++a) { g.origin[a] = 0.f; g.dim[a] = 1; }
+  if (vp.passthrough || vp.div_b[0] < 1 || vp.div_b[1] < 1 || vp.div_b[2] < 1) return false;
+  const double vol = (double)vp.div_b[0] * (double)vp.div_b[1] * (double)vp.div_b[2];
+  if (vol > 2147483647.0) return false;   // (the voxel keys are the tie-breaking ids: non-negative ints)
+  // the cell count prod ceil(div_b / m) does not grow with m: the smallest m >= 2 that fits the budget by bisection
+  auto cells = [&](int mm) {
+    int64_t nc_ = 1;
+    for (int a = 0; a < 3; ++a) nc_ *= (int64_t)((vp.div_b[a] + mm - 1) / mm);
+    return nc_;
+  };
+  const int64_t budget = cap > 0 ? (int64_t)cap : 1;
+  int lo = 2, hi = 2;                        // invariant below: cells(hi) <= budget, cells(lo - 1) > budget or lo == 2
+  while (cells(hi) > budget) {
+    if (hi >= (1 << 30)) return false;
+    lo = hi + 1;
+    hi *= 2;
+  }
+  while (lo < hi) {
+    const int mid = lo + (hi - lo) / 2;
+    if (cells(mid) <= budget) hi = mid; else lo = mid + 1;
+  }
+  const int m = hi;
+  const int64_t nc = cells(m);
+  uint64_t msub = 1;
+  for (int a = 0; a < 3; ++a) {
+    g.dim[a] = (vp.div_b[a] + m - 1) / m;
+    f.sub[a] = vp.div_b[a] < m ? vp.div_b[a] : m;
+    msub *= (uint64_t)f.sub[a];
+  }
+  if (msub > 0xFFFFFFFFull || (uint64_t)nc * msub > 0xFFFFFFFEull) return false;   // (0xFFFFFFFF = kInvalidKey)
+  f.m = m; f.msub = (uint32_t)msub;
+  g.ncells = (int)nc;
+  // voxel i of axis a covers [(min_b + i) / inv_leaf, (min_b + i + 1) / inv_leaf) up to the rounding of PCL's float product
+  g.h = (float)((double)m / (double)vp.inv_leaf);
+  g.inv_h = 1.0f / g.h;
+  for (int a = 0; a < 3; ++a) g.origin[a] = (float)((double)vp.min_b[a] / (double)vp.inv_leaf);
+  f.ok = 1;
+  return true;
+}
+
+// the key of one raw point (the float operations of voxel_key, i.e. of pcl::VoxelGrid)
+S3D_HD uint32_t fused_key(const VoxelParams& vp, const GridParams& g, const FusedGrid& f, float x, float y, float z) {
+  const int i0 = (int)(floorf(x * vp.inv_leaf) - (float)vp.min_b[0]);
+  const int i1 = (int)(floorf(y * vp.inv_leaf) - (float)vp.min_b[1]);
+  const int i2 = (int)(floorf(z * vp.inv_leaf) - (float)vp.min_b[2]);
+  const int c0 = i0 / f.m, c1 = i1 / f.m, c2 = i2 / f.m;
+  const uint32_t cell = (uint32_t)(c0 + g.dim[0] * (c1 + g.dim[1] * c2));
+  const uint32_t sub = (uint32_t)((i0 - c0 * f.m) + f.sub[0] * ((i1 - c1 * f.m) + f.sub[1] * (i2 - c2 * f.m)));
+  return cell * f.msub + sub;
+}
+
+// key -> cell id, cell coordinates and PCL's voxel key (the tie-breaking id)
+S3D_HD void fused_decode(const VoxelParams& vp, const GridParams& g, const FusedGrid& f, uint32_t key, int* cell, int c[3],
+                         uint32_t* voxel) {
+  const uint32_t ce = key / f.msub;
+  uint32_t su = key - ce * f.msub;
+  const int s0 = (int)(su % (uint32_t)f.sub[0]); su /= (uint32_t)f.sub[0];
+  const int s1 = (int)(su % (uint32_t)f.sub[1]);
+  const int s2 = (int)(su / (uint32_t)f.sub[1]);
+  uint32_t r = ce;
+  c[0] = (int)(r % (uint32_t)g.dim[0]); r /= (uint32_t)g.dim[0];
+  c[1] = (int)(r % (uint32_t)g.dim[1]);
+  c[2] = (int)(r / (uint32_t)g.dim[1]);
+  *cell = (int)ce;
+  *voxel = (uint32_t)((c[0] * f.m + s0) + (c[1] * f.m + s1) * vp.div_b[0] + (c[2] * f.m + s2) * vp.div_b[0] * vp.div_b[1]);
+}
+
+// does the point lie in the box of cell c (+- kFusedCellTol cells)?  What the searches assume of a stored point.
+S3D_HD bool fused_inside(const GridParams& g, const int c[3], float x, float y, float z) {
+  const float p[3] = {x, y, z};
+  bool ok = true;
+  for (int a = 0; a < 3; ++a) {
+    const float fcell = (p[a] - g.origin[a]) * g.inv_h - (float)c[a];
+    ok = ok && fcell >= -kFusedCellTol && fcell <= 1.0f + kFusedCellTol;
+  }
+  return ok;
+}
+
 // pcl::RadiusOutlierRemoval on the search grid: how many points p of the cloud (the query itself included)
 // have float d2(q, p) <= r2f; the scan stops as soon as `need` are found.  reach >= sqrt(r2f) * (1 + 1e-5): the
 // box of cells that can hold such a point.
@@ -719,7 +825,10 @@ S3D_HD float knn_key_d2(double key) {
 // FULL: k == KMAX is known at compile time (the default k = 20 on the <20> instantiation): `worst` is then simply
 // the last slot; with a run-time k the compiler evaluates the 20-way select chain after EVERY insertion
 // (80 v_cndmask per insertion, a fifth of the kernel's instructions).
-template <int KMAX, bool FULL = false, typename F4T = void>
+// BYPOS (the fused pre-pass, whose points carry PCL's voxel key in .w instead of an index): the low word of a key is the
+// candidate's POSITION in pts, which is what the caller gathers the neighbours by; equal distances then order by
+// position (cell, then voxel order) instead of by index.
+template <int KMAX, bool FULL = false, bool BYPOS = false, typename F4T = void>
 S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cell_start,
                            const F4T* __restrict__ pts, float qx, float qy, float qz, int k,
                            unsigned long long (&keys_out)[KMAX]) {
@@ -737,11 +846,11 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
   face = fmaxf(face - 2.0e-3f, 0.f);
   const int rmax = imax(imax(g.dim[0], g.dim[1]), g.dim[2]);
   // one candidate -> sorted list (unrolled min/max chain); `worst` mirrors keys[k-1]
-#define S3D_KNN_INSERT(P_, D2_)                                                                    \
+#define S3D_KNN_INSERT(P_, POS_, D2_)                                                                   \
   {                                                                                                \
     double c = __builtin_bit_cast(double,                                                          \
         ((unsigned long long)(__builtin_bit_cast(uint32_t, (D2_)) + 0x00800000u) << 32) |          \
-        (unsigned long long)__builtin_bit_cast(uint32_t, (P_).w));                                 \
+        (unsigned long long)(BYPOS ? (uint32_t)(POS_) : __builtin_bit_cast(uint32_t, (P_).w)));    \
     if (c < worst) {                                                                               \
       knn_chain<KMAX>(keys, c);                                                                    \
       if (FULL || k == KMAX) {                                                                     \
@@ -789,18 +898,22 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
         return t + b_;                                                                                           \
       };                                                                                                         \
       F4T na = pts[0], nb = pts[0];                                                                              \
-      if (total > 0) { na = pts[flatpos(0u)]; nb = pts[flatpos(total > 1 ? 1u : 0u)]; }                          \
+      uint32_t ia = 0, ib = 0;                                                                                   \
+      if (total > 0) { ia = flatpos(0u); ib = flatpos(total > 1 ? 1u : 0u); na = pts[ia]; nb = pts[ib]; }        \
       for (uint32_t t = 0; t < total; t += 2) {                                                                  \
         const F4T pa = na, pb = nb;                                                                              \
+        const uint32_t ja = ia, jb = ib;                                                                         \
         const bool two = t + 1 < total;                                                                          \
         if (t + 2 < total) {                                                                                     \
-          na = pts[flatpos(t + 2)];                                                                              \
-          nb = pts[flatpos(t + 3 < total ? t + 3 : t + 2)];                                                      \
+          ia = flatpos(t + 2);                                                                                   \
+          ib = flatpos(t + 3 < total ? t + 3 : t + 2);                                                           \
+          na = pts[ia];                                                                                          \
+          nb = pts[ib];                                                                                          \
         }                                                                                                        \
         const float da = dist2(qx, qy, qz, pa.x, pa.y, pa.z);                                                    \
         const float db = dist2(qx, qy, qz, pb.x, pb.y, pb.z);                                                    \
-        S3D_KNN_INSERT(pa, da)                                                                                   \
-        if (two) S3D_KNN_INSERT(pb, db)                                                                          \
+        S3D_KNN_INSERT(pa, ja, da)                                                                               \
+        if (two) S3D_KNN_INSERT(pb, jb, db)                                                                      \
       }                                                                                                          \
     }
     S3D_KNN_PHASE(0, 5)
@@ -836,32 +949,31 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
     // software-pipelined: the two points of step t+2 are requested before the insertion chains of
     // step t run, so the chains (~200 instructions) cover the load latency
     F4T na = pts[0], nb = pts[0];
+    uint32_t ia = 0, ib = 0;
     if (total > 0) {
-      uint32_t ka, kb;
-      S3D_KNN_FLATPOS(0u, ka)
-      S3D_KNN_FLATPOS((total > 1 ? 1u : 0u), kb)
-      na = pts[ka]; nb = pts[kb];
+      S3D_KNN_FLATPOS(0u, ia)
+      S3D_KNN_FLATPOS((total > 1 ? 1u : 0u), ib)
+      na = pts[ia]; nb = pts[ib];
     }
     for (uint32_t t = 0; t < total; t += 2) {
       F4T pa = na, pb = nb;
+      uint32_t ja = ia, jb = ib;
       const bool two = t + 1 < total;
       if (!S3D_KNN_PREFETCH && t > 0) {
-        uint32_t ka, kb;
-        S3D_KNN_FLATPOS(t, ka)
-        S3D_KNN_FLATPOS((two ? t + 1 : t), kb)
-        pa = pts[ka]; pb = pts[kb];
+        S3D_KNN_FLATPOS(t, ja)
+        S3D_KNN_FLATPOS((two ? t + 1 : t), jb)
+        pa = pts[ja]; pb = pts[jb];
       }
       if (S3D_KNN_PREFETCH && t + 2 < total) {
-        uint32_t ka, kb;
         const uint32_t t3 = t + 3 < total ? t + 3 : t + 2;
-        S3D_KNN_FLATPOS(t + 2, ka)
-        S3D_KNN_FLATPOS(t3, kb)
-        na = pts[ka]; nb = pts[kb];
+        S3D_KNN_FLATPOS(t + 2, ia)
+        S3D_KNN_FLATPOS(t3, ib)
+        na = pts[ia]; nb = pts[ib];
       }
       const float da = dist2(qx, qy, qz, pa.x, pa.y, pa.z);
       const float db = dist2(qx, qy, qz, pb.x, pb.y, pb.z);
-      S3D_KNN_INSERT(pa, da)
-      if (two) S3D_KNN_INSERT(pb, db)
+      S3D_KNN_INSERT(pa, ja, da)
+      if (two) S3D_KNN_INSERT(pb, jb, db)
     }
 #undef S3D_KNN_FLATPOS
 #endif
@@ -916,7 +1028,7 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
               for (int u = 0; u < 4; ++u) {
                 if (kk + u < e) {
                   const float d2 = dist2(qx, qy, qz, pp[u].x, pp[u].y, pp[u].z);
-                  S3D_KNN_INSERT(pp[u], d2)
+                  S3D_KNN_INSERT(pp[u], kk + u, d2)
                 }
               }
             }
@@ -952,7 +1064,7 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
           for (uint32_t kk = s; kk < e; ++kk) {
             const F4T p = pts[kk];
             const float d2 = dist2(qx, qy, qz, p.x, p.y, p.z);
-            S3D_KNN_INSERT(p, d2)
+            S3D_KNN_INSERT(p, kk, d2)
           }
         }
       }

@@ -49,6 +49,7 @@ struct SlotDev {          // one cloud of the batch
   unsigned int bb[6];     // bbox as order-preserving uint (min xyz, max xyz), atomics
   VoxelParams vp;
   GridParams  g;
+  FusedGrid   fz;         // the fused pre-pass (s3d_core.h "K2 + K3 in one sort"): ok = 1 served, < 0 the host must re-run
 };
 
 struct PairDev {          // one align() job
@@ -246,6 +247,24 @@ __global__ void k_voxel_params(SlotDev* slots, RunParams rp, int nslots) {
     s.vp = voxel_params_from_bbox(mn, mx, rp.leaf);
   }
   s.n_sort = s.n_raw;
+  s.fz.ok = 0;
+}
+
+// the fused pre-pass, after k_voxel_params: the search grid laid over the voxel lattice (fused_grid_from_voxels) - the
+// one sort then orders the raw points by (cell, voxel).  An empty slot: a one-cell grid, nothing to sort (every key is
+// invalid), nothing that could go wrong; a slot the scheme cannot serve: ok < 0, a one-cell grid, every key invalid.
+// (A kernel of its own: inlined into k_voxel_params the two bodies crash hipcc 7.2's instruction selection.)
+__global__ void k_fused_grid_params(SlotDev* slots, int nslots) {
+  const int si = blockIdx.x * blockDim.x + threadIdx.x;
+  if (si >= nslots) return;
+  SlotDev& s = slots[si];
+  VoxelParams v = s.vp;
+  if (s.n_raw <= 0 || s.bb[0] == 0xFFFFFFFFu) v.passthrough = 0;
+  GridParams g;
+  FusedGrid f;
+  fused_grid_from_voxels(v, s.cell_cap, g, f);
+  s.g = g;
+  s.fz = f;
 }
 
 // leaf <= 0: the filtered cloud is the raw cloud (PointCloudSensor.cpp:125-131)
@@ -358,7 +377,7 @@ __global__ void __launch_bounds__(kBlock) k_keys_hist(const SlotDev* __restrict_
   constexpr int NB = 1 << BITS;
   __shared__ unsigned int hist[kSortPlaces][NB];
   const SlotDev& s = slots[blockIdx.y];
-  const int n = WHICH == 0 ? s.n_raw : s.n;
+  const int n = WHICH == 1 ? s.n : s.n_raw;
   const int nb = (n + kSortTile - 1) / kSortTile;
   if ((int)blockIdx.x >= nb) return;
   const int places = sweep_passes > 0 ? sweep_passes : 1;
@@ -375,6 +394,10 @@ __global__ void __launch_bounds__(kBlock) k_keys_hist(const SlotDev* __restrict_
         const float4 v = s.raw[i];
         key = kInvalidKey;
         if (finite3(v.x, v.y, v.z)) key = s.vp.passthrough ? (uint32_t)i : voxel_key(s.vp, v.x, v.y, v.z);
+      } else if (WHICH == 2) {   // the fused pre-pass: (cell, voxel) keys of the raw points
+        const float4 v = s.raw[i];
+        key = kInvalidKey;
+        if (s.fz.ok > 0 && finite3(v.x, v.y, v.z)) key = fused_key(s.vp, s.g, s.fz, v.x, v.y, v.z);
       } else {
         const float4 p = filt[s.off + i];
         key = (uint32_t)grid_cell_of_point(s.g, p.x, p.y, p.z);
@@ -857,6 +880,80 @@ __global__ void __launch_bounds__(kBlock) k_centroids(const SlotDev* __restrict_
   block_bbox_merge<false>(mn, mx, blockbb + ((size_t)slot_i * nb_max + chunk_i) * 6);
 }
 
+// The fused pre-pass (s3d_core.h "K2 + K3 in one sort"): the raw points are sorted by (cell, voxel), so the centroids
+// come out in cell order and this kernel writes what k_centroids + k_keys_hist<1> + the grid sort + k_grid_finalize
+// produced: the cell-sorted points (w = PCL's voxel key: the tie-breaking id), their xyz-only copy and the cell table.
+// Cell table by gap fill as in k_grid_finalize: the head at rank `pos` owns the cells (cell of the previous head, own
+// cell]; the previous head's cell is read off the key of the element before the run (the last element of the previous
+// voxel).  The LAST head also owns the tail (own cell, ncells] = pos + 1 = the number of centroids; a cloud without a
+// valid point gets its all-zero table from the first thread of its first block.
+// A centroid is checked against the box of its cell (fused_inside): float sums of many far-away points can leave it
+// outside its voxel by more than the searches allow for - the slot then reports ok = -2 and the host re-runs the batch
+// on the two-sort path.
+__device__ __forceinline__ void cell_gap_fill(uint32_t* __restrict__ cs, int lo, int hi, uint32_t val) {
+  // cells lo..hi (inclusive; none when hi < lo) get `val`: short gaps by the owning lane, long ones by the whole wave
+  const int gap = hi - lo + 1;
+  if (gap > 0 && gap <= 8)
+    for (int c = lo; c <= hi; ++c) cs[c] = val;
+  unsigned long long big = __ballot(gap > 8);
+  const int lane = lane_id();
+  while (big) {
+    const int src = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const int l = __shfl(lo, src, kWave), h = __shfl(hi, src, kWave);
+    const uint32_t v = (uint32_t)__shfl((int)val, src, kWave);
+    for (int c = l + lane; c <= h; c += kWave) cs[c] = v;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_centroids_fused(SlotDev* __restrict__ slots, const uint32_t* __restrict__ keys,
+                                                             const uint32_t* __restrict__ vals,
+                                                             const uint32_t* __restrict__ blockcnt,
+                                                             float4* __restrict__ sorted, CorrVec* __restrict__ sorted3,
+                                                             uint32_t* __restrict__ cell_start, int nb_max, int nslots) {
+  __shared__ int lds4[4];
+  int slot_i, chunk_i;
+  nn_block_map(nb_max, nslots, &slot_i, &chunk_i);
+  if (slot_i >= nslots) return;
+  SlotDev& s = slots[slot_i];
+  const int base = chunk_i * kBlock;
+  if (base >= s.n_raw && chunk_i != 0) return;          // (block 0 stays: an empty cloud still needs its cell table)
+  const int i = base + threadIdx.x;
+  const uint32_t* __restrict__ k = keys + s.off;
+  const uint32_t* __restrict__ v = vals + s.off;
+  uint32_t* __restrict__ cs = cell_start + s.cell_off;
+  const bool head = i < s.n_raw && voxel_head(k, i);
+  float4 p_first = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (head) p_first = s.raw[v[i]];
+  int total;
+  const int pos = block_excl_flag(head, &total, lds4) + (int)blockcnt[(size_t)slot_i * nb_max + chunk_i];
+  int lo = 0, hi = -1, lo2 = 0, hi2 = -1;
+  uint32_t val = 0, val2 = 0;
+  if (head) {
+    const uint32_t key = k[i];
+    float sx = 0.f + p_first.x, sy = 0.f + p_first.y, sz = 0.f + p_first.z;   // (pcl::VoxelGrid: float sums in index order)
+    int j = i + 1;
+    for (; j < s.n_raw && k[j] == key; ++j) {
+      const float4 p = s.raw[v[j]];
+      sx += p.x; sy += p.y; sz += p.z;
+    }
+    const float c = (float)(j - i);
+    const float qx = sx / c, qy = sy / c, qz = sz / c;
+    int cell, cc[3];
+    uint32_t voxel;
+    fused_decode(s.vp, s.g, s.fz, key, &cell, cc, &voxel);
+    sorted[s.off + pos] = make_float4(qx, qy, qz, __uint_as_float(voxel));
+    if (sorted3) { CorrVec q3; q3.x = qx; q3.y = qy; q3.z = qz; sorted3[s.off + pos] = q3; }
+    if (!fused_inside(s.g, cc, qx, qy, qz)) s.fz.ok = -2;     // (any number of threads may store the same value)
+    lo = i == 0 ? 0 : (int)(k[i - 1] / s.fz.msub) + 1;
+    hi = cell; val = (uint32_t)pos;
+    if (j >= s.n_raw || k[j] == kInvalidKey) { lo2 = cell + 1; hi2 = s.g.ncells; val2 = (uint32_t)pos + 1u; }
+  }
+  if (i == 0 && (s.n_raw <= 0 || k[0] == kInvalidKey)) { lo2 = 0; hi2 = s.g.ncells; val2 = 0u; }
+  cell_gap_fill(cs, lo, hi, val);
+  cell_gap_fill(cs, lo2, hi2, val2);
+}
+
 // ------------------------------------------------------------------ K3: search grid
 
 // One wave per slot.  blockbb != nullptr: the bbox of the filtered cloud comes as six words per 256-point block of
@@ -986,16 +1083,18 @@ __global__ void __launch_bounds__(kBlock) k_normals(const SlotDev* __restrict__ 
 #endif
 // one point of slot `s` (position i of its cell-sorted order) through the exact 64-bit search: neighbours, PCL
 // moments, closed-form normal; a point the closed form declines goes to the eigen fallback list
-template <int KMAX, bool FULL>
+// BYPOS (fused pre-pass): the points carry no index into `filt` (which does not exist then) - the keys name positions in
+// `sorted`, and the neighbours are gathered from there (the same xyz)
+template <int KMAX, bool FULL, bool BYPOS = false>
 __device__ __forceinline__ void knn_moments_point(const SlotDev& s, int i, const float4* __restrict__ filt,
                                                   const float4* __restrict__ sorted,
                                                   const uint32_t* __restrict__ cell_start, double* __restrict__ moments,
                                                   size_t plane, int k, NormalRec* __restrict__ normals,
                                                   int* __restrict__ fallback_count, int* __restrict__ fallback_list) {
-  const float4* __restrict__ P = filt + s.off;
+  const float4* __restrict__ P = (BYPOS ? sorted : filt) + s.off;
   const float4 q = sorted[s.off + i];
   unsigned long long keys[KMAX];
-  const int cnt = grid_knn_sorted<KMAX, FULL>(s.g, cell_start + s.cell_off, sorted + s.off, q.x, q.y, q.z, k, keys);
+  const int cnt = grid_knn_sorted<KMAX, FULL, BYPOS>(s.g, cell_start + s.cell_off, sorted + s.off, q.x, q.y, q.z, k, keys);
   Moments m;
   moments_init(m);
 #pragma unroll
@@ -1018,7 +1117,7 @@ __device__ __forceinline__ void knn_moments_point(const SlotDev& s, int i, const
   fallback_list[atomicAdd(fallback_count, 1)] = s.off + i;
 }
 
-template <int KMAX, bool FULL = false>
+template <int KMAX, bool FULL = false, bool BYPOS = false>
 __global__ void __launch_bounds__(kBlock, S3D_KNN_WAVES) s3d_knn_moments_kernel(const SlotDev* __restrict__ slots,
                                                                   const float4* __restrict__ filt,
                                                                   const float4* __restrict__ sorted,
@@ -1036,7 +1135,7 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_WAVES) s3d_knn_moments_kernel(
   const SlotDev& s = slots[slot_list[li]];
   const int i = chunk * kBlock + threadIdx.x;
   if (i >= s.n) return;
-  knn_moments_point<KMAX, FULL>(s, i, filt, sorted, cell_start, moments, plane, k, normals, fallback_count, fallback_list);
+  knn_moments_point<KMAX, FULL, BYPOS>(s, i, filt, sorted, cell_start, moments, plane, k, normals, fallback_count, fallback_list);
 }
 
 // ---- K4, round 3 (k = K known at compile time): 32-bit keys + v_med3_u32 insertion + per-query segment table in LDS
@@ -1113,7 +1212,7 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN3_WAVES) s3d_knn3_moments_kerne
 #ifndef S3D_KNN_REDO_WAVES
 #define S3D_KNN_REDO_WAVES 3
 #endif
-template <int KMAX, bool FULL, bool THIN>
+template <int KMAX, bool FULL, bool THIN, bool BYPOS = false>
 __global__ void __launch_bounds__(kBlock, S3D_KNN_REDO_WAVES) s3d_knn_moments_redo_kernel(const SlotDev* __restrict__ slots,
                                                                        const float4* __restrict__ filt,
                                                                        const float4* __restrict__ sorted,
@@ -1135,8 +1234,8 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_REDO_WAVES) s3d_knn_moments_re
   }
   for (int j = first; j < count; j += stride) {
     const int2 e = redo_list[j];
-    knn_moments_point<KMAX, FULL>(slots[e.x], e.y, filt, sorted, cell_start, moments, plane, k, normals, fallback_count,
-                                  fallback_list);
+    knn_moments_point<KMAX, FULL, BYPOS>(slots[e.x], e.y, filt, sorted, cell_start, moments, plane, k, normals, fallback_count,
+                                         fallback_list);
   }
 }
 

@@ -106,6 +106,74 @@ Grid build_grid(const Cloud& c, float h0, int cells_per_point) {
   return G;
 }
 
+// The fused pre-pass (round 5, s3d_core.h "K2 + K3 in one sort") as the device runs it: bbox of the finite raw points,
+// pcl::VoxelGrid's lattice, the search grid over that lattice, ONE stable sort of the raw points by (cell, voxel) key,
+// centroids by float sums in index order, written in cell order with PCL's voxel key as the tie-breaking id, and the
+// cell table.  ok = FusedGrid::ok as the device would report it (< 0: the host falls back to the two-sort path).
+struct Fused {
+  Grid G;              // sorted[].w = voxel key bits
+  VoxelParams vp;
+  FusedGrid fz;
+  std::vector<int> cell;   // cell id of every centroid
+};
+Fused build_fused(const float* xyz, int n, int stride, double leaf, int cells_per_point) {
+  Fused F;
+  std::vector<F4> raw;
+  raw.reserve(n);
+  for (int i = 0; i < n; ++i) {
+    const float* p = xyz + (size_t)i * stride;
+    raw.push_back({p[0], p[1], p[2], 1.f});
+  }
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  bool any = false;
+  for (const F4& q : raw) {
+    if (!(std::isfinite(q.x) && std::isfinite(q.y) && std::isfinite(q.z))) continue;
+    any = true;
+    const float v[3] = {q.x, q.y, q.z};
+    for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], v[a]); mx[a] = std::max(mx[a], v[a]); }
+  }
+  if (!any) {
+    F.vp.inv_leaf = 1.f; F.vp.passthrough = 0;
+    for (int a = 0; a < 3; ++a) { F.vp.min_b[a] = 0; F.vp.div_b[a] = 1; }
+  } else {
+    F.vp = voxel_params_from_bbox(mn, mx, (float)leaf);
+  }
+  const int cap = (int)std::max<int64_t>(std::min<int64_t>((int64_t)cells_per_point * (int64_t)n, 1 << 24), 64);
+  fused_grid_from_voxels(F.vp, cap, F.G.g, F.fz);
+  std::vector<std::pair<uint32_t, int>> kv;
+  for (size_t i = 0; i < raw.size(); ++i) {
+    const F4& q = raw[i];
+    if (F.fz.ok > 0 && std::isfinite(q.x) && std::isfinite(q.y) && std::isfinite(q.z))
+      kv.push_back({fused_key(F.vp, F.G.g, F.fz, q.x, q.y, q.z), (int)i});
+  }
+  std::stable_sort(kv.begin(), kv.end(), [](auto& a, auto& b) { return a.first < b.first; });
+  F.G.cell_start.assign((size_t)F.G.g.ncells + 1, 0);
+  int prev_cell = -1;
+  for (size_t i = 0; i < kv.size();) {
+    size_t j = i;
+    float sx = 0, sy = 0, sz = 0;
+    while (j < kv.size() && kv[j].first == kv[i].first) {
+      const F4& p = raw[kv[j].second];
+      sx += p.x; sy += p.y; sz += p.z;
+      ++j;
+    }
+    const float c = (float)(j - i);
+    const float qx = sx / c, qy = sy / c, qz = sz / c;
+    int cell, cc[3];
+    uint32_t voxel;
+    fused_decode(F.vp, F.G.g, F.fz, kv[i].first, &cell, cc, &voxel);
+    if (!fused_inside(F.G.g, cc, qx, qy, qz)) F.fz.ok = -2;
+    const uint32_t pos = (uint32_t)F.G.sorted.size();
+    for (int ce = prev_cell + 1; ce <= cell; ++ce) F.G.cell_start[ce] = pos;     // the gap fill of k_centroids_fused
+    prev_cell = cell;
+    F.G.sorted.push_back({qx, qy, qz, __builtin_bit_cast(float, voxel)});
+    F.cell.push_back(cell);
+    i = j;
+  }
+  for (int ce = prev_cell + 1; ce <= F.G.g.ncells; ++ce) F.G.cell_start[ce] = (uint32_t)F.G.sorted.size();
+  return F;
+}
+
 struct D3 { double x, y, z; };
 std::vector<D3> normals(const Cloud& c, const Grid& G, int k) {
   std::vector<D3> out(c.pts.size());
@@ -220,6 +288,91 @@ void emu_knn3_check(const float* xyz, int n, float h0, int cpp, long long* out) 
     std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
     if (a != b) ++out[2];
     if (!same_order) ++out[3];
+  }
+}
+
+// ---- the fused pre-pass (round 5) ----------------------------------------------------------------------------------
+// centroids in cell order with their voxel keys and cells; info = {ok, m, dim0, dim1, dim2, ncells, msub, structural
+// errors (cell table not monotone / a point not in the cell range the table gives / cells or voxel keys not ascending)}
+int emu_fused_voxel(const float* xyz, int n, int stride, double leaf, int cpp, float* out_xyz, unsigned* out_voxel,
+                    int* out_cell, long long* info, float* grid) {
+  Fused F = build_fused(xyz, n, stride, leaf, cpp);
+  long long bad = 0;
+  const size_t m = F.G.sorted.size();
+  for (size_t i = 0; i < m; ++i) {
+    out_xyz[i * 3] = F.G.sorted[i].x; out_xyz[i * 3 + 1] = F.G.sorted[i].y; out_xyz[i * 3 + 2] = F.G.sorted[i].z;
+    out_voxel[i] = __builtin_bit_cast(uint32_t, F.G.sorted[i].w);
+    out_cell[i] = F.cell[i];
+    const uint32_t a = F.G.cell_start[F.cell[i]], b = F.G.cell_start[F.cell[i] + 1];
+    if (!(a <= i && i < b)) ++bad;
+    if (i > 0 && (F.cell[i] < F.cell[i - 1] || (F.cell[i] == F.cell[i - 1] && out_voxel[i] <= out_voxel[i - 1]))) ++bad;
+  }
+  for (int c = 0; c < F.G.g.ncells; ++c) if (F.G.cell_start[c] > F.G.cell_start[c + 1]) ++bad;
+  if (F.G.cell_start[0] != 0 || F.G.cell_start[F.G.g.ncells] != m) ++bad;
+  info[0] = F.fz.ok; info[1] = F.fz.m; info[2] = F.G.g.dim[0]; info[3] = F.G.g.dim[1]; info[4] = F.G.g.dim[2];
+  info[5] = F.G.g.ncells; info[6] = F.fz.msub; info[7] = bad;
+  if (grid) { grid[0] = F.G.g.origin[0]; grid[1] = F.G.g.origin[1]; grid[2] = F.G.g.origin[2]; grid[3] = F.G.g.h; }
+  return (int)m;
+}
+
+// every search of the registration on a fused grid: queries qry (m x 3) against the filtered cloud of `src`.
+// mode 0: grid_nn1_box with the given hints, 1: its first-pass (FAST) form, 2: grid_nn1_scan27, 3: scan27 PRESCAN.
+// Outputs per query: voxel key of the neighbour (0xFFFFFFFF: none / declined), float d2, answered flag.
+void emu_fused_nn(const float* src, int n, int stride, double leaf, int cpp, const float* qry, int m, float max_d,
+                  const float* hint, int mode, unsigned* nn_voxel, float* d2, int* answered) {
+  Fused F = build_fused(src, n, stride, leaf, cpp);
+  const GridParams& g = F.G.g;
+  const uint32_t* cs = F.G.cell_start.data();
+  const F4* pts = F.G.sorted.data();
+  for (int i = 0; i < m; ++i) {
+    const float x = qry[i * 3], y = qry[i * 3 + 1], z = qry[i * 3 + 2];
+    NNResult r;
+    bool ok = true;
+    if (mode == 0) r = grid_nn1_box(g, cs, pts, x, y, z, max_d, hint[i]);
+    else if (mode == 1) r = grid_nn1_box<true>(g, cs, pts, x, y, z, max_d, hint[i]);
+    else {
+      uint32_t tab[kKnn3Segs];
+      ok = mode == 3 ? grid_nn1_scan27<1>(g, cs, pts, x, y, z, tab, 1, r, 3.0e38f)
+                     : grid_nn1_scan27(g, cs, pts, x, y, z, tab, 1, r, 3.0e38f);
+    }
+    answered[i] = ok ? 1 : 0;
+    const bool have = ok && r.pos >= 0;
+    nn_voxel[i] = have ? __builtin_bit_cast(uint32_t, pts[r.pos].w) : 0xFFFFFFFFu;
+    d2[i] = have ? r.d2 : 3.0e38f;
+    if (have && r.idx != __builtin_bit_cast(int, pts[r.pos].w)) answered[i] = -1;   // (position and id must name one point)
+  }
+}
+
+// k-NN on a fused grid: the med3 pre-pass against the exact search BY POSITION (grid_knn_sorted<.., BYPOS>), and the
+// exact search by position against a brute-force scan.  out[0] = points, [1] = declined by med3, [2] = answered with a
+// different 20-neighbour set, [3] = exact searches (sampled) whose set differs from brute force
+void emu_fused_knn_check(const float* xyz, int n, int stride, double leaf, int cpp, long long* out) {
+  Fused F = build_fused(xyz, n, stride, leaf, cpp);
+  const GridParams& g = F.G.g;
+  const int np_ = (int)F.G.sorted.size();
+  out[0] = np_; out[1] = out[2] = out[3] = 0;
+  for (int i = 0; i < np_; ++i) {
+    const F4& q = F.G.sorted[i];
+    unsigned long long ref[20];
+    const int cnt = grid_knn_sorted<20, true, true>(g, F.G.cell_start.data(), F.G.sorted.data(), q.x, q.y, q.z, 20, ref);
+    std::vector<uint32_t> b;
+    for (int j = 0; j < cnt; ++j) b.push_back((uint32_t)(ref[j] & 0xFFFFFFFFull));
+    std::sort(b.begin(), b.end());
+    if (i % 37 == 0) {   // brute force: the 20 smallest (d2, position)
+      std::vector<std::pair<float, uint32_t>> all;
+      for (int j = 0; j < np_; ++j) all.push_back({dist2(q.x, q.y, q.z, F.G.sorted[j].x, F.G.sorted[j].y, F.G.sorted[j].z), (uint32_t)j});
+      std::partial_sort(all.begin(), all.begin() + std::min(20, np_), all.end());
+      std::vector<uint32_t> c;
+      for (int j = 0; j < std::min(20, np_); ++j) c.push_back(all[j].second);
+      std::sort(c.begin(), c.end());
+      if (c != b) ++out[3];
+    }
+    uint32_t tab[kKnn3Segs], keys[21];
+    if (!grid_knn_med3<21>(g, F.G.cell_start.data(), F.G.sorted.data(), q.x, q.y, q.z, tab, 1, keys)) { ++out[1]; continue; }
+    std::vector<uint32_t> a;
+    for (int j = 0; j < 20; ++j) a.push_back(knn3_position(keys[j], tab, 1));
+    std::sort(a.begin(), a.end());
+    if (a != b) ++out[2];
   }
 }
 

@@ -354,3 +354,108 @@ def test_normal_record_round_trip(emu):
         assert np.array_equal(fpart, n.astype(np.float32))
         worst = max(worst, float(np.abs(out - n).max()))
     assert worst <= 2.0 ** -34 + 1e-18, worst
+
+
+# ------------------------------------------------------------------ round 5: the fused pre-pass (one sort for K2 + K3)
+
+up = C.POINTER(C.c_uint)
+
+
+def _fused_voxel(emu, cloud, leaf, cpp=2):
+    c = np.ascontiguousarray(cloud[:, :3], np.float32)
+    xyz = np.empty((len(c) + 1, 3), np.float32)
+    vox = np.empty(len(c) + 1, np.uint32)
+    cell = np.empty(len(c) + 1, np.int32)
+    info = np.zeros(8, np.int64)
+    grid = np.zeros(4, np.float32)
+    n = emu.emu_fused_voxel(c.ctypes.data_as(fp), len(c), 3, C.c_double(leaf), cpp, xyz.ctypes.data_as(fp),
+                            vox.ctypes.data_as(up), cell.ctypes.data_as(ip), info.ctypes.data_as(C.POINTER(C.c_longlong)),
+                            grid.ctypes.data_as(fp))
+    return xyz[:n], vox[:n], cell[:n], info, grid
+
+
+@pytest.mark.parametrize("leaf,cpp", [(0.1, 2), (0.2, 2), (0.2, 16), (0.5, 1), (1.0, 2), (0.07, 2)])
+def test_fused_prepass_centroids_are_pcl_voxelgrid(emu, oracle_mod, fixture_clouds, leaf, cpp):
+    """ONE sort on (cell, voxel) keys yields exactly pcl::VoxelGrid's centroids: sorted by the voxel key they travel with
+    they ARE the oracle's output, bit for bit and in its order; in cell order they fill the cell table consistently and
+    every one lies in the box of its cell (the searches' assumption)."""
+    for cloud in fixture_clouds[:2]:
+        ref, _ = oracle_mod.voxel_downsample(cloud, leaf)
+        xyz, vox, cell, info, grid = _fused_voxel(emu, cloud, leaf, cpp)
+        assert info[0] == 1 and info[7] == 0, info
+        assert info[5] == info[2] * info[3] * info[4] and info[5] <= max(cpp * len(cloud), 64) and info[1] >= 2
+        order = np.argsort(vox, kind="stable")
+        assert len(np.unique(vox)) == len(vox) == len(ref)
+        assert np.array_equal(xyz[order], ref)
+        # geometry: the centroid lies in its cell (+- 1e-3 cell)
+        cz, r = np.divmod(cell, info[2] * info[3]); cy, cx = np.divmod(r, info[2])
+        f = (xyz.astype(np.float64) - grid[:3].astype(np.float64)) / float(grid[3]) - np.stack([cx, cy, cz], 1)
+        assert f.min() >= -1e-3 and f.max() <= 1 + 1e-3, (f.min(), f.max())
+
+
+def test_fused_prepass_edge_cases(emu, oracle_mod, fixture_clouds):
+    """empty / all-non-finite / one point / a flat cloud / non-finite points mixed in / PCL's index overflow"""
+    c = fixture_clouds[0][:, :3]
+    xyz, vox, cell, info, _ = _fused_voxel(emu, np.zeros((0, 3), np.float32), 0.2)
+    assert len(xyz) == 0 and info[0] == 1 and info[7] == 0
+    xyz, vox, cell, info, _ = _fused_voxel(emu, np.full((5, 3), np.nan, np.float32), 0.2)
+    assert len(xyz) == 0 and info[0] == 1 and info[7] == 0
+    xyz, vox, cell, info, _ = _fused_voxel(emu, c[:1], 0.2)
+    assert len(xyz) == 1 and info[0] == 1 and info[7] == 0 and np.array_equal(xyz, c[:1])
+    flat = c[:5000].copy(); flat[:, 2] = 1.25
+    ref, _ = oracle_mod.voxel_downsample(flat, 0.1)
+    xyz, vox, cell, info, _ = _fused_voxel(emu, flat, 0.1)
+    assert info[0] == 1 and info[7] == 0 and info[4] == 1 and np.array_equal(xyz[np.argsort(vox)], ref)
+    dirty = c[:4000].copy(); dirty[::7, 1] = np.inf; dirty[3::11, 0] = np.nan
+    ref, _ = oracle_mod.voxel_downsample(dirty, 0.3)
+    xyz, vox, cell, info, _ = _fused_voxel(emu, dirty, 0.3)
+    assert info[0] == 1 and info[7] == 0 and np.array_equal(xyz[np.argsort(vox)], ref)
+    # leaf far too small for the extent: PCL refuses (index overflow, output = input) - the fused path must decline
+    xyz, vox, cell, info, _ = _fused_voxel(emu, c[:2000], 1e-5)
+    assert info[0] < 0 and len(xyz) == 0 and info[7] == 0
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("leaf,cpp", [(0.2, 2), (0.1, 2), (0.3, 16)])
+def test_fused_prepass_searches_are_exact(emu, oracle_mod, fixture_clouds, leaf, cpp, mode):
+    """Every 1-NN search of the registration on the fused grid returns the oracle's neighbour (named by its voxel key =
+    its rank in pcl::VoxelGrid's output) and float d2: the box search from any hint, its first-pass form, the flat
+    27-cell scan and its pre-scan form (which may decline, never answer wrongly)."""
+    src = np.ascontiguousarray(fixture_clouds[0][:, :3])
+    v1, _ = oracle_mod.voxel_downsample(src, leaf)
+    v2, _ = oracle_mod.voxel_downsample(fixture_clouds[1], leaf)
+    _, vox1, _, info, _ = _fused_voxel(emu, src, leaf, cpp)
+    keys_sorted = np.sort(vox1)                       # rank in this array = index in the oracle's filtered cloud
+    rng = np.random.default_rng(7)
+    far = rng.uniform(-150, 150, (300, 3)).astype(np.float32)
+    q = np.ascontiguousarray(np.concatenate([v2[::3], far, v1[:300]]))
+    oi, od = oracle_mod.nn_search(v1, q)
+    hint = rng.uniform(0.0, 3.0, len(q)).astype(np.float32)
+    nnv = np.empty(len(q), np.uint32); d2 = np.empty(len(q), np.float32); ans = np.empty(len(q), np.int32)
+    emu.emu_fused_nn(src.ctypes.data_as(fp), len(src), 3, C.c_double(leaf), cpp, q.ctypes.data_as(fp), len(q),
+                     C.c_float(2.5), hint.ctypes.data_as(fp), mode, nnv.ctypes.data_as(up), d2.ctypes.data_as(fp),
+                     ans.ctypes.data_as(ip))
+    assert (ans >= 0).all()
+    a = ans == 1
+    have = a & (nnv != 0xFFFFFFFF)
+    idx = np.full(len(q), -1, np.int64)
+    idx[have] = np.searchsorted(keys_sorted, nnv[have])
+    m = od < 2.5 ** 2
+    if mode < 2:
+        assert a.all()
+        assert np.array_equal(idx[m], oi[m]) and np.array_equal(d2[m], od[m])
+        assert np.all((idx[~m] == -1) | (d2[~m] >= 2.5 ** 2))
+    else:
+        assert a.mean() > 0.3
+        assert np.array_equal(idx[a], oi[a]) and np.array_equal(d2[a], od[a])
+
+
+@pytest.mark.parametrize("leaf,cpp", [(0.3, 2), (0.2, 2), (0.5, 16)])
+def test_fused_prepass_knn_is_exact(emu, fixture_clouds, leaf, cpp):
+    """k-NN on the fused grid: the exact search that names its neighbours by POSITION equals a brute-force scan, and the
+    med3 pre-pass returns that set for every point it answers."""
+    src = np.ascontiguousarray(fixture_clouds[0][:, :3])
+    out = np.zeros(4, np.int64)
+    emu.emu_fused_knn_check(src.ctypes.data_as(fp), len(src), 3, C.c_double(leaf), cpp, out.ctypes.data_as(C.POINTER(C.c_longlong)))
+    assert out[0] > 1000 and out[2] == 0 and out[3] == 0, out
+    assert out[1] < 0.7 * out[0], out

@@ -1,0 +1,136 @@
+"""GPU tests of the fused pre-pass (round 5; s3d_core.h "K2 + K3 in one sort", k_centroids_fused): a registration batch
+sorts its raw points ONCE, by (search cell, voxel), instead of by voxel key and then by cell id.
+
+  * the filtered clouds are pcl::VoxelGrid's, bit for bit (against the oracle and against the two-sort path);
+  * the nearest neighbours found on the fused grid are the oracle's (index and float d2) and the two-sort path's;
+  * registrations agree with the two-sort path far inside the north-star tolerance (the query ORDER differs, so the
+    double sums differ in their last bits; identical statuses and iteration counts) and with the oracle at 1e-4;
+  * a cloud the scheme cannot serve makes the host run the batch again on the two-sort path: same records, counted.
+"""
+import numpy as np
+import pytest
+
+from conftest import transform_delta
+
+pytestmark = pytest.mark.gpu
+
+
+def _by_id(r):
+    """(filtered source in id order, filtered target in id order, per target point in id order: neighbour rank, d2)"""
+    so, to = np.argsort(r["source_id"], kind="stable"), np.argsort(r["target_id"], kind="stable")
+    rank_of_pos = np.empty(len(so), np.int64)
+    rank_of_pos[so] = np.arange(len(so))
+    nn = np.where(r["pos"] >= 0, rank_of_pos[np.maximum(r["pos"], 0)], -1)
+    return r["source_xyz"][so], r["target_xyz"][to], nn[to], r["d2"][to]
+
+
+@pytest.mark.parametrize("leaf", [0.2, 0.1, 0.35])
+def test_fused_prepass_clouds_and_neighbours_are_exact(gpu_ctx, oracle_mod, fixture_clouds, leaf):
+    a, b = gpu_ctx.upload(fixture_clouds[0]), gpu_ctx.upload(fixture_clouds[1])
+    try:
+        f = gpu_ctx.debug_filtered_nn(a, b, leaf, True, 2.5)
+        t = gpu_ctx.debug_filtered_nn(a, b, leaf, False, 2.5)
+    finally:
+        a.release(); b.release()
+    assert f["fused_ok"] == 1
+    vs, _ = oracle_mod.voxel_downsample(fixture_clouds[0], leaf)
+    vt, _ = oracle_mod.voxel_downsample(fixture_clouds[1], leaf)
+    fs, ft, fnn, fd2 = _by_id(f)
+    ts, tt, tnn, td2 = _by_id(t)
+    assert np.array_equal(fs, vs) and np.array_equal(ft, vt)          # pcl::VoxelGrid, in its order
+    assert np.array_equal(ts, vs) and np.array_equal(tt, vt)
+    oi, od = oracle_mod.nn_search(vs, vt)
+    m = od < 2.5 ** 2
+    assert m.mean() > 0.9
+    assert np.array_equal(fnn[m], oi[m]) and np.array_equal(fd2[m], od[m])
+    assert np.array_equal(tnn[m], oi[m]) and np.array_equal(td2[m], od[m])
+    # beyond max_d a search may stop early or report a farther point - never one inside the gate
+    assert np.all((fnn[~m] == -1) | (fd2[~m] >= 2.5 ** 2)) and np.all((tnn[~m] == -1) | (td2[~m] >= 2.5 ** 2))
+    # the ids of the fused path are voxel keys: strictly ascending inside a cell run is checked on the CPU
+    # (tests/test_emu_core.py); here: unique, and not simply 0..n-1
+    assert len(np.unique(f["source_id"])) == len(f["source_id"]) and f["source_id"].max() > len(vs)
+
+
+def test_fused_prepass_on_the_benchmark_clouds(gpu_ctx, oracle_mod):
+    """the benchmark's own workload (100 k-point synthetic scans, 0.02 m voxels: search cells of ~18 voxels)"""
+    import slam3d_amd as s3d
+    src, tgt, _ = s3d.make_pair(100_000, 3)
+    a, b = gpu_ctx.upload(src), gpu_ctx.upload(tgt)
+    try:
+        f = gpu_ctx.debug_filtered_nn(a, b, 0.02, True, 2.5)
+        t = gpu_ctx.debug_filtered_nn(a, b, 0.02, False, 2.5)
+    finally:
+        a.release(); b.release()
+    assert f["fused_ok"] == 1
+    vs, _ = oracle_mod.voxel_downsample(src, 0.02)
+    fs, ft, fnn, fd2 = _by_id(f)
+    ts, tt, tnn, td2 = _by_id(t)
+    assert np.array_equal(fs, vs) and np.array_equal(fs, ts) and np.array_equal(ft, tt)
+    inr = td2 < 2.5 ** 2
+    assert inr.mean() > 0.99 and np.array_equal(fnn[inr], tnn[inr]) and np.array_equal(fd2[inr], td2[inr])
+    assert np.all(fd2[~inr] >= 2.5 ** 2)
+
+
+@pytest.mark.parametrize("alg", ["gicp", "icp"])
+def test_fused_prepass_registrations_match_two_sort_path_and_oracle(gpu_ctx, oracle_mod, fixture_clouds, alg):
+    import slam3d_amd as s3d
+    algo = s3d.ALG_GICP if alg == "gicp" else s3d.ALG_ICP
+    dev = [gpu_ctx.upload(c) for c in fixture_clouds]
+    syn = [s3d.make_pair(40_000, s)[:2] for s in (1, 2)]
+    sdev = [(gpu_ctx.upload(x), gpu_ctx.upload(y)) for x, y in syn]
+    before = gpu_ctx.fused_reruns()
+    try:
+        for dens, src, tgt in ((0.2, dev[:3], dev[1:4]), (0.35, dev[:3], dev[1:4]),
+                               (0.05, [p[0] for p in sdev], [p[1] for p in sdev])):
+            p = s3d.default_params(registration_algorithm=algo, point_cloud_density=dens)
+            r1, i1 = gpu_ctx.align_batch(src, tgt, None, p, want_infos=True)
+            r0, i0 = gpu_ctx.align_batch(src, tgt, None, p, s3d.ExecOptions(debug_flags=s3d.api.DBG_NO_FUSED_PREPASS),
+                                         want_infos=True)
+            assert np.array_equal(r1[:, 13:], r0[:, 13:])                  # iterations, correspondences, status
+            assert [(x["n_source_filtered"], x["n_target_filtered"]) for x in i1] == \
+                   [(x["n_source_filtered"], x["n_target_filtered"]) for x in i0]
+            for k in range(len(src)):
+                T1 = np.eye(4); T1[:3, :] = r1[k, :12].reshape(4, 3).T
+                T0 = np.eye(4); T0[:3, :] = r0[k, :12].reshape(4, 3).T
+                dt, dr = transform_delta(T0, T1)
+                assert dt < 2e-6 and dr < 2e-7, (dens, k, dt, dr)
+                assert abs(r1[k, 12] - r0[k, 12]) < 1e-6 * max(1.0, abs(r0[k, 12]))
+        assert gpu_ctx.fused_reruns() == before
+        # against the oracle (smooth-objective mode for GICP), the fixture pairs at the reference's default density
+        p = s3d.default_params(registration_algorithm=algo)
+        r1 = gpu_ctx.align_batch(dev[:3], dev[1:4], None, p)
+        oracle_mod.set_eval_precision(2 if alg == "gicp" else 0)
+        try:
+            for k in range(3):
+                so, To, io = oracle_mod.align(fixture_clouds[k], fixture_clouds[k + 1], np.eye(4),
+                                              oracle_mod.default_params(registration_algorithm=algo))
+                T1 = np.eye(4); T1[:3, :] = r1[k, :12].reshape(4, 3).T
+                dt, dr = transform_delta(To, T1)
+                assert so == 0 and r1[k, 15] == 0 and r1[k, 13] == io["iterations"] and dt < 1e-4 and dr < 1e-4, (k, dt, dr)
+        finally:
+            oracle_mod.set_eval_precision(0)
+    finally:
+        for h in dev + [x for p_ in sdev for x in p_]:
+            h.release()
+
+
+def test_fused_prepass_falls_back_to_two_sorts(gpu_ctx, fixture_clouds):
+    """A voxel size PCL itself refuses (its index would overflow: pcl::VoxelGrid returns the input unfiltered) cannot be
+    served by the fused keys either: the device says so, the host runs the batch again on the two-sort path, and the
+    records are that path's bit for bit.  One bad cloud in a batch is enough."""
+    import slam3d_amd as s3d
+    small = [np.ascontiguousarray(c[::6, :3]) for c in fixture_clouds[:3]]
+    dev = [gpu_ctx.upload(c) for c in small]
+    try:
+        p = s3d.default_params(point_cloud_density=2e-5, maximum_iterations=8)
+        before = gpu_ctx.fused_reruns()
+        r1, i1 = gpu_ctx.align_batch(dev[:2], dev[1:3], None, p, want_infos=True)
+        assert gpu_ctx.fused_reruns() == before + 1
+        r0, i0 = gpu_ctx.align_batch(dev[:2], dev[1:3], None, p, s3d.ExecOptions(debug_flags=s3d.api.DBG_NO_FUSED_PREPASS),
+                                     want_infos=True)
+        assert gpu_ctx.fused_reruns() == before + 1
+        assert np.array_equal(r1, r0) and i1 == i0
+        assert i1[0]["n_source_filtered"] == len(small[0])             # (passthrough: nothing was filtered)
+    finally:
+        for h in dev:
+            h.release()
