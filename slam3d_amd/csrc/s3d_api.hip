@@ -125,8 +125,10 @@ std::atomic<unsigned long long> g_cloud_uid{1};
 // device-computed part of its SlotDev.  ONE device allocation per entry.
 struct CacheKey {
   unsigned long long uid; uint32_t leaf_bits, h0_bits; int cell_cap;
+  int layout;       // 0: two sorts (filt in voxel order + cell-sorted copies); 1: the fused pre-pass (no filt, the grid on
+                    // the voxel lattice, voxel keys as ids) - a registration and an NDT call on one cloud keep separate entries
   bool operator<(const CacheKey& o) const {
-    return std::tie(uid, leaf_bits, h0_bits, cell_cap) < std::tie(o.uid, o.leaf_bits, o.h0_bits, o.cell_cap);
+    return std::tie(uid, leaf_bits, h0_bits, cell_cap, layout) < std::tie(o.uid, o.leaf_bits, o.h0_bits, o.cell_cap, o.layout);
   }
 };
 struct CacheEntry {
@@ -165,7 +167,8 @@ struct s3d_context {
   s3d_map_profile map_prof{};
   // workspace (grown on demand, reused across calls)
   DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, sorted3, normals, moments, cell_start, counts, digit_tot, blockcnt, blockbb,
-      corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active, knn_list, knn_fallback, knn_redo, wave_recs, t_hist, worklist, rec_list, rec_counts, search_list;
+      corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active, knn_list, knn_fallback, knn_redo, wave_recs, t_hist, worklist, rec_list, rec_counts, search_list,
+      sorted3q, qperm, normals_q, qstart;   // (experiment: S3D_DBG_TILE_QUERIES)
   int* h_active = nullptr;  // pinned
   // pinned staging of the slot / pair records (up and down): a copy from or to pageable memory stalls the stream for
   // tens of microseconds, which a single-pair registration of ~1.5 ms notices
@@ -304,7 +307,9 @@ struct Batch {
   uint32_t* vB() { return (uint32_t*)ctx->valsB.p; }
   float4* filt() { return (float4*)ctx->filt.p; }
   float4* sorted() { return (float4*)ctx->sorted.p; }
-  CorrVec* sorted3() { return has_sorted3 ? (CorrVec*)ctx->sorted3.p : nullptr; }
+  CorrVec* sorted3() { return !has_sorted3 ? nullptr : tile_queries ? (CorrVec*)ctx->sorted3q.p : (CorrVec*)ctx->sorted3.p; }
+  bool tile_queries = false;   // experiment (S3D_DBG_TILE_QUERIES): the query streams in block order, see k_qorder_starts
+  NormalRec* query_normals() { return tile_queries ? (NormalRec*)ctx->normals_q.p : normals(); }
   bool has_sorted3 = false;
   NormalRec* normals() { return (NormalRec*)ctx->normals.p; }
   uint32_t* cells() { return (uint32_t*)ctx->cell_start.p; }
@@ -376,6 +381,7 @@ struct Batch {
     std::memcpy(&k.leaf_bits, &rp.leaf, 4);
     std::memcpy(&k.h0_bits, &rp.h0, 4);
     k.cell_cap = h_slots[(size_t)slot].cell_cap;
+    k.layout = fused ? 1 : 0;
     return k;
   }
 
@@ -427,7 +433,7 @@ struct Batch {
       const SlotDev& sl = h_slots[(size_t)j];
       const size_t n = (size_t)sl.n;
       if (n) {
-        cp.push_back({e.block + e.o_filt, filt() + sl.off, 16 * n});
+        if (!fused) cp.push_back({e.block + e.o_filt, filt() + sl.off, 16 * n});
         cp.push_back({e.block + e.o_sorted, sorted() + sl.off, 16 * n});
         if (has_sorted3) cp.push_back({e.block + e.o_sorted3, sorted3() + sl.off, sizeof(CorrVec) * n});
         if (slot_has_normals[(size_t)j]) cp.push_back({e.block + e.o_normals, normals() + sl.off, sizeof(NormalRec) * n});
@@ -462,7 +468,7 @@ struct Batch {
       CacheEntry e;
       const size_t cells_n = (size_t)sl.g.ncells + 1;
       auto place = [&](size_t bytes) { const size_t o = e.bytes; e.bytes += (bytes + 255) & ~(size_t)255; return o; };
-      e.o_filt = place(16 * n); e.o_sorted = place(16 * n); e.o_sorted3 = place(sizeof(CorrVec) * n);
+      e.o_filt = place(fused ? 0 : 16 * n); e.o_sorted = place(16 * n); e.o_sorted3 = place(sizeof(CorrVec) * n);
       e.o_normals = place(sizeof(NormalRec) * n); e.o_cells = place(4 * cells_n);
       e.bytes = std::max<size_t>(e.bytes, 256);
       // make room: least-recently-used entries that this call does not use
@@ -480,7 +486,7 @@ struct Batch {
       // optional optimisation into a failed call
       if (hipMalloc((void**)&e.block, e.bytes) != hipSuccess) { (void)hipGetLastError(); e.block = nullptr; continue; }
       if (n) {
-        cp.push_back({filt() + sl.off, e.block + e.o_filt, 16 * n});
+        if (!fused) cp.push_back({filt() + sl.off, e.block + e.o_filt, 16 * n});
         cp.push_back({sorted() + sl.off, e.block + e.o_sorted, 16 * n});
         if (has_sorted3) cp.push_back({sorted3() + sl.off, e.block + e.o_sorted3, sizeof(CorrVec) * n});
         if (normals_now) cp.push_back({normals() + sl.off, e.block + e.o_normals, sizeof(NormalRec) * n});
@@ -497,7 +503,20 @@ struct Batch {
     HIPCHK(hipStreamSynchronize(st));   // the arena may be re-carved by the next call on another stream order
   }
 
+  bool registration_batch = false;   // set by the callers of run_all(): GICP / point-to-plane on this batch's pairs
+  void assign_want_normals() {
+    // which clouds need the k-NN pre-pass: GICP uses the covariances of both clouds of a pair, point-to-plane only
+    // the normals of the searched one (PCL target = slam3d source); a batch without pairs is s3d_knn_normals
+    for (SlotDev& sl : h_slots) sl.want_normals = h_pairs.empty() ? 1 : 0;
+    for (const PairDev& pr : h_pairs) {
+      h_slots[pr.slot_s].want_normals = 1;
+      if (rp.algorithm != 0) h_slots[pr.slot_t].want_normals = 1;
+    }
+  }
   void allocate(bool icp_buffers = true) {
+    has_sorted3 = icp_buffers;
+    fused = registration_batch && fused_wanted();    // (before the cache look-up: the layout is part of an entry's key)
+    tile_queries = fused && !use_cache && rp.algorithm != 0 && (opts.debug_flags & S3D_DBG_TILE_QUERIES);
     order_slots_for_cache(icp_buffers);
     if (total_pts > (size_t)0x7FFFFFF0 || total_cells > (size_t)0x7FFFFFF0 || total_corr > (size_t)0x7FFFFFF0)
       throw HipError{hipErrorInvalidValue, "batch too large for 32-bit offsets", __LINE__};
@@ -542,25 +561,21 @@ struct Batch {
                 {&ctx->search_list, sizeof(uint4) * (icp_buffers && settled_wanted() ? (size_t)kNNSearchSublists * (size_t)search_sub_cap() : 1)},
                 {&ctx->t_hist, sizeof(Mat4f) * (icp_buffers ? (size_t)std::max(1, P()) * (size_t)hist_stride() : 1)},
                 {&ctx->knn_list, sizeof(int) * (size_t)std::max(1, C())},
-                {&ctx->knn_fallback, sizeof(int) * npi}, {&ctx->knn_redo, sizeof(int2) * npi}});
+                {&ctx->knn_fallback, sizeof(int) * npi}, {&ctx->knn_redo, sizeof(int2) * npi},
+                {&ctx->sorted3q, tile_queries ? 12 * npi : 4}, {&ctx->qperm, tile_queries ? 4 * npi : 4},
+                {&ctx->normals_q, tile_queries ? sizeof(NormalRec) * npi : 4},
+                {&ctx->qstart, tile_queries ? 4 * std::max<size_t>(total_cells, 4) : 4}});
     if (!ctx->h_active) HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
 
-    // which clouds need the k-NN pre-pass: GICP uses the covariances of both clouds of a pair, point-to-plane only
-    // the normals of the searched one (PCL target = slam3d source); a batch without pairs is s3d_knn_normals
-    for (SlotDev& sl : h_slots) {
-      sl.want_normals = h_pairs.empty() ? 1 : 0;
+    assign_want_normals();
+    for (SlotDev& sl : h_slots)
       for (int a = 0; a < 3; ++a) { sl.bb[a] = 0xFFFFFFFFu; sl.bb[3 + a] = 0u; }   // empty bbox: k_bbox<0> starts from it
-    }
-    for (const PairDev& pr : h_pairs) {
-      h_slots[pr.slot_s].want_normals = 1;
-      if (rp.algorithm != 0) h_slots[pr.slot_t].want_normals = 1;
-    }
     for (int j = Cu; j < C(); ++j) {   // cached clouds: the device-computed part of the slot record, normals if they match
       const CacheEntry& e = *slot_entry[(size_t)j];
       SlotDev& sl = h_slots[(size_t)j];
       sl.n = e.snap.n; sl.n_sort = 0;
       std::memcpy(sl.bb, e.snap.bb, sizeof sl.bb);
-      sl.vp = e.snap.vp; sl.g = e.snap.g;
+      sl.vp = e.snap.vp; sl.g = e.snap.g; sl.fz = e.snap.fz;
       if (sl.want_normals && icp_buffers && e.k_normals != 0 && e.k_normals == rp.k && (e.has_sorted3 || !icp_buffers)) {
         slot_has_normals[(size_t)j] = 1;
         sl.want_normals = 0;
@@ -688,11 +703,11 @@ struct Batch {
   // raw points sorted by (search cell, voxel) - the centroids then come out in cell order and the centroid kernel writes
   // the cell-sorted arrays and the cell table itself.  Against stage_voxel + stage_grid: no k_keys_hist<1>, no second
   // sort (two 9-bit passes at the benchmark), no k_grid_finalize, no `filt`.  Wanted by run_all() for GICP / point-to-plane
-  // with a voxel filter and k <= 32, without the pre-pass cache (whose entries hold `filt`); a slot it cannot serve
-  // reports so (FusedGrid::ok < 0) and run_all() runs the batch again on the two-sort path.
+  // with a voxel filter and k <= 32 (cache entries of this layout hold no `filt` and are keyed apart); a slot it cannot
+  // serve reports so (FusedGrid::ok < 0) and run_all() runs the batch again on the two-sort path.
   bool fused = false;
   bool fused_wanted() const {
-    return rp.leaf > 0.f && !use_cache && rp.k <= 32 && has_sorted3 && !(opts.debug_flags & S3D_DBG_NO_FUSED_PREPASS);
+    return rp.leaf > 0.f && rp.k <= 32 && has_sorted3 && !(opts.debug_flags & S3D_DBG_NO_FUSED_PREPASS);
   }
   void stage_prepass_fused() {
     hipStream_t st = ctx->stream;
@@ -710,7 +725,12 @@ struct Batch {
     k_heads_count<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), kA(), bc, nb_head);
     k_heads_scan<<<NS, kBlock, 0, st>>>(d_slots(), bc, nb_head);
     k_centroids_fused<<<(unsigned)((NS >= 8 ? cdiv(NS, 8) * 8 : NS) * nb_head), kBlock, 0, st>>>(
-        d_slots(), kA(), vA(), bc, sorted(), sorted3(), cells(), nb_head, NS);
+        d_slots(), kA(), vA(), bc, sorted(), tile_queries ? nullptr : sorted3(), cells(), nb_head, NS, tile_queries ? kB() : nullptr);
+    if (tile_queries) {
+      k_qorder_starts<<<NS, kBlock, 0, st>>>(d_slots(), cells(), (uint32_t*)ctx->qstart.p);
+      k_qorder_apply<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), sorted(), kB(), cells(), (uint32_t*)ctx->qstart.p,
+                                                           (CorrVec*)ctx->sorted3q.p, (uint32_t*)ctx->qperm.p);
+    }
   }
 
   // K3: dense search grid + cell-sorted copy of every slot that is not restored from the cache
@@ -910,7 +930,8 @@ struct Batch {
       s3d_nn_search_kernel<0><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc, cmp, nullptr,
                                                        nullptr, 0);
     else
-      s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc, 0,
+      s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc,
+                                                       (opts.debug_flags & 0x40000000u) ? 1 : 0,
                                                        settled_used ? wave_recs() : nullptr, t_hist(), hist_stride());
   }
   // first outer iteration (0-based) that runs record-wise: the pass after the two flat-scan passes.  Pass 4 still
@@ -962,7 +983,7 @@ struct Batch {
     double* part = (double*)ctx->partials.p;
     if (rp.algorithm)
       s3d_gicp_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
-          d_pairs(), d_slots(), sorted3(), normals(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp);
+          d_pairs(), d_slots(), sorted3(), query_normals(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp);
     if (!rp.algorithm)
       s3d_p2plane_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
           d_pairs(), d_slots(), sorted3(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp);
@@ -1053,7 +1074,6 @@ struct Batch {
       HIPCHK(hipEventRecord(ctx->ev[i], st));
     };
     ctx->prof = s3d_profile{};
-    fused = fused_wanted();
     for (int attempt = 0; attempt < 2; ++attempt) {
       mark(0);
       if (fused) stage_prepass_fused(); else stage_voxel();
@@ -1061,6 +1081,9 @@ struct Batch {
       if (!fused) stage_grid();
       mark(2);
       stage_normals();
+      if (tile_queries)
+        k_qorder_normals<<<dim3(nb_head, C()), kBlock, 0, st>>>(d_slots(), normals(), (uint32_t*)ctx->qperm.p,
+                                                                (NormalRec*)ctx->normals_q.p);
       mark(3);
       stage_icp();
       mark(4);
@@ -1075,9 +1098,16 @@ struct Batch {
       // its cell by more than the searches' margin): the whole batch again on the two-sort path, from the records as
       // allocate() uploaded them
       fused = false;
+      tile_queries = false;
       ++ctx->fused_reruns;
       h_slots = h_slots0;
       h_pairs = h_pairs0;
+      if (Cu < C()) {   // clouds restored from fused-layout cache entries: computed again like the others
+        Cu = C();
+        slot_entry.assign((size_t)C(), nullptr);
+        slot_has_normals.assign((size_t)C(), 0);
+        assign_want_normals();
+      }
       upload_records();
     }
     store_to_cache(true);
@@ -1653,6 +1683,7 @@ int align_dev(s3d_context* ctx, s3d_cloud* ps, s3d_cloud* pt, const double guess
   } else {
     b.set_params(params, opts);
     b.add_pairs(1, &ps, &pt, guess);
+    b.registration_batch = true;
     b.allocate();
     b.run_all();
     status = b.finish_pair(0, params, guess, result, info);
@@ -1828,7 +1859,7 @@ int s3d_context_cache_control(s3d_context* ctx, long long limit_bytes, int clear
 // ---- the cached pre-pass products of one cloud as a host blob (checkpoints: GraphSerialization.cpp:14-66 writes one
 // <index>.s3dm per vertex; a caller can put this blob next to it and hand it back after fromFolder, :68-135)
 namespace {
-constexpr uint32_t kBlobMagic = 0x42443353u, kBlobEntryMagic = 0x45443353u, kBlobVersion = 2u;   // "S3DB", "S3DE"; 2: payload hash per entry
+constexpr uint32_t kBlobMagic = 0x42443353u, kBlobEntryMagic = 0x45443353u, kBlobVersion = 3u;   // "S3DB", "S3DE"; 2: payload hash per entry; 3: layout + fused grid
 struct BlobHeader { uint32_t magic, version, entries, n_raw; unsigned long long points_hash; };
 struct BlobEntry {
   uint32_t magic, leaf_bits, h0_bits; int cell_cap;
@@ -1836,7 +1867,9 @@ struct BlobEntry {
   unsigned int bb[6];
   s3d::VoxelParams vp;
   s3d::GridParams g;
-  unsigned long long payload_bytes;   // filt 16 n | sorted 16 n | sorted3 sizeof(CorrVec) n | normals 16 n | cells 4 (ncells + 1)
+  int layout;                         // CacheKey::layout (1: the fused pre-pass - no filt, sorted.w = voxel keys)
+  s3d::FusedGrid fz;
+  unsigned long long payload_bytes;   // filt 16 n (layout 0 only) | sorted 16 n | sorted3 sizeof(CorrVec) n | normals 16 n | cells 4 (ncells + 1)
   unsigned long long payload_hash;    // FNV-1a of those bytes: a damaged checkpoint is refused, not installed
 };
 unsigned long long fnv1a64(const void* data, size_t bytes) {
@@ -1856,8 +1889,8 @@ unsigned long long cloud_points_hash(s3d_context* ctx, const s3d_cloud* c) {
   for (int i = 0; i < c->n; ++i) for (int a = 0; a < 3; ++a) xyz[(size_t)i * 3 + a] = h[(size_t)i * 4 + a];
   return fnv1a64(xyz.data(), xyz.size() * 4);
 }
-size_t blob_payload_bytes(int n, int ncells) {
-  return (size_t)n * (16 + 16 + sizeof(CorrVec) + sizeof(NormalRec)) + 4 * ((size_t)ncells + 1);
+size_t blob_payload_bytes(int n, int ncells, int layout) {
+  return (size_t)n * ((layout ? 0 : 16) + 16 + sizeof(CorrVec) + sizeof(NormalRec)) + 4 * ((size_t)ncells + 1);
 }
 }  // namespace
 
@@ -1870,7 +1903,7 @@ long long s3d_cloud_cache_export(s3d_context* ctx, const s3d_cloud* cloud, void*
     uint32_t entries = 0;
     auto first = ctx->cache.lower_bound(CacheKey{cloud->uid, 0, 0, 0});
     for (auto it = first; it != ctx->cache.end() && it->first.uid == cloud->uid; ++it) {
-      need += sizeof(BlobEntry) + blob_payload_bytes(it->second.snap.n, it->second.snap.g.ncells);
+      need += sizeof(BlobEntry) + blob_payload_bytes(it->second.snap.n, it->second.snap.g.ncells, it->first.layout);
       ++entries;
     }
     if (entries == 0) return 0;                                   // nothing cached for this cloud
@@ -1890,10 +1923,10 @@ long long s3d_cloud_cache_export(s3d_context* ctx, const s3d_cloud* cloud, void*
       E.magic = kBlobEntryMagic; E.leaf_bits = it->first.leaf_bits; E.h0_bits = it->first.h0_bits; E.cell_cap = it->first.cell_cap;
       E.n = e.snap.n; E.ncells = e.snap.g.ncells; E.k_normals = e.k_normals; E.has_sorted3 = e.has_sorted3 ? 1 : 0;
       std::memcpy(E.bb, e.snap.bb, sizeof E.bb);
-      E.vp = e.snap.vp; E.g = e.snap.g;
-      E.payload_bytes = blob_payload_bytes(e.snap.n, e.snap.g.ncells);
+      E.vp = e.snap.vp; E.g = e.snap.g; E.layout = it->first.layout; E.fz = e.snap.fz;
+      E.payload_bytes = blob_payload_bytes(e.snap.n, e.snap.g.ncells, E.layout);
       std::memcpy(out, &E, sizeof E); out += sizeof E;
-      const size_t parts[5][2] = {{e.o_filt, 16 * n}, {e.o_sorted, 16 * n}, {e.o_sorted3, sizeof(CorrVec) * n},
+      const size_t parts[5][2] = {{e.o_filt, E.layout ? 0 : 16 * n}, {e.o_sorted, 16 * n}, {e.o_sorted3, sizeof(CorrVec) * n},
                                   {e.o_normals, sizeof(NormalRec) * n}, {e.o_cells, 4 * cells_n}};
       for (int a = 0; a < 5; ++a) {
         const bool valid = !((a == 2 && !e.has_sorted3) || (a == 3 && e.k_normals == 0));   // never written: zeros
@@ -1935,7 +1968,8 @@ int s3d_cloud_cache_import(s3d_context* ctx, const s3d_cloud* cloud, const void*
       if (end - scan < (long long)sizeof E) { ctx->err = "cache blob: truncated"; return S3D_STATUS_INVALID_ARGUMENT; }
       std::memcpy(&E, scan, sizeof E); scan += sizeof E;
       if (E.magic != kBlobEntryMagic || E.n < 0 || E.n > cloud->n || E.ncells < 0 || E.ncells != E.g.ncells || E.ncells > E.cell_cap ||
-          E.payload_bytes != blob_payload_bytes(E.n, E.ncells) || (unsigned long long)(end - scan) < E.payload_bytes) {
+          (E.layout != 0 && E.layout != 1) || E.payload_bytes != blob_payload_bytes(E.n, E.ncells, E.layout) ||
+          (unsigned long long)(end - scan) < E.payload_bytes) {
         ctx->err = "cache blob: corrupt entry";
         return S3D_STATUS_INVALID_ARGUMENT;
       }
@@ -1947,8 +1981,8 @@ int s3d_cloud_cache_import(s3d_context* ctx, const s3d_cloud* cloud, const void*
                 E.g.dim[2] > 0;
       if (ok) {
         const size_t n = (size_t)E.n;
-        const char* sorted_at = scan + 16 * n;
-        const char* cells_at = scan + n * (16 + 16 + sizeof(CorrVec) + sizeof(NormalRec));
+        const char* sorted_at = scan + (E.layout ? 0 : 16 * n);
+        const char* cells_at = scan + n * ((E.layout ? 0 : 16) + 16 + sizeof(CorrVec) + sizeof(NormalRec));
         uint32_t prev = 0;
         for (size_t c = 0; ok && c <= (size_t)E.ncells; ++c) {
           uint32_t v;
@@ -1960,8 +1994,9 @@ int s3d_cloud_cache_import(s3d_context* ctx, const s3d_cloud* cloud, const void*
         for (size_t k = 0; ok && k < n; ++k) {
           uint32_t w;
           std::memcpy(&w, sorted_at + 16 * k + 12, 4);
-          ok = w < (uint32_t)E.n;
+          ok = E.layout ? w < 0x80000000u : w < (uint32_t)E.n;   // (an index into filt, or PCL's voxel key: a non-negative int)
         }
+        if (E.layout) ok = ok && E.fz.ok == 1 && E.fz.m >= 2 && E.fz.msub >= 1;
       }
       if (!ok) { ctx->err = "cache blob: damaged payload (checksum / cell table / indices)"; return S3D_STATUS_INVALID_ARGUMENT; }
       scan += E.payload_bytes;
@@ -1970,18 +2005,18 @@ int s3d_cloud_cache_import(s3d_context* ctx, const s3d_cloud* cloud, const void*
     for (uint32_t i = 0; i < H.entries; ++i) {
       BlobEntry E;
       std::memcpy(&E, in, sizeof E); in += sizeof E;
-      const CacheKey key{cloud->uid, E.leaf_bits, E.h0_bits, E.cell_cap};
+      const CacheKey key{cloud->uid, E.leaf_bits, E.h0_bits, E.cell_cap, E.layout};
       auto old = ctx->cache.find(key);
       if (old != ctx->cache.end()) { HIPCHK(hipStreamSynchronize(ctx->stream)); ctx->cache_drop(old); }
       CacheEntry e;
       const size_t n = (size_t)E.n, cells_n = (size_t)E.ncells + 1;
       auto place = [&](size_t bytes) { const size_t o = e.bytes; e.bytes += (bytes + 255) & ~(size_t)255; return o; };
-      e.o_filt = place(16 * n); e.o_sorted = place(16 * n); e.o_sorted3 = place(sizeof(CorrVec) * n);
+      e.o_filt = place(E.layout ? 0 : 16 * n); e.o_sorted = place(16 * n); e.o_sorted3 = place(sizeof(CorrVec) * n);
       e.o_normals = place(sizeof(NormalRec) * n); e.o_cells = place(4 * cells_n);
       e.bytes = std::max<size_t>(e.bytes, 256);
       if (ctx->cache_bytes + e.bytes > ctx->cache_limit) { in += E.payload_bytes; continue; }   // over the budget: stays uncached
       if (hipMalloc((void**)&e.block, e.bytes) != hipSuccess) { (void)hipGetLastError(); in += E.payload_bytes; continue; }
-      const size_t parts[5][2] = {{e.o_filt, 16 * n}, {e.o_sorted, 16 * n}, {e.o_sorted3, sizeof(CorrVec) * n},
+      const size_t parts[5][2] = {{e.o_filt, E.layout ? 0 : 16 * n}, {e.o_sorted, 16 * n}, {e.o_sorted3, sizeof(CorrVec) * n},
                                   {e.o_normals, sizeof(NormalRec) * n}, {e.o_cells, 4 * cells_n}};
       for (int a = 0; a < 5; ++a) {
         if (parts[a][1]) HIPCHK(hipMemcpyAsync(e.block + parts[a][0], in, parts[a][1], hipMemcpyHostToDevice, ctx->stream));
@@ -1991,7 +2026,7 @@ int s3d_cloud_cache_import(s3d_context* ctx, const s3d_cloud* cloud, const void*
       std::memset(&e.snap, 0, sizeof e.snap);
       e.snap.n_raw = cloud->n; e.snap.cell_cap = E.cell_cap; e.snap.n = E.n;
       std::memcpy(e.snap.bb, E.bb, sizeof E.bb);
-      e.snap.vp = E.vp; e.snap.g = E.g;
+      e.snap.vp = E.vp; e.snap.g = E.g; e.snap.fz = E.fz;
       e.k_normals = E.k_normals; e.has_sorted3 = E.has_sorted3 != 0;
       e.last_use = ctx->cache_clock;
       ctx->cache_bytes += e.bytes;
@@ -2111,6 +2146,7 @@ int s3d_align_batch(s3d_context* ctx, int n_pairs, s3d_cloud* const* sources, s3
     b.use_cache = opts && opts->cache_prepass != 0;
     b.set_params(params, opts);
     b.add_pairs(n_pairs, sources, targets, guesses);
+    b.registration_batch = true;
     b.allocate();
     b.run_all();
     for (int p = 0; p < n_pairs; ++p) {
