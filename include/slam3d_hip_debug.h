@@ -26,9 +26,6 @@
 
 #define S3D_DBG_NO_FUSED_PREPASS   0x10000000u /* registration pre-pass as two sorts (voxel keys, then cell ids) instead of
                                                   the one sort on (cell, voxel) keys                                     */
-#define S3D_DBG_TILE_QUERIES       0x20000000u /* EXPERIMENT (opt-in, changes the order of the sums): the query streams of a
-                                                  GICP batch in 4 x 4 x 4-cell block order instead of cell order          */
-
 /* ---- test hooks: exported by the library, used by tests/ only ---------------------------------------------------- */
 #ifdef __cplusplus
 extern "C" {

@@ -167,8 +167,7 @@ struct s3d_context {
   s3d_map_profile map_prof{};
   // workspace (grown on demand, reused across calls)
   DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, sorted3, normals, moments, cell_start, counts, digit_tot, blockcnt, blockbb,
-      corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active, knn_list, knn_fallback, knn_redo, wave_recs, t_hist, worklist, rec_list, rec_counts, search_list,
-      sorted3q, qperm, normals_q, qstart;   // (experiment: S3D_DBG_TILE_QUERIES)
+      corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active, knn_list, knn_fallback, knn_redo, wave_recs, t_hist, worklist, rec_list, rec_counts, search_list;
   int* h_active = nullptr;  // pinned
   // pinned staging of the slot / pair records (up and down): a copy from or to pageable memory stalls the stream for
   // tens of microseconds, which a single-pair registration of ~1.5 ms notices
@@ -307,9 +306,7 @@ struct Batch {
   uint32_t* vB() { return (uint32_t*)ctx->valsB.p; }
   float4* filt() { return (float4*)ctx->filt.p; }
   float4* sorted() { return (float4*)ctx->sorted.p; }
-  CorrVec* sorted3() { return !has_sorted3 ? nullptr : tile_queries ? (CorrVec*)ctx->sorted3q.p : (CorrVec*)ctx->sorted3.p; }
-  bool tile_queries = false;   // experiment (S3D_DBG_TILE_QUERIES): the query streams in block order, see k_qorder_starts
-  NormalRec* query_normals() { return tile_queries ? (NormalRec*)ctx->normals_q.p : normals(); }
+  CorrVec* sorted3() { return has_sorted3 ? (CorrVec*)ctx->sorted3.p : nullptr; }
   bool has_sorted3 = false;
   NormalRec* normals() { return (NormalRec*)ctx->normals.p; }
   uint32_t* cells() { return (uint32_t*)ctx->cell_start.p; }
@@ -516,7 +513,6 @@ struct Batch {
   void allocate(bool icp_buffers = true) {
     has_sorted3 = icp_buffers;
     fused = registration_batch && fused_wanted();    // (before the cache look-up: the layout is part of an entry's key)
-    tile_queries = fused && !use_cache && rp.algorithm != 0 && (opts.debug_flags & S3D_DBG_TILE_QUERIES);
     order_slots_for_cache(icp_buffers);
     if (total_pts > (size_t)0x7FFFFFF0 || total_cells > (size_t)0x7FFFFFF0 || total_corr > (size_t)0x7FFFFFF0)
       throw HipError{hipErrorInvalidValue, "batch too large for 32-bit offsets", __LINE__};
@@ -561,10 +557,7 @@ struct Batch {
                 {&ctx->search_list, sizeof(uint4) * (icp_buffers && settled_wanted() ? (size_t)kNNSearchSublists * (size_t)search_sub_cap() : 1)},
                 {&ctx->t_hist, sizeof(Mat4f) * (icp_buffers ? (size_t)std::max(1, P()) * (size_t)hist_stride() : 1)},
                 {&ctx->knn_list, sizeof(int) * (size_t)std::max(1, C())},
-                {&ctx->knn_fallback, sizeof(int) * npi}, {&ctx->knn_redo, sizeof(int2) * npi},
-                {&ctx->sorted3q, tile_queries ? 12 * npi : 4}, {&ctx->qperm, tile_queries ? 4 * npi : 4},
-                {&ctx->normals_q, tile_queries ? sizeof(NormalRec) * npi : 4},
-                {&ctx->qstart, tile_queries ? 4 * std::max<size_t>(total_cells, 4) : 4}});
+                {&ctx->knn_fallback, sizeof(int) * npi}, {&ctx->knn_redo, sizeof(int2) * npi}});
     if (!ctx->h_active) HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
 
     assign_want_normals();
@@ -725,12 +718,7 @@ struct Batch {
     k_heads_count<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), kA(), bc, nb_head);
     k_heads_scan<<<NS, kBlock, 0, st>>>(d_slots(), bc, nb_head);
     k_centroids_fused<<<(unsigned)((NS >= 8 ? cdiv(NS, 8) * 8 : NS) * nb_head), kBlock, 0, st>>>(
-        d_slots(), kA(), vA(), bc, sorted(), tile_queries ? nullptr : sorted3(), cells(), nb_head, NS, tile_queries ? kB() : nullptr);
-    if (tile_queries) {
-      k_qorder_starts<<<NS, kBlock, 0, st>>>(d_slots(), cells(), (uint32_t*)ctx->qstart.p);
-      k_qorder_apply<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), sorted(), kB(), cells(), (uint32_t*)ctx->qstart.p,
-                                                           (CorrVec*)ctx->sorted3q.p, (uint32_t*)ctx->qperm.p);
-    }
+        d_slots(), kA(), vA(), bc, sorted(), sorted3(), cells(), nb_head, NS);
   }
 
   // K3: dense search grid + cell-sorted copy of every slot that is not restored from the cache
@@ -931,7 +919,7 @@ struct Batch {
                                                        nullptr, 0);
     else
       s3d_nn_search_kernel<1><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc,
-                                                       (opts.debug_flags & 0x40000000u) ? 1 : 0,
+                                                       (dbg_nn & 65536) ? 0 : 1,   // (block compaction: 1.5 % of the queries search, scattered over all waves - 0.355 -> 0.29 ms at 256 pairs)
                                                        settled_used ? wave_recs() : nullptr, t_hist(), hist_stride());
   }
   // first outer iteration (0-based) that runs record-wise: the pass after the two flat-scan passes.  Pass 4 still
@@ -983,7 +971,7 @@ struct Batch {
     double* part = (double*)ctx->partials.p;
     if (rp.algorithm)
       s3d_gicp_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
-          d_pairs(), d_slots(), sorted3(), query_normals(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp);
+          d_pairs(), d_slots(), sorted3(), normals(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp);
     if (!rp.algorithm)
       s3d_p2plane_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
           d_pairs(), d_slots(), sorted3(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp);
@@ -1081,9 +1069,6 @@ struct Batch {
       if (!fused) stage_grid();
       mark(2);
       stage_normals();
-      if (tile_queries)
-        k_qorder_normals<<<dim3(nb_head, C()), kBlock, 0, st>>>(d_slots(), normals(), (uint32_t*)ctx->qperm.p,
-                                                                (NormalRec*)ctx->normals_q.p);
       mark(3);
       stage_icp();
       mark(4);
@@ -1098,7 +1083,6 @@ struct Batch {
       // its cell by more than the searches' margin): the whole batch again on the two-sort path, from the records as
       // allocate() uploaded them
       fused = false;
-      tile_queries = false;
       ++ctx->fused_reruns;
       h_slots = h_slots0;
       h_pairs = h_pairs0;

@@ -910,8 +910,7 @@ __global__ void __launch_bounds__(kBlock) k_centroids_fused(SlotDev* __restrict_
                                                              const uint32_t* __restrict__ vals,
                                                              const uint32_t* __restrict__ blockcnt,
                                                              float4* __restrict__ sorted, CorrVec* __restrict__ sorted3,
-                                                             uint32_t* __restrict__ cell_start, int nb_max, int nslots,
-                                                             uint32_t* __restrict__ cell_of = nullptr) {
+                                                             uint32_t* __restrict__ cell_start, int nb_max, int nslots) {
   __shared__ int lds4[4];
   int slot_i, chunk_i;
   nn_block_map(nb_max, nslots, &slot_i, &chunk_i);
@@ -945,7 +944,6 @@ __global__ void __launch_bounds__(kBlock) k_centroids_fused(SlotDev* __restrict_
     fused_decode(s.vp, s.g, s.fz, key, &cell, cc, &voxel);
     sorted[s.off + pos] = make_float4(qx, qy, qz, __uint_as_float(voxel));
     if (sorted3) { CorrVec q3; q3.x = qx; q3.y = qy; q3.z = qz; sorted3[s.off + pos] = q3; }
-    if (cell_of) cell_of[s.off + pos] = (uint32_t)cell;
     if (!fused_inside(s.g, cc, qx, qy, qz)) s.fz.ok = -2;     // (any number of threads may store the same value)
     lo = i == 0 ? 0 : (int)(k[i - 1] / s.fz.msub) + 1;
     hi = cell; val = (uint32_t)pos;
@@ -954,89 +952,6 @@ __global__ void __launch_bounds__(kBlock) k_centroids_fused(SlotDev* __restrict_
   if (i == 0 && (s.n_raw <= 0 || k[0] == kInvalidKey)) { lo2 = 0; hi2 = s.g.ncells; val2 = 0u; }
   cell_gap_fill(cs, lo, hi, val);
   cell_gap_fill(cs, lo2, hi2, val2);
-}
-
-// ---- experiment (round 5, S3D_DBG_TILE_QUERIES): the QUERY stream of a cloud in block order.
-// The search structure (`sorted`, cell_start) keeps its cell order - a row of cells must stay one contiguous run - but the
-// order in which a cloud's points are taken as queries (sorted3, the query-side normals, every corr_* array, the
-// 64-query records) is free.  In cell order a wave is a strip of ~25 cells along x; here the cells are taken in blocks of
-// kQB^3 (z-major over blocks, then z, y, x inside a block), so that a wave's 64 queries fill a compact box whatever the
-// orientation of the surface they lie on.  k_qorder_starts: one workgroup per cloud, the first query position of every
-// cell (an exclusive scan of the cell counts in block order); k_qorder_apply: the permuted xyz copy and the permutation.
-constexpr int kQB = 4;
-__global__ void __launch_bounds__(kBlock) k_qorder_starts(const SlotDev* __restrict__ slots, const uint32_t* __restrict__ cell_start,
-                                                           uint32_t* __restrict__ qstart) {
-  __shared__ uint32_t part[kBlock];
-  __shared__ uint32_t running;
-  const SlotDev& s = slots[blockIdx.x];
-  const uint32_t* __restrict__ cs = cell_start + s.cell_off;
-  uint32_t* __restrict__ qs = qstart + s.cell_off;
-  const int d0 = s.g.dim[0], d1 = s.g.dim[1], d2 = s.g.dim[2];
-  const int nbx = (d0 + kQB - 1) / kQB, nby = (d1 + kQB - 1) / kQB, nbz = (d2 + kQB - 1) / kQB;
-  const int nblocks = nbx * nby * nbz;
-  if (threadIdx.x == 0) running = 0;
-  __syncthreads();
-  for (int base = 0; base < nblocks; base += kBlock) {
-    const int b = base + (int)threadIdx.x;
-    const int bx = b % nbx, by = (b / nbx) % nby, bz = b / (nbx * nby);
-    const int xa = bx * kQB, xb = imin(xa + kQB, d0);
-    uint32_t count = 0;
-    if (b < nblocks)
-      for (int dz = 0; dz < kQB; ++dz)
-        for (int dy = 0; dy < kQB; ++dy) {
-          const int cz = bz * kQB + dz, cy = by * kQB + dy;
-          if (cz < d2 && cy < d1) {
-            const int row = d0 * (cy + d1 * cz);
-            count += cs[row + xb] - cs[row + xa];
-          }
-        }
-    part[threadIdx.x] = count;
-    __syncthreads();
-    uint32_t v = count;
-    for (int o = 1; o < kBlock; o <<= 1) {
-      const uint32_t t = (threadIdx.x >= (unsigned)o) ? part[threadIdx.x - o] : 0u;
-      __syncthreads();
-      v += t;
-      part[threadIdx.x] = v;
-      __syncthreads();
-    }
-    uint32_t q = running + v - count;
-    if (b < nblocks)
-      for (int dz = 0; dz < kQB; ++dz)
-        for (int dy = 0; dy < kQB; ++dy) {
-          const int cz = bz * kQB + dz, cy = by * kQB + dy;
-          if (cz < d2 && cy < d1) {
-            const int row = d0 * (cy + d1 * cz);
-            for (int c = row + xa; c < row + xb; ++c) { qs[c] = q; q += cs[c + 1] - cs[c]; }
-          }
-        }
-    __syncthreads();
-    if (threadIdx.x == kBlock - 1) running += v;
-    __syncthreads();
-  }
-}
-
-__global__ void __launch_bounds__(kBlock) k_qorder_apply(const SlotDev* __restrict__ slots, const float4* __restrict__ sorted,
-                                                          const uint32_t* __restrict__ cell_of,
-                                                          const uint32_t* __restrict__ cell_start,
-                                                          const uint32_t* __restrict__ qstart, CorrVec* __restrict__ sorted3q,
-                                                          uint32_t* __restrict__ qperm) {
-  const SlotDev& s = slots[blockIdx.y];
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= s.n) return;
-  const uint32_t c = cell_of[s.off + i];
-  const uint32_t q = qstart[s.cell_off + c] + ((uint32_t)i - cell_start[s.cell_off + c]);
-  sorted3q[s.off + q] = corr_vec(sorted[s.off + i]);
-  qperm[s.off + q] = (uint32_t)i;
-}
-
-// the normals of a cloud (cell order, as the search gathers them) once more in query order, for K6's stream
-__global__ void __launch_bounds__(kBlock) k_qorder_normals(const SlotDev* __restrict__ slots, const NormalRec* __restrict__ normals,
-                                                            const uint32_t* __restrict__ qperm, NormalRec* __restrict__ normals_q) {
-  const SlotDev& s = slots[blockIdx.y];
-  const int q = blockIdx.x * kBlock + threadIdx.x;
-  if (q >= s.n) return;
-  normals_q[s.off + q] = normals[s.off + qperm[s.off + q]];
 }
 
 // ------------------------------------------------------------------ K3: search grid
