@@ -204,6 +204,9 @@ def main():
     value = total_pairs / elapsed
     rec_local = last.cpu().numpy() if hasattr(last, "cpu") else last
     n_ok = int((rec_local[:, 15] == 0).sum())
+    # (N > 1: `last` holds the gathered records of every rank - each rank's pairs come from their own generator seeds, so
+    # the transforms are all different unless two ranks registered the same pairs)
+    distinct = int(len({rec_local[i, :12].tobytes() for i in range(rec_local.shape[0])}))
 
     line = None
     if rank == 0:
@@ -558,6 +561,7 @@ def main():
             "step_ms": step_ms,
             "stage_ms": {k: round(v, 3) for k, v in prof.items() if k.endswith("_ms") and k != "nn_launch_ms"},
             "nn_launch_ms": prof["nn_launch_ms"],
+            "distinct_pairs_gathered": distinct,
             "accuracy": {"status_ok": n_ok, "median_err_m": float(np.median(errs)), "max_err_m": float(np.max(errs))},
             "input_generation_s": round(gen_s, 1),
         }

@@ -736,21 +736,27 @@ def test_ndt_batch_mixed_inputs(gpu_ctx, fixture_clouds):
     assert st == 0 and np.array_equal(s3d.api.record_transform(rec[4]), T)
 
 
-def test_bench_two_ranks_share_one_gpu_over_gloo():
-    """The multi-rank path of bench.py (pair sharding, all-gather of the edge records, max-over-ranks timing) with
-    two ranks on this one GPU: S3D_BENCH_BACKEND=gloo maps ranks to devices modulo the device count."""
+@pytest.mark.parametrize("ranks,port", [(2, 29521), (8, 29537)])
+def test_bench_ranks_share_one_gpu_over_gloo(ranks, port):
+    """The multi-rank path of bench.py (pair sharding, all-gather of the edge records, max-over-ranks timing) with two
+    and with EIGHT ranks - the driver's 8-GPU launch line - on this one GPU: S3D_BENCH_BACKEND=gloo maps ranks to devices
+    modulo the device count.  Every rank registers its own pairs (distinct generator seeds: rank * pairs + i), rank 0
+    gathers all of them, and the C-ABI sweep over the same rank count returns the single-context records."""
     import subprocess
     import sys
     from conftest import ROOT
     env = dict(os.environ, S3D_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                                   "--master-addr", "127.0.0.1", "--master-port", "29521", os.path.join(ROOT, "bench.py"),
-                                   "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "4", "--points", "20000",
-                                   "--no-cpu"], stderr=subprocess.DEVNULL, cwd=ROOT, env=env, timeout=600)
+    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                                   "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--pairs", "4", "--points", "20000",
+                                   "--no-cpu"], stderr=subprocess.DEVNULL, cwd=ROOT, env=env, timeout=900)
     line = json.loads(out.decode().strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["pairs_per_gpu"] == 4
-    assert line["accuracy"]["status_ok"] == 8          # the gathered records of both ranks
+    assert line["n_gpus"] == ranks and line["scaling"] == "weak" and line["config"]["pairs_per_gpu"] == 4
+    assert line["accuracy"]["status_ok"] == 4 * ranks          # the gathered records of all ranks
     assert line["value"] > 0 and line["cpu_baseline"] is None
+    assert line["distinct_pairs_gathered"] == 4 * ranks        # no rank registered another rank's pairs
+    sw = line["sweep_abi"]
+    assert sw["ranks"] == ranks and sw["equals_single_context"] is True and sw["pairs"] == 4 * ranks
 
 
 def test_concurrent_callers(gpu_ctx, fixture_clouds):

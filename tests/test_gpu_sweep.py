@@ -133,6 +133,24 @@ def test_sweep_two_and_three_contexts_on_one_device_equal_the_single_context(gpu
     assert ranks == 2
 
 
+def test_sweep_eight_ranks_on_one_device_equal_the_single_context(gpu_ctx):
+    """The 8-GPU layout of BASELINE configs[3] / [4] with its eight ranks on this one GPU: 18 pairs over 8 ranks
+    (contiguous blocks of ceil(18 / 8) = 3: six ranks busy, two with an empty block), shared clouds, every rank holding every edge after the gather; and fewer pairs
+    than ranks (5 pairs: three ranks idle)."""
+    import slam3d_amd as s3d
+    coll, ranks = _sweep_case(gpu_ctx, [0] * 8, 9, 8000, s3d.ALG_GICP)
+    assert coll == "copy" and ranks == 8
+    sw = s3d.Sweep([0] * 8)
+    try:
+        assert [sw.shard_range(18, r) for r in range(8)] == [(0, 3), (3, 6), (6, 9), (9, 12), (12, 15), (15, 18), (18, 18), (18, 18)]
+        a, b, _ = s3d.make_pair(6000, 2)
+        ha, hb = sw.upload(a), sw.upload(b)
+        rec = sw.align_batch([ha] * 5, [hb] * 5, None, s3d.default_params(point_cloud_density=0.1))
+        assert rec.shape == (5, 16) and (rec[:, 15] == 0).all() and all(np.array_equal(rec[0], r) for r in rec)
+    finally:
+        sw.close()
+
+
 def test_sweep_single_rank_goes_through_rccl(gpu_ctx):
     """One rank per distinct device is the RCCL configuration: with the one device of this box the communicator
     (ncclCommInitAll) and the ncclAllGather of the records are the real thing, just with one rank."""
