@@ -26,6 +26,11 @@
 
 #define S3D_DBG_NO_FUSED_PREPASS   0x10000000u /* registration pre-pass as two sorts (voxel keys, then cell ids) instead of
                                                   the one sort on (cell, voxel) keys                                     */
+#define S3D_DBG_KNN_NO_FAR_COOP    0x20000000u /* k-NN pre-pass: the far declines of the fast path through the per-lane exact
+                                                  search, whatever the batch size (default: small batches take the
+                                                  wave-cooperative kernel)                                               */
+#define S3D_DBG_KNN_FORCE_FAR_COOP 0x40000000u /* ... through the wave-cooperative kernel, whatever the batch size          */
+
 /* ---- test hooks: exported by the library, used by tests/ only ---------------------------------------------------- */
 #ifdef __cplusplus
 extern "C" {

@@ -781,8 +781,26 @@ struct Batch {
     if (k == 20 && !exact64 && max_n < kKnn3MaxPoints) {
       int* redo_count = fb_count + 1;
       int2* redo_list = (int2*)ctx->knn_redo.p;
-      s3d_knn3_moments_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), sorted(), cells(), mom, mom_plane, nb_head, d_list, NL, normals(), fb_count, fb_list, redo_count, redo_list);
-      const bool thin = (long long)NL * max_n <= 2000000ll;   // a few clouds: the redo list's latency counts (see the kernel)
+      // the FAR declines (the 20th neighbour more than kKnn3FarRings cells away: sparse parts of a real scan) of a SMALL
+      // batch on a list of their own, served wave-cooperatively (s3d_knn_moments_far_kernel): a lone registration of two
+      // of the reference's scans waits 0.55 ms less for the slowest lanes of the per-lane search (2.05 -> 1.50 ms); a large
+      // batch is a matter of throughput, where 64 per-lane searches per wave win (96 pairs of those scans: normals 4.2
+      // against 5.3 ms; the synthetic benchmark 7.35 against 7.8).  S3D_DBG_KNN_NO_FAR_COOP / _FORCE_FAR_COOP: A/B
+      const bool small_batch = (long long)NL * max_n <= 2000000ll;
+      const bool coop = (opts.debug_flags & S3D_DBG_KNN_NO_FAR_COOP) ? false
+                        : (opts.debug_flags & S3D_DBG_KNN_FORCE_FAR_COOP) ? true : small_batch;
+      int* far_count = coop ? (int*)ctx->n_active.p + 7 : nullptr;
+      const int redo_cap = (int)std::min<size_t>(std::max<size_t>(total_pts, 4), 0x7FFFFFF0);
+      if (far_count) HIPCHK(hipMemsetAsync(far_count, 0, sizeof(int), st));
+      s3d_knn3_moments_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), sorted(), cells(), mom, mom_plane, nb_head, d_list, NL, normals(), fb_count, fb_list, redo_count, redo_list, far_count, redo_cap);
+      if (far_count) {
+        const int fblocks = (int)std::min<long long>(std::max<long long>((long long)NL * max_n / 64, 256), 16384);
+        if (fused)
+          s3d_knn_moments_far_kernel<20, true><<<fblocks, kWave, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, far_count, redo_list, redo_cap);
+        else
+          s3d_knn_moments_far_kernel<20, false><<<fblocks, kWave, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, far_count, redo_list, redo_cap);
+      }
+      const bool thin = small_batch;   // a few clouds: the redo list's latency counts (see the kernel)
       if (thin && !fused)
         s3d_knn_moments_redo_kernel<20, true, true><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list);
       else if (!fused)
@@ -936,7 +954,7 @@ struct Batch {
   }
   int search_parts() const {   // waves per search list: about one per 3 000 queries of the batch (a settled pass searches
     const long long q = (long long)P() * std::max(max_n_t, 1);   // one query in ~6 000), 1 ... 16
-    return (int)std::max<long long>(1, std::min<long long>(16, q / (3000ll * kNNSearchSublists) + 1));
+    return (int)std::max<long long>(4, std::min<long long>(16, q / (3000ll * kNNSearchSublists) + 1));
   }
   int rec_blocks() const {
     const int nrec = cdiv(std::max(max_n_t, 1), kWave), rpt = rec_per_thread();

@@ -1041,38 +1041,92 @@ S3D_HD int grid_knn_sorted(const GridParams& g, const uint32_t* __restrict__ cel
       return cnt < k ? cnt : k;
     }
   }
-  for (int r = 2; r <= rmax; ++r) {
-    const int z0 = imax(iz - r, 0), z1 = imin(iz + r, g.dim[2] - 1);
-    const int y0 = imax(iy - r, 0), y1 = imin(iy + r, g.dim[1] - 1);
-    const int xl = ix - r, xh = ix + r;
-    for (int cz = z0; cz <= z1; ++cz) {
-      const bool zface = (cz == iz - r) || (cz == iz + r);
-      for (int cy = y0; cy <= y1; ++cy) {
-        const bool full = zface || (cy == iy - r) || (cy == iy + r);
-        const int rowbase = g.dim[0] * (cy + g.dim[1] * cz);
-        for (int part = 0; part < 2; ++part) {
-          int xa, xb;
-          if (full) {
-            if (part) break;
-            xa = imax(xl, 0); xb = imin(xh, g.dim[0] - 1);
-          } else {
-            xa = xb = part ? xh : xl;
-            if (xa < 0 || xa >= g.dim[0]) continue;
-          }
-          if (xa > xb) continue;
-          const uint32_t s = cell_start[rowbase + xa], e = cell_start[rowbase + xb + 1];
-          for (uint32_t kk = s; kk < e; ++kk) {
-            const F4T p = pts[kk];
-            const float d2 = dist2(qx, qy, qz, p.x, p.y, p.z);
-            S3D_KNN_INSERT(p, kk, d2)
+  // ---- beyond: (round 5) whole rings only while the list is not full - a point in a sparse part of the cloud.  Once it
+  // is, its k-th distance bounds the true one and ONE pruned box finishes the search: the rows of the box of that
+  // (shrinking) radius, slab-tested and cut to the chord of the ball, the cube of rings already examined left out.
+  // (Until round 4 the rings went on un-pruned until the bound proved the list: (2r + 1)^2 row look-ups per ring, nearly
+  // all of them empty - on the reference's scans, whose far field is rings of points metres apart, 13 % of the points
+  // took this path and it was most of the pre-pass.)
+  int rex = 1;                       // the cube of rings <= rex has been examined
+  if (worst == kInf) {
+    for (int r = 2; r <= rmax; ++r) {
+      const int z0 = imax(iz - r, 0), z1 = imin(iz + r, g.dim[2] - 1);
+      const int y0 = imax(iy - r, 0), y1 = imin(iy + r, g.dim[1] - 1);
+      const int xl = ix - r, xh = ix + r;
+      for (int cz = z0; cz <= z1; ++cz) {
+        const bool zface = (cz == iz - r) || (cz == iz + r);
+        for (int cy = y0; cy <= y1; ++cy) {
+          const bool full = zface || (cy == iy - r) || (cy == iy + r);
+          const int rowbase = g.dim[0] * (cy + g.dim[1] * cz);
+          for (int part = 0; part < 2; ++part) {
+            int xa, xb;
+            if (full) {
+              if (part) break;
+              xa = imax(xl, 0); xb = imin(xh, g.dim[0] - 1);
+            } else {
+              xa = xb = part ? xh : xl;
+              if (xa < 0 || xa >= g.dim[0]) continue;
+            }
+            if (xa > xb) continue;
+            const uint32_t s = cell_start[rowbase + xa], e = cell_start[rowbase + xb + 1];
+            for (uint32_t kk = s; kk < e; ++kk) {
+              const F4T p = pts[kk];
+              const float d2 = dist2(qx, qy, qz, p.x, p.y, p.z);
+              S3D_KNN_INSERT(p, kk, d2)
+            }
           }
         }
       }
+      rex = r;
+      if (worst != kInf) break;
     }
-    const float bound = ((float)r + face) * g.h;
-    if (worst != kInf) {
-      const float dk = knn_key_d2(worst);
-      if (dk <= bound * bound) break;
+  }
+  if (worst != kInf) {
+    const float bound = ((float)rex + face) * g.h;
+    float lim2 = knn_key_d2(worst);
+    if (lim2 > bound * bound) {
+      const float eps = 2.0e-3f * g.h;
+      const float R = sqrt_bound(lim2) * 1.0001f + eps;
+      const int z0 = imax(grid_coord(g, 2, qz - R), 0), z1 = imin(grid_coord(g, 2, qz + R), g.dim[2] - 1);
+      const int y0 = imax(grid_coord(g, 1, qy - R), 0), y1 = imin(grid_coord(g, 1, qy + R), g.dim[1] - 1);
+      for (int cz = z0; cz <= z1; ++cz) {
+        const float zlo = g.origin[2] + (float)cz * g.h;
+        const float fz2 = fmaxf(fmaxf(zlo - qz, qz - (zlo + g.h)) - eps, 0.f);
+        if (fz2 * fz2 > lim2) continue;
+        for (int cy = y0; cy <= y1; ++cy) {
+          const float ylo = g.origin[1] + (float)cy * g.h;
+          const float fy2 = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.h)) - eps, 0.f);
+          const float rowd2 = fy2 * fy2 + fz2 * fz2;
+          if (rowd2 > lim2) continue;
+          const float rx = sqrt_bound(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
+          const int xa = imax(grid_coord(g, 0, qx - rx), 0);
+          const int xb = imin(grid_coord(g, 0, qx + rx), g.dim[0] - 1);
+          const bool inner = cy >= iy - rex && cy <= iy + rex && cz >= iz - rex && cz <= iz + rex;
+          const int rowbase = g.dim[0] * (cy + g.dim[1] * cz);
+          for (int part = 0; part < 2; ++part) {
+            int sa, sb;
+            if (!inner) { if (part) break; sa = xa; sb = xb; }
+            else if (part == 0) { sa = xa; sb = imin(xb, ix - rex - 1); }    // left of the examined cube
+            else { sa = imax(xa, ix + rex + 1); sb = xb; }                   // right of it
+            if (sa > sb) continue;
+            const uint32_t s = cell_start[rowbase + sa], e = cell_start[rowbase + sb + 1];
+            for (uint32_t kk = s; kk < e; kk += 4) {      // four loads in flight per step
+              const uint32_t last = e - 1;
+              F4T pp[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) pp[u] = pts[kk + u < e ? kk + u : last];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                if (kk + u < e) {
+                  const float d2 = dist2(qx, qy, qz, pp[u].x, pp[u].y, pp[u].z);
+                  S3D_KNN_INSERT(pp[u], kk + u, d2)
+                }
+              }
+            }
+          }
+          lim2 = fminf(lim2, knn_key_d2(worst));
+        }
+      }
     }
   }
 #undef S3D_KNN_INSERT
@@ -1106,6 +1160,10 @@ constexpr uint32_t kKnn3OffMask = (1u << kKnn3OffBits) - 1u;
 constexpr int kKnn3IdBits = kKnn3OffBits + 4;
 constexpr uint32_t kKnn3IdMask = (1u << kKnn3IdBits) - 1u, kKnn3Sentinel = 0xFFFFFFFFu;
 constexpr int kKnn3MaxPoints = 1 << (32 - kKnn3OffBits);   // positions must fit a table entry
+#ifndef S3D_KNN3_FAR_RINGS
+#define S3D_KNN3_FAR_RINGS 4
+#endif
+constexpr int kKnn3FarRings = S3D_KNN3_FAR_RINGS;          // a declined query whose K-th neighbour may lie farther than this many cells is "far"
 
 S3D_HD uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1334,8 +1392,12 @@ S3D_HD bool knn3_unambiguous(const uint32_t (&keys)[KL]) {
 // ascending truncated distance, (key >> 7) & 15 = table entry, key & 127 = offset (knn3_position); false: not
 // answered (see above).  tab: kKnn3Segs entries of this lane, stride tstride.
 template <int KL, typename F4T>
+// far (may be null): set when the query is declined because its K-th neighbour lies beyond the 5x5x5 cells (or the cells
+// hold fewer than K points) - a point in a sparse part of the cloud, whose exact search is a long walk (the caller
+// serves those wave-cooperatively, s3d_knn_moments_far_kernel); left alone otherwise.
 S3D_HD bool grid_knn_med3(const GridParams& g, const uint32_t* __restrict__ cell_start, const F4T* __restrict__ pts,
-                          float qx, float qy, float qz, uint32_t* tab, int tstride, uint32_t (&keys)[KL]) {
+                          float qx, float qy, float qz, uint32_t* tab, int tstride, uint32_t (&keys)[KL],
+                          bool* far = nullptr) {
 #pragma unroll
   for (int j = 0; j < KL; ++j) keys[j] = kKnn3Sentinel;
   int nseg;
@@ -1344,7 +1406,16 @@ S3D_HD bool grid_knn_med3(const GridParams& g, const uint32_t* __restrict__ cell
   knn3_scan<KL>(keys, tab, tstride, 0, nseg, pts, qx, qy, qz);
   float lim2 = 0.f;
   const int st = knn3_after27<KL>(g, knn3_face(g, qx, qy, qz), keys, lim2);
-  if (st == 2) return false;
+  if (st == 2) {
+    // how far?  An upper bound of the K-th distance is known (the K-th of the 27 cells' points, if they hold K at all).
+    // Up to kKnn3FarRings cells the per-lane ring search is a fair walk; beyond, or with fewer than K points in the 27
+    // cells, it is a long one
+    if (far) {
+      const float reach = (float)kKnn3FarRings * g.h;
+      *far = keys[KL - 2] == kKnn3Sentinel || knn3_key_d2_upper(keys[KL - 2]) > reach * reach;
+    }
+    return false;
+  }
   if (st == 1) {
     const int first = nseg;
     if (!knn3_build_shell(g, cell_start, qx, qy, qz, lim2, tab, tstride, nseg, total)) return false;

@@ -1159,7 +1159,8 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN3_WAVES) s3d_knn3_moments_kerne
                                                                    int nslots, NormalRec* __restrict__ normals,
                                                                    int* __restrict__ fallback_count,
                                                                    int* __restrict__ fallback_list,
-                                                                   int* __restrict__ redo_count, int2* __restrict__ redo_list) {
+                                                                   int* __restrict__ redo_count, int2* __restrict__ redo_list,
+                                                                   int* __restrict__ far_count, int redo_cap) {
   constexpr int KL = K + 1;
   __shared__ uint32_t tab[kKnn3Segs * kBlock];   // entry j of thread t at tab[j * kBlock + t]: conflict-free columns
   int li, chunk;
@@ -1173,8 +1174,12 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN3_WAVES) s3d_knn3_moments_kerne
   const float4 q = pts[i];
   uint32_t keys[KL];
   uint32_t* ctab = tab + threadIdx.x;
-  if (!grid_knn_med3<KL>(s.g, cell_start + s.cell_off, pts, q.x, q.y, q.z, ctab, kBlock, keys)) {
-    redo_list[atomicAdd(redo_count, 1)] = make_int2(slot, i);
+  bool far = false;
+  if (!grid_knn_med3<KL>(s.g, cell_start + s.cell_off, pts, q.x, q.y, q.z, ctab, kBlock, keys, far_count ? &far : nullptr)) {
+    // two lists in one buffer: the near declines (ties, table overflow) grow from the front, the FAR ones - the K-th
+    // neighbour beyond the 5x5x5 cells - from the back (s3d_knn_moments_far_kernel)
+    if (far) redo_list[redo_cap - 1 - atomicAdd(far_count, 1)] = make_int2(slot, i);
+    else redo_list[atomicAdd(redo_count, 1)] = make_int2(slot, i);
     return;
   }
   Moments mo;
@@ -1236,6 +1241,167 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_REDO_WAVES) s3d_knn_moments_re
     const int2 e = redo_list[j];
     knn_moments_point<KMAX, FULL, BYPOS>(slots[e.x], e.y, filt, sorted, cell_start, moments, plane, k, normals, fallback_count,
                                          fallback_list);
+  }
+}
+
+// ---- K4, round 5: the FAR declines of the fast path, wave-cooperatively.
+// A point in a sparse part of a scan (the far field of a lidar: ring spacings of metres against a cell edge sized for
+// the dense near field) has its 20th neighbour many cells away: the exact per-lane search walks ring after ring, (2r + 1)^2
+// dependent row look-ups each - on the reference's scans 13 % of the points, and ONE registration of two such scans
+// spent 0.86 of its 2.1 ms waiting for the slowest lane of that kernel.  Here a wave serves one such point at a time, as
+// wave_nn1_coop does for the 1-NN: the rows of the box [q - d, q + d] one per lane (range look-up), their points dealt
+// over the lanes, the packed keys ((d2 bits + 2^23) << 32 | id, the keys of grid_knn_sorted) collected in LDS and the K
+// smallest extracted by K wave-wide minimum reductions; d doubles while the box holds fewer than K points and is then
+// set to the K-th distance found - two or three attempts of two memory round trips each.  Same K keys in the same
+// order as the per-lane search (same ids, same tie rule), so the same moments and normal bit for bit.
+constexpr int kKnnFarCap = 2048;     // candidate keys held in LDS at a time (the K best so far included)
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t = (unsigned long long)__shfl_xor((long long)v, o, kWave);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+// the K smallest of buf[0, n) into buf[0, min(K, n)) in ascending order (keys are distinct and > 0); returns their number
+template <int K>
+__device__ __forceinline__ int wave_select_smallest(unsigned long long* buf, unsigned long long* sel, int n) {
+  const int lane = lane_id();
+  const int m = n < K ? n : K;
+  unsigned long long last = 0ull;
+  for (int j = 0; j < m; ++j) {
+    unsigned long long mine = ~0ull;
+    for (int i = lane; i < n; i += kWave) {
+      const unsigned long long v = buf[i];
+      mine = (v > last && v < mine) ? v : mine;
+    }
+    last = wave_min_u64(mine);
+    if (lane == 0) sel[j] = last;
+  }
+  __syncthreads();   // (the block is ONE wave: the LDS stores above before the loads below)
+  for (int i = lane; i < m; i += kWave) buf[i] = sel[i];
+  __syncthreads();
+  return m;
+}
+
+template <int K, bool BYPOS>
+__global__ void __launch_bounds__(kWave) s3d_knn_moments_far_kernel(const SlotDev* __restrict__ slots,
+                                                                     const float4* __restrict__ filt,
+                                                                     const float4* __restrict__ sorted,
+                                                                     const uint32_t* __restrict__ cell_start,
+                                                                     double* __restrict__ moments, size_t plane, int k,
+                                                                     NormalRec* __restrict__ normals,
+                                                                     int* __restrict__ fallback_count,
+                                                                     int* __restrict__ fallback_list,
+                                                                     const int* __restrict__ far_count,
+                                                                     const int2* __restrict__ redo_list, int redo_cap) {
+  __shared__ unsigned long long buf[kKnnFarCap + kWave];
+  __shared__ unsigned long long sel[K];
+  const int count = *far_count;
+  const int lane = lane_id();
+  for (int j = blockIdx.x; j < count; j += gridDim.x) {
+    const int2 e = redo_list[redo_cap - 1 - j];
+    const int slot = __builtin_amdgcn_readfirstlane(e.x), i = __builtin_amdgcn_readfirstlane(e.y);
+    const SlotDev& s = slots[slot];
+    const GridParams& g = s.g;
+    const uint32_t* __restrict__ cs = cell_start + s.cell_off;
+    const float4* __restrict__ pts = sorted + s.off;
+    const float4 q = pts[i];
+    int nbest = 0;
+    float d = 3.0f * g.h;
+    for (int attempt = 0; attempt < 48; ++attempt) {
+      const float m = d * 1.0001f + 2.0e-3f * g.h;
+      const int x0 = imax(grid_coord(g, 0, q.x - m), 0), x1 = imin(grid_coord(g, 0, q.x + m), g.dim[0] - 1);
+      const int y0 = imax(grid_coord(g, 1, q.y - m), 0), y1 = imin(grid_coord(g, 1, q.y + m), g.dim[1] - 1);
+      const int z0 = imax(grid_coord(g, 2, q.z - m), 0), z1 = imin(grid_coord(g, 2, q.z + m), g.dim[2] - 1);
+      const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dim[0] - 1 && y1 == g.dim[1] - 1 && z1 == g.dim[2] - 1;
+      const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+      const int nrows = (x0 <= x1 && ny > 0 && nz > 0) ? ny * nz : 0;
+      // how many points does the box hold?  (row look-ups only: a box that is too small costs one round trip)
+      uint32_t total = 0;
+      for (int base = 0; base < nrows; base += kWave) {
+        const int r = base + lane;
+        uint32_t len = 0;
+        if (r < nrows) {
+          const int rowbase = g.dim[0] * ((y0 + r % ny) + g.dim[1] * (z0 + r / ny));
+          len = cs[rowbase + x1 + 1] - cs[rowbase + x0];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) len += (uint32_t)__shfl_xor((int)len, o, kWave);
+        total += len;
+      }
+      if (total < (uint32_t)K && !whole) { d *= 2.0f; continue; }
+      // the candidates' keys into LDS, the K smallest kept whenever the buffer fills
+      nbest = 0;
+      int nbuf = 0;
+      for (int base = 0; base < nrows; base += kWave) {
+        const int r = base + lane;
+        uint32_t rs = 0, len = 0;
+        if (r < nrows) {
+          const int rowbase = g.dim[0] * ((y0 + r % ny) + g.dim[1] * (z0 + r / ny));
+          rs = cs[rowbase + x0];
+          len = cs[rowbase + x1 + 1] - rs;
+        }
+        uint32_t incl = len;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+          const uint32_t t = (uint32_t)__shfl_up((int)incl, o, kWave);
+          if (lane >= o) incl += t;
+        }
+        const uint32_t tb = (uint32_t)__shfl((int)incl, kWave - 1, kWave);
+        for (uint32_t t0 = 0; t0 < tb; t0 += kWave) {
+          if (nbuf > kKnnFarCap) nbuf = wave_select_smallest<K>(buf, sel, nbuf);   // (room for 64 more keys below)
+          const uint32_t t = t0 + (uint32_t)lane;
+          int lo = 0, hi = kWave - 1;      // first lane whose inclusive count exceeds t
+#pragma unroll
+          for (int step = 0; step < 6; ++step) {
+            const int mid = (lo + hi) >> 1;
+            const uint32_t v = (uint32_t)__shfl((int)incl, mid, kWave);
+            if (t >= v) lo = mid + 1; else hi = mid;
+          }
+          const uint32_t row_incl = (uint32_t)__shfl((int)incl, lo, kWave), row_len = (uint32_t)__shfl((int)len, lo, kWave);
+          const uint32_t row_rs = (uint32_t)__shfl((int)rs, lo, kWave);
+          const bool have = t < tb;
+          const uint32_t pos = have ? row_rs + (t - (row_incl - row_len)) : 0u;
+          const float4 p = pts[pos];
+          const float d2 = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
+          const unsigned long long key = ((unsigned long long)(__float_as_uint(d2) + 0x00800000u) << 32) |
+                                         (unsigned long long)(BYPOS ? pos : __float_as_uint(p.w));
+          const unsigned long long hm = __ballot(have);
+          if (have) buf[nbuf + (int)__popcll(hm & ((1ull << lane) - 1ull))] = key;
+          nbuf += (int)__popcll(hm);
+          __syncthreads();
+        }
+      }
+      nbest = wave_select_smallest<K>(buf, sel, nbuf);
+      if (nbest < K) break;                       // (only when the box is the whole grid: the cloud has fewer than K points)
+      const float d2k = __uint_as_float((uint32_t)(sel[K - 1] >> 32) - 0x00800000u);
+      if (d2k <= d * d) break;                    // nothing outside the box can be nearer than the K-th
+      d = sqrtf(d2k) * 1.0001f + 1.0e-6f;         // the exact radius: the next attempt proves
+    }
+    // the neighbours' moments in ascending (d2, id): PCL's summation order - lane j fetches neighbour j, then every
+    // lane runs the same sums (uniform values through the shuffles)
+    const float4* __restrict__ P = (BYPOS ? sorted : filt) + s.off;
+    const int cnt = nbest < k ? nbest : k;
+    float4 pn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < cnt) pn = P[(uint32_t)(sel[lane] & 0xFFFFFFFFull)];
+    Moments mo;
+    moments_init(mo);
+    for (int n = 0; n < cnt; ++n) moments_add(mo, __shfl(pn.x, n, kWave), __shfl(pn.y, n, kWave), __shfl(pn.z, n, kWave));
+    double nrm[3];
+    const bool direct = moments_normal_direct(mo, k, nrm);
+    if (lane == 0) {
+      if (direct) {
+        normals[s.off + i] = normal_encode(nrm);
+      } else {
+        double* o = moments + (size_t)(s.off + i);
+        o[0] = mo.mean[0]; o[plane] = mo.mean[1]; o[2 * plane] = mo.mean[2];
+        o[3 * plane] = mo.c00; o[4 * plane] = mo.c10; o[5 * plane] = mo.c11;
+        o[6 * plane] = mo.c20; o[7 * plane] = mo.c21; o[8 * plane] = mo.c22;
+        fallback_list[atomicAdd(fallback_count, 1)] = s.off + i;
+      }
+    }
+    __syncthreads();
   }
 }
 

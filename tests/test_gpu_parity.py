@@ -659,14 +659,21 @@ def test_fast_paths_are_bitwise_neutral(gpu_ctx, fixture_clouds):
     cases = [(fixture_clouds[1], fixture_clouds[2], s3d.default_params(maximum_iterations=12), 1),
              (fixture_clouds[0], fixture_clouds[1], s3d.default_params(), 0),
              (a, b, s3d.default_params(point_cloud_density=0.02, maximum_iterations=20), 1)]
+    # (round 5) on both layouts of the pre-pass - one sort on (cell, voxel) keys, or voxel sort + grid sort - whose results
+    # differ from each other in the last bits (another query order); DBG_KNN_NO_FAR_COOP: the far declines of the k-NN
+    # fast path through the per-lane search instead of the wave-cooperative kernel
     for src, tgt, p, force in cases:
-        st0, T0, i0 = gpu_ctx.align(src, tgt, np.eye(4), p, s3d.ExecOptions(force_iterations=force))
-        assert st0 == 0
-        for flags in (A.DBG_NN_NO_FIRST_KERNEL, A.DBG_NN_NO_SCAN27, A.DBG_NN_NO_FIRST_KERNEL | A.DBG_NN_NO_SCAN27,
-                      A.DBG_NN_FORCE_SETTLED, A.DBG_SCAN27_NO_COMPACT, A.DBG_KNN_EXACT64, A.DBG_SORT_CLASSIC,
-                      A.DBG_SORT_ONESWEEP, A.DBG_SORT_FULL_KEYS, A.DBG_SORT_FULL_KEYS | A.DBG_SORT_CLASSIC):
-            st1, T1, i1 = gpu_ctx.align(src, tgt, np.eye(4), p, s3d.ExecOptions(force_iterations=force, debug_flags=flags))
-            assert st1 == 0 and np.array_equal(T0, T1) and i0 == i1, hex(flags)
+        for base in (0, A.DBG_NO_FUSED_PREPASS):
+            st0, T0, i0 = gpu_ctx.align(src, tgt, np.eye(4), p, s3d.ExecOptions(force_iterations=force, debug_flags=base))
+            assert st0 == 0
+            for flags in (A.DBG_NN_NO_FIRST_KERNEL, A.DBG_NN_NO_SCAN27, A.DBG_NN_NO_FIRST_KERNEL | A.DBG_NN_NO_SCAN27,
+                          A.DBG_NN_FORCE_SETTLED, A.DBG_SCAN27_NO_COMPACT, A.DBG_KNN_EXACT64, A.DBG_KNN_NO_FAR_COOP,
+                          A.DBG_KNN_FORCE_FAR_COOP,
+                          A.DBG_SORT_CLASSIC, A.DBG_SORT_ONESWEEP, A.DBG_SORT_FULL_KEYS,
+                          A.DBG_SORT_FULL_KEYS | A.DBG_SORT_CLASSIC):
+                st1, T1, i1 = gpu_ctx.align(src, tgt, np.eye(4), p,
+                                            s3d.ExecOptions(force_iterations=force, debug_flags=base | flags))
+                assert st1 == 0 and np.array_equal(T0, T1) and i0 == i1, (hex(base), hex(flags))
 
 
 def test_million_point_pair(gpu_ctx, oracle_mod):
