@@ -642,14 +642,14 @@ struct Batch {
     const unsigned blocks = (unsigned)((nslots >= 8 ? cdiv(nslots, 8) * 8 : nslots) * nb_sort);
     if (!sort_classic) {
       if (!sort_used) {     // the first sort of this batch clears the error word (stream order: before any look-back)
-        HIPCHK(hipMemsetAsync((int*)ctx->n_active.p + 6, 0, sizeof(int), st));
+        HIPCHK(hipMemsetAsync((int*)ctx->n_active.p + 7, 0, sizeof(int), st));
         sort_used = true;
       }
       if (!hist_done) {
         sort_prepare(nslots);
         k_sort_hist_all<BITS><<<dim3(nb_sort, nslots), kBlock, 0, st>>>(gslots, ki, dtot, cnt, passes, nb_sort);
       }
-      int* err = (int*)ctx->n_active.p + 6;
+      int* err = (int*)ctx->n_active.p + 7;
       for (int p = 0; p < passes; ++p) {
         k_sort_onesweep<BITS><<<blocks, kBlock, 0, st>>>(gslots, ki, vi, ko, vo, cnt, dtot, p, nb_sort, nslots, err);
         std::swap(ki, ko);
@@ -774,7 +774,7 @@ struct Batch {
     // the points whose normal the closed form declines (s3d_kernels.h): a device-side list, counted in n_active[4]
     int* fb_count = (int*)ctx->n_active.p + 4;
     int* fb_list = (int*)ctx->knn_fallback.p;
-    HIPCHK(hipMemsetAsync(fb_count, 0, 2 * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(fb_count, 0, 3 * sizeof(int), st));   // eigen fallback, near redo, far / cooperative list
     // k = 20 (the reference default): 32-bit keys + med3 insertion; what it does not answer goes through the exact
     // 64-bit search (redo list, counted in n_active[5]).  S3D_DBG_KNN_EXACT64: the 64-bit search for every point.
     const bool exact64 = (opts.debug_flags & S3D_DBG_KNN_EXACT64) != 0;
@@ -789,10 +789,12 @@ struct Batch {
       const bool small_batch = (long long)NL * max_n <= 2000000ll;
       const bool coop = (opts.debug_flags & S3D_DBG_KNN_NO_FAR_COOP) ? false
                         : (opts.debug_flags & S3D_DBG_KNN_FORCE_FAR_COOP) ? true : small_batch;
-      int* far_count = coop ? (int*)ctx->n_active.p + 7 : nullptr;
+      int* far_count = coop ? fb_count + 2 : nullptr;
       const int redo_cap = (int)std::min<size_t>(std::max<size_t>(total_pts, 4), 0x7FFFFFF0);
-      if (far_count) HIPCHK(hipMemsetAsync(far_count, 0, sizeof(int), st));
-      s3d_knn3_moments_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), sorted(), cells(), mom, mom_plane, nb_head, d_list, NL, normals(), fb_count, fb_list, redo_count, redo_list, far_count, redo_cap);
+      // (a small batch hands EVERY decline to the cooperative kernel - also the near ones, ties and table overflows, whose
+      // per-lane search keeps a wave busy with one lane: far_all)
+      const int far_all = coop && small_batch ? 1 : 0;
+      s3d_knn3_moments_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), sorted(), cells(), mom, mom_plane, nb_head, d_list, NL, normals(), fb_count, fb_list, redo_count, redo_list, far_count, redo_cap, far_all);
       if (far_count) {
         const int fblocks = (int)std::min<long long>(std::max<long long>((long long)NL * max_n / 64, 256), 16384);
         if (fused)
@@ -801,7 +803,9 @@ struct Batch {
           s3d_knn_moments_far_kernel<20, false><<<fblocks, kWave, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, far_count, redo_list, redo_cap);
       }
       const bool thin = small_batch;   // a few clouds: the redo list's latency counts (see the kernel)
-      if (thin && !fused)
+      if (far_all) {
+        // nothing on the near list
+      } else if (thin && !fused)
         s3d_knn_moments_redo_kernel<20, true, true><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list);
       else if (!fused)
         s3d_knn_moments_redo_kernel<20, true, false><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list);
@@ -1001,14 +1005,15 @@ struct Batch {
     hipStream_t st = ctx->stream;
     if (P() == 0) return;
     int* d_active = (int*)ctx->n_active.p;
-    k_pair_init<<<cdiv(P(), 64), 64, 0, st>>>(d_pairs(), P(), d_active);
-    // no radius hint for the first NN pass: fill the distances with NaN (0xFF bytes)
-    HIPCHK(hipMemsetAsync(ctx->corr_d2.p, 0xFF, 4 * std::max<size_t>(total_corr, 4), st));
-    HIPCHK(hipMemsetAsync(ctx->corr_lb.p, 0, 4 * std::max<size_t>(total_corr, 4), st));
-    HIPCHK(hipMemsetAsync((int*)ctx->n_active.p + 8, 0, 8 * sizeof(int), st));   // worklist counters of the scan27 passes
-    // the 64-query records of the settled passes: touch = -1 ("never evaluated record-wise")
-    HIPCHK(hipMemsetAsync(ctx->wave_recs.p, 0xFF, sizeof(WaveRec) * (std::max<size_t>(total_corr, 4) / kWave + 1), st));
-    HIPCHK(hipMemsetAsync(ctx->rec_counts.p, 0, sizeof(int) * 2 * (kNNRecSublists + kNNSearchSublists), st));   // the record / search list counters
+    {   // pair state, "no radius hint" / "nothing known" for every correspondence, the 64-query records "never evaluated",
+        // the list counters: one launch (k_icp_reset)
+      const size_t ncorr = std::max<size_t>(total_corr, 4);
+      const size_t nrec_words = (ncorr / kWave + 1) * (sizeof(WaveRec) / 4);
+      const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>(cdiv((int)std::min<size_t>(ncorr, 0x7FFFFFFF), kBlock * 4), 1), 8192);
+      k_icp_reset<<<blocks, kBlock, 0, st>>>(d_pairs(), P(), d_active, (uint32_t*)ctx->corr_d2.p, (uint32_t*)ctx->corr_lb.p, ncorr,
+                                              (uint32_t*)ctx->wave_recs.p, nrec_words, (int*)ctx->rec_counts.p,
+                                              2 * (kNNRecSublists + kNNSearchSublists));
+    }
 
     settled_used = true;
     const float max_d = (float)(rp.max_corr * 1.0001);
@@ -1063,7 +1068,7 @@ struct Batch {
     // the one-sweep sort's look-back gives up after ~4 M polls instead of hanging the device: that must not pass silently
     int* sort_err = (int*)(stage + bs + bp);
     *sort_err = 0;
-    if (sort_used) HIPCHK(hipMemcpyAsync(sort_err, (int*)ctx->n_active.p + 6, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (sort_used) HIPCHK(hipMemcpyAsync(sort_err, (int*)ctx->n_active.p + 7, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     if (*sort_err) throw HipError{hipErrorLaunchFailure, "radix sort: a tile waited for its predecessor beyond the poll limit", __LINE__};

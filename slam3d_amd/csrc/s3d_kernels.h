@@ -1160,7 +1160,7 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN3_WAVES) s3d_knn3_moments_kerne
                                                                    int* __restrict__ fallback_count,
                                                                    int* __restrict__ fallback_list,
                                                                    int* __restrict__ redo_count, int2* __restrict__ redo_list,
-                                                                   int* __restrict__ far_count, int redo_cap) {
+                                                                   int* __restrict__ far_count, int redo_cap, int far_all) {
   constexpr int KL = K + 1;
   __shared__ uint32_t tab[kKnn3Segs * kBlock];   // entry j of thread t at tab[j * kBlock + t]: conflict-free columns
   int li, chunk;
@@ -1178,7 +1178,7 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN3_WAVES) s3d_knn3_moments_kerne
   if (!grid_knn_med3<KL>(s.g, cell_start + s.cell_off, pts, q.x, q.y, q.z, ctab, kBlock, keys, far_count ? &far : nullptr)) {
     // two lists in one buffer: the near declines (ties, table overflow) grow from the front, the FAR ones - the K-th
     // neighbour beyond the 5x5x5 cells - from the back (s3d_knn_moments_far_kernel)
-    if (far) redo_list[redo_cap - 1 - atomicAdd(far_count, 1)] = make_int2(slot, i);
+    if (far || far_all) redo_list[redo_cap - 1 - atomicAdd(far_count, 1)] = make_int2(slot, i);
     else redo_list[atomicAdd(redo_count, 1)] = make_int2(slot, i);
     return;
   }
@@ -1254,7 +1254,8 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_REDO_WAVES) s3d_knn_moments_re
 // smallest extracted by K wave-wide minimum reductions; d doubles while the box holds fewer than K points and is then
 // set to the K-th distance found - two or three attempts of two memory round trips each.  Same K keys in the same
 // order as the per-lane search (same ids, same tie rule), so the same moments and normal bit for bit.
-constexpr int kKnnFarCap = 2048;     // candidate keys held in LDS at a time (the K best so far included)
+constexpr int kKnnFarCap = 448;      // candidate keys held in LDS at a time (the K best so far included): 4 KB per wave, so
+                                     // that the LDS does not cap the waves per compute unit (2048 keys: 9 blocks, 159 -> us)
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -1436,6 +1437,29 @@ __global__ void k_pair_init(PairDev* pairs, int npairs, int* n_active) {
   P.inner_total = 0; P.evals_total = 0;
   P.T = mat4f_identity(); P.prev = mat4f_identity(); P.final_T = P.guess; P.T_nn = mat4f_identity();
   P.fitness = 0.0; P.fit_count = 0;
+}
+
+// Everything the ICP loop wants cleared before its first pass, in ONE launch (round 5; six hipMemsetAsync calls + k_pair_init
+// were seven launches of ~5 us each in front of a lone registration): the pair records; corr_d2 = NaN ("no radius hint"),
+// corr_lb = 0 ("nothing known"); the 64-query records = 0xFF.. ("never evaluated record-wise"); the record / search list
+// counters and the scan27 worklist counters.
+__global__ void __launch_bounds__(kBlock) k_icp_reset(PairDev* pairs, int npairs, int* n_active, uint32_t* __restrict__ corr_d2,
+                                                       uint32_t* __restrict__ corr_lb, size_t ncorr,
+                                                       uint32_t* __restrict__ rec_words, size_t nrec_words,
+                                                       int* __restrict__ rec_counts, int nrec_counts) {
+  const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x, stride = (size_t)gridDim.x * kBlock;
+  if (t == 0) *n_active = npairs;
+  if (t < 8) n_active[8 + t] = 0;
+  for (size_t p = t; p < (size_t)npairs; p += stride) {
+    PairDev& P = pairs[p];
+    P.active = 1; P.converged = 0; P.iterations = 0; P.correspondences = 0;
+    P.inner_total = 0; P.evals_total = 0;
+    P.T = mat4f_identity(); P.prev = mat4f_identity(); P.final_T = P.guess; P.T_nn = mat4f_identity();
+    P.fitness = 0.0; P.fit_count = 0;
+  }
+  for (size_t i = t; i < (size_t)nrec_counts; i += stride) rec_counts[i] = 0;
+  for (size_t i = t; i < nrec_words; i += stride) rec_words[i] = 0xFFFFFFFFu;
+  for (size_t i = t; i < ncorr; i += stride) { corr_d2[i] = 0xFFFFFFFFu; corr_lb[i] = 0u; }
 }
 
 // ------------------------------------------------------------------ K5: transform + exact 1-NN
@@ -2039,6 +2063,54 @@ __global__ void __launch_bounds__(kBlock, 8) s3d_nn_record_touch_kernel(const Pa
   }
 }
 
+// ONE query served by the whole wave (wave_nn1_coop): everything known about it (point, bound, previous distance,
+// previous neighbour's position and copy) fetched in one round trip - every lane the same addresses -, nn_query's seed
+// rules, the stores of nn_query by one lane.  qi: the query's place in sorted3, ci: its correspondence's place.
+__device__ __forceinline__ void nn_search_one_coop(const PairDev& P, const SlotDev& Ss, const NNArrays& A, float max_d, int dbg,
+                                                   int qi, int ci) {
+  const CorrVec p0 = A.sorted3[qi];
+  const float lbs = A.corr_lb[ci];
+  const float prev = A.corr_d2[ci];
+  const int prev_pos = A.corr_idx[ci];
+  const CorrVec ps = A.corr_q[ci];
+  const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
+  const F3 q = xf_eigen(P.T, pg.x, pg.y, pg.z);
+  // nn_query's seed rules (speed only)
+  float move = 3.0e38f;
+  if (lbs != 0.f && !(dbg & 64)) {
+    const F3 qo = xf_eigen(P.T_nn, pg.x, pg.y, pg.z);
+    move = sqrtf(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
+  }
+  const float h = Ss.g.h;
+  const bool has_prev = prev >= 0.f && prev < 1.0e30f;
+  const bool near_seed = has_prev && prev < h * h;
+  const bool far_seed = has_prev && !near_seed && move < kNNRevalSlack * h && !(dbg & 128);
+  const float hint = has_prev ? fminf(sqrtf(prev) * 1.25f + 0.05f * h, h) : 3.0f * h;
+  const uint32_t* __restrict__ cs = A.cell_start + Ss.cell_off;
+  const float4* __restrict__ tp = A.sorted + Ss.off;
+  NNResult r;
+  if (near_seed && lbs > 0.f)     // (lbs > 0: the copy of the previous neighbour is a real point)
+    r = wave_nn1_coop(Ss.g, cs, tp, q.x, q.y, q.z, max_d, hint, -1, false, dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z));
+  else
+    r = wave_nn1_coop(Ss.g, cs, tp, q.x, q.y, q.z, max_d, hint, (near_seed || far_seed) ? prev_pos : -1, far_seed);
+  // the stores of nn_query, by one lane
+  if (lane_id() != 0) return;
+  A.corr_idx[ci] = r.pos;
+  A.corr_d2[ci] = r.d2;
+  const float lbv = nn_lower_bound_others(r);
+  A.corr_lb[ci] = r.pos >= 0 ? lbv : -lbv;
+  if (r.pos >= 0) {
+    if (!(lbs > 0.f && r.pos == prev_pos)) {     // (the previous neighbour confirmed: its copies are in place)
+      A.corr_q[ci] = corr_vec(A.sorted[Ss.off + r.pos]);
+      A.corr_n[ci] = A.normals[Ss.off + r.pos];
+    }
+  } else {
+    CorrVec none;
+    none.x = none.y = none.z = __int_as_float(0x7F800000);
+    A.corr_q[ci] = none;
+  }
+}
+
 // The queries the touch kernel listed: the general search of nn_query (PHASE 2: "has failed its re-validation
 // already"), laid out for LATENCY.  A settled pass has a few thousand of them and the launch lasts as long as one of
 // them does - a chain of dependent loads, each a cold miss somewhere in a 10 GB workspace: through nn_query 40 us.
@@ -2081,50 +2153,7 @@ __global__ void __launch_bounds__(kWave) s3d_nn_record_search_kernel(const PairD
     const uint4 e = mylist[j];
     const int pair = __builtin_amdgcn_readfirstlane((int)e.x), qi = __builtin_amdgcn_readfirstlane((int)e.y);
     const int ci = __builtin_amdgcn_readfirstlane((int)e.z), ss = __builtin_amdgcn_readfirstlane((int)e.w);
-    // one round trip: the query, what is known about it, the two records (every lane the same addresses)
-    const CorrVec p0 = A.sorted3[qi];
-    const float lbs = A.corr_lb[ci];
-    const float prev = A.corr_d2[ci];
-    const int prev_pos = A.corr_idx[ci];
-    const CorrVec ps = A.corr_q[ci];
-    const PairDev& P = pairs[pair];
-    const SlotDev& Ss = slots[ss];
-    const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
-    const F3 q = xf_eigen(P.T, pg.x, pg.y, pg.z);
-    // nn_query's seed rules (speed only)
-    float move = 3.0e38f;
-    if (lbs != 0.f && !(dbg & 64)) {
-      const F3 qo = xf_eigen(P.T_nn, pg.x, pg.y, pg.z);
-      move = sqrtf(dist2(q.x, q.y, q.z, qo.x, qo.y, qo.z));
-    }
-    const float h = Ss.g.h;
-    const bool has_prev = prev >= 0.f && prev < 1.0e30f;
-    const bool near_seed = has_prev && prev < h * h;
-    const bool far_seed = has_prev && !near_seed && move < kNNRevalSlack * h && !(dbg & 128);
-    const float hint = has_prev ? fminf(sqrtf(prev) * 1.25f + 0.05f * h, h) : 3.0f * h;
-    const uint32_t* __restrict__ cs = A.cell_start + Ss.cell_off;
-    const float4* __restrict__ tp = A.sorted + Ss.off;
-    NNResult r;
-    if (near_seed && lbs > 0.f)     // (lbs > 0: the copy of the previous neighbour is a real point)
-      r = wave_nn1_coop(Ss.g, cs, tp, q.x, q.y, q.z, max_d, hint, -1, false, dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z));
-    else
-      r = wave_nn1_coop(Ss.g, cs, tp, q.x, q.y, q.z, max_d, hint, (near_seed || far_seed) ? prev_pos : -1, far_seed);
-    // the stores of nn_query, by one lane
-    if (lane_id() != 0) continue;
-    A.corr_idx[ci] = r.pos;
-    A.corr_d2[ci] = r.d2;
-    const float lbv = nn_lower_bound_others(r);
-    A.corr_lb[ci] = r.pos >= 0 ? lbv : -lbv;
-    if (r.pos >= 0) {
-      if (!(lbs > 0.f && r.pos == prev_pos)) {     // (the previous neighbour confirmed: its copies are in place)
-        A.corr_q[ci] = corr_vec(A.sorted[Ss.off + r.pos]);
-        A.corr_n[ci] = A.normals[Ss.off + r.pos];
-      }
-    } else {
-      CorrVec none;
-      none.x = none.y = none.z = __int_as_float(0x7F800000);
-      A.corr_q[ci] = none;
-    }
+    nn_search_one_coop(pairs[pair], slots[ss], A, max_d, dbg, qi, ci);
   }
 }
 
@@ -2286,6 +2315,20 @@ __global__ void __launch_bounds__(kWave) s3d_nn_worklist_kernel(const PairDev* _
                                                                  const uint32_t* __restrict__ work_index,
                                                                  int* __restrict__ work_count_next) {
   const int count = *work_count;
+  if (count <= 2 * (int)gridDim.x && !(dbg & 2048)) {
+    // (round 5) a SHORT list - a lone registration, a small batch: one query per wave and trip, wave-cooperative.  What a
+    // scan27 pass declines is mostly queries without a near neighbour (a part of one scan the other does not cover), each
+    // a walk through a wide box: eight of them per wave, each lane on its own, made the launch as long as the slowest
+    // walk - 75 us per pass of one registration of two of the reference's scans, 2 x 75 us of its 1.5 ms.
+    for (int j = blockIdx.x; j < count; j += gridDim.x) {
+      const int pair = __builtin_amdgcn_readfirstlane((int)work_pair[j]);
+      const int i = __builtin_amdgcn_readfirstlane((int)work_index[j]);
+      const PairDev& P = pairs[pair];
+      nn_search_one_coop(P, slots[P.slot_s], A, max_d, dbg, slots[P.slot_t].off + i, P.corr_off + i);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *work_count_next = 0;
+    return;
+  }
   const int per = count <= 8 * (int)gridDim.x ? 8 : kWave;
   for (int j0 = blockIdx.x * per; j0 < count; j0 += gridDim.x * per) {   // (whole waves stay: nn_query votes)
     const int j = j0 + (int)threadIdx.x;
