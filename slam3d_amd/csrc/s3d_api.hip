@@ -683,7 +683,7 @@ struct Batch {
                                                                 sort_classic ? 0 : 4, (uint32_t*)ctx->digit_tot.p);
       sort(SortPlan{4, 8}, NS, true);
       uint32_t* bc = (uint32_t*)ctx->blockcnt.p;
-      k_heads_count<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), kA(), bc, nb_head);
+      k_heads_count<<<dim3(cdiv(nb_head, kHeadsChunksPerBlock), NS), kBlock, 0, st>>>(d_slots(), kA(), bc, nb_head);
       k_heads_scan<<<NS, kBlock, 0, st>>>(d_slots(), bc, nb_head);
       k_centroids<<<(unsigned)((NS >= 8 ? cdiv(NS, 8) * 8 : NS) * nb_head), kBlock, 0, st>>>(d_slots(), kA(), vA(), bc, filt(),
                                                                                                (unsigned int*)ctx->blockbb.p, nb_head, NS);
@@ -715,7 +715,7 @@ struct Batch {
                                                               sort_classic ? 0 : 4, (uint32_t*)ctx->digit_tot.p);
     sort(SortPlan{4, 8}, NS, true);      // (32-bit keys: the host does not know how many bits a slot's keys use)
     uint32_t* bc = (uint32_t*)ctx->blockcnt.p;
-    k_heads_count<<<dim3(nb_head, NS), kBlock, 0, st>>>(d_slots(), kA(), bc, nb_head);
+    k_heads_count<<<dim3(cdiv(nb_head, kHeadsChunksPerBlock), NS), kBlock, 0, st>>>(d_slots(), kA(), bc, nb_head);
     k_heads_scan<<<NS, kBlock, 0, st>>>(d_slots(), bc, nb_head);
     k_centroids_fused<<<(unsigned)((NS >= 8 ? cdiv(NS, 8) * 8 : NS) * nb_head), kBlock, 0, st>>>(
         d_slots(), kA(), vA(), bc, sorted(), sorted3(), cells(), nb_head, NS);

@@ -238,12 +238,13 @@ struct FusedGrid {
   int sub[3];       // sub-voxel radix per axis
   uint32_t msub;    // sub[0] * sub[1] * sub[2]
   int ok;           // 1: served; 0: not attempted; < 0: this slot cannot use the fused path (see above)
+  unsigned long long msub_magic;   // ceil(2^64 / msub) (msub >= 2): key / msub = high 64 bits of key * magic, exactly
 };
 constexpr float kFusedCellTol = 1.0e-3f;   // a stored point may lie this far (in cells) outside its cell's box: half of
                                            // the 2e-3 margin every search adds for the rounding of cell assignments
 
 S3D_HD bool fused_grid_from_voxels(const VoxelParams& vp, int cap, GridParams& g, FusedGrid& f) {
-  f.m = 1; f.sub[0] = f.sub[1] = f.sub[2] = 1; f.msub = 1; f.ok = -1;
+  f.m = 1; f.sub[0] = f.sub[1] = f.sub[2] = 1; f.msub = 1; f.ok = -1; f.msub_magic = 0ull;
   g.h = 1.f; g.inv_h = 1.f; g.ncells = 1;
   for (int a = 0; a < 3; ++a) { g.origin[a] = 0.f; g.dim[a] = 1; }
   if (vp.passthrough || vp.div_b[0] < 1 || vp.div_b[1] < 1 || vp.div_b[2] < 1) return false;
@@ -276,6 +277,7 @@ S3D_HD bool fused_grid_from_voxels(const VoxelParams& vp, int cap, GridParams& g
   }
   if (msub > 0xFFFFFFFFull || (uint64_t)nc * msub > 0xFFFFFFFEull) return false;   // (0xFFFFFFFF = kInvalidKey)
   f.m = m; f.msub = (uint32_t)msub;
+  f.msub_magic = msub >= 2 ? (0xFFFFFFFFFFFFFFFFull / msub) + 1ull : 0ull;
   g.ncells = (int)nc;
   // voxel i of axis a covers [(min_b + i) / inv_leaf, (min_b + i + 1) / inv_leaf) up to the rounding of PCL's float product
   g.h = (float)((double)m / (double)vp.inv_leaf);
@@ -295,6 +297,26 @@ S3D_HD uint32_t fused_key(const VoxelParams& vp, const GridParams& g, const Fuse
   const uint32_t sub = (uint32_t)((i0 - c0 * f.m) + f.sub[0] * ((i1 - c1 * f.m) + f.sub[1] * (i2 - c2 * f.m)));
   return cell * f.msub + sub;
 }
+
+// key -> cell id without a division: for key < 2^32 and msub < 2^32 the high 64 bits of key * ceil(2^64 / msub) are
+// floor(key / msub) exactly (the error term key * e / (msub 2^64), e < msub, is below 2^-32 < 1 / msub)
+S3D_HD uint32_t fused_cell_of_key(const FusedGrid& f, uint32_t key) {
+  if (f.msub < 2u) return key;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__umul64hi((unsigned long long)key, f.msub_magic);
+#else
+  return (uint32_t)(((unsigned __int128)key * (unsigned __int128)f.msub_magic) >> 64);
+#endif
+}
+
+// PCL's voxel key (the tie-breaking id) of a voxel from one of its raw points: pcl::VoxelGrid's own float operations
+S3D_HD uint32_t fused_voxel_of_point(const VoxelParams& vp, float x, float y, float z) { return voxel_key(vp, x, y, z); }
+
+// does the point lie in cell `cell` as the searches see it?  Fast path: the cell its position falls into IS the cell;
+// otherwise (a centroid within rounding of a cell face, or outside its voxel by the rounding of its float sums) the
+// tolerance test against the decoded cell coordinates
+S3D_HD bool fused_point_in_cell(const VoxelParams& vp, const GridParams& g, const FusedGrid& f, uint32_t key, int cell,
+                                float x, float y, float z);
 
 // key -> cell id, cell coordinates and PCL's voxel key (the tie-breaking id)
 S3D_HD void fused_decode(const VoxelParams& vp, const GridParams& g, const FusedGrid& f, uint32_t key, int* cell, int c[3],
@@ -321,6 +343,18 @@ S3D_HD bool fused_inside(const GridParams& g, const int c[3], float x, float y, 
     ok = ok && fcell >= -kFusedCellTol && fcell <= 1.0f + kFusedCellTol;
   }
   return ok;
+}
+
+S3D_HD bool fused_point_in_cell(const VoxelParams& vp, const GridParams& g, const FusedGrid& f, uint32_t key, int cell,
+                                float x, float y, float z) {
+  const int ix = grid_coord(g, 0, x), iy = grid_coord(g, 1, y), iz = grid_coord(g, 2, z);
+  if (ix >= 0 && ix < g.dim[0] && iy >= 0 && iy < g.dim[1] && iz >= 0 && iz < g.dim[2] &&
+      ix + g.dim[0] * (iy + g.dim[1] * iz) == cell)
+    return true;
+  int c2, cc[3];
+  uint32_t voxel;
+  fused_decode(vp, g, f, key, &c2, cc, &voxel);
+  return fused_inside(g, cc, x, y, z);
 }
 
 // pcl::RadiusOutlierRemoval on the search grid: how many points p of the cloud (the query itself included)

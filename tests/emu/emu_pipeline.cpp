@@ -159,10 +159,18 @@ Fused build_fused(const float* xyz, int n, int stride, double leaf, int cells_pe
     }
     const float c = (float)(j - i);
     const float qx = sx / c, qy = sy / c, qz = sz / c;
-    int cell, cc[3];
-    uint32_t voxel;
-    fused_decode(F.vp, F.G.g, F.fz, kv[i].first, &cell, cc, &voxel);
-    if (!fused_inside(F.G.g, cc, qx, qy, qz)) F.fz.ok = -2;
+    // as k_centroids_fused: the cell by the multiply-high, the id from the run's first raw point, the check from the position;
+    // the decode (the definition of both) must agree
+    const int cell = (int)fused_cell_of_key(F.fz, kv[i].first);
+    const F4& pf = raw[kv[i].second];
+    const uint32_t voxel = fused_voxel_of_point(F.vp, pf.x, pf.y, pf.z);
+    {
+      int cell2, cc[3];
+      uint32_t voxel2;
+      fused_decode(F.vp, F.G.g, F.fz, kv[i].first, &cell2, cc, &voxel2);
+      if (cell2 != cell || voxel2 != voxel) { std::fprintf(stderr, "emu: fused decode mismatch\n"); std::abort(); }
+    }
+    if (!fused_point_in_cell(F.vp, F.G.g, F.fz, kv[i].first, cell, qx, qy, qz)) F.fz.ok = -2;
     const uint32_t pos = (uint32_t)F.G.sorted.size();
     for (int ce = prev_cell + 1; ce <= cell; ++ce) F.G.cell_start[ce] = pos;     // the gap fill of k_centroids_fused
     prev_cell = cell;
