@@ -134,3 +134,33 @@ def test_fused_prepass_falls_back_to_two_sorts(gpu_ctx, fixture_clouds):
     finally:
         for h in dev:
             h.release()
+
+
+def test_fused_fallback_with_cached_clouds_in_the_batch(gpu_ctx, fixture_clouds):
+    """The fallback run must also recompute the clouds that were restored from fused-layout cache entries: cloud A is
+    cached by a first call; the second call pairs it with a cloud whose extent PCL's index cannot hold at this voxel size
+    (the fused keys decline it), so the whole batch - A included - runs again on the two-sort path.  Records == the same
+    batch with the fused path switched off and no cache, bit for bit."""
+    import slam3d_amd as s3d
+    a = np.ascontiguousarray(fixture_clouds[0][::4, :3])
+    b = np.ascontiguousarray(fixture_clouds[1][::4, :3])
+    huge = np.ascontiguousarray(b * np.float32(3000.0))          # ~300 km across: 0.2 m voxels overflow PCL's int index
+    gpu_ctx.cache_control(clear=True)
+    da, db, dh = gpu_ctx.upload(a), gpu_ctx.upload(b), gpu_ctx.upload(huge)
+    try:
+        p = s3d.default_params(maximum_iterations=6)
+        on = s3d.ExecOptions(cache_prepass=1)
+        gpu_ctx.align_batch([da], [db], None, p, on)               # A and B cached in the fused layout
+        assert gpu_ctx.cache_control()["entries"] == 2
+        before = gpu_ctx.fused_reruns()
+        got = gpu_ctx.align_batch([da, da], [db, dh], None, p, on)
+        assert gpu_ctx.fused_reruns() == before + 1
+        want = gpu_ctx.align_batch([da, da], [db, dh], None, p, s3d.ExecOptions(debug_flags=s3d.api.DBG_NO_FUSED_PREPASS))
+        assert np.array_equal(got, want)
+        # and the fused entries are still good for the next fused batch
+        again = gpu_ctx.align_batch([da], [db], None, p, on)
+        assert np.array_equal(again[0], gpu_ctx.align_batch([da], [db], None, p)[0])
+    finally:
+        for h in (da, db, dh):
+            h.release()
+        gpu_ctx.cache_control(clear=True)
