@@ -9,9 +9,15 @@ from bench import kernel_source_hash
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = list(csv.DictReader(open(f"{R}/{c}/p_counter_collection.csv")))
+    # (round 5: the counter passes run the driver's whole command; the launches of the BATCH workload are those with the
+    # largest grid of their kernel - the single-pair / real-scan legs launch the same kernels on smaller grids)
+    biggest = collections.defaultdict(int)
+    for r in rows:
+        if r["Counter_Name"] == c and r.get("Grid_Size"):
+            biggest[r["Kernel_Name"]] = max(biggest[r["Kernel_Name"]], int(r["Grid_Size"]))
     agg = collections.defaultdict(list)
     for r in rows:
-        if r["Counter_Name"] == c:
+        if r["Counter_Name"] == c and (not r.get("Grid_Size") or int(r["Grid_Size"]) == biggest[r["Kernel_Name"]]):
             agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     summ = sorted(((k, sum(v) / len(v), len(v)) for k, v in agg.items()), key=lambda x: -x[1] * x[2])
     with open(f"{D}/rocprofv3_pmc_{c}_summary.csv", "w") as f:
@@ -29,7 +35,7 @@ hbm = int(2 * out["FETCH_SIZE"] * 1024 + out["WRITE_SIZE"] * 1024)
 json.dump({"kernel": "s3d_nn_first_kernel + s3d_nn_scan27_kernel + s3d_nn_worklist_kernel + s3d_nn_search_kernel<0> + s3d_nn_record_{test,touch,search}_kernel (per pass of the ICP loop)", "fetch_size_kb_per_launch": round(out["FETCH_SIZE"], 1),
            "write_size_kb_per_launch": round(out["WRITE_SIZE"], 1), "hbm_bytes_per_launch": hbm,
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is",
-           "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --no-cpu --no-single --no-real --steps 2 --warmup 1",
+           "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --gpus 1 --steps 20 --warmup 5 (the driver's command; batch launches selected by grid size)",
            "workload": "256 pairs x 100k points, 20 iterations (bench default)",
            "kernel_src_sha256": kernel_source_hash(), "round": ROUND},
           open(os.path.join(ROOT, "profiles/nn_traffic.json"), "w"), indent=1)
@@ -42,7 +48,7 @@ if os.path.exists(f"{R}/stats1M/b_kernel_stats.csv"):
     shutil.copy(f"{R}/stats1M/b_kernel_stats.csv", f"{D}/rocprofv3_kernel_stats_bench_1M_50it.csv")
     shutil.copy(f"{R}/bench_1M_under_rocprof.json", f"{D}/bench_1M_under_rocprof.json")
 d = json.load(open(f"{D}/bench_default.json"))
-print("default", d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["avg_launch_ms"], d["roofline"]["achieved"],
+print("default", d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"].get("frac_search_passes"), d["roofline"]["avg_launch_ms"], d["roofline"]["achieved"],
       d["cpu_baseline"]["value"], d["cpu_baseline_parallel"]["value"], d["single_pair"], d["stage_ms"], d["nn_launch_ms"][:6])
 d = json.load(open(f"{D}/bench_under_rocprof.json")); print("rocprof", d["value"], d["roofline"]["avg_launch_ms"])
 rows = list(csv.DictReader(open(f"{D}/rocprofv3_kernel_stats_bench_default.csv")))
