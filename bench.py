@@ -84,6 +84,9 @@ def main():
                     help="skip the single-pair latency (BASELINE.json configs[1]) that is otherwise measured after the "
                          "timed region: with it off every s3d_nn_search_kernel<0> launch of the run belongs to the "
                          "batch workload (rocprofv3 average == roofline.avg_launch_ms, the profiles/ cross-check)")
+    ap.add_argument("--no-search-frac", action="store_true",
+                    help="skip the profile=2 run behind roofline.frac_search_passes (its counters slow the first passes: under "
+                         "rocprofv3 --stats it would pollute the per-kernel averages the profiles/ cross-check reads)")
     ap.add_argument("--extras", action="store_true",
                     help="also time the first-iteration NN launch and the other algorithm of the path")
     args = ap.parse_args()
@@ -267,6 +270,8 @@ def main():
         # the kernels - the times are the profile=1 run's) priced at the same algorithmic bytes, and the counter-measured
         # HBM traffic of the family over its time.
         try:
+            if args.no_search_frac:
+                raise RuntimeError("skipped (--no-search-frac)")
             popts2 = s3d.ExecOptions(force_iterations=1, check_interval=0, grid_cells_per_point=args.cells_per_point, profile=2)
             ctx.align_batch(src, tgt, guesses, params, popts2)
             prof2 = ctx.last_profile()

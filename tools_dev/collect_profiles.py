@@ -24,13 +24,28 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         f.write("Kernel_Name,mean_%s_KB_per_launch,launches\n" % c)
         for k, m, n in summ:
             f.write('"%s",%.1f,%d\n' % (k, m, n))
-    # the NN family of the ICP loop: s3d_nn_first_kernel + s3d_nn_search_kernel<0>, per launch over all their launches
-    # per PASS of the ICP loop (a scan27 pass is two launches: the scan and its worklist)
-    fam = [x for x in summ if any(k in x[0] for k in ("nn_search_kernel<0>", "nn_first_kernel", "nn_scan27_kernel", "nn_worklist_kernel",
-                                                        "nn_record_test_kernel", "nn_record_touch_kernel", "nn_record_search_kernel"))]
-    # launches that START a pass: the worklist / touch<true> / record search kernels follow another kernel of their pass
-    passes = sum(n for k, _, n in fam if not any(t in k for t in ("nn_worklist_kernel", "nn_record_touch_kernel<true>", "nn_record_search_kernel")))
-    out[c] = sum(m * n for _, m, n in fam) / passes
+    # the NN family of the ICP loop, per PASS, over the steps of the BATCH workload only (round 5: the rows are in
+    # dispatch order; a batch step runs from its s3d_nn_first_kernel - the launch with the largest grid of that kernel -
+    # to the fitness pass s3d_nn_search_kernel<1>, and every family kernel in between belongs to one of its passes)
+    FAM = ("nn_search_kernel<0>", "nn_first_kernel", "nn_scan27_kernel", "nn_worklist_kernel", "nn_record_test_kernel",
+           "nn_record_touch_kernel", "nn_record_search_kernel")
+    seq = [(r["Kernel_Name"], float(r["Counter_Value"]), int(r["Grid_Size"] or 0)) for r in rows if r["Counter_Name"] == c]
+    G = max(g for k, _, g in seq if "nn_first_kernel" in k)
+    steps, cur, npass = [], None, 0
+    STARTS = ("nn_first_kernel", "nn_scan27_kernel", "nn_record_test_kernel", "nn_record_touch_kernel<false>", "nn_search_kernel<0>")
+    for k, v, g in seq:
+        if "nn_first_kernel" in k and g == G:
+            cur, npass = 0.0, 0
+        if cur is None:
+            continue
+        if "nn_search_kernel<1>" in k:
+            steps.append(cur / max(npass, 1)); cur = None
+            continue
+        if any(t in k for t in FAM):
+            cur += v
+            npass += 1 if any(t in k for t in STARTS) else 0
+    out[c] = sum(steps) / len(steps)
+    print(c, "batch steps", len(steps), "passes per step", npass, "KB per pass", round(out[c], 1))
 hbm = int(2 * out["FETCH_SIZE"] * 1024 + out["WRITE_SIZE"] * 1024)
 json.dump({"kernel": "s3d_nn_first_kernel + s3d_nn_scan27_kernel + s3d_nn_worklist_kernel + s3d_nn_search_kernel<0> + s3d_nn_record_{test,touch,search}_kernel (per pass of the ICP loop)", "fetch_size_kb_per_launch": round(out["FETCH_SIZE"], 1),
            "write_size_kb_per_launch": round(out["WRITE_SIZE"], 1), "hbm_bytes_per_launch": hbm,

@@ -17,13 +17,13 @@ python3 tools_dev/fixture.py > $O/fixture_batch.txt 2>&1
 PROFILE=2 python3 tools_dev/fixture.py > $O/fixture_batch_profile2.txt 2>&1
 python3 tools_dev/ndt_try.py > $O/ndt_try.txt 2>&1
 python3 tools_dev/plane_time.py > $O/plane_time.txt 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -o b -- python3 bench.py --no-cpu --no-single --no-real 2>/dev/null | grep '^{"metric' | tail -1 > $P/bench_under_rocprof.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -o b -- python3 bench.py --no-cpu --no-single --no-real --no-search-frac 2>/dev/null | grep '^{"metric' | tail -1 > $P/bench_under_rocprof.json
 # round 5: the counter passes run the DRIVER's command (every leg of the default line); collect_profiles.py keeps the
 # launches of the batch workload by their grid size
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/FETCH_SIZE -o p -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/WRITE_SIZE -o p -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > /dev/null 2>&1
 # round 4: BASELINE configs[4]'s per-GPU share under the kernel trace (why is its first pass 2.2x worse per query?)
-rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats1M -o b -- python3 bench.py --pairs 32 --points 1000000 --iters 50 --steps 2 --warmup 1 --no-cpu --no-single --no-real 2>/dev/null | grep '^{"metric' | tail -1 > $P/bench_1M_under_rocprof.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats1M -o b -- python3 bench.py --pairs 32 --points 1000000 --iters 50 --steps 2 --warmup 1 --no-cpu --no-single --no-real --no-search-frac 2>/dev/null | grep '^{"metric' | tail -1 > $P/bench_1M_under_rocprof.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/map -o m -- python3 bench_map.py --no-cpu > /dev/null 2>&1
 # rocprofv3 nests its output under a host-name directory: flatten
 for d in stats FETCH_SIZE WRITE_SIZE map stats1M; do find $P/$d -mindepth 2 -type f -exec mv {} $P/$d/ \; ; done
