@@ -836,10 +836,11 @@ struct Batch {
       s3d_knn_moments_kernel<32><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
     s3d_normals_fallback_kernel<<<256, kBlock, 0, st>>>(fb_count, fb_list, mom, mom_plane, normals(), k);
     if (opts.debug_flags & S3D_DBG_PRINT_KNN) {   // dev aid: how many points took the eigen fallback / the exact-search redo
-      int cnt[2];
+      int cnt[3];
       HIPCHK(hipMemcpyAsync(cnt, fb_count, sizeof cnt, hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
-      std::fprintf(stderr, "[s3d] k-NN pre-pass: %zu points, eigen fallback %d, exact-search redo %d\n", total_pts, cnt[0], cnt[1]);
+      std::fprintf(stderr, "[s3d] k-NN pre-pass: %zu points, eigen fallback %d, exact-search redo %d, cooperative (far) list %d\n",
+                   total_pts, cnt[0], cnt[1], cnt[2]);
     }
   }
 

@@ -1265,8 +1265,9 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_REDO_WAVES) s3d_knn_moments_re
 // smallest extracted by K wave-wide minimum reductions; d doubles while the box holds fewer than K points and is then
 // set to the K-th distance found - two or three attempts of two memory round trips each.  Same K keys in the same
 // order as the per-lane search (same ids, same tie rule), so the same moments and normal bit for bit.
-constexpr int kKnnFarCap = 448;      // candidate keys held in LDS at a time (the K best so far included): 4 KB per wave, so
-                                     // that the LDS does not cap the waves per compute unit (2048 keys: 9 blocks, 159 -> us)
+constexpr int kFarRowBatches = 8;    // batches of 64 rows whose range loads are in flight together
+constexpr int kKnnFarCap = 64;       // candidate keys held in LDS before the K smallest are selected (the K best so far
+                                     // included): with 64 more appended at most 128, i.e. always the rank form of the selection
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -1275,20 +1276,35 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
   }
   return v;
 }
-// the K smallest of buf[0, n) into buf[0, min(K, n)) in ascending order (keys are distinct and > 0); returns their number
+// the K smallest of buf[0, n) into buf[0, min(K, n)) in ascending order (keys are distinct and > 0); returns their number.
+// Up to 128 keys - the usual case: the box is grown until it holds K points - by RANK: every lane counts the keys below
+// its own against broadcast reads of the buffer (no cross-lane traffic: the K wave-wide minimum reductions of the general
+// form are 12 LDS-crossbar permutes each, 10 us per selection, most of a far query's time).
 template <int K>
 __device__ __forceinline__ int wave_select_smallest(unsigned long long* buf, unsigned long long* sel, int n) {
   const int lane = lane_id();
   const int m = n < K ? n : K;
-  unsigned long long last = 0ull;
-  for (int j = 0; j < m; ++j) {
-    unsigned long long mine = ~0ull;
-    for (int i = lane; i < n; i += kWave) {
-      const unsigned long long v = buf[i];
-      mine = (v > last && v < mine) ? v : mine;
+  if (n <= 2 * kWave) {
+    const unsigned long long a = lane < n ? buf[lane] : ~0ull, b = lane + kWave < n ? buf[lane + kWave] : ~0ull;
+    int ra = 0, rb = 0;
+    for (int j = 0; j < n; ++j) {
+      const unsigned long long kj = buf[j];       // (every lane the same address: a broadcast read)
+      ra += kj < a ? 1 : 0;
+      rb += kj < b ? 1 : 0;
     }
-    last = wave_min_u64(mine);
-    if (lane == 0) sel[j] = last;
+    if (lane < n && ra < K) sel[ra] = a;
+    if (lane + kWave < n && rb < K) sel[rb] = b;
+  } else {
+    unsigned long long last = 0ull;
+    for (int j = 0; j < m; ++j) {
+      unsigned long long mine = ~0ull;
+      for (int i = lane; i < n; i += kWave) {
+        const unsigned long long v = buf[i];
+        mine = (v > last && v < mine) ? v : mine;
+      }
+      last = wave_min_u64(mine);
+      if (lane == 0) sel[j] = last;
+    }
   }
   __syncthreads();   // (the block is ONE wave: the LDS stores above before the loads below)
   for (int i = lane; i < m; i += kWave) buf[i] = sel[i];
@@ -1329,62 +1345,71 @@ __global__ void __launch_bounds__(kWave) s3d_knn_moments_far_kernel(const SlotDe
       const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dim[0] - 1 && y1 == g.dim[1] - 1 && z1 == g.dim[2] - 1;
       const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
       const int nrows = (x0 <= x1 && ny > 0 && nz > 0) ? ny * nz : 0;
-      // how many points does the box hold?  (row look-ups only: a box that is too small costs one round trip)
+      // ONE pass over the rows of the box, kFarRowBatches batches of 64 rows at a time with their range loads in flight together: an
+      // isolated point - the 20th neighbour tens of metres away - grows its box to ~10 000 rows, nearly all empty, and
+      // the launch lasts as long as that walk.  The few points of a box that turns out too small are evaluated for
+      // nothing; the rows are what costs.
       uint32_t total = 0;
-      for (int base = 0; base < nrows; base += kWave) {
-        const int r = base + lane;
-        uint32_t len = 0;
-        if (r < nrows) {
-          const int rowbase = g.dim[0] * ((y0 + r % ny) + g.dim[1] * (z0 + r / ny));
-          len = cs[rowbase + x1 + 1] - cs[rowbase + x0];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) len += (uint32_t)__shfl_xor((int)len, o, kWave);
-        total += len;
-      }
-      if (total < (uint32_t)K && !whole) { d *= 2.0f; continue; }
-      // the candidates' keys into LDS, the K smallest kept whenever the buffer fills
       nbest = 0;
       int nbuf = 0;
-      for (int base = 0; base < nrows; base += kWave) {
-        const int r = base + lane;
-        uint32_t rs = 0, len = 0;
-        if (r < nrows) {
-          const int rowbase = g.dim[0] * ((y0 + r % ny) + g.dim[1] * (z0 + r / ny));
-          rs = cs[rowbase + x0];
-          len = cs[rowbase + x1 + 1] - rs;
-        }
-        uint32_t incl = len;
+      // a box that reaches into a dense part of the cloud holds thousands of points (an isolated point 10 m from the rest:
+      // 6 840): once K keys are selected, only candidates below the K-th enter the buffer
+      unsigned long long thr = ~0ull;
+      for (int base = 0; base < nrows; base += kFarRowBatches * kWave) {
+        uint32_t rs4[kFarRowBatches], len4[kFarRowBatches];
 #pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-          const uint32_t t = (uint32_t)__shfl_up((int)incl, o, kWave);
-          if (lane >= o) incl += t;
-        }
-        const uint32_t tb = (uint32_t)__shfl((int)incl, kWave - 1, kWave);
-        for (uint32_t t0 = 0; t0 < tb; t0 += kWave) {
-          if (nbuf > kKnnFarCap) nbuf = wave_select_smallest<K>(buf, sel, nbuf);   // (room for 64 more keys below)
-          const uint32_t t = t0 + (uint32_t)lane;
-          int lo = 0, hi = kWave - 1;      // first lane whose inclusive count exceeds t
-#pragma unroll
-          for (int step = 0; step < 6; ++step) {
-            const int mid = (lo + hi) >> 1;
-            const uint32_t v = (uint32_t)__shfl((int)incl, mid, kWave);
-            if (t >= v) lo = mid + 1; else hi = mid;
+        for (int u = 0; u < kFarRowBatches; ++u) {
+          const int r = base + u * kWave + lane;
+          rs4[u] = 0; len4[u] = 0;
+          if (r < nrows) {
+            const int rowbase = g.dim[0] * ((y0 + r % ny) + g.dim[1] * (z0 + r / ny));
+            rs4[u] = cs[rowbase + x0];
+            len4[u] = cs[rowbase + x1 + 1] - rs4[u];
           }
-          const uint32_t row_incl = (uint32_t)__shfl((int)incl, lo, kWave), row_len = (uint32_t)__shfl((int)len, lo, kWave);
-          const uint32_t row_rs = (uint32_t)__shfl((int)rs, lo, kWave);
-          const bool have = t < tb;
-          const uint32_t pos = have ? row_rs + (t - (row_incl - row_len)) : 0u;
-          const float4 p = pts[pos];
-          const float d2 = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
-          const unsigned long long key = ((unsigned long long)(__float_as_uint(d2) + 0x00800000u) << 32) |
-                                         (unsigned long long)(BYPOS ? pos : __float_as_uint(p.w));
-          const unsigned long long hm = __ballot(have);
-          if (have) buf[nbuf + (int)__popcll(hm & ((1ull << lane) - 1ull))] = key;
-          nbuf += (int)__popcll(hm);
-          __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < kFarRowBatches; ++u) {
+          const uint32_t rs = rs4[u], len = len4[u];
+          if (__ballot(len != 0u) == 0ull) continue;         // (an empty batch of rows: the usual case far out)
+          uint32_t incl = len;
+#pragma unroll
+          for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, o, kWave);
+            if (lane >= o) incl += t;
+          }
+          const uint32_t tb = (uint32_t)__shfl((int)incl, kWave - 1, kWave);
+          total += tb;
+          for (uint32_t t0 = 0; t0 < tb; t0 += kWave) {
+            if (nbuf > kKnnFarCap) {                   // (room for 64 more keys below)
+              nbuf = wave_select_smallest<K>(buf, sel, nbuf);
+              if (nbuf == K) thr = sel[K - 1];
+            }
+            const uint32_t t = t0 + (uint32_t)lane;
+            int lo = 0, hi = kWave - 1;      // first lane whose inclusive count exceeds t
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+              const int mid = (lo + hi) >> 1;
+              const uint32_t v = (uint32_t)__shfl((int)incl, mid, kWave);
+              if (t >= v) lo = mid + 1; else hi = mid;
+            }
+            const uint32_t row_incl = (uint32_t)__shfl((int)incl, lo, kWave), row_len = (uint32_t)__shfl((int)len, lo, kWave);
+            const uint32_t row_rs = (uint32_t)__shfl((int)rs, lo, kWave);
+            const bool in_box = t < tb;
+            const uint32_t pos = in_box ? row_rs + (t - (row_incl - row_len)) : 0u;
+            const float4 p = pts[pos];
+            const float d2 = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
+            const unsigned long long key = ((unsigned long long)(__float_as_uint(d2) + 0x00800000u) << 32) |
+                                           (unsigned long long)(BYPOS ? pos : __float_as_uint(p.w));
+            const bool have = in_box && key < thr;
+            const unsigned long long hm = __ballot(have);
+            if (hm == 0ull) continue;
+            if (have) buf[nbuf + (int)__popcll(hm & ((1ull << lane) - 1ull))] = key;
+            nbuf += (int)__popcll(hm);
+            __syncthreads();
+          }
         }
       }
+      if (total < (uint32_t)K && !whole) { d *= 2.0f; continue; }
       nbest = wave_select_smallest<K>(buf, sel, nbuf);
       if (nbest < K) break;                       // (only when the box is the whole grid: the cloud has fewer than K points)
       const float d2k = __uint_as_float((uint32_t)(sel[K - 1] >> 32) - 0x00800000u);
