@@ -988,8 +988,12 @@ struct Batch {
 
   // one outer iteration: correspondences (K5), accumulate (K6), controller (K7)
   void launch_iteration(int it, float max_d, int prof_slot) {
-    // passes 3-5: a third of the lanes still search, scattered over all waves -> block-compacting variant
-    launch_nn(0, max_d, prof_slot, it >= 2 && it <= 4, it);   // (the counters cost two atomics per searching wave)
+    // (the block-compacting variant of the general kernel served passes 3-5 until round 4, when those passes of a large batch
+    // got kernels of their own; for the small batches that still come here it is neutral on synthetic pairs - 1, 16, 40
+    // pairs: 1.277 / 2.92 / 5.57 ms with, 1.264 / 2.97 / 5.56 without - and costs one registration of two of the reference's
+    // scans 40 us: packed into a few waves, its ~600 queries without a neighbour walk their 50-row balls lane by lane,
+    // while spread one or two to a wave they are served cooperatively.  Off for the ICP passes; the fitness pass keeps it.)
+    launch_nn(0, max_d, prof_slot, false, it);   // (the counters cost two atomics per searching wave)
     launch_iteration_after_nn();
   }
   void launch_iteration_after_nn() {
@@ -1035,7 +1039,7 @@ struct Batch {
             ctx->nn_ev.push_back(a); ctx->nn_ev.push_back(b);
           }
           HIPCHK(hipEventRecord(ctx->nn_ev[2 * it], st));
-          launch_nn(0, max_d, opts.profile >= 2 ? it : -1, it >= 2 && it <= 4, it);
+          launch_nn(0, max_d, opts.profile >= 2 ? it : -1, false, it);
           HIPCHK(hipEventRecord(ctx->nn_ev[2 * it + 1], st));
           launch_iteration_after_nn();
         } else {
