@@ -878,7 +878,11 @@ struct Batch {
     // that switch the re-validation off imply it)
     // (measured per 128 pairs: pass 2 1.47 -> 0.99 ms, pass 3 0.90 -> 0.80 ms with the compacting form; passes 4 and 5,
     // where 2 % and 0.1 % of the queries search, are slower this way: 0.39 -> 0.55, 0.15 -> 0.19 ms)
-    constexpr int scan27_passes = 2;
+    // (round 5) a batch that is NOT served record-wise keeps the flat scan for passes 4-5 as well: on the reference's scans
+    // 27 % / 7 % of the queries still search there, and the general kernel's seeded box search is ~8x slower per searched
+    // query than the flat scan (one real pair: passes 4-5 0.10 + 0.11 ms); on a synthetic pair, where 2 % search, it costs
+    // a few microseconds per pass (a block scan and the worklist launch)
+    const int scan27_passes = settled_wanted() ? 2 : 4;
     if (family && it >= 1 && it <= scan27_passes && !(dbg_nn & (524288 | 128 | 2048)) && max_n < kKnn3MaxPoints) {
       int* wc = (int*)ctx->n_active.p + 8;              // eight counters, used in turn (zeroed by stage_icp / the drain)
       const bool compact27 = !(opts.debug_flags & S3D_DBG_SCAN27_NO_COMPACT);
