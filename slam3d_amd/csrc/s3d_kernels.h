@@ -2175,12 +2175,45 @@ __global__ void __launch_bounds__(kWave) s3d_nn_record_search_kernel(const PairD
   if ((int)blockIdx.x < kNNSearchSublists / kWave) search_counts_next[blockIdx.x * kWave + threadIdx.x] = 0;   // the next pass appends here
   const uint4* __restrict__ mylist = search_list + (size_t)sub * search_cap;
   if (count > 4 * parts) {
+    // (round 5) a long list is first tried with the FLAT scan of the 27 cells, the previous neighbour's copy as the seed
+    // that cuts them (grid_nn1_scan27, as passes 2-3 run it): per searched query the general box search is several times
+    // slower, and nearly every listed query of passes 4-5 has its neighbour within a cell.  What the scan declines goes
+    // through nn_query as before.
+    __shared__ uint32_t tab[kKnn3Segs * kWave];
     for (int j0 = part * kWave; j0 < count; j0 += parts * kWave) {   // (whole waves stay: nn_query votes)
       const int j = j0 + (int)threadIdx.x;
       const bool need = j < count;
       const uint4 e = mylist[need ? j : 0];
       const PairDev& P = pairs[e.x];
-      nn_query<0, 2>(P, slots[P.slot_t], slots[P.slot_s], (int)e.x, (int)e.z - P.corr_off, need, A, max_d, dbg | 2048, nullptr,
+      const SlotDev& Ss = slots[P.slot_s];
+      bool done = false;
+      if (!(dbg & 524288) && need && Ss.n < kKnn3MaxPoints) {      // (S3D_DBG_NN_NO_SCAN27 switches this off too)
+        const int ci = (int)e.z;
+        const CorrVec p0 = A.sorted3[e.y];
+        const float lbs = A.corr_lb[ci];
+        const F3 pg = xf_pcl(P.guess, p0.x, p0.y, p0.z);
+        const F3 q = xf_eigen(P.T, pg.x, pg.y, pg.z);
+        float seed_d2 = 3.0e38f;
+        int prev_pos = -1;
+        if (lbs > 0.f) {
+          const CorrVec ps = A.corr_q[ci];
+          seed_d2 = dist2(q.x, q.y, q.z, ps.x, ps.y, ps.z);
+          prev_pos = A.corr_idx[ci];
+        }
+        NNResult r;
+        if (grid_nn1_scan27<0>(Ss.g, A.cell_start + Ss.cell_off, A.sorted + Ss.off, q.x, q.y, q.z, tab + threadIdx.x, kWave, r,
+                               seed_d2)) {
+          A.corr_idx[ci] = r.pos;
+          A.corr_d2[ci] = r.d2;
+          A.corr_lb[ci] = nn_lower_bound_others(r);
+          if (r.pos != prev_pos) {                 // (the previous neighbour confirmed: its copies are in place)
+            A.corr_q[ci] = corr_vec(A.sorted[Ss.off + r.pos]);
+            A.corr_n[ci] = A.normals[Ss.off + r.pos];
+          }
+          done = true;
+        }
+      }
+      nn_query<0, 2>(P, slots[P.slot_t], Ss, (int)e.x, (int)e.z - P.corr_off, need && !done, A, max_d, dbg | 2048, nullptr,
                      nullptr, P.T_nn);
     }
     return;
