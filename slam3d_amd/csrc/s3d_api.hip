@@ -651,7 +651,12 @@ struct Batch {
       }
       int* err = (int*)ctx->n_active.p + 7;
       for (int p = 0; p < passes; ++p) {
-        k_sort_onesweep<BITS><<<blocks, kBlock, 0, st>>>(gslots, ki, vi, ko, vo, cnt, dtot, p, nb_sort, nslots, err);
+        // (hist_done: the keys come from k_keys_hist, whose values are the identity and are not stored: the first pass
+        // takes an element's index for its value)
+        if (p == 0 && hist_done)
+          k_sort_onesweep<BITS, true><<<blocks, kBlock, 0, st>>>(gslots, ki, vi, ko, vo, cnt, dtot, p, nb_sort, nslots, err);
+        else
+          k_sort_onesweep<BITS, false><<<blocks, kBlock, 0, st>>>(gslots, ki, vi, ko, vo, cnt, dtot, p, nb_sort, nslots, err);
         std::swap(ki, ko);
         std::swap(vi, vo);
       }
@@ -662,7 +667,10 @@ struct Batch {
       if (p > 0 || !hist_done) k_sort_hist<BITS><<<dim3(nb_sort, nslots), kBlock, 0, st>>>(gslots, ki, cnt, shift, nb_sort);
       if (nb_sort <= kSortTileMajor) k_sort_scan_tiles<BITS><<<nslots, 256, 0, st>>>(gslots, cnt, dtot, nb_sort);
       else k_sort_scan_rows<BITS><<<dim3(NB / (kBlock / kWave), nslots), kBlock, 0, st>>>(gslots, cnt, dtot, nb_sort);
-      k_sort_scatter<BITS><<<blocks, kBlock, 0, st>>>(gslots, ki, vi, ko, vo, cnt, dtot, shift, nb_sort, nslots);
+      if (p == 0 && hist_done)
+        k_sort_scatter<BITS, true><<<blocks, kBlock, 0, st>>>(gslots, ki, vi, ko, vo, cnt, dtot, shift, nb_sort, nslots);
+      else
+        k_sort_scatter<BITS, false><<<blocks, kBlock, 0, st>>>(gslots, ki, vi, ko, vo, cnt, dtot, shift, nb_sort, nslots);
       std::swap(ki, ko);
       std::swap(vi, vo);
     }

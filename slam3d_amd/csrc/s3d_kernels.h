@@ -403,7 +403,8 @@ __global__ void __launch_bounds__(kBlock) k_keys_hist(const SlotDev* __restrict_
         key = (uint32_t)grid_cell_of_point(s.g, p.x, p.y, p.z);
       }
       keys[s.off + i] = key;
-      vals[s.off + i] = (uint32_t)i;
+      // (no values are written: they are the identity, which the first pass of the sort supplies itself - 4 bytes per
+      // element less to write here and to read there)
       atomicAdd(&hist[0][key & (uint32_t)(NB - 1)], 1u);
       for (int p = 1; p < sweep_passes; ++p) atomicAdd(&hist[p][(key >> (BITS * p)) & (uint32_t)(NB - 1)], 1u);
     }
@@ -519,7 +520,7 @@ __device__ __forceinline__ void sort_rank_rounds(const uint32_t (&key)[ROUNDS], 
 // Stable scatter of one 4096-element tile.  Two block barriers around the digit scans, two around the LDS staging:
 // the tile is first put in digit order in LDS, then written out with consecutive threads on consecutive addresses of
 // each digit run (a direct scatter issues 64 unrelated 4-byte stores per wave and array).
-template <int BITS>
+template <int BITS, bool IDENT = false>
 __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restrict__ slots,
                                                           const uint32_t* __restrict__ keys_in,
                                                           const uint32_t* __restrict__ vals_in,
@@ -556,7 +557,7 @@ __global__ void __launch_bounds__(kBlock) k_sort_scatter(const SlotDev* __restri
   for (int r = 0; r < kRounds; ++r) {                       // all loads up front (independent)
     const int i = base + r * kWave + lane;
     key[r] = 0; val[r] = 0;
-    if (i < n) { key[r] = keys_in[s.off + i]; val[r] = vals_in[s.off + i]; }
+    if (i < n) { key[r] = keys_in[s.off + i]; val[r] = IDENT ? (uint32_t)i : vals_in[s.off + i]; }   // (IDENT: the values are the identity, not stored)
   }
   sort_rank_rounds<BITS, kRounds>(key, rank, base, n, shift, wave_cnt[w]);
   __syncthreads();
@@ -653,7 +654,7 @@ __global__ void __launch_bounds__(kBlock) k_sort_hist_all(const SlotDev* __restr
   for (int d = threadIdx.x; d < NB; d += kBlock) state[((size_t)blockIdx.y * nb_max + blockIdx.x) * NB + d] = 0u;
 }
 
-template <int BITS>
+template <int BITS, bool IDENT = false>
 __global__ void __launch_bounds__(kBlock) k_sort_onesweep(const SlotDev* __restrict__ slots,
                                                            const uint32_t* __restrict__ keys_in,
                                                            const uint32_t* __restrict__ vals_in,
@@ -689,7 +690,7 @@ __global__ void __launch_bounds__(kBlock) k_sort_onesweep(const SlotDev* __restr
   for (int r = 0; r < kRounds; ++r) {                       // all loads up front (independent)
     const int i = base + r * kWave + lane;
     key[r] = 0; val[r] = 0;
-    if (i < n) { key[r] = keys_in[s.off + i]; val[r] = vals_in[s.off + i]; }
+    if (i < n) { key[r] = keys_in[s.off + i]; val[r] = IDENT ? (uint32_t)i : vals_in[s.off + i]; }   // (IDENT: the values are the identity, not stored)
   }
   sort_rank_rounds<BITS, kRounds>(key, rank, base, n, shift, wave_cnt[w]);
   __syncthreads();
