@@ -934,9 +934,10 @@ struct Batch {
         else
           s3d_nn_record_test_kernel<1><<<(unsigned)nblocks, kBlock, 0, st>>>(
               d_pairs(), d_slots(), bpp, P(), wave_recs(), t_hist(), hist_stride(), cnt, nsub, sub_cap, rl, pc);
-        // one wave per failing record while at most a quarter of the records fail (the waves without an entry leave
-        // after one load); beyond that the waves loop
-        const long long waves = std::max<long long>(std::min<long long>((long long)P() * nrec, 7168), (long long)P() * nrec / 4);
+        // one wave per failing record while at most an eighth of the records fail (the waves without an entry leave
+        // after one load); beyond that the waves loop.  (A quarter until round 5: a settled pass fails ~10 %, and the
+        // dispatch of the empty waves was 5 of its 63 us; a sixteenth costs pass 5, which fails 18 %, more than it saves.)
+        const long long waves = std::max<long long>(std::min<long long>((long long)P() * nrec, 7168), (long long)P() * nrec / 8);
         const int tblocks = std::max(cdiv(cdiv((int)waves, kBlock / kWave), nsub), 1) * nsub;   // a multiple of nsub blocks
         s3d_nn_record_touch_kernel<true><<<(unsigned)tblocks, kBlock, 0, st>>>(
             d_pairs(), d_slots(), A, max_d, chunks, P(), wave_recs(), t_hist(), hist_stride(), cnt, nsub, sub_cap, rl, cnt_next,
