@@ -164,3 +164,30 @@ def test_fused_fallback_with_cached_clouds_in_the_batch(gpu_ctx, fixture_clouds)
         for h in (da, db, dh):
             h.release()
         gpu_ctx.cache_control(clear=True)
+
+
+@pytest.mark.parametrize("density", [0.0, 0.25])
+def test_far_knn_paths_agree_on_isolated_points_and_ties(gpu_ctx, density):
+    """The three exact routes of the k-NN pre-pass for what its fast path declines - per-lane search (finishing with one
+    pruned box), the wave-cooperative kernel for small batches, and the latter forced - on clouds built to hurt: a scan
+    plus isolated points tens of metres from anything (their 20-neighbour balls reach into the dense part: thousands of
+    candidates), a lattice patch (every distance a tie) and, without a voxel filter, exact duplicates.  density 0: the
+    two-sort layout (ids = indices); 0.25: the fused layout (ids = voxel keys, neighbours named by position)."""
+    import slam3d_amd as s3d
+    A = s3d.api
+    rng = np.random.default_rng(11)
+    a, b, _ = s3d.make_pair(30000, 5)
+    far = rng.uniform(-150, 150, (60, 3)).astype(np.float32)
+    g = np.arange(12, dtype=np.float32) * np.float32(0.5)
+    lattice = np.stack(np.meshgrid(g, g, g[:3], indexing="ij"), -1).reshape(-1, 3) + np.float32([60, 60, 0])
+    extra = [far, lattice] + ([a[:200]] if density == 0.0 else [])          # (exact duplicates only without a filter)
+    ca = np.ascontiguousarray(np.concatenate([a] + extra))
+    cb = np.ascontiguousarray(np.concatenate([b] + extra))
+    p = s3d.default_params(point_cloud_density=density, maximum_iterations=5)
+    recs = []
+    for flags in (0, A.DBG_KNN_NO_FAR_COOP, A.DBG_KNN_FORCE_FAR_COOP, A.DBG_KNN_EXACT64):
+        st, T, info = gpu_ctx.align(ca, cb, np.eye(4), p, s3d.ExecOptions(force_iterations=1, debug_flags=flags))
+        assert st == 0, (hex(flags), st)
+        recs.append((T, info))
+    for T, info in recs[1:]:
+        assert np.array_equal(T, recs[0][0]) and info == recs[0][1]
