@@ -970,13 +970,11 @@ struct Batch {
     const long long recs = (long long)(std::max<size_t>(total_corr, 4) / kWave + 1);
     return (int)std::min<long long>((recs / kNNSearchSublists + 1) * kWave, 0x7FFFFFF0);
   }
-  int search_parts() const {   // waves per search list: about one per 3 000 queries of the batch (a settled pass searches
-    const long long q = (long long)P() * std::max(max_n_t, 1);   // one query in ~6 000), 1 ... 16
-    return 16;   // (round 5: always the most - a surplus wave leaves after one load, and on real scans, whose settled passes
-                 // list ten times the searches of the synthetic ones, a short list shared by 16 waves is served in a third of
-                 // the time; the formula below gave 1 for 96 pairs of the reference's scans, 9 for the benchmark)
-    return (int)std::max<long long>(4, std::min<long long>(16, q / (3000ll * kNNSearchSublists) + 1));
-  }
+  // waves per search list.  Always 16 (round 5): a surplus wave leaves after one load, and on real scans, whose settled
+  // passes list ten times the searches of the synthetic ones, a short list shared by 16 waves is served in a third of the
+  // time (until then: one wave per ~3 000 queries of the batch, 1 ... 16 - 1 for 96 pairs of the reference's scans, 9
+  // for the benchmark)
+  int search_parts() const { return 16; }
   int rec_blocks() const {
     const int nrec = cdiv(std::max(max_n_t, 1), kWave), rpt = rec_per_thread();
     const int pairs8 = P() >= 8 ? cdiv(P(), 8) * 8 : std::max(P(), 1);
