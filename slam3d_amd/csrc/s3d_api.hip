@@ -535,8 +535,10 @@ struct Batch {
     const size_t nc = std::max<size_t>(total_corr, 4);
     const size_t npi = icp_buffers ? np : 4;
     has_sorted3 = icp_buffers;
-    ctx->carve({{&ctx->slots, sizeof(SlotDev) * std::max(1, C())},
-                {&ctx->pairs, sizeof(PairDev) * std::max(1, P())},
+    // the batch's records live in ONE region - slots | pairs | a 16-byte tail (the sort's error word) | the list of the
+    // slots K4 runs on - so that they go up in one copy and come back in one (round 5: six 4-us copies and a fill in front
+    // of and behind a lone registration were three)
+    ctx->carve({{&ctx->slots, records_bytes() + 64},
                 {&ctx->keysA, 4 * np}, {&ctx->keysB, 4 * np}, {&ctx->valsA, 4 * np}, {&ctx->valsB, 4 * np},
                 {&ctx->filt, 16 * np}, {&ctx->sorted, 16 * np}, {&ctx->sorted3, 12 * npi}, {&ctx->normals, sizeof(NormalRec) * npi}, {&ctx->moments, 72 * npi},
                 {&ctx->cell_start, 4 * std::max<size_t>(total_cells, 4)},
@@ -556,8 +558,11 @@ struct Batch {
                 {&ctx->rec_counts, sizeof(int) * 2 * (kNNRecSublists + kNNSearchSublists)},
                 {&ctx->search_list, sizeof(uint4) * (icp_buffers && settled_wanted() ? (size_t)kNNSearchSublists * (size_t)search_sub_cap() : 1)},
                 {&ctx->t_hist, sizeof(Mat4f) * (icp_buffers ? (size_t)std::max(1, P()) * (size_t)hist_stride() : 1)},
-                {&ctx->knn_list, sizeof(int) * (size_t)std::max(1, C())},
                 {&ctx->knn_fallback, sizeof(int) * npi}, {&ctx->knn_redo, sizeof(int2) * npi}});
+    ctx->pairs.p = (char*)ctx->slots.p + slots_bytes();
+    ctx->pairs.cap = sizeof(PairDev) * (size_t)P();
+    ctx->knn_list.p = (char*)ctx->slots.p + slots_bytes() + pairs_bytes() + 16;
+    ctx->knn_list.cap = sizeof(int) * (size_t)C();
     if (!ctx->h_active) HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
 
     assign_want_normals();
@@ -581,12 +586,22 @@ struct Batch {
   }
   std::vector<SlotDev> h_slots0;
   std::vector<PairDev> h_pairs0;
+  size_t slots_bytes() const { return sizeof(SlotDev) * (size_t)C(); }
+  size_t pairs_bytes() const { return sizeof(PairDev) * (size_t)P(); }
+  size_t records_bytes() const { return slots_bytes() + pairs_bytes() + 16 + sizeof(int) * (size_t)C(); }
+  int* sort_err_dev() { return (int*)((char*)ctx->slots.p + slots_bytes() + pairs_bytes()); }
   void upload_records() {
     hipStream_t st = ctx->stream;
-    const size_t bs = sizeof(SlotDev) * (size_t)C(), bp = sizeof(PairDev) * (size_t)P();
-    char* stage = ctx->stage_host(bs + bp + 16);
-    if (bs) { std::memcpy(stage, h_slots.data(), bs); HIPCHK(hipMemcpyAsync(ctx->slots.p, stage, bs, hipMemcpyHostToDevice, st)); }
-    if (bp) { std::memcpy(stage + bs, h_pairs.data(), bp); HIPCHK(hipMemcpyAsync(ctx->pairs.p, stage + bs, bp, hipMemcpyHostToDevice, st)); }
+    const size_t bs = slots_bytes(), bp = pairs_bytes();
+    knn_slots.clear();               // the slots K4 runs on (stage_normals)
+    for (int c = 0; c < C(); ++c)
+      if (h_slots[(size_t)c].want_normals) knn_slots.push_back(c);
+    char* stage = ctx->stage_host(records_bytes());
+    if (bs) std::memcpy(stage, h_slots.data(), bs);
+    if (bp) std::memcpy(stage + bs, h_pairs.data(), bp);
+    std::memset(stage + bs + bp, 0, 16);           // (the sort's error word starts at zero)
+    if (!knn_slots.empty()) std::memcpy(stage + bs + bp + 16, knn_slots.data(), sizeof(int) * knn_slots.size());
+    HIPCHK(hipMemcpyAsync(ctx->slots.p, stage, bs + bp + 16 + sizeof(int) * knn_slots.size(), hipMemcpyHostToDevice, st));
   }
 
   // segmented LSD radix sort of (keys, vals) of every slot: `passes` digits of `bits` bits (8, 9 or 10).
@@ -641,15 +656,12 @@ struct Batch {
     SlotDev* gslots = d_slots();
     const unsigned blocks = (unsigned)((nslots >= 8 ? cdiv(nslots, 8) * 8 : nslots) * nb_sort);
     if (!sort_classic) {
-      if (!sort_used) {     // the first sort of this batch clears the error word (stream order: before any look-back)
-        HIPCHK(hipMemsetAsync((int*)ctx->n_active.p + 7, 0, sizeof(int), st));
-        sort_used = true;
-      }
+      sort_used = true;     // (the error word was zeroed with the records' upload)
       if (!hist_done) {
         sort_prepare(nslots);
         k_sort_hist_all<BITS><<<dim3(nb_sort, nslots), kBlock, 0, st>>>(gslots, ki, dtot, cnt, passes, nb_sort);
       }
-      int* err = (int*)ctx->n_active.p + 7;
+      int* err = sort_err_dev();
       for (int p = 0; p < passes; ++p) {
         // (hist_done: the keys come from k_keys_hist, whose values are the identity and are not stored: the first pass
         // takes an element's index for its value)
@@ -769,14 +781,9 @@ struct Batch {
     }
     double* mom = (double*)ctx->moments.p;
     const size_t mom_plane = std::max<size_t>(total_pts, 4);   // nine planes, one double per point each
-    std::vector<int>& list = knn_slots;   // (a member: the asynchronous copy below reads it)
-    list.clear();
-    for (int c = 0; c < C(); ++c)
-      if (h_slots[(size_t)c].want_normals) list.push_back(c);
-    const int NL = (int)list.size();
+    const int NL = (int)knn_slots.size();   // (the list went up with the records: upload_records)
     if (NL == 0) return;
     int* d_list = (int*)ctx->knn_list.p;
-    HIPCHK(hipMemcpyAsync(d_list, list.data(), sizeof(int) * (size_t)NL, hipMemcpyHostToDevice, st));
     const int slots8 = NL >= 8 ? cdiv(NL, 8) * 8 : NL;
     dim3 grid((unsigned)(slots8 * nb_head));
     // the points whose normal the closed form declines (s3d_kernels.h): a device-side list, counted in n_active[4]
@@ -1080,15 +1087,14 @@ struct Batch {
 
   void download() {
     hipStream_t st = ctx->stream;
-    const size_t bs = sizeof(SlotDev) * (size_t)C(), bp = sizeof(PairDev) * (size_t)P();
-    char* stage = ctx->stage_host(bs + bp + 16);   // (the uploads of this call have completed by now: stream order)
-    if (bs) HIPCHK(hipMemcpyAsync(stage, ctx->slots.p, bs, hipMemcpyDeviceToHost, st));
-    if (bp) HIPCHK(hipMemcpyAsync(stage + bs, ctx->pairs.p, bp, hipMemcpyDeviceToHost, st));
-    // the one-sweep sort's look-back gives up after ~4 M polls instead of hanging the device: that must not pass silently
+    const size_t bs = slots_bytes(), bp = pairs_bytes();
+    char* stage = ctx->stage_host(records_bytes());   // (the uploads of this call have completed by now: stream order)
+    // slots, pairs and the sort's error word in one copy (the one-sweep sort's look-back gives up after ~4 M polls instead
+    // of hanging the device: that must not pass silently)
     int* sort_err = (int*)(stage + bs + bp);
-    *sort_err = 0;
-    if (sort_used) HIPCHK(hipMemcpyAsync(sort_err, (int*)ctx->n_active.p + 7, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(stage, ctx->slots.p, bs + bp + 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (!sort_used) *sort_err = 0;
     HIPCHK(hipGetLastError());
     if (*sort_err) throw HipError{hipErrorLaunchFailure, "radix sort: a tile waited for its predecessor beyond the poll limit", __LINE__};
     if (bs) std::memcpy(h_slots.data(), stage, bs);
