@@ -719,6 +719,7 @@ struct Batch {
   // with a voxel filter and k <= 32 (cache entries of this layout hold no `filt` and are keyed apart); a slot it cannot
   // serve reports so (FusedGrid::ok < 0) and run_all() runs the batch again on the two-sort path.
   bool fused = false;
+  bool k4_counters_zeroed = false;   // the pre-pass's first kernel has cleared K4's list counters (stage_normals need not)
   bool fused_wanted() const {
     return rp.leaf > 0.f && rp.k <= 32 && has_sorted3 && !(opts.debug_flags & S3D_DBG_NO_FUSED_PREPASS);
   }
@@ -727,10 +728,12 @@ struct Batch {
     const int NS = Cu;
     if (NS == 0) return;
     sort_choose();
-    k_bbox<0><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), NS), kBlock, 0, st>>>(d_slots(), filt());
+    // (the first kernel also clears the sort's digit totals and K4's list counters: two fill launches less)
+    k_bbox<0><<<dim3(cdiv(std::max(max_n, 1), kBlock * 4), NS), kBlock, 0, st>>>(
+        d_slots(), filt(), sort_classic ? nullptr : (uint32_t*)ctx->digit_tot.p, (int*)ctx->n_active.p + 4);
+    k4_counters_zeroed = true;
     k_voxel_params<<<cdiv(NS, 64), 64, 0, st>>>(d_slots(), rp, NS);
     k_fused_grid_params<<<cdiv(NS, 64), 64, 0, st>>>(d_slots(), NS);
-    sort_prepare(NS);
     k_keys_hist<2, 8><<<dim3(nb_sort, NS), kBlock, 0, st>>>(d_slots(), filt(), kA(), vA(), (uint32_t*)ctx->counts.p, nb_sort,
                                                               sort_classic ? 0 : 4, (uint32_t*)ctx->digit_tot.p);
     sort(SortPlan{4, 8}, NS, true);      // (32-bit keys: the host does not know how many bits a slot's keys use)
@@ -789,7 +792,9 @@ struct Batch {
     // the points whose normal the closed form declines (s3d_kernels.h): a device-side list, counted in n_active[4]
     int* fb_count = (int*)ctx->n_active.p + 4;
     int* fb_list = (int*)ctx->knn_fallback.p;
-    HIPCHK(hipMemsetAsync(fb_count, 0, 3 * sizeof(int), st));   // eigen fallback, near redo, far / cooperative list
+    if (!k4_counters_zeroed)
+      HIPCHK(hipMemsetAsync(fb_count, 0, 3 * sizeof(int), st));   // eigen fallback, near redo, far / cooperative list
+    k4_counters_zeroed = false;
     // k = 20 (the reference default): 32-bit keys + med3 insertion; what it does not answer goes through the exact
     // 64-bit search (redo list, counted in n_active[5]).  S3D_DBG_KNN_EXACT64: the 64-bit search for every point.
     const bool exact64 = (opts.debug_flags & S3D_DBG_KNN_EXACT64) != 0;

@@ -208,8 +208,18 @@ __device__ __forceinline__ void block_bbox_merge(unsigned int (&mn)[3], unsigned
 }
 
 // which = 0: raw points (n_raw); 1: filtered points (n)
+// zero_digit_tot / zero_counters (may be null): what the stages after this first kernel of the pre-pass want cleared - the
+// digit totals of the one-sweep sort (kSortPlaces << kSortMaxBits words per slot) and the three K4 list counters - so
+// that a lone registration does not pay two more 4-us fill launches
 template <int WHICH>
-__global__ void __launch_bounds__(kBlock) k_bbox(SlotDev* slots, const float4* __restrict__ filt) {
+__global__ void __launch_bounds__(kBlock) k_bbox(SlotDev* slots, const float4* __restrict__ filt,
+                                                  uint32_t* __restrict__ zero_digit_tot = nullptr,
+                                                  int* __restrict__ zero_counters = nullptr) {
+  if (blockIdx.x == 0) {
+    if (zero_digit_tot)
+      for (int d = threadIdx.x; d < (4 << 10); d += kBlock) zero_digit_tot[(size_t)blockIdx.y * (4 << 10) + d] = 0u;
+    if (zero_counters && blockIdx.y == 0 && threadIdx.x < 3) zero_counters[threadIdx.x] = 0;
+  }
   SlotDev& s = slots[blockIdx.y];
   const int n = WHICH == 0 ? s.n_raw : s.n;
   const float4* __restrict__ p = WHICH == 0 ? s.raw : filt + s.off;
@@ -369,6 +379,7 @@ __global__ void __launch_bounds__(kBlock) k_sort_hist(const SlotDev* __restrict_
 // sweep_passes > 0 (the one-sweep sort below): the digit totals of that many BITS-bit places go to digit_tot_all instead,
 // and `counts` is the look-back state, whose row of this tile is zeroed.
 constexpr int kSortPlaces = 4;
+static_assert(kSortPlaces == 4 && kSortMaxBits == 10, "k_bbox clears (4 << 10) digit totals per slot");
 template <int WHICH, int BITS>
 __global__ void __launch_bounds__(kBlock) k_keys_hist(const SlotDev* __restrict__ slots, const float4* __restrict__ filt,
                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
