@@ -9,8 +9,8 @@ import pytest
 from conftest import ROOT
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "slam3d_hip.h")).read()
+def declared_symbols(header="slam3d_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(s3d_[a-z0-9_]+)\s*\(", text)))
 
@@ -25,6 +25,13 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "missing export: " + n
     L = slam3d_amd.load_library()
     assert sorted(L._s3d_symbols) == names     # the binding declares exactly the header's functions
+    # the test hooks of include/slam3d_hip_debug.h (not API: the public header must not pull them in)
+    hooks = declared_symbols("slam3d_hip_debug.h")
+    assert hooks == ["s3d_debug_filtered_nn", "s3d_debug_fused_reruns"]
+    for n in hooks:
+        assert hasattr(lib, n), "missing export: " + n
+    public = open(os.path.join(ROOT, "include", "slam3d_hip.h")).read()
+    assert "#include \"slam3d_hip_debug.h\"" not in public and "#define S3D_DBG_" not in public
 
 
 def test_struct_layouts_match_the_header(tmp_path):
