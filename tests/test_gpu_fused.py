@@ -191,3 +191,54 @@ def test_far_knn_paths_agree_on_isolated_points_and_ties(gpu_ctx, density):
         recs.append((T, info))
     for T, info in recs[1:]:
         assert np.array_equal(T, recs[0][0]) and info == recs[0][1]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fused_prepass_fuzz_on_odd_clouds(gpu_ctx, oracle_mod, seed):
+    """Random odd inputs through the fused pre-pass: volumes, planes with far outliers, a line, exact duplicates, the
+    benchmark scene, non-finite points, random voxel sizes (some of which PCL's index cannot hold).  Wherever the device
+    says it served the cloud (fused_ok == 1) the filtered cloud is pcl::VoxelGrid's bit for bit and the neighbours are the
+    oracle's; otherwise it must have declined, never produced something else."""
+    import slam3d_amd as s3d
+    rng = np.random.default_rng(seed)
+
+    def cloud(kind, n):
+        if kind == 0:
+            return rng.uniform(-20, 20, (n, 3)).astype(np.float32)
+        if kind == 1:
+            p = rng.uniform(-30, 30, (n, 3)).astype(np.float32)
+            p[: n // 2, 2] = rng.normal(0, 0.02, n // 2)
+            p[-5:] *= 40
+            return p
+        if kind == 2:
+            return (rng.normal(0, 1, (n, 3)) * [30, 0.05, 0.05]).astype(np.float32)
+        if kind == 3:
+            return np.repeat(rng.uniform(-5, 5, (max(n // 8, 1), 3)).astype(np.float32), 8, 0)
+        return s3d.make_scene_cloud(n, int(rng.integers(1 << 30))).astype(np.float32)
+
+    served = declined = 0
+    for case in range(14):
+        kind = int(rng.integers(5)); n = int(rng.integers(150, 40000))
+        a, b = cloud(kind, n), cloud(kind, max(n // 2, 120))
+        if rng.random() < 0.3:
+            a = a.copy(); a[rng.integers(0, len(a), 7)] = np.nan; a[rng.integers(0, len(a), 3), 1] = np.inf
+        leaf = float(rng.choice([0.003, 0.05, 0.2, 0.5, 1.0, 3.0]))
+        da, db = gpu_ctx.upload(a), gpu_ctx.upload(b)
+        try:
+            f = gpu_ctx.debug_filtered_nn(da, db, leaf, True, 2.5)
+        finally:
+            da.release(); db.release()
+        if f["fused_ok"] != 1:
+            declined += 1
+            continue
+        served += 1
+        va, _ = oracle_mod.voxel_downsample(a, leaf)
+        vb, _ = oracle_mod.voxel_downsample(b, leaf)
+        fs, ft, fnn, fd2 = _by_id(f)
+        assert np.array_equal(fs, va) and np.array_equal(ft, vb), (seed, case, kind, n, leaf)
+        if len(va) and len(vb):
+            oi, od = oracle_mod.nn_search(va, vb)
+            m = od < 2.5 ** 2
+            assert np.array_equal(fnn[m], oi[m]) and np.array_equal(fd2[m], od[m]), (seed, case, kind, n, leaf)
+            assert np.all((fnn[~m] == -1) | (fd2[~m] >= 2.5 ** 2))
+    assert served >= 8, (served, declined)
