@@ -34,7 +34,8 @@ typedef struct s3d_cloud   s3d_cloud;   /* a device-resident point cloud (immuta
 /* knobs that are not part of slam3d::RegistrationParameters */
 typedef struct s3d_exec_options {
   int force_iterations;     /* != 0: run exactly maximum_iterations outer iterations (bench mode, no early exit) */
-  int check_interval;       /* host polls "all pairs converged" every N outer iterations (0 = default 4)          */
+  int check_interval;       /* 0 (default): the device reports its progress, the host never waits inside the loop;
+                               N > 0: the host polls "all pairs converged" every N outer iterations instead       */
   int grid_cells_per_point; /* search-grid budget, cells per input point (0 = default 2)                         */
   int profile;              /* != 0: record per-stage HIP-event timings, read with s3d_last_profile();
                                >= 2: also count the searched queries per NN launch (slows the first passes)      */

@@ -168,7 +168,9 @@ struct s3d_context {
   // workspace (grown on demand, reused across calls)
   DevBuf slots, pairs, keysA, keysB, valsA, valsB, filt, sorted, sorted3, normals, moments, cell_start, counts, digit_tot, blockcnt, blockbb,
       corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active, knn_list, knn_fallback, knn_redo, wave_recs, t_hist, worklist, rec_list, rec_counts, search_list;
-  int* h_active = nullptr;  // pinned
+  int* h_active = nullptr;  // pinned: [0] the polled active-pair counter, [4], [5] the ICP loop's progress words (stage_icp)
+  int* h_active_dev = nullptr;   // the same words as the device addresses them
+  int icp_tag_counter = 0;
   // pinned staging of the slot / pair records (up and down): a copy from or to pageable memory stalls the stream for
   // tens of microseconds, which a single-pair registration of ~1.5 ms notices
   char* h_stage = nullptr;
@@ -316,7 +318,6 @@ struct Batch {
   void set_params(const s3d_reg_params* p, const s3d_exec_options* o) {
     if (o) opts = *o;
     dbg_nn = (int)(opts.debug_flags & 0x001FFFFFu);
-    if (opts.check_interval <= 0) opts.check_interval = 4;
     if (opts.grid_cells_per_point <= 0) opts.grid_cells_per_point = 2;
     rp.algorithm = p->registration_algorithm == S3D_ALG_ICP ? 0 : 1;
     rp.k = p->correspondence_randomness;
@@ -563,7 +564,11 @@ struct Batch {
     ctx->pairs.cap = sizeof(PairDev) * (size_t)P();
     ctx->knn_list.p = (char*)ctx->slots.p + slots_bytes() + pairs_bytes() + 16;
     ctx->knn_list.cap = sizeof(int) * (size_t)C();
-    if (!ctx->h_active) HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
+    if (!ctx->h_active) {
+      HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
+      std::memset(ctx->h_active, 0, 64);
+      if (hipHostGetDevicePointer((void**)&ctx->h_active_dev, ctx->h_active, 0) != hipSuccess) ctx->h_active_dev = nullptr;
+    }
 
     assign_want_normals();
     for (SlotDev& sl : h_slots)
@@ -1028,10 +1033,22 @@ struct Batch {
     if (!rp.algorithm)
       s3d_p2plane_accumulate_kernel<<<dim3(accum_blocks, P()), kBlock, 0, st>>>(
           d_pairs(), d_slots(), sorted3(), (CorrVec*)ctx->corr_q.p, (NormalRec*)ctx->corr_n.p, part, rp);
-    s3d_icp_control_kernel<<<P(), kCtrlThreads, 0, st>>>(d_pairs(), part, rp, (int*)ctx->n_active.p, t_hist(), hist_stride());
+    s3d_icp_control_kernel<<<P(), kCtrlThreads, 0, st>>>(d_pairs(), part, rp, (int*)ctx->n_active.p, t_hist(), hist_stride(),
+                                                         icp_host_word, icp_launch++, icp_tag);
   }
+  // the progress word of this batch's ICP loop (stage_icp; null: nobody listens), the index of the next controller launch
+  int* icp_host_word = nullptr;
+  int icp_launch = 0, icp_tag = 0;
 
-  // K5-K7 loop.  The host only polls the active-pair counter every check_interval iterations.
+  // K5-K7 loop.  Converged pairs stop on the device at once (every kernel of an iteration leaves when its pair is
+  // inactive); what the host has to learn is when to stop LAUNCHING.  Default (check_interval = 0): the controller kernel
+  // reports through two words of pinned host memory - the index of the newest iteration whose controller has started, and
+  // a tag once the last active pair has stopped - and the host launches iteration `it` as soon as iteration it - kIcpAhead
+  // is reported, never waiting for the stream: no copy, no drained queue (the stream wait + copy of a poll left the device
+  // idle for ~28 us, twice in a registration of two of the reference's scans), at most kIcpAhead empty iterations after
+  // the last pair has stopped.  check_interval = N > 0: the host copies the active-pair counter every N iterations and
+  // waits for it (the form of rounds 1-4).  Forced iterations: everything is launched at once.
+  static constexpr int kIcpAhead = 2;
   void stage_icp() {
     hipStream_t st = ctx->stream;
     if (P() == 0) return;
@@ -1050,26 +1067,59 @@ struct Batch {
     const float max_d = (float)(rp.max_corr * 1.0001);
     const bool prof = opts.profile != 0;
     if (prof) HIPCHK(hipMemsetAsync((int*)ctx->n_active.p + 16, 0, 4 * 64 * sizeof(int), st));
+    auto launch_one = [&](int it) {
+      if (prof) {
+        if ((int)ctx->nn_ev.size() < 2 * (it + 1)) {
+          hipEvent_t a, b;
+          HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+          ctx->nn_ev.push_back(a); ctx->nn_ev.push_back(b);
+        }
+        HIPCHK(hipEventRecord(ctx->nn_ev[2 * it], st));
+        launch_nn(0, max_d, opts.profile >= 2 ? it : -1, false, it);
+        HIPCHK(hipEventRecord(ctx->nn_ev[2 * it + 1], st));
+        launch_iteration_after_nn();
+      } else {
+        launch_iteration(it, max_d, -1);
+      }
+      ctx->prof.nn_launches = it + 1;
+    };
+    icp_host_word = nullptr; icp_launch = 0; icp_tag = 0;
+    ctx->prof.nn_launches = 0;
+    if (!rp.force_iterations && opts.check_interval <= 0 && ctx->h_active_dev) {
+      // (every earlier call of this context has waited for its stream: nothing on the device still writes these words)
+      volatile int* hw = ctx->h_active + 4;
+      icp_tag = ++ctx->icp_tag_counter;
+      if (icp_tag == 0) icp_tag = ++ctx->icp_tag_counter;
+      hw[0] = -1; hw[1] = 0;
+      __atomic_thread_fence(__ATOMIC_SEQ_CST);
+      icp_host_word = ctx->h_active_dev + 4;
+      for (int it = 0; it < rp.max_iterations; ++it) {
+        bool done = false;
+        for (unsigned spins = 1;; ++spins) {
+          if (__atomic_load_n((const int*)&hw[1], __ATOMIC_ACQUIRE) == icp_tag) { done = true; break; }
+          if (__atomic_load_n((const int*)&hw[0], __ATOMIC_RELAXED) >= it - kIcpAhead) break;
+          if ((spins & 1023u) == 0) {
+            // a failed launch or a drained stream must not leave the host spinning
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) {
+              done = __atomic_load_n((const int*)&hw[1], __ATOMIC_ACQUIRE) == icp_tag;
+              break;
+            }
+            if (q != hipErrorNotReady) HIPCHK(q);
+          }
+          __builtin_ia32_pause();
+        }
+        if (done) break;
+        launch_one(it);
+      }
+      icp_host_word = nullptr;
+      return;
+    }
     // segments of iterations between two polls of the active-pair counter (all of them when the count is forced)
-    const int seg = rp.force_iterations ? std::max(rp.max_iterations, 1) : opts.check_interval;
+    const int seg = rp.force_iterations ? std::max(rp.max_iterations, 1) : std::max(opts.check_interval, 1);
     for (int it0 = 0; it0 < rp.max_iterations; it0 += seg) {
       const int it1 = std::min(it0 + seg, rp.max_iterations);
-      for (int it = it0; it < it1; ++it) {
-        if (prof) {
-          if ((int)ctx->nn_ev.size() < 2 * (it + 1)) {
-            hipEvent_t a, b;
-            HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-            ctx->nn_ev.push_back(a); ctx->nn_ev.push_back(b);
-          }
-          HIPCHK(hipEventRecord(ctx->nn_ev[2 * it], st));
-          launch_nn(0, max_d, opts.profile >= 2 ? it : -1, false, it);
-          HIPCHK(hipEventRecord(ctx->nn_ev[2 * it + 1], st));
-          launch_iteration_after_nn();
-        } else {
-          launch_iteration(it, max_d, -1);
-        }
-      }
-      ctx->prof.nn_launches = it1;
+      for (int it = it0; it < it1; ++it) launch_one(it);
       if (!rp.force_iterations && it1 < rp.max_iterations) {
         HIPCHK(hipMemcpyAsync(ctx->h_active, d_active, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));

@@ -2576,8 +2576,16 @@ constexpr int kCtrlGroups = 8;      // the root of the fixed summation tree: 8 g
 static_assert(kAccumVB % kCtrlGroups == 0 && kAccumVB % 8 == 0, "the tree roots deal the virtual blocks in whole groups");
 constexpr int kCtrlThreads = 128;   // threads that load the tree root (the stand-alone kernel's block size: more
                                     // would cap the optimiser's registers below the 256 it uses)
+// host_word (may be null; pinned host memory the device writes through): [0] the index of the newest outer iteration
+// whose controller has started (written by the kernel, block 0), [1] = tag once the last active pair of the batch has
+// stopped - what the host throttles and ends its launch loop by (Batch::stage_icp) without ever waiting for the stream.
+__device__ __forceinline__ void icp_report_done(int* n_active, int* host_word, int tag) {
+  if (atomicSub(n_active, 1) == 1 && host_word)
+    __hip_atomic_store(host_word + 1, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ void icp_control_pair(PairDev& P, const double* __restrict__ pair_partials, const RunParams& rp,
-                                                 int* n_active, Mat4f* __restrict__ pair_hist, int hist_stride) {
+                                                 int* n_active, Mat4f* __restrict__ pair_hist, int hist_stride,
+                                                 int* host_word = nullptr, int tag = 0) {
   __shared__ double grp[kCtrlGroups][GQ_NACC];
   __shared__ double acc[GQ_NACC];
   const bool gicp = rp.algorithm != 0;
@@ -2644,7 +2652,7 @@ __device__ __forceinline__ void icp_control_pair(PairDev& P, const double* __res
   if (pair_hist && it - 1 < hist_stride) pair_hist[it - 1] = prev;
   if (rc) {  // PCLException path: loop breaks, converged_ stays false
     P.active = 0; P.converged = 0;
-    atomicSub(n_active, 1);
+    icp_report_done(n_active, host_word, tag);
     return;
   }
   P.inner_total += inner; P.evals_total += evals;
@@ -2652,7 +2660,7 @@ __device__ __forceinline__ void icp_control_pair(PairDev& P, const double* __res
   P.iterations = it;
   if (it >= rp.max_iterations || (!rp.force_iterations && delta < 1.0)) {
     P.converged = 1; P.active = 0; P.prev = T;
-    atomicSub(n_active, 1);
+    icp_report_done(n_active, host_word, tag);
   }
 }
 
@@ -2661,11 +2669,14 @@ __device__ __forceinline__ void icp_control_pair(PairDev& P, const double* __res
 // accumulate kernel's: 240 -> 328, one wave per SIMD instead of two, which costs more than the launch.)
 __global__ void __launch_bounds__(kCtrlThreads) s3d_icp_control_kernel(PairDev* pairs, const double* __restrict__ partials,
                                                                         RunParams rp, int* n_active,
-                                                                        Mat4f* __restrict__ T_hist, int hist_stride) {
+                                                                        Mat4f* __restrict__ T_hist, int hist_stride,
+                                                                        int* host_word, int launch, int tag) {
+  if (host_word && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(host_word, launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   PairDev& P = pairs[blockIdx.x];
   if (!P.active) return;
   icp_control_pair(P, partials + (size_t)blockIdx.x * kAccumVB * GQ_NACC, rp, n_active,
-                   T_hist ? T_hist + (size_t)blockIdx.x * hist_stride : nullptr, hist_stride);
+                   T_hist ? T_hist + (size_t)blockIdx.x * hist_stride : nullptr, hist_stride, host_word, tag);
 }
 
 // GICP: Mahalanobis matrix + 73-term quadratic form (s3d_core.h "GICP quadratic form")

@@ -251,8 +251,9 @@ def test_omp_enumerators_follow_the_build_switch(gpu_ctx, oracle_mod):
 
 
 def test_check_interval_does_not_change_results(gpu_ctx, fixture_clouds):
-    """s3d_exec_options.check_interval (how often the host polls "all pairs converged"; 0 = default 4) is a polling
-    cadence only: converged pairs stop iterating on the device at once, whatever the interval."""
+    """s3d_exec_options.check_interval (N > 0: how often the host polls "all pairs converged") is a polling
+    cadence only: converged pairs stop iterating on the device at once, whatever the interval; the default (0) is the
+    device-reported progress word - the host never waits inside the loop."""
     import slam3d_amd as s3d
     p = s3d.default_params()
     ref = gpu_ctx.align(fixture_clouds[0], fixture_clouds[1], np.eye(4), p)
@@ -764,6 +765,26 @@ def test_bench_ranks_share_one_gpu_over_gloo(ranks, port):
     assert line["distinct_pairs_gathered"] == 4 * ranks        # no rank registered another rank's pairs
     sw = line["sweep_abi"]
     assert sw["ranks"] == ranks and sw["equals_single_context"] is True and sw["pairs"] == 4 * ranks
+
+
+def test_bench_nccl_branch_with_one_rank():
+    """The branch of bench.py the driver's multi-GPU runs take - torch.distributed over nccl (= RCCL), the edge records
+    gathered by all_gather_into_tensor on DEVICE tensors, barrier + max-over-ranks timing - with the one rank a 1-GPU
+    box admits (RCCL: one rank per device), launched with the driver's own command line (S3D_BENCH_FORCE_DIST=1 keeps
+    the collective path for world size 1)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, S3D_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("S3D_BENCH_BACKEND", None)
+    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                                   "--master-addr", "127.0.0.1", "--master-port", "29551", os.path.join(ROOT, "bench.py"),
+                                   "--gpus", "1", "--steps", "2", "--warmup", "1", "--pairs", "4", "--points", "20000",
+                                   "--no-cpu"], stderr=subprocess.DEVNULL, cwd=ROOT, env=env, timeout=900)
+    line = json.loads(out.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["pairs_per_gpu"] == 4
+    assert "RCCL" in line["config"]["collective"] and not line["config"].get("ranks_share_devices", False)
+    assert line["accuracy"]["status_ok"] == 4 and line["distinct_pairs_gathered"] == 4 and line["value"] > 0
 
 
 def test_concurrent_callers(gpu_ctx, fixture_clouds):
