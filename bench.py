@@ -330,6 +330,44 @@ def main():
                       "ms_per_new_scan_cache_off": round(res["cache_off"], 3),
                       "ms_per_new_scan_cache_on": round(res["cache_on"], 3),
                       "links_per_s_cache_on": round(nb / res["cache_on"] * 1e3, 1)}
+        # ---- secondary: two batches in flight.  A sweep (BASELINE configs[3]: 512 pairs per GPU) is a sequence of batches,
+        # and the tail of one - the settled ICP passes, one-wave-per-pair controller launches - leaves most of the chip
+        # idle while the next one's pre-pass could run.  The library serialises calls per context and runs calls on two
+        # contexts side by side, so a caller pipelines with two contexts and two host threads (s3d_align_batch_multi with
+        # the device listed twice does the same inside the C ABI); one 512-pair call gets the same rate.  The SAME
+        # batches as the timed region, every step still paying the whole pre-pass; never part of `value`.
+        inflight = None
+        if not args.no_single and world == 1 and args.pairs >= 16:
+            import threading
+            ctx2 = s3d.Context(local_rank)
+            both2 = ctx2.upload_many([p[0] for p in pairs] + [p[1] for p in pairs])
+            lanes = [(ctx, src, tgt), (ctx2, both2[:len(pairs)], both2[len(pairs):])]
+            rec2 = None
+            for _ in range(2):
+                rec2 = ctx2.align_batch(lanes[1][1], lanes[1][2], guesses, params, opts)
+            per_lane = max(args.steps // 2, 3)
+
+            def lane_loop(k):
+                c, a, b = lanes[k]
+                for _ in range(per_lane):
+                    c.align_batch(a, b, guesses, params, opts)
+
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            th = [threading.Thread(target=lane_loop, args=(k,)) for k in range(2)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            torch.cuda.synchronize()
+            fl_ms = (time.perf_counter() - t1) / (2 * per_lane) * 1e3
+            inflight = {"workload": "the timed region's batches, two in flight (two contexts, two host threads, %d batches "
+                                    "each)" % per_lane,
+                        "ms_per_batch": round(fl_ms, 3), "registrations_per_s": round(args.pairs / fl_ms * 1e3, 2),
+                        "records_equal_serial": bool(np.array_equal(rec2, rec_local))}
+            for c in both2:
+                c.release()
+            ctx2.close()
         if args.extras:
             single = single or {}
             nn0 = ctx.profile_nn_kernel(src, tgt, guesses, params, reps=args.nn_reps)
@@ -562,6 +600,7 @@ def main():
                       (2 * args.pairs, 2 * args.pairs * args.points * 12 / 1e6),
             "single_pair": single,
             "mapper_pattern": mapper,
+            "two_in_flight": inflight,
             "sweep_abi": sweep_abi,
             "step_ms": step_ms,
             "stage_ms": {k: round(v, 3) for k, v in prof.items() if k.endswith("_ms") and k != "nn_launch_ms"},
