@@ -1116,7 +1116,8 @@ struct Batch {
       return;
     }
     // segments of iterations between two polls of the active-pair counter (all of them when the count is forced)
-    const int seg = rp.force_iterations ? std::max(rp.max_iterations, 1) : std::max(opts.check_interval, 1);
+    // (check_interval <= 0 here: the progress words could not be mapped - the poll of rounds 1-4, every 4 iterations)
+    const int seg = rp.force_iterations ? std::max(rp.max_iterations, 1) : (opts.check_interval > 0 ? opts.check_interval : 4);
     for (int it0 = 0; it0 < rp.max_iterations; it0 += seg) {
       const int it1 = std::min(it0 + seg, rp.max_iterations);
       for (int it = it0; it < it1; ++it) launch_one(it);
