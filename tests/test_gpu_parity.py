@@ -727,6 +727,21 @@ def test_bench_contract_line(tmp_path):
     assert line["cpu_baseline_parallel"]["cores"] == 2
 
 
+def test_bench_two_in_flight_equals_serial():
+    """bench.py's `two_in_flight` leg (the timed region's batches on two contexts from two host threads): reported beside
+    `value`, and the records of the second context equal the serial ones bit for bit."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "16", "--points", "20000",
+                                   "--steps", "2", "--warmup", "1", "--no-cpu", "--no-real"],
+                                  stderr=subprocess.DEVNULL, cwd=ROOT).decode().strip().splitlines()
+    line = json.loads(out[-1])
+    fl = line["two_in_flight"]
+    assert fl["records_equal_serial"] is True and fl["registrations_per_s"] > 0 and fl["ms_per_batch"] > 0
+    assert line["value"] > 0 and line["accuracy"]["status_ok"] == 16
+
+
 def test_ndt_batch_mixed_inputs(gpu_ctx, fixture_clouds):
     """one cloud shared by several pairs, a pair below the 100-point gate and a sparse (cell-less) target in ONE batch"""
     import slam3d_amd as s3d
