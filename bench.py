@@ -61,6 +61,30 @@ def _self_launch(n):
     return subprocess.call(cmd, env=env, cwd=ROOT)
 
 
+def _usable_cpus():
+    """(CPUs this process can keep busy, the cgroup quota in CPUs or None): affinity mask, capped by cpu.max / cfs quota"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,7 +99,7 @@ def main():
                     help="pairs timed one after another on the CPU oracle (rank 0, N=1): ~12 s at the default size")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="also time this many pairs on as many oracle threads at once (cpu_baseline_parallel); 0 = every "
-                         "core of the host (os.cpu_count(), SURVEY 8d 'all cores, pair-parallel'), 1 = off")
+                         "CPU this process may use (affinity mask and cgroup quota; SURVEY 8d 'all cores, pair-parallel'), 1 = off")
     ap.add_argument("--no-real", action="store_true", help="skip the real_scans block (the reference's own scans and defaults)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--nn-reps", type=int, default=20)
@@ -527,6 +551,16 @@ def main():
         pcl_state = "not checked"
         if not args.no_cpu and world == 1:
             import oracle
+            # The port allocates and frees its work arrays per call; with glibc's defaults every large block is an mmap /
+            # munmap pair and its pages are faulted in again - from many threads at once that is one process-wide lock
+            # (8 threads: 3.2x one thread; with the blocks kept on the heap 7.3x).  Keep them: M_MMAP_THRESHOLD,
+            # M_TRIM_THRESHOLD, M_ARENA_MAX.  A fairer all-cores figure, and 4 % for the one-thread figure.
+            try:
+                import ctypes
+                _libc = ctypes.CDLL("libc.so.6")
+                _libc.mallopt(-3, 1 << 30); _libc.mallopt(-1, (1 << 31) - 1); _libc.mallopt(-8, max(os.cpu_count() or 1, 8))
+            except OSError:
+                pass
             op = oracle.default_params(registration_algorithm=alg, point_cloud_density=args.density,
                                        maximum_iterations=args.iters, max_correspondence_distance=2.5,
                                        correspondence_randomness=20)
@@ -536,20 +570,23 @@ def main():
                 oracle.align(pairs[i][0], pairs[i][1], np.eye(4), op, force_iterations=True)
                 times.append(time.perf_counter() - tc)
             # the same port on many cores at once (independent pairs, one thread each; ctypes releases the GIL)
-            nthr = max(1, min(args.cpu_threads if args.cpu_threads > 0 else (os.cpu_count() or 1), os.cpu_count() or 1,
-                              args.pairs))
+            # the cores this process may actually use: its affinity mask and its cgroup's CPU quota (the GPU boxes of this
+            # pool show 256 CPUs and grant 16: 256 threads there are throttled to ~8 cores' worth of progress)
+            usable, quota = _usable_cpus()
+            nthr = max(1, min(args.cpu_threads if args.cpu_threads > 0 else usable, usable, args.pairs))
             cpu_par = None
             if nthr > 1:
                 def _one(i):
                     oracle.align(pairs[i][0], pairs[i][1], np.eye(4), op, force_iterations=True)
+                npar = nthr * max(1, min(4, args.pairs // nthr))      # a few pairs per thread: >= 10 s of sample
                 tp0 = time.perf_counter()
                 with ThreadPool(nthr) as pool:
-                    pool.map(_one, range(nthr))
+                    pool.map(_one, range(npar), chunksize=1)
                 tpar = time.perf_counter() - tp0
-                cpu_par = {"value": round(nthr / tpar, 3), "unit": "registrations/s", "cores": nthr, "kind": "port",
-                           "host_cpus": os.cpu_count(),
-                           "sample": "%d pairs of this workload registered concurrently, one oracle thread each, %.1f s"
-                                     % (nthr, tpar)}
+                cpu_par = {"value": round(npar / tpar, 3), "unit": "registrations/s", "cores": nthr, "kind": "port",
+                           "host_cpus": os.cpu_count(), "cpu_quota": quota,
+                           "sample": "%d pairs of this workload on %d oracle threads at once (glibc kept from returning "
+                                     "the work arrays to the kernel: mallopt), %.1f s" % (npar, nthr, tpar)}
             # the reference's own arithmetic, where this host has PCL (oracle/pcl, built by __graft_entry__.build())
             from oracle import pcl_pin
             pcl_state = pcl_pin.status()
