@@ -1500,8 +1500,9 @@ S3D_HD bool grid_nn1_scan27(const GridParams& g, const uint32_t* __restrict__ ce
     best = f64_min_raw(best, c_);                                                                      \
   }
   bool prescanned = false;
+  const int base_own = g.dim[0] * (iy + g.dim[1] * iz);          // the query's own row
   if (PRESCAN == 2 || (PRESCAN == 1 && seed_d2 >= 1.0e30f)) {   // (2: also next to a seed, whichever is nearer)
-    const int rowbase = g.dim[0] * (iy + g.dim[1] * iz);
+    const int rowbase = base_own;
     const uint32_t a = cell_start[rowbase + imax(ix - 1, 0)], b = cell_start[rowbase + imin(ix + 1, g.dim[0] - 1) + 1];
     for (uint32_t k = a; k < b; k += 2) {          // two loads in flight
       const bool v1 = k + 1 < b;
@@ -1522,17 +1523,30 @@ S3D_HD bool grid_nn1_scan27(const GridParams& g, const uint32_t* __restrict__ ce
     const float b2 = cut ? br * br : 3.0e38f;
     if (cut) reach = br * 0.9999f;
     const float eps = 2.0e-3f * g.h;
+    // (round 5: the kernels of passes 2-3 run at 60-80 % of the VALU issue rate and this per-query set-up is more than half
+    // of their instructions - the slab distances of the three y and the three z layers are computed once instead of per
+    // row, the row bases by additions from the own row's instead of a 64-bit multiply-add and a 32-bit multiply, both
+    // quarter-rate, per row)
+    float fy2[3] = {0.f, 0.f, 0.f}, fz2[3] = {0.f, 0.f, 0.f};
+    if (cut) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float ylo = g.origin[1] + (float)(iy + j - 1) * g.h, zlo = g.origin[2] + (float)(iz + j - 1) * g.h;
+        const float fy = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.h)) - eps, 0.f);
+        const float fz = fmaxf(fmaxf(zlo - qz, qz - (zlo + g.h)) - eps, 0.f);
+        fy2[j] = fy * fy; fz2[j] = fz * fz;
+      }
+    }
+    const int xa0 = imax(ix - 1, 0), xb0 = imin(ix + 1, g.dim[0] - 1);
+    const int stride_y = g.dim[0], stride_z = g.dim[0] * g.dim[1];
     uint32_t rs[9], re[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {   // nine row ranges fetched as one batch
       const int cy = iy + (k % 3) - 1, cz = iz + (k / 3) - 1;
       bool in = cy >= 0 && cy < g.dim[1] && cz >= 0 && cz < g.dim[2];
-      int xa = imax(ix - 1, 0), xb = imin(ix + 1, g.dim[0] - 1);
+      int xa = xa0, xb = xb0;
       if (cut) {
-        const float ylo = g.origin[1] + (float)cy * g.h, zlo = g.origin[2] + (float)cz * g.h;
-        const float fy = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.h)) - eps, 0.f);
-        const float fz = fmaxf(fmaxf(zlo - qz, qz - (zlo + g.h)) - eps, 0.f);
-        const float rowd2 = fy * fy + fz * fz;
+        const float rowd2 = fy2[k % 3] + fz2[k / 3];
         in = in && rowd2 <= b2;
         const float rx = sqrt_bound(fmaxf(b2 - rowd2, 0.f)) * 1.0001f + eps;
         xa = imax(xa, grid_coord(g, 0, qx - rx));
@@ -1540,7 +1554,7 @@ S3D_HD bool grid_nn1_scan27(const GridParams& g, const uint32_t* __restrict__ ce
       }
       in = in && xa <= xb;
       if (PRESCAN && k == 4) in = in && !prescanned;          // (the own row is done)
-      const int rowbase = in ? g.dim[0] * (cy + g.dim[1] * cz) : 0;
+      const int rowbase = in ? base_own + ((k % 3) - 1) * stride_y + ((k / 3) - 1) * stride_z : 0;
       const uint32_t a = cell_start[rowbase + (in ? xa : 0)], b = cell_start[rowbase + (in ? xb + 1 : 0)];
       rs[k] = a; re[k] = in ? b : a;
     }
