@@ -10,13 +10,13 @@ for ln in text[start + 1:]:
     m = re.match(r'^(\.LBB\d+_\d+):', s)
     if m:
         blocks.append(cur); cur = [m.group(1), 0, 0, []]; continue
+    if s.startswith('.Lfunc_end'): break
     if not s or s.startswith(';') or s.startswith('.'): continue
     op = s.split()[0]
     cur[1] += 1
     if op.startswith('v_'): cur[2] += 1
     if 'branch' in op: cur[3].append(op[2:] + '->' + s.split()[-1])
     if op.startswith(('global_load', 'ds_', 'global_store', 'scratch', 'buffer_')): cur[3].append(op)
-    if op == 's_endpgm': break
 blocks.append(cur)
 tot = 0
 for b in blocks:
