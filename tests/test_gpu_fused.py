@@ -7,6 +7,8 @@ sorts its raw points ONCE, by (search cell, voxel), instead of by voxel key and 
     double sums differ in their last bits; identical statuses and iteration counts) and with the oracle at 1e-4;
   * a cloud the scheme cannot serve makes the host run the batch again on the two-sort path: same records, counted.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -193,7 +195,16 @@ def test_far_knn_paths_agree_on_isolated_points_and_ties(gpu_ctx, density):
         assert np.array_equal(T, recs[0][0]) and info == recs[0][1]
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+def _fuzz_seeds():
+    """1, 2, 3 + S3D_FUZZ_SEEDS = "first:last" (a dev run over more seeds: tools_dev/README.md)"""
+    extra = os.environ.get("S3D_FUZZ_SEEDS", "")
+    if ":" in extra:
+        a, b = extra.split(":")
+        return [1, 2, 3] + list(range(int(a), int(b) + 1))
+    return [1, 2, 3]
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds())
 def test_fused_prepass_fuzz_on_odd_clouds(gpu_ctx, oracle_mod, seed):
     """Random odd inputs through the fused pre-pass: volumes, planes with far outliers, a line, exact duplicates, the
     benchmark scene, non-finite points, random voxel sizes (some of which PCL's index cannot hold).  Wherever the device
@@ -241,4 +252,4 @@ def test_fused_prepass_fuzz_on_odd_clouds(gpu_ctx, oracle_mod, seed):
             m = od < 2.5 ** 2
             assert np.array_equal(fnn[m], oi[m]) and np.array_equal(fd2[m], od[m]), (seed, case, kind, n, leaf)
             assert np.all((fnn[~m] == -1) | (fd2[~m] >= 2.5 ** 2))
-    assert served >= 8, (served, declined)
+    assert served >= (8 if seed <= 3 else 3), (served, declined)      # (the committed seeds serve 8+ of their 14 cases)
