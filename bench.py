@@ -371,10 +371,15 @@ def main():
                 rec2 = ctx2.align_batch(lanes[1][1], lanes[1][2], guesses, params, opts)
             per_lane = max(args.steps // 2, 3)
 
+            lane_errors = []
+
             def lane_loop(k):
                 c, a, b = lanes[k]
-                for _ in range(per_lane):
-                    c.align_batch(a, b, guesses, params, opts)
+                try:
+                    for _ in range(per_lane):
+                        c.align_batch(a, b, guesses, params, opts)
+                except Exception as e:      # (a thread's exception would otherwise vanish and leave a wrong figure)
+                    lane_errors.append(str(e)[:200])
 
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -389,6 +394,8 @@ def main():
                                     "each)" % per_lane,
                         "ms_per_batch": round(fl_ms, 3), "registrations_per_s": round(args.pairs / fl_ms * 1e3, 2),
                         "records_equal_serial": bool(np.array_equal(rec2, rec_local))}
+            if lane_errors:
+                inflight = {"error": lane_errors[0]}
             for c in both2:
                 c.release()
             ctx2.close()

@@ -170,7 +170,7 @@ struct s3d_context {
       corr_idx, corr_d2, corr_lb, corr_q, corr_n, partials, n_active, knn_list, knn_fallback, knn_redo, wave_recs, t_hist, worklist, rec_list, rec_counts, search_list;
   int* h_active = nullptr;  // pinned: [0] the polled active-pair counter, [4], [5] the ICP loop's progress words (stage_icp)
   int* h_active_dev = nullptr;   // the same words as the device addresses them
-  int icp_tag_counter = 0;
+  unsigned icp_tag_counter = 0;   // (wraps; 0 is skipped: the words' idle value)
   // pinned staging of the slot / pair records (up and down): a copy from or to pageable memory stalls the stream for
   // tens of microseconds, which a single-pair registration of ~1.5 ms notices
   char* h_stage = nullptr;
@@ -1088,8 +1088,8 @@ struct Batch {
     if (!rp.force_iterations && opts.check_interval <= 0 && ctx->h_active_dev) {
       // (every earlier call of this context has waited for its stream: nothing on the device still writes these words)
       volatile int* hw = ctx->h_active + 4;
-      icp_tag = ++ctx->icp_tag_counter;
-      if (icp_tag == 0) icp_tag = ++ctx->icp_tag_counter;
+      if (++ctx->icp_tag_counter == 0u) ++ctx->icp_tag_counter;
+      icp_tag = (int)ctx->icp_tag_counter;
       hw[0] = -1; hw[1] = 0;
       __atomic_thread_fence(__ATOMIC_SEQ_CST);
       icp_host_word = ctx->h_active_dev + 4;
