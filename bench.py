@@ -35,13 +35,11 @@ def _gen_pair(args):
 
 
 def kernel_source_hash():
-    """sha256 over the device sources: roofline.traffic (PMC passes, profiles/nn_traffic.json) is attached only while
-    the kernels it was measured on are the kernels that run."""
-    import hashlib
-    h = hashlib.sha256()
-    for f in ("s3d_kernels.h", "s3d_core.h"):
-        h.update(open(os.path.join(ROOT, "slam3d_amd", "csrc", f), "rb").read())
-    return h.hexdigest()
+    """sha256 over every source of libslam3d_hip.so (kernels AND the host file that holds the pass thresholds) - the
+    hash the binary carries (s3d_source_hash): roofline.traffic / roofline.valu (PMC passes, profiles/nn_traffic.json)
+    are attached only while the code they were measured on is the code that runs."""
+    from slam3d_amd import api
+    return api.source_hash()
 
 
 def _free_port():

@@ -154,8 +154,8 @@ class PointCloudSensor : public ScanSensor {
   void setMeasurementStorage(MeasurementStorage* s) { mStorage = s; }
   // Not in the reference (PointCloudSensor.cpp:127-131 re-filters both clouds in every align()): keep the voxel
   // filter / search grid / k-NN normals of every measurement's device cloud in HBM between createConstraint calls
-  // (s3d_exec_options.cache_prepass).  On by default: a mapper links every scan to several others
-  // (ScanSensor.cpp:113, :179-201); the results are bit-identical either way.
+  // (s3d_exec_options.cache_prepass).  Off by default, like the C ABI and the reference; worth switching on in a
+  // mapper, which links every scan to several others (ScanSensor.cpp:113, :179-201).  Results are bit-identical either way.
   void setPrepassCache(bool on) { mPrepassCache = on; }
   PointCloud::Ptr removeOutliers(PointCloud::Ptr source, double radius, unsigned min_neighbors) const;
   PointCloud::Ptr getAccumulatedCloud(const VertexObjectList& vertices) const;
@@ -235,7 +235,7 @@ class PointCloudSensor : public ScanSensor {
               std::vector<s3d_cloud*>& clouds, std::vector<double>& poses) const;
   PointCloud::Ptr download(s3d_cloud* c) const;
   MeasurementStorage* mStorage = nullptr;
-  bool mPrepassCache = true;
+  bool mPrepassCache = false;
   PointCloudMeasurement::Ptr mInitialMap;
   // the sweep (ranks, communicators) of the last device list and the sweep clouds of the measurements it has seen
   struct SweepEntry { s3d_sweep_cloud* cloud; ptr::weak_ptr<Measurement> owner; unsigned long long last_use; };

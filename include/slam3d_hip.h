@@ -73,6 +73,10 @@ typedef struct s3d_exec_options {
  * C++ mirror do). */
 #define S3D_ABI_VERSION 4
 int  s3d_abi_version(void);
+/* sha256 (hex) of the sources this binary was compiled from (csrc/Makefile: s3d_api.hip, its headers and the three
+ * public headers, in that order).  A binding that sits next to the sources compares and refuses a stale binary
+ * (slam3d_amd/api.py); measurements attached to a build (profiles/nn_traffic.json) are keyed by it. */
+const char* s3d_source_hash(void);
 
 typedef struct s3d_align_info {   /* diagnostics of one align() */
   int    n_source_filtered, n_target_filtered;   /* points after the voxel filter            */
@@ -336,14 +340,6 @@ typedef struct s3d_link_policy {   /* ScanSensor's knobs, constructor defaults S
 int  s3d_link_candidates(int n_vertices, const double* positions, const unsigned char* linkable, int n_edges,
                          const s3d_graph_edge* edges, int vertex, const s3d_link_policy* policy, int* out_sources,
                          int capacity, int* n_out);
-
-/* ---- measurement hook (bench.py roofline): time `reps` launches of the NN-search kernel
- *          as a FIRST correspondence pass (transformation_ = I, no radius hints, no re-validation
- *          of earlier correspondences — the most expensive pass of a registration) with HIP events
- *          on the context's stream.  n_queries / n_targets: points after the voxel filter. */
-int  s3d_profile_nn_kernel(s3d_context* ctx, int n_pairs, s3d_cloud* const* sources, s3d_cloud* const* targets,
-                           const double* guesses, const s3d_reg_params* params, int reps, double* avg_ms,
-                           long long* n_queries, long long* n_targets);
 
 #ifdef __cplusplus
 }

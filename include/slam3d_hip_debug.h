@@ -35,6 +35,12 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* throws inside an entry point, under the same guard every entry point has: kind 0 a HIP error, 1 std::bad_alloc,
+ * 2 std::length_error, 3 std::runtime_error, 4 something that is not a std::exception, 5 std::bad_alloc on a worker
+ * thread of s3d_cloud_upload_many's kind.  Must come back as a status (BACKEND_ERROR; INVALID_ARGUMENT for 2) with
+ * s3d_last_error set, never as an exception or an abort (the reference's callers catch std::exception and log:
+ * ScanSensor.cpp:74-77, :124-127). */
+int s3d_debug_raise(s3d_context* ctx, int kind);
 /* batches of this context that the fused pre-pass could not serve and that ran again on the two-sort path */
 long long s3d_debug_fused_reruns(s3d_context* ctx);
 /* the registration's pre-pass (fused != 0: one sort; 0: two) of two device clouds at voxel size `leaf`, then one
@@ -44,6 +50,13 @@ long long s3d_debug_fused_reruns(s3d_context* ctx);
 int s3d_debug_filtered_nn(s3d_context* ctx, s3d_cloud* source, s3d_cloud* target, double leaf, int fused,
                           double max_distance, int capacity, float* source_sorted_xyzw, int* n_source,
                           float* target_sorted_xyzw, int* n_target, int* corr_pos, float* corr_d2, int* fused_ok);
+/* ---- measurement hook (bench.py roofline): time `reps` launches of the NN-search kernel
+ *          as a FIRST correspondence pass (transformation_ = I, no radius hints, no re-validation
+ *          of earlier correspondences — the most expensive pass of a registration) with HIP events
+ *          on the context's stream.  n_queries / n_targets: points after the voxel filter. */
+int  s3d_profile_nn_kernel(s3d_context* ctx, int n_pairs, s3d_cloud* const* sources, s3d_cloud* const* targets,
+                           const double* guesses, const s3d_reg_params* params, int reps, double* avg_ms,
+                           long long* n_queries, long long* n_targets);
 #ifdef __cplusplus
 }
 #endif

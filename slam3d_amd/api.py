@@ -103,15 +103,43 @@ def lib_path():
     return _LIB
 
 
+_SOURCES = [os.path.join(_CSRC, f) for f in ("s3d_api.hip", "s3d_kernels.h", "s3d_core.h", "s3d_ndt.h", "s3d_sweep.h",
+                                              "s3d_candidates.h")] + \
+           [os.path.join(_HERE, "..", "include", f) for f in ("slam3d_hip.h", "slam3d_hip_debug.h",
+                                                              "slam3d_registration_types.h")]
+
+
+def source_hash():
+    """sha256 over the sources of libslam3d_hip.so, in the order of csrc/Makefile (SRCS then DEPS): what
+    s3d_source_hash() of a binary built from this tree returns."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in _SOURCES:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def binary_source_hash(path=None):
+    """s3d_source_hash() of a built library, read from the file's bytes (no dlopen: the file may be about to be
+    rebuilt); '' if it carries none."""
+    import re
+    path = path or _LIB
+    if not os.path.exists(path):
+        return ""
+    with open(path, "rb") as fh:
+        m = re.search(rb"S3D_SOURCE_HASH=([0-9a-f]{64})", fh.read())
+    return m.group(1).decode() if m else ""
+
+
 def build(force=False, verbose=False):
-    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("s3d_api.hip", "s3d_kernels.h", "s3d_core.h", "s3d_ndt.h", "s3d_sweep.h",
-                                              "s3d_candidates.h", "Makefile")]
-    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("slam3d_hip.h", "slam3d_hip_debug.h",
-                                                               "slam3d_registration_types.h")]
-    stale = force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU).  Stale = the hash compiled
+    into the binary differs from the hash of the sources next to it (not file times: a pushed tree has fresh ones)."""
+    stale = force or not os.path.exists(_LIB) or binary_source_hash() != source_hash()
     if stale:
-        cmd = ["make", "-C", _CSRC] + (["-B"] if force else [])
+        if _lib is not None:
+            raise BackendError("libslam3d_hip.so is already loaded and stale: rebuild in a fresh process")
+        cmd = ["make", "-C", _CSRC, "-B"]
         subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
     return _LIB
 
@@ -141,6 +169,7 @@ def load_library():
     pp, op = C.POINTER(RegParams), C.POINTER(ExecOptions)
     sig = {
         "s3d_abi_version": (C.c_int, []),
+        "s3d_source_hash": (C.c_char_p, []),
         "s3d_context_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
         "s3d_context_create_priority": (C.c_int, [C.c_int, C.c_int, C.POINTER(vp)]),
         "s3d_context_create_cu_mask": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_int, C.POINTER(vp)]),
@@ -178,8 +207,6 @@ def load_library():
         "s3d_fit_plane": (C.c_int, [vp, fp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.POINTER(PlaneFit)]),
         "s3d_fill_ground_plane": (C.c_int, [vp, fp, C.c_int, C.c_int, C.c_double, C.c_double, fp, C.c_int, ip,
                                             C.POINTER(PlaneFit)]),
-        "s3d_profile_nn_kernel": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, pp, C.c_int, dp,
-                                            C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
         "s3d_sweep_create": (C.c_int, [C.c_int, ip, C.POINTER(vp)]),
         "s3d_sweep_create_cu_mask": (C.c_int, [C.c_int, ip, C.POINTER(C.c_uint32), C.c_int, C.POINTER(vp)]),
         "s3d_cu_masks": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int]),
@@ -199,12 +226,20 @@ def load_library():
     }
     debug_sig = {     # include/slam3d_hip_debug.h: test hooks, not part of the drop-in API
         "s3d_debug_fused_reruns": (C.c_longlong, [vp]),
+        "s3d_debug_raise": (C.c_int, [vp, C.c_int]),
+        "s3d_profile_nn_kernel": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, pp, C.c_int, dp,
+                                            C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
         "s3d_debug_filtered_nn": (C.c_int, [vp, vp, vp, C.c_double, C.c_int, C.c_double, C.c_int, fp, ip, fp, ip, ip, fp, ip]),
     }
     for name, (res, args) in list(sig.items()) + list(debug_sig.items()):
         f = getattr(L, name)  # AttributeError if the symbol is not exported
         f.restype = res
         f.argtypes = args
+    if not os.environ.get("S3D_LIB_PATH") and all(os.path.exists(f) for f in _SOURCES):
+        got, want = L.s3d_source_hash().decode(), source_hash()
+        if got != want:     # (an A/B build named by S3D_LIB_PATH is what its user says it is)
+            raise BackendError("libslam3d_hip.so was built from other sources (binary %s..., tree %s...): run "
+                               "`python -c 'import __graft_entry__ as g; g.build()'`" % (got[:12], want[:12]))
     if L.s3d_abi_version() != ABI_VERSION:
         raise BackendError("libslam3d_hip.so has ABI version %d, this binding %d: rebuild the library" %
                            (L.s3d_abi_version(), ABI_VERSION))
@@ -611,15 +646,15 @@ class Context:
         what a checkpoint stores next to the measurement's .s3dm file."""
         need = self._L.s3d_cloud_cache_export(self._h, cloud.handle, None, 0)
         if need < 0:
-            self._check(int(need))
-            raise ValueError("s3d_cloud_cache_export: status %d" % need)
+            self._check(int(-need))
+            raise ValueError("s3d_cloud_cache_export: status %d" % -need)
         if need == 0:
             return b""
         buf = C.create_string_buffer(int(need))
         got = self._L.s3d_cloud_cache_export(self._h, cloud.handle, buf, int(need))
         if got != need:
-            self._check(int(got))
-            raise ValueError("s3d_cloud_cache_export: status %d" % got)
+            self._check(int(-got) if got < 0 else 0)
+            raise ValueError("s3d_cloud_cache_export: %d instead of %d bytes" % (got, need))
         return buf.raw
 
     def cache_import(self, cloud, blob):

@@ -12,10 +12,14 @@
 #include <cstdio>
 #include <cstring>
 #include <chrono>
+#include <exception>
 #include <map>
 #include <random>
+#include <set>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <tuple>
@@ -63,6 +67,13 @@ struct HipError {
   } while (0)
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline void cpu_relax() {   // the body of a host spin loop
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#else
+  std::this_thread::yield();
+#endif
+}
 
 // ---- host-side 4x4 double algebra for the acceptance gate (PointCloudSensor.cpp:167-172)
 #define HM(m, r, c) ((m)[(c) * 4 + (r)])
@@ -149,6 +160,8 @@ struct s3d_context {
   unsigned long long cache_clock = 0;
   long long cache_hits = 0, cache_misses = 0;
   long long fused_reruns = 0;   // batches the fused pre-pass could not serve and ran again on the two-sort path
+  // (cloud uid, voxel size as float bits) that made a batch run again: such batches start on the two-sort path
+  std::set<std::pair<unsigned long long, uint32_t>> fused_unservable;
   void cache_drop(std::map<CacheKey, CacheEntry>::iterator it) {
     if (it->second.block) (void)hipFree(it->second.block);
     cache_bytes -= it->second.bytes;
@@ -157,6 +170,7 @@ struct s3d_context {
   void cache_clear() { while (!cache.empty()) cache_drop(cache.begin()); }
   void cache_forget_cloud(unsigned long long uid) {
     for (auto it = cache.lower_bound(CacheKey{uid, 0, 0, 0}); it != cache.end() && it->first.uid == uid;) cache_drop(it++);
+    fused_unservable.erase(fused_unservable.lower_bound({uid, 0u}), fused_unservable.upper_bound({uid, 0xFFFFFFFFu}));
   }
   int device = 0;
   hipStream_t stream = nullptr;
@@ -272,6 +286,36 @@ int fail(s3d_context* ctx, const HipError& e) {
                 e.what);
   if (ctx) ctx->err = buf;
   return e.status;
+}
+
+// The boundary never lets an exception out (an extern "C" function left by unwinding is std::terminate in the host
+// application; the reference's callers catch std::exception and log: ScanSensor.cpp:74-77, :124-127, :159-166).  Called
+// from a catch (...) block of an entry point: classifies the exception in flight, records the message, returns the status.
+int fail_current(s3d_context* ctx, std::string* err_out = nullptr) noexcept {
+  int status = S3D_STATUS_BACKEND_ERROR;
+  const char* msg = "unknown exception";
+  char buf[256];
+  try {
+    throw;
+  } catch (const HipError& e) {
+    try { const int st = fail(ctx, e); if (err_out && ctx) *err_out = ctx->err; return st; } catch (...) { return e.status; }
+  } catch (const std::bad_alloc&) {
+    msg = "out of host memory (std::bad_alloc)";
+  } catch (const std::length_error& e) {
+    std::snprintf(buf, sizeof buf, "size beyond what a host container can hold (std::length_error: %s)", e.what());
+    msg = buf;
+    status = S3D_STATUS_INVALID_ARGUMENT;
+  } catch (const std::exception& e) {
+    std::snprintf(buf, sizeof buf, "host exception: %s", e.what());
+    msg = buf;
+  } catch (...) {
+  }
+  try {
+    if (ctx) ctx->err = msg;
+    if (err_out) *err_out = msg;
+  } catch (...) {
+  }
+  return status;
 }
 
 // device -> host copy ON THE CONTEXT'S STREAM, then a wait for that stream: a plain hipMemcpy runs on the legacy null
@@ -501,6 +545,7 @@ struct Batch {
     HIPCHK(hipStreamSynchronize(st));   // the arena may be re-carved by the next call on another stream order
   }
 
+  uint32_t leaf_bits() const { uint32_t b; std::memcpy(&b, &rp.leaf, 4); return b; }
   bool registration_batch = false;   // set by the callers of run_all(): GICP / point-to-plane on this batch's pairs
   void assign_want_normals() {
     // which clouds need the k-NN pre-pass: GICP uses the covariances of both clouds of a pair, point-to-plane only
@@ -514,6 +559,11 @@ struct Batch {
   void allocate(bool icp_buffers = true) {
     has_sorted3 = icp_buffers;
     fused = registration_batch && fused_wanted();    // (before the cache look-up: the layout is part of an entry's key)
+    // a caller-held cloud that the fused pre-pass could not serve once (a property of the cloud and the voxel size: PCL's
+    // index overflow, a key beyond 32 bits, a centroid outside its cell) would double the cost of every batch it is
+    // part of: remembered per (cloud, voxel size), such batches start on the two-sort path
+    if (fused && !ctx->fused_unservable.empty())
+      for (const s3d_cloud* c : slot_clouds) fused = fused && !ctx->fused_unservable.count({c->uid, leaf_bits()});
     order_slots_for_cache(icp_buffers);
     if (total_pts > (size_t)0x7FFFFFF0 || total_cells > (size_t)0x7FFFFFF0 || total_corr > (size_t)0x7FFFFFF0)
       throw HipError{hipErrorInvalidValue, "batch too large for 32-bit offsets", __LINE__};
@@ -565,7 +615,13 @@ struct Batch {
     ctx->knn_list.p = (char*)ctx->slots.p + slots_bytes() + pairs_bytes() + 16;
     ctx->knn_list.cap = sizeof(int) * (size_t)C();
     if (!ctx->h_active) {
-      HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
+      // (mapped + coherent asked for by name: the device's stores to the progress words must be visible to the spinning
+      // host thread without a stream wait, whatever the runtime's default for plain pinned memory is)
+      if (hipHostMalloc((void**)&ctx->h_active, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->h_active = nullptr;
+        HIPCHK(hipHostMalloc((void**)&ctx->h_active, 64));
+      }
       std::memset(ctx->h_active, 0, 64);
       if (hipHostGetDevicePointer((void**)&ctx->h_active_dev, ctx->h_active, 0) != hipSuccess) ctx->h_active_dev = nullptr;
     }
@@ -1093,6 +1149,7 @@ struct Batch {
       hw[0] = -1; hw[1] = 0;
       __atomic_thread_fence(__ATOMIC_SEQ_CST);
       icp_host_word = ctx->h_active_dev + 4;
+      try {
       for (int it = 0; it < rp.max_iterations; ++it) {
         bool done = false;
         for (unsigned spins = 1;; ++spins) {
@@ -1107,10 +1164,17 @@ struct Batch {
             }
             if (q != hipErrorNotReady) HIPCHK(q);
           }
-          __builtin_ia32_pause();
+          cpu_relax();
         }
         if (done) break;
         launch_one(it);
+      }
+      } catch (...) {
+        // controller launches still in flight would write this call's words into the next call's freshly reset ones
+        // (harmless for termination - the tag - but the throttle could run further ahead than kIcpAhead)
+        (void)hipStreamSynchronize(st);
+        icp_host_word = nullptr;
+        throw;
       }
       icp_host_word = nullptr;
       return;
@@ -1188,6 +1252,9 @@ struct Batch {
       // allocate() uploaded them
       fused = false;
       ++ctx->fused_reruns;
+      if (use_cache || ctx->fused_unservable.size() < 4096)     // (bounded: handles of the host-buffer entry points die with the call)
+        for (int j = 0; j < Cu; ++j)
+          if (h_slots[(size_t)j].fz.ok <= 0) ctx->fused_unservable.insert({slot_clouds[(size_t)j]->uid, leaf_bits()});
       h_slots = h_slots0;
       h_pairs = h_pairs0;
       if (Cu < C()) {   // clouds restored from fused-layout cache entries: computed again like the others
@@ -1346,7 +1413,7 @@ void upload_many(s3d_context* ctx, int n_clouds, const float* const* xyz, const 
     }
   }
   std::atomic<int> next{0};
-  std::vector<HipError> errs;
+  std::vector<std::exception_ptr> errs;   // (any exception: one that left a std::thread's function would be std::terminate)
   std::mutex errs_mtx;
   auto work = [&](int t) {
     try {
@@ -1372,9 +1439,9 @@ void upload_many(s3d_context* ctx, int n_clouds, const float* const* xyz, const 
         k ^= 1;
       }
       HIPCHK(hipStreamSynchronize(L.st));
-    } catch (const HipError& e) {
+    } catch (...) {
       std::lock_guard<std::mutex> lock(errs_mtx);
-      errs.push_back(e);
+      errs.push_back(std::current_exception());
     }
   };
   std::vector<std::thread> th;
@@ -1391,7 +1458,7 @@ void upload_many(s3d_context* ctx, int n_clouds, const float* const* xyz, const 
   if (!errs.empty()) {
     // (kernels of the lanes that did not fail may still be writing into the block the caller is about to drop)
     for (int t = 0; t < lanes; ++t) (void)hipStreamSynchronize(ctx->upload_lanes[(size_t)t].st);
-    throw errs[0];
+    std::rethrow_exception(errs[0]);
   }
   for (int i = 0; i < n_clouds; ++i) {
     s3d_cloud* c = out[i];
@@ -1797,7 +1864,7 @@ static int create_constraint_impl(s3d_context* ctx, s3d_cloud* source, const dou
                                   double covariance_scale, const s3d_exec_options* opts, double relative_pose[16],
                                   double information[36], s3d_align_info* info, bool persistent);
 
-void s3d_default_params(s3d_reg_params* p) {
+void s3d_default_params(s3d_reg_params* p) try {
   p->registration_algorithm = S3D_ALG_GICP;
   p->point_cloud_density = 0.2;
   p->max_fitness_score = 2.0;
@@ -1813,11 +1880,16 @@ void s3d_default_params(s3d_reg_params* p) {
   p->resolution = 1.0f;
   p->step_size = 0.05;
   p->outlier_ratio = 0.35;
-}
+} catch (...) {}   // (a destructor-like entry point has no status to return)
 
 int s3d_abi_version(void) { return S3D_ABI_VERSION; }
+#ifndef S3D_SOURCE_HASH
+#define S3D_SOURCE_HASH "unhashed build (compiled without csrc/Makefile)"
+#endif
+static const char kSourceHashTag[] = "S3D_SOURCE_HASH=" S3D_SOURCE_HASH;   // (findable in the file without loading it)
+const char* s3d_source_hash(void) { return kSourceHashTag + 16; }
 
-int s3d_backend_info(int device, char* buf, int len) {
+int s3d_backend_info(int device, char* buf, int len) try {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
     if (buf && len > 0) std::snprintf(buf, len, "no HIP device");
@@ -1829,12 +1901,12 @@ int s3d_backend_info(int device, char* buf, int len) {
     std::snprintf(buf, len, "%s|%s|%d|%zu", prop.name, prop.gcnArchName, prop.multiProcessorCount,
                   (size_t)prop.totalGlobalMem);
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(nullptr); }
 
 static int context_create(int device, void* hip_stream, int priority_class, s3d_context** out,
                           const uint32_t* cu_mask = nullptr, int cu_words = 0);
 int s3d_context_create(int device, void* hip_stream, s3d_context** out) { return context_create(device, hip_stream, 0, out); }
-int s3d_cu_masks(int device, int reserved_cus, uint32_t* reserved_mask, uint32_t* rest_mask, int max_words) {
+int s3d_cu_masks(int device, int reserved_cus, uint32_t* reserved_mask, uint32_t* rest_mask, int max_words) try {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return -1;
   hipDeviceProp_t prop;
@@ -1844,20 +1916,20 @@ int s3d_cu_masks(int device, int reserved_cus, uint32_t* reserved_mask, uint32_t
   for (int w = 0; w < words; ++w) { reserved_mask[w] = 0u; rest_mask[w] = 0u; }
   for (int c = 0; c < cus; ++c) (c < reserved_cus ? reserved_mask : rest_mask)[c / 32] |= 1u << (c % 32);
   return words;
-}
-int s3d_context_create_cu_mask(int device, const uint32_t* cu_mask, int n_words, s3d_context** out) {
+} catch (...) { return fail_current(nullptr); }
+int s3d_context_create_cu_mask(int device, const uint32_t* cu_mask, int n_words, s3d_context** out) try {
   if (!cu_mask || n_words <= 0 || n_words > 32) return S3D_STATUS_INVALID_ARGUMENT;
   bool any = false;
   for (int i = 0; i < n_words; ++i) any = any || cu_mask[i] != 0u;
   if (!any) return S3D_STATUS_INVALID_ARGUMENT;
   return context_create(device, nullptr, 0, out, cu_mask, n_words);
-}
-int s3d_context_create_priority(int device, int priority_class, s3d_context** out) {
+} catch (...) { return fail_current(nullptr); }
+int s3d_context_create_priority(int device, int priority_class, s3d_context** out) try {
   if (priority_class < 0 || priority_class > 1) return S3D_STATUS_INVALID_ARGUMENT;
   return context_create(device, nullptr, priority_class, out);
-}
+} catch (...) { return fail_current(nullptr); }
 static int context_create(int device, void* hip_stream, int priority_class, s3d_context** out, const uint32_t* cu_mask,
-                          int cu_words) {
+                          int cu_words) try {
   if (!out) return S3D_STATUS_INVALID_ARGUMENT;
   *out = nullptr;
   int count = 0;
@@ -1888,16 +1960,16 @@ static int context_create(int device, void* hip_stream, int priority_class, s3d_
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 4 < ctx->cache_limit) ctx->cache_limit = free_b / 4;
     }
-  } catch (const HipError& e) {
-    fail(ctx, e);
+  } catch (...) {
+    fail_current(ctx);
     delete ctx;
     return S3D_STATUS_BACKEND_ERROR;
   }
   *out = ctx;
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(nullptr); }
 
-void s3d_context_destroy(s3d_context* ctx) {
+void s3d_context_destroy(s3d_context* ctx) try {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -1911,17 +1983,17 @@ void s3d_context_destroy(s3d_context* ctx) {
   ctx->release_upload_lanes();
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
-}
+} catch (...) {}   // (a destructor-like entry point has no status to return)
 
 const char* s3d_last_error(const s3d_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-int s3d_last_profile(const s3d_context* ctx, s3d_profile* out) {
+int s3d_last_profile(const s3d_context* ctx, s3d_profile* out) try {
   if (!ctx || !out) return S3D_STATUS_INVALID_ARGUMENT;
   *out = ctx->prof;
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(nullptr); }
 
-int s3d_context_cache_control(s3d_context* ctx, long long limit_bytes, int clear, s3d_cache_stats* stats) {
+int s3d_context_cache_control(s3d_context* ctx, long long limit_bytes, int clear, s3d_cache_stats* stats) try {
   if (!ctx) return S3D_STATUS_INVALID_ARGUMENT;
   try {
     ScopedDevice sd(ctx);
@@ -1934,15 +2006,15 @@ int s3d_context_cache_control(s3d_context* ctx, long long limit_bytes, int clear
         if (it->second.last_use < victim->second.last_use) victim = it;
       ctx->cache_drop(victim);
     }
-  } catch (const HipError& e) {
-    return fail(ctx, e);
+  } catch (...) {
+    return fail_current(ctx);
   }
   if (stats) {
     stats->entries = (long long)ctx->cache.size(); stats->bytes = (long long)ctx->cache_bytes;
     stats->hits = ctx->cache_hits; stats->misses = ctx->cache_misses;
   }
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
 // ---- the cached pre-pass products of one cloud as a host blob (checkpoints: GraphSerialization.cpp:14-66 writes one
 // <index>.s3dm per vertex; a caller can put this blob next to it and hand it back after fromFolder, :68-135)
@@ -1960,6 +2032,34 @@ struct BlobEntry {
   unsigned long long payload_bytes;   // filt 16 n (layout 0 only) | sorted 16 n | sorted3 sizeof(CorrVec) n | normals 16 n | cells 4 (ncells + 1)
   unsigned long long payload_hash;    // FNV-1a of those bytes: a damaged checkpoint is refused, not installed
 };
+// version 2 (the revision before the fused pre-pass): the same entry without `layout` and `fz` - still accepted by
+// s3d_cloud_cache_import as layout 0 (a checkpoint written by that revision stays valid); export writes version 3
+struct BlobEntryV2 {
+  uint32_t magic, leaf_bits, h0_bits; int cell_cap;
+  int n, ncells, k_normals, has_sorted3;
+  unsigned int bb[6];
+  s3d::VoxelParams vp;
+  s3d::GridParams g;
+  unsigned long long payload_bytes, payload_hash;
+};
+// the entry header at `at` of a blob of `version` as a version-3 entry; returns the header's size in the blob (0: truncated)
+size_t blob_read_entry(uint32_t version, const char* at, const char* end, BlobEntry* E) {
+  if (version >= 3u) {
+    if (end - at < (long long)sizeof *E) return 0;
+    std::memcpy(E, at, sizeof *E);
+    return sizeof *E;
+  }
+  BlobEntryV2 o;
+  if (end - at < (long long)sizeof o) return 0;
+  std::memcpy(&o, at, sizeof o);
+  std::memset(E, 0, sizeof *E);
+  E->magic = o.magic; E->leaf_bits = o.leaf_bits; E->h0_bits = o.h0_bits; E->cell_cap = o.cell_cap;
+  E->n = o.n; E->ncells = o.ncells; E->k_normals = o.k_normals; E->has_sorted3 = o.has_sorted3;
+  std::memcpy(E->bb, o.bb, sizeof o.bb);
+  E->vp = o.vp; E->g = o.g; E->layout = 0;
+  E->payload_bytes = o.payload_bytes; E->payload_hash = o.payload_hash;
+  return sizeof o;
+}
 unsigned long long fnv1a64(const void* data, size_t bytes) {
   const unsigned char* p = (const unsigned char*)data;
   unsigned long long h = 1469598103934665603ull;
@@ -1982,8 +2082,8 @@ size_t blob_payload_bytes(int n, int ncells, int layout) {
 }
 }  // namespace
 
-long long s3d_cloud_cache_export(s3d_context* ctx, const s3d_cloud* cloud, void* buffer, long long capacity) {
-  if (!ctx || !cloud) return S3D_STATUS_INVALID_ARGUMENT;
+long long s3d_cloud_cache_export(s3d_context* ctx, const s3d_cloud* cloud, void* buffer, long long capacity) try {
+  if (!ctx || !cloud || capacity < 0) return -(long long)S3D_STATUS_INVALID_ARGUMENT;   // (< 0: a status, as the header says)
   try {
     ScopedDevice sd(ctx);
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2031,12 +2131,12 @@ long long s3d_cloud_cache_export(s3d_context* ctx, const s3d_cloud* cloud, void*
       std::memcpy(at, &E, sizeof E);
     }
     return (long long)need;
-  } catch (const HipError& e) {
-    return fail(ctx, e);
+  } catch (...) {
+    return -(long long)fail_current(ctx);
   }
-}
+} catch (...) { return -(long long)fail_current(ctx); }
 
-int s3d_cloud_cache_import(s3d_context* ctx, const s3d_cloud* cloud, const void* blob, long long size) {
+int s3d_cloud_cache_import(s3d_context* ctx, const s3d_cloud* cloud, const void* blob, long long size) try {
   if (!ctx || !cloud || !blob || size < (long long)sizeof(BlobHeader)) return S3D_STATUS_INVALID_ARGUMENT;
   try {
     ScopedDevice sd(ctx);
@@ -2044,7 +2144,7 @@ int s3d_cloud_cache_import(s3d_context* ctx, const s3d_cloud* cloud, const void*
     const char* const end = in + size;
     BlobHeader H;
     std::memcpy(&H, in, sizeof H); in += sizeof H;
-    if (H.magic != kBlobMagic || H.version != kBlobVersion) { ctx->err = "cache blob: bad magic / version"; return S3D_STATUS_INVALID_ARGUMENT; }
+    if (H.magic != kBlobMagic || (H.version != kBlobVersion && H.version != 2u)) { ctx->err = "cache blob: bad magic / version"; return S3D_STATUS_INVALID_ARGUMENT; }
     if ((int)H.n_raw != cloud->n || H.points_hash != cloud_points_hash(ctx, cloud)) {
       ctx->err = "cache blob: made from a different point cloud";
       return S3D_STATUS_INVALID_ARGUMENT;
@@ -2053,8 +2153,9 @@ int s3d_cloud_cache_import(s3d_context* ctx, const s3d_cloud* cloud, const void*
     const char* scan = in;
     for (uint32_t i = 0; i < H.entries; ++i) {
       BlobEntry E;
-      if (end - scan < (long long)sizeof E) { ctx->err = "cache blob: truncated"; return S3D_STATUS_INVALID_ARGUMENT; }
-      std::memcpy(&E, scan, sizeof E); scan += sizeof E;
+      const size_t head = blob_read_entry(H.version, scan, end, &E);
+      if (!head) { ctx->err = "cache blob: truncated"; return S3D_STATUS_INVALID_ARGUMENT; }
+      scan += head;
       if (E.magic != kBlobEntryMagic || E.n < 0 || E.n > cloud->n || E.ncells < 0 || E.ncells != E.g.ncells || E.ncells > E.cell_cap ||
           (E.layout != 0 && E.layout != 1) || E.payload_bytes != blob_payload_bytes(E.n, E.ncells, E.layout) ||
           (unsigned long long)(end - scan) < E.payload_bytes) {
@@ -2092,7 +2193,7 @@ int s3d_cloud_cache_import(s3d_context* ctx, const s3d_cloud* cloud, const void*
     ++ctx->cache_clock;
     for (uint32_t i = 0; i < H.entries; ++i) {
       BlobEntry E;
-      std::memcpy(&E, in, sizeof E); in += sizeof E;
+      in += blob_read_entry(H.version, in, end, &E);
       const CacheKey key{cloud->uid, E.leaf_bits, E.h0_bits, E.cell_cap, E.layout};
       auto old = ctx->cache.find(key);
       if (old != ctx->cache.end()) { HIPCHK(hipStreamSynchronize(ctx->stream)); ctx->cache_drop(old); }
@@ -2121,27 +2222,27 @@ int s3d_cloud_cache_import(s3d_context* ctx, const s3d_cloud* cloud, const void*
       ctx->cache[key] = e;
     }
     return S3D_STATUS_OK;
-  } catch (const HipError& e) {
-    return fail(ctx, e);
+  } catch (...) {
+    return fail_current(ctx);
   }
-}
+} catch (...) { return fail_current(ctx); }
 
-int s3d_cloud_upload(s3d_context* ctx, const float* xyz, int n, int stride, s3d_cloud** out) {
+int s3d_cloud_upload(s3d_context* ctx, const float* xyz, int n, int stride, s3d_cloud** out) try {
   if (!ctx || !out || n < 0 || stride < 3 || (n > 0 && !xyz)) return S3D_STATUS_INVALID_ARGUMENT;
   s3d_cloud* c = new s3d_cloud();
   try {
     ScopedDevice sd(ctx);
     upload_cloud(ctx, xyz, n, stride, c);
-  } catch (const HipError& e) {
+  } catch (...) {
     free_cloud(c);
     delete c;
-    return fail(ctx, e);
+    return fail_current(ctx);
   }
   *out = c;
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
-int s3d_cloud_upload_many(s3d_context* ctx, int n_clouds, const float* const* xyz, const int* n, int stride, s3d_cloud** out) {
+int s3d_cloud_upload_many(s3d_context* ctx, int n_clouds, const float* const* xyz, const int* n, int stride, s3d_cloud** out) try {
   if (!ctx || n_clouds < 0 || stride < 3 || (n_clouds > 0 && (!xyz || !n || !out))) return S3D_STATUS_INVALID_ARGUMENT;
   for (int i = 0; i < n_clouds; ++i)
     if (n[i] < 0 || (n[i] > 0 && !xyz[i])) return S3D_STATUS_INVALID_ARGUMENT;
@@ -2151,15 +2252,15 @@ int s3d_cloud_upload_many(s3d_context* ctx, int n_clouds, const float* const* xy
   try {
     ScopedDevice sd(ctx);
     upload_many(ctx, n_clouds, xyz, n, stride, made.data());
-  } catch (const HipError& e) {
+  } catch (...) {
     for (s3d_cloud* c : made) delete c;
-    return fail(ctx, e);
+    return fail_current(ctx);
   }
   for (int i = 0; i < n_clouds; ++i) out[i] = made[(size_t)i];
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
-int s3d_cloud_wrap_device(s3d_context* ctx, const void* device_float4, int n, s3d_cloud** out) {
+int s3d_cloud_wrap_device(s3d_context* ctx, const void* device_float4, int n, s3d_cloud** out) try {
   if (!ctx || !out || n < 0 || (n > 0 && !device_float4)) return S3D_STATUS_INVALID_ARGUMENT;
   s3d_cloud* c = new s3d_cloud();
   c->d = (float4*)device_float4;
@@ -2168,11 +2269,11 @@ int s3d_cloud_wrap_device(s3d_context* ctx, const void* device_float4, int n, s3
   c->uid = g_cloud_uid++;
   *out = c;
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
 int s3d_cloud_size(const s3d_cloud* c) { return c ? c->n : 0; }
 
-void s3d_cloud_release(s3d_context* ctx, s3d_cloud* c) {
+void s3d_cloud_release(s3d_context* ctx, s3d_cloud* c) try {
   if (!c) return;
   if (ctx) {
     std::lock_guard<std::mutex> lock(ctx->mtx);
@@ -2184,11 +2285,11 @@ void s3d_cloud_release(s3d_context* ctx, s3d_cloud* c) {
     free_cloud(c);
   }
   delete c;
-}
+} catch (...) {}   // (a destructor-like entry point has no status to return)
 
 int s3d_align_batch(s3d_context* ctx, int n_pairs, s3d_cloud* const* sources, s3d_cloud* const* targets,
                     const double* guesses, const s3d_reg_params* params, const s3d_exec_options* opts,
-                    s3d_edge_record* records, s3d_align_info* infos) {
+                    s3d_edge_record* records, s3d_align_info* infos) try {
   if (!ctx || n_pairs < 0 || !params || (n_pairs > 0 && (!sources || !targets || !guesses || !records)))
     return S3D_STATUS_INVALID_ARGUMENT;
   const int alg = check_algorithm(params, opts);
@@ -2250,15 +2351,15 @@ int s3d_align_batch(s3d_context* ctx, int n_pairs, s3d_cloud* const* sources, s3
       r.status = st;
       if (infos) infos[p] = info;
     }
-  } catch (const HipError& e) {
-    return fail(ctx, e);
+  } catch (...) {
+    return fail_current(ctx);
   }
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
 int s3d_align(s3d_context* ctx, const float* source_xyz, int n_source, int stride_source, const float* target_xyz,
               int n_target, int stride_target, const double guess[16], const s3d_reg_params* params,
-              const s3d_exec_options* opts, double result[16], s3d_align_info* info) {
+              const s3d_exec_options* opts, double result[16], s3d_align_info* info) try {
   if (!ctx || !guess || !params || !result || n_source < 0 || n_target < 0 || stride_source < 3 || stride_target < 3)
     return S3D_STATUS_INVALID_ARGUMENT;
   for (int i = 0; i < 16; ++i) result[i] = (i % 5 == 0) ? 1.0 : 0.0;
@@ -2272,20 +2373,20 @@ int s3d_align(s3d_context* ctx, const float* source_xyz, int n_source, int strid
     status = align_dev(ctx, &cs, &ct, guess, params, opts, result, info, false);
     free_cloud(&cs);
     free_cloud(&ct);
-  } catch (const HipError& e) {
+  } catch (...) {
     free_cloud(&cs);
     free_cloud(&ct);
-    return fail(ctx, e);
+    return fail_current(ctx);
   }
   return status;
-}
+} catch (...) { return fail_current(ctx); }
 
 int s3d_create_constraint(s3d_context* ctx, const float* source_xyz, int n_source, int stride_source,
                           const double source_sensor_pose[16], const float* target_xyz, int n_target,
                           int stride_target, const double target_sensor_pose[16], const double odometry[16], int loop,
                           const s3d_reg_params* fine, const s3d_reg_params* coarse, double covariance_scale,
                           const s3d_exec_options* opts, double relative_pose[16], double information[36],
-                          s3d_align_info* info) {
+                          s3d_align_info* info) try {
   if (!ctx || !source_sensor_pose || !target_sensor_pose || !odometry || !fine || (loop && !coarse) ||
       !relative_pose || !information || n_source < 0 || n_target < 0 || stride_source < 3 || stride_target < 3)
     return S3D_STATUS_INVALID_ARGUMENT;
@@ -2294,10 +2395,10 @@ int s3d_create_constraint(s3d_context* ctx, const float* source_xyz, int n_sourc
     ScopedDevice sd(ctx);
     upload_cloud(ctx, source_xyz, n_source, stride_source, &cs);
     upload_cloud(ctx, target_xyz, n_target, stride_target, &ct);
-  } catch (const HipError& e) {
+  } catch (...) {
     free_cloud(&cs);
     free_cloud(&ct);
-    return fail(ctx, e);
+    return fail_current(ctx);
   }
   const int st = create_constraint_impl(ctx, &cs, source_sensor_pose, &ct, target_sensor_pose, odometry, loop, fine,
                                         coarse, covariance_scale, opts, relative_pose, information, info, false);
@@ -2308,10 +2409,10 @@ int s3d_create_constraint(s3d_context* ctx, const float* source_xyz, int n_sourc
     free_cloud(&ct);
   }
   return st;
-}
+} catch (...) { return fail_current(ctx); }
 
 int s3d_voxel_downsample(s3d_context* ctx, const float* xyz, int n, int stride, double leaf_size, float* out_xyz,
-                         int* n_out) {
+                         int* n_out) try {
   if (!ctx || !n_out || n < 0 || stride < 3 || (n > 0 && (!xyz || !out_xyz))) return S3D_STATUS_INVALID_ARGUMENT;
   *n_out = 0;
   if (n == 0) return S3D_STATUS_OK;  // PointCloudSensor.cpp:193
@@ -2338,15 +2439,15 @@ int s3d_voxel_downsample(s3d_context* ctx, const float* xyz, int n, int stride, 
     }
     *n_out = m;
     free_cloud(&c);
-  } catch (const HipError& e) {
+  } catch (...) {
     free_cloud(&c);
-    return fail(ctx, e);
+    return fail_current(ctx);
   }
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
 int s3d_nn_search(s3d_context* ctx, const float* target_xyz, int n, int stride_t, const float* query_xyz, int m,
-                  int stride_q, double max_distance, int* idx, float* d2) {
+                  int stride_q, double max_distance, int* idx, float* d2) try {
   if (!ctx || n < 0 || m < 0 || stride_t < 3 || stride_q < 3 || (m > 0 && (!idx || !d2 || !query_xyz)) ||
       (n > 0 && !target_xyz))
     return S3D_STATUS_INVALID_ARGUMENT;
@@ -2382,15 +2483,15 @@ int s3d_nn_search(s3d_context* ctx, const float* target_xyz, int n, int stride_t
     }
     free_cloud(&ct);
     free_cloud(&cq);
-  } catch (const HipError& e) {
+  } catch (...) {
     free_cloud(&ct);
     free_cloud(&cq);
-    return fail(ctx, e);
+    return fail_current(ctx);
   }
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
-int s3d_knn_normals(s3d_context* ctx, const float* xyz, int n, int stride, int k, float* normals_xyz) {
+int s3d_knn_normals(s3d_context* ctx, const float* xyz, int n, int stride, int k, float* normals_xyz) try {
   if (!ctx || n < 0 || stride < 3 || k < 1 || k > 64 || (n > 0 && (!xyz || !normals_xyz)))
     return S3D_STATUS_INVALID_ARGUMENT;
   if (k > n) return S3D_STATUS_INVALID_ARGUMENT;  // PCL: "Number of points in cloud is less than k"
@@ -2421,14 +2522,35 @@ int s3d_knn_normals(s3d_context* ctx, const float* xyz, int n, int stride, int k
       normals_xyz[(size_t)i * 3 + 2] = tmp[i].z;
     }
     free_cloud(&c);
-  } catch (const HipError& e) {
+  } catch (...) {
     free_cloud(&c);
-    return fail(ctx, e);
+    return fail_current(ctx);
   }
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
 // ---- test hooks (include/slam3d_hip_debug.h): not part of the drop-in API
+int s3d_debug_raise(s3d_context* ctx, int kind) try {
+  if (!ctx) return S3D_STATUS_INVALID_ARGUMENT;
+  ScopedDevice sd(ctx);
+  switch (kind) {
+    case 0: HIPCHK(hipErrorInvalidValue); break;
+    case 1: throw std::bad_alloc();
+    case 2: throw std::length_error("vector::reserve");
+    case 3: throw std::runtime_error("raised on request");
+    case 4: throw 42;
+    case 5: {
+      std::exception_ptr err;
+      std::thread t([&] { try { throw std::bad_alloc(); } catch (...) { err = std::current_exception(); } });
+      t.join();
+      if (err) std::rethrow_exception(err);
+      break;
+    }
+    default: return S3D_STATUS_INVALID_ARGUMENT;
+  }
+  return S3D_STATUS_OK;
+} catch (...) { return fail_current(ctx); }
+
 long long s3d_debug_fused_reruns(s3d_context* ctx) { return ctx ? ctx->fused_reruns : -1; }
 
 // The pre-pass of a registration (voxel filter + search grid, fused or as two sorts) and ONE nearest-neighbour pass of
@@ -2438,7 +2560,7 @@ long long s3d_debug_fused_reruns(s3d_context* ctx) { return ctx ? ctx->fused_rer
 // the source's array and the float d2.
 int s3d_debug_filtered_nn(s3d_context* ctx, s3d_cloud* source, s3d_cloud* target, double leaf, int fused,
                           double max_distance, int capacity, float* source_sorted_xyzw, int* n_source,
-                          float* target_sorted_xyzw, int* n_target, int* corr_pos, float* corr_d2, int* fused_ok) {
+                          float* target_sorted_xyzw, int* n_target, int* corr_pos, float* corr_d2, int* fused_ok) try {
   if (!ctx || !source || !target || !(leaf > 0.0) || capacity < 0 || !n_source || !n_target || !fused_ok)
     return S3D_STATUS_INVALID_ARGUMENT;
   try {
@@ -2473,25 +2595,25 @@ int s3d_debug_filtered_nn(s3d_context* ctx, s3d_cloud* source, s3d_cloud* target
       copy_to_host(ctx, corr_pos, (int*)ctx->corr_idx.p + P.corr_off, sizeof(int) * (size_t)St.n);
       copy_to_host(ctx, corr_d2, (float*)ctx->corr_d2.p + P.corr_off, sizeof(float) * (size_t)St.n);
     }
-  } catch (const HipError& e) {
-    return fail(ctx, e);
+  } catch (...) {
+    return fail_current(ctx);
   }
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
-int s3d_cloud_download(s3d_context* ctx, const s3d_cloud* c, float* xyz, int stride) {
+int s3d_cloud_download(s3d_context* ctx, const s3d_cloud* c, float* xyz, int stride) try {
   if (!ctx || !c || stride < 3 || (c->n > 0 && !xyz)) return S3D_STATUS_INVALID_ARGUMENT;
   try {
     ScopedDevice sd(ctx);
     download_packed(ctx, c, xyz, stride);
-  } catch (const HipError& e) {
-    return fail(ctx, e);
+  } catch (...) {
+    return fail_current(ctx);
   }
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
 int s3d_cloud_accumulate(s3d_context* ctx, int n_clouds, s3d_cloud* const* clouds, const double* poses,
-                         const double frame[16], s3d_cloud** out) {
+                         const double frame[16], s3d_cloud** out) try {
   if (!ctx || !out || n_clouds < 0 || (n_clouds > 0 && (!clouds || !poses))) return S3D_STATUS_INVALID_ARGUMENT;
   for (int i = 0; i < n_clouds; ++i)
     if (!clouds[i]) return S3D_STATUS_INVALID_ARGUMENT;
@@ -2499,43 +2621,43 @@ int s3d_cloud_accumulate(s3d_context* ctx, int n_clouds, s3d_cloud* const* cloud
   try {
     ScopedDevice sd(ctx);
     accumulate_dev(ctx, n_clouds, clouds, poses, frame, c);
-  } catch (const HipError& e) {
+  } catch (...) {
     free_cloud(c);
     delete c;
-    return fail(ctx, e);
+    return fail_current(ctx);
   }
   *out = c;
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
 int s3d_align_clouds(s3d_context* ctx, s3d_cloud* source, s3d_cloud* target, const double guess[16],
                      const s3d_reg_params* params, const s3d_exec_options* opts, double result[16],
-                     s3d_align_info* info) {
+                     s3d_align_info* info) try {
   if (!ctx || !source || !target || !guess || !params || !result) return S3D_STATUS_INVALID_ARGUMENT;
   for (int i = 0; i < 16; ++i) result[i] = (i % 5 == 0) ? 1.0 : 0.0;
   if (info) std::memset(info, 0, sizeof *info);
   try {
     ScopedDevice sd(ctx);
     return align_dev(ctx, source, target, guess, params, opts, result, info, true);
-  } catch (const HipError& e) {
-    return fail(ctx, e);
+  } catch (...) {
+    return fail_current(ctx);
   }
-}
+} catch (...) { return fail_current(ctx); }
 
 int s3d_create_constraint_clouds(s3d_context* ctx, s3d_cloud* source, const double source_sensor_pose[16],
                                  s3d_cloud* target, const double target_sensor_pose[16], const double odometry[16],
                                  int loop, const s3d_reg_params* fine, const s3d_reg_params* coarse,
                                  double covariance_scale, const s3d_exec_options* opts, double relative_pose[16],
-                                 double information[36], s3d_align_info* info) {
+                                 double information[36], s3d_align_info* info) try {
   return create_constraint_impl(ctx, source, source_sensor_pose, target, target_sensor_pose, odometry, loop, fine, coarse,
                                 covariance_scale, opts, relative_pose, information, info, true);
-}
+} catch (...) { return fail_current(ctx); }
 
 static int create_constraint_impl(s3d_context* ctx, s3d_cloud* source, const double source_sensor_pose[16],
                                   s3d_cloud* target, const double target_sensor_pose[16], const double odometry[16],
                                   int loop, const s3d_reg_params* fine, const s3d_reg_params* coarse,
                                   double covariance_scale, const s3d_exec_options* opts, double relative_pose[16],
-                                  double information[36], s3d_align_info* info, bool persistent) {
+                                  double information[36], s3d_align_info* info, bool persistent) try {
   if (!ctx || !source || !target || !source_sensor_pose || !target_sensor_pose || !odometry || !fine ||
       (loop && !coarse) || !relative_pose || !information)
     return S3D_STATUS_INVALID_ARGUMENT;
@@ -2558,32 +2680,32 @@ static int create_constraint_impl(s3d_context* ctx, s3d_cloud* source, const dou
     if (st != S3D_STATUS_OK) return st;
     mat4d_mul(source_sensor_pose, result, tmp);   // :295
     mat4d_mul(tmp, tinv, relative_pose);
-  } catch (const HipError& e) {
-    return fail(ctx, e);
+  } catch (...) {
+    return fail_current(ctx);
   }
   for (int i = 0; i < 36; ++i) information[i] = 0.0;
   for (int i = 0; i < 6; ++i) information[i * 6 + i] = 1.0 / covariance_scale;  // :296-298
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
 int s3d_remove_outliers_cloud(s3d_context* ctx, const s3d_cloud* in, double radius, unsigned min_neighbors,
-                              s3d_cloud** out) {
+                              s3d_cloud** out) try {
   if (!ctx || !in || !out) return S3D_STATUS_INVALID_ARGUMENT;
   s3d_cloud* c = new s3d_cloud();
   try {
     ScopedDevice sd(ctx);
     remove_outliers_dev(ctx, in, radius, min_neighbors, c, nullptr);
-  } catch (const HipError& e) {
+  } catch (...) {
     free_cloud(c);
     delete c;
-    return fail(ctx, e);
+    return fail_current(ctx);
   }
   *out = c;
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
 int s3d_remove_outliers(s3d_context* ctx, const float* xyz, int n, int stride, double radius, unsigned min_neighbors,
-                        float* out_xyz, int* n_out) {
+                        float* out_xyz, int* n_out) try {
   if (!ctx || !n_out || n < 0 || stride < 3 || (n > 0 && (!xyz || !out_xyz))) return S3D_STATUS_INVALID_ARGUMENT;
   *n_out = 0;
   if (n == 0) return S3D_STATUS_OK;
@@ -2596,13 +2718,13 @@ int s3d_remove_outliers(s3d_context* ctx, const float* xyz, int n, int stride, d
     *n_out = kept.n;
     free_cloud(&in);
     free_cloud(&kept);
-  } catch (const HipError& e) {
+  } catch (...) {
     free_cloud(&in);
     free_cloud(&kept);
-    return fail(ctx, e);
+    return fail_current(ctx);
   }
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
 // ---- B4: fillGroundPlane (PointCloudSensor.cpp:362-388) ------------------------------------------------
 // pcl::RandomSampleConsensus<SampleConsensusModelPlane>::computeModel with the model's fixed seed.  The sample
@@ -2755,21 +2877,21 @@ int fill_ground_points(const float coeffs[4], double radius, double map_resoluti
 }  // namespace
 
 int s3d_fit_plane(s3d_context* ctx, const float* xyz, int n, int stride, double threshold, int max_iterations,
-                  double probability, s3d_plane_fit* out) {
+                  double probability, s3d_plane_fit* out) try {
   if (!ctx || !out || n < 0 || stride < 3 || (n > 0 && !xyz) || !(threshold >= 0) || max_iterations < 0 ||
       !(probability > 0 && probability < 1))
     return S3D_STATUS_INVALID_ARGUMENT;
   try {
     ScopedDevice sd(ctx);
     fit_plane_dev(ctx, xyz, n, stride, threshold, max_iterations, probability, out);
-  } catch (const HipError& e) {
-    return fail(ctx, e);
+  } catch (...) {
+    return fail_current(ctx);
   }
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
 int s3d_fill_ground_plane(s3d_context* ctx, const float* xyz, int n, int stride, double radius, double map_resolution,
-                          float* out_xyz, int out_capacity, int* n_out, s3d_plane_fit* fit) {
+                          float* out_xyz, int out_capacity, int* n_out, s3d_plane_fit* fit) try {
   if (!ctx || !n_out || out_capacity < 0 || (out_capacity > 0 && !out_xyz) || !(radius > 0))
     return S3D_STATUS_INVALID_ARGUMENT;
   *n_out = 0;
@@ -2781,25 +2903,25 @@ int s3d_fill_ground_plane(s3d_context* ctx, const float* xyz, int n, int stride,
   if (!f.found) return S3D_STATUS_TOO_FEW_POINTS;
   *n_out = fill_ground_points(f.coefficients, radius, map_resolution, out_xyz, out_capacity);
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
-int s3d_voxel_downsample_cloud(s3d_context* ctx, const s3d_cloud* in, double leaf_size, s3d_cloud** out) {
+int s3d_voxel_downsample_cloud(s3d_context* ctx, const s3d_cloud* in, double leaf_size, s3d_cloud** out) try {
   if (!ctx || !in || !out) return S3D_STATUS_INVALID_ARGUMENT;
   s3d_cloud* c = new s3d_cloud();
   try {
     ScopedDevice sd(ctx);
     voxel_dev(ctx, in, leaf_size, c, nullptr);
-  } catch (const HipError& e) {
+  } catch (...) {
     free_cloud(c);
     delete c;
-    return fail(ctx, e);
+    return fail_current(ctx);
   }
   *out = c;
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
 int s3d_build_map(s3d_context* ctx, int n_clouds, s3d_cloud* const* clouds, const double* poses, double outlier_radius,
-                  unsigned outlier_neighbors, double map_resolution, s3d_cloud** out_map) {
+                  unsigned outlier_neighbors, double map_resolution, s3d_cloud** out_map) try {
   if (!ctx || !out_map || n_clouds < 0 || (n_clouds > 0 && (!clouds || !poses))) return S3D_STATUS_INVALID_ARGUMENT;
   for (int i = 0; i < n_clouds; ++i)
     if (!clouds[i]) return S3D_STATUS_INVALID_ARGUMENT;
@@ -2824,26 +2946,26 @@ int s3d_build_map(s3d_context* ctx, int n_clouds, s3d_cloud* const* clouds, cons
     mp.n_map = map->n;
     mp.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ctx->map_prof = mp;
-  } catch (const HipError& e) {
+  } catch (...) {
     free_cloud(&accu);
     free_cloud(&kept);
     free_cloud(map);
     delete map;
-    return fail(ctx, e);
+    return fail_current(ctx);
   }
   *out_map = map;
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
-int s3d_last_map_profile(const s3d_context* ctx, s3d_map_profile* out) {
+int s3d_last_map_profile(const s3d_context* ctx, s3d_map_profile* out) try {
   if (!ctx || !out) return S3D_STATUS_INVALID_ARGUMENT;
   *out = ctx->map_prof;
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(nullptr); }
 
 int s3d_profile_nn_kernel(s3d_context* ctx, int n_pairs, s3d_cloud* const* sources, s3d_cloud* const* targets,
                           const double* guesses, const s3d_reg_params* params, int reps, double* avg_ms,
-                          long long* n_queries, long long* n_targets) {
+                          long long* n_queries, long long* n_targets) try {
   if (!ctx || n_pairs <= 0 || !sources || !targets || !guesses || !params || reps <= 0 || !avg_ms)
     return S3D_STATUS_INVALID_ARGUMENT;
   try {
@@ -2880,11 +3002,11 @@ int s3d_profile_nn_kernel(s3d_context* ctx, int n_pairs, s3d_cloud* const* sourc
     *avg_ms = (double)ms / reps;
     if (n_queries) *n_queries = nq;
     if (n_targets) *n_targets = nt;
-  } catch (const HipError& e) {
-    return fail(ctx, e);
+  } catch (...) {
+    return fail_current(ctx);
   }
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(ctx); }
 
 }  // extern "C"
 

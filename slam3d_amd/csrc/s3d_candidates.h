@@ -35,7 +35,7 @@ inline float graph_distance(int n, const std::vector<std::vector<std::pair<int, 
 
 extern "C" int s3d_link_candidates(int n_vertices, const double* positions, const unsigned char* linkable, int n_edges,
                                    const s3d_graph_edge* edges, int vertex, const s3d_link_policy* policy,
-                                   int* out_sources, int capacity, int* n_out) {
+                                   int* out_sources, int capacity, int* n_out) try {
   if (n_out) *n_out = 0;
   if (n_vertices < 0 || !positions || n_edges < 0 || (n_edges > 0 && !edges) || !policy || !n_out || vertex < 0 ||
       vertex >= n_vertices || capacity < 0 || (capacity > 0 && !out_sources))
@@ -82,4 +82,4 @@ extern "C" int s3d_link_candidates(int n_vertices, const double* positions, cons
   }
   *n_out = written;
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(nullptr); }

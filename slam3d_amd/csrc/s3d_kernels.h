@@ -1864,6 +1864,11 @@ __global__ void __launch_bounds__(kBlock, S3D_NN_WAVES) s3d_nn_search_kernel(con
   if ((int)(threadIdx.x & ~(kWave - 1)) >= n0 + n1) return;        // whole wave without work
   const bool need = (int)threadIdx.x < n0 + n1;
   const int j = chunk * kBlock + (need ? order[threadIdx.x] : 0);
+  // (query j may belong to ANOTHER wave's record; Tref stays this wave's.  A PHASE 2 query has failed its proof already
+  // and nn_query uses Tref from here on only for `move`, which decides whether a far previous neighbour is tried as a
+  // seed first: a heuristic for where the search starts - the search itself is exact whatever it is told.  In the ICP
+  // passes every record of a block has the same Tref; in the fitness pass after record-wise passes a neighbouring
+  // record's touch pass may differ, and the seed decision is then made against that record's displacement.)
   nn_query<MODE, 2>(P, St, Ss, pair, j, need, A, max_d, dbg, prof_counts, nullptr, Tref);
 }
 

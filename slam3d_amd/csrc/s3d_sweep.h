@@ -74,7 +74,7 @@ struct RankWorker {
         std::function<void()> j = std::move(job);
         has_job = false;
         lk.unlock();
-        j();
+        try { j(); } catch (...) {}   // (the jobs report through their status slots; nothing may leave a thread's function)
         lk.lock();
         done = true;
         cv.notify_all();
@@ -116,15 +116,15 @@ struct s3d_sweep {
 
 extern "C" {
 
-void s3d_sweep_shard_range(int n_pairs, int n_ranks, int rank, int* lo, int* hi) {
+void s3d_sweep_shard_range(int n_pairs, int n_ranks, int rank, int* lo, int* hi) try {
   // contiguous blocks of ceil(n / ranks) pairs; the last ranks may be short or empty (== slam3d_amd/sweep.py)
   const int per = n_ranks > 0 ? (n_pairs + n_ranks - 1) / n_ranks : 0;
   const int l = std::min(rank * per, n_pairs);
   if (lo) *lo = l;
   if (hi) *hi = std::min(l + per, n_pairs);
-}
+} catch (...) {}   // (a destructor-like entry point has no status to return)
 
-void s3d_sweep_destroy(s3d_sweep* sw) {
+void s3d_sweep_destroy(s3d_sweep* sw) try {
   if (!sw) return;
   for (auto& w : sw->workers) if (w) w->shutdown();
   for (s3d_edge_record* p : sw->stage) if (p) (void)hipHostFree(p);
@@ -137,22 +137,23 @@ void s3d_sweep_destroy(s3d_sweep* sw) {
     if (r < (int)sw->ctx.size() && sw->ctx[r]) s3d_context_destroy(sw->ctx[r]);
   }
   delete sw;
-}
+} catch (...) {}   // (a destructor-like entry point has no status to return)
 
 static int sweep_create(int n_devices, const int* devices, const uint32_t* cu_mask, int cu_words, s3d_sweep** out);
-int s3d_sweep_create(int n_devices, const int* devices, s3d_sweep** out) {
+int s3d_sweep_create(int n_devices, const int* devices, s3d_sweep** out) try {
   return sweep_create(n_devices, devices, nullptr, 0, out);
-}
-int s3d_sweep_create_cu_mask(int n_devices, const int* devices, const uint32_t* cu_mask, int n_words, s3d_sweep** out) {
+} catch (...) { return fail_current(nullptr); }
+int s3d_sweep_create_cu_mask(int n_devices, const int* devices, const uint32_t* cu_mask, int n_words, s3d_sweep** out) try {
   if (!cu_mask || n_words <= 0 || n_words > 32) return S3D_STATUS_INVALID_ARGUMENT;
   return sweep_create(n_devices, devices, cu_mask, n_words, out);
-}
+} catch (...) { return fail_current(nullptr); }
 static int sweep_create(int n_devices, const int* devices, const uint32_t* cu_mask, int cu_words, s3d_sweep** out) {
   if (!out || n_devices < 0) return S3D_STATUS_INVALID_ARGUMENT;
   *out = nullptr;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return S3D_STATUS_BACKEND_ERROR;   // no CPU fallback
   s3d_sweep* sw = new s3d_sweep();
+  try {
   if (n_devices == 0 || !devices) {
     const int n = n_devices == 0 ? count : n_devices;
     for (int d = 0; d < n; ++d) sw->devices.push_back(d % count);
@@ -201,6 +202,10 @@ static int sweep_create(int n_devices, const int* devices, const uint32_t* cu_ma
       return S3D_STATUS_BACKEND_ERROR;
     }
   }
+  } catch (...) {   // (a host container that could not grow, a worker thread that could not start)
+    s3d_sweep_destroy(sw);
+    return fail_current(nullptr);
+  }
   *out = sw;
   return S3D_STATUS_OK;
 }
@@ -210,7 +215,7 @@ const char* s3d_sweep_collective(const s3d_sweep* sw) { return sw ? sw->collecti
 const char* s3d_sweep_last_error(const s3d_sweep* sw) { return sw ? sw->err.c_str() : "null sweep"; }
 s3d_context* s3d_sweep_context(s3d_sweep* sw, int rank) { return (sw && rank >= 0 && rank < sw->R()) ? sw->ctx[rank] : nullptr; }
 
-int s3d_sweep_cloud_create(s3d_sweep* sw, const float* xyz, int n, int stride, s3d_sweep_cloud** out) {
+int s3d_sweep_cloud_create(s3d_sweep* sw, const float* xyz, int n, int stride, s3d_sweep_cloud** out) try {
   if (!sw || !out || n < 0 || stride < 3 || (n > 0 && !xyz)) return S3D_STATUS_INVALID_ARGUMENT;
   s3d_sweep_cloud* c = new s3d_sweep_cloud();
   c->n = n; c->stride = stride;
@@ -225,9 +230,9 @@ int s3d_sweep_cloud_create(s3d_sweep* sw, const float* xyz, int n, int stride, s
   c->dev.assign(sw->R(), nullptr);
   *out = c;
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(nullptr, sw ? &sw->err : nullptr); }
 
-void s3d_sweep_cloud_release(s3d_sweep* sw, s3d_sweep_cloud* c) {
+void s3d_sweep_cloud_release(s3d_sweep* sw, s3d_sweep_cloud* c) try {
   if (!c) return;
   if (sw) {
     std::lock_guard<std::mutex> lock(sw->mtx);
@@ -236,11 +241,11 @@ void s3d_sweep_cloud_release(s3d_sweep* sw, s3d_sweep_cloud* c) {
   }
   if (c->xyz) (void)hipHostFree(c->xyz);
   delete c;
-}
+} catch (...) {}   // (a destructor-like entry point has no status to return)
 
 int s3d_align_batch_multi(s3d_sweep* sw, int n_pairs, s3d_sweep_cloud* const* sources, s3d_sweep_cloud* const* targets,
                           const double* guesses, const s3d_reg_params* params, const s3d_exec_options* opts,
-                          s3d_edge_record* records) {
+                          s3d_edge_record* records) try {
   if (!sw || n_pairs < 0 || !params || (n_pairs > 0 && (!sources || !targets || !guesses || !records)))
     return S3D_STATUS_INVALID_ARGUMENT;
   for (int p = 0; p < n_pairs; ++p)
@@ -253,7 +258,7 @@ int s3d_align_batch_multi(s3d_sweep* sw, int n_pairs, s3d_sweep_cloud* const* so
   std::vector<int> status(R, S3D_STATUS_OK);
   std::vector<std::string> errs(R);
   // ---- every rank: its block of the pair list on its own GPU, records staged in its send buffer
-  auto work = [&](int r) {
+  auto work_body = [&](int r) {
     int lo, hi;
     s3d_sweep_shard_range(n_pairs, R, r, &lo, &hi);
     const int m = hi - lo;
@@ -309,6 +314,9 @@ int s3d_align_batch_multi(s3d_sweep* sw, int n_pairs, s3d_sweep_cloud* const* so
                "hipMemcpyAsync(records)")) return;
     (void)hipok(hipStreamSynchronize(sw->coll[r]), "hipStreamSynchronize");   // (the next call reuses the staging)
   };
+  auto work = [&](int r) {   // a rank's exception becomes its status (the worker thread must not be left by unwinding)
+    try { work_body(r); } catch (...) { status[r] = fail_current(nullptr, &errs[r]); if (status[r] != S3D_STATUS_BACKEND_ERROR) status[r] = S3D_STATUS_BACKEND_ERROR; }
+  };
   if (R == 1) {
     work(0);
   } else {
@@ -361,11 +369,11 @@ int s3d_align_batch_multi(s3d_sweep* sw, int n_pairs, s3d_sweep_cloud* const* so
     if (hi > lo) std::memcpy(records + lo, all.data() + (size_t)r * per, (size_t)(hi - lo) * rec_bytes);
   }
   return worst;
-}
+} catch (...) { return fail_current(nullptr, sw ? &sw->err : nullptr); }
 
 // the gathered records as rank `rank` holds them in HBM after the last s3d_align_batch_multi (tests: every rank
 // must hold every edge): n_pairs records in pair order
-int s3d_sweep_gathered_records(s3d_sweep* sw, int rank, int n_pairs, s3d_edge_record* records) {
+int s3d_sweep_gathered_records(s3d_sweep* sw, int rank, int n_pairs, s3d_edge_record* records) try {
   if (!sw || rank < 0 || rank >= sw->R() || n_pairs < 0 || (n_pairs > 0 && !records)) return S3D_STATUS_INVALID_ARGUMENT;
   if (n_pairs == 0) return S3D_STATUS_OK;
   std::lock_guard<std::mutex> lock(sw->mtx);
@@ -384,6 +392,6 @@ int s3d_sweep_gathered_records(s3d_sweep* sw, int rank, int n_pairs, s3d_edge_re
     if (hi > lo) std::memcpy(records + lo, all.data() + (size_t)r * per, (size_t)(hi - lo) * rec_bytes);
   }
   return S3D_STATUS_OK;
-}
+} catch (...) { return fail_current(nullptr, sw ? &sw->err : nullptr); }
 
 }  // extern "C"

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(L._s3d_symbols) == names     # the binding declares exactly the header's functions
     # the test hooks of include/slam3d_hip_debug.h (not API: the public header must not pull them in)
     hooks = declared_symbols("slam3d_hip_debug.h")
-    assert hooks == ["s3d_debug_filtered_nn", "s3d_debug_fused_reruns"]
+    assert hooks == ["s3d_debug_filtered_nn", "s3d_debug_fused_reruns", "s3d_debug_raise", "s3d_profile_nn_kernel"]
     for n in hooks:
         assert hasattr(lib, n), "missing export: " + n
     public = open(os.path.join(ROOT, "include", "slam3d_hip.h")).read()

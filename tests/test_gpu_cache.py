@@ -154,6 +154,48 @@ def test_checkpoint_round_trip_of_the_cached_products(gpu_ctx, fixture_clouds):
             c.release()
 
 
+def test_import_accepts_the_previous_blob_version(gpu_ctx, fixture_clouds):
+    """Blob version 3 added `layout` and the fused grid to every entry; a checkpoint written by the revision before
+    (version 2: the same entry without the two fields, always the two-sort layout) must still load.  The
+    version-2 bytes are made here from a version-3 export of two-sort entries (NDT registrations take that path)."""
+    import struct
+    import slam3d_amd as s3d
+    gpu_ctx.cache_control(clear=True)
+    cl = [gpu_ctx.upload(c) for c in fixture_clouds[:2]]
+    p = s3d.default_params(registration_algorithm=s3d.ALG_NDT, maximum_iterations=8)
+    try:
+        want = gpu_ctx.align_batch([cl[0]], [cl[1]], None, p, _opts(s3d, False))
+        gpu_ctx.align_batch([cl[0]], [cl[1]], None, p, _opts(s3d, True))
+        blobs3 = [gpu_ctx.cache_export(c) for c in cl]
+        blobs2 = []
+        for b in blobs3:
+            magic, version, entries, n_raw, ph = struct.unpack_from("<IIIIQ", b, 0)
+            assert (magic, version, entries) == (0x42443353, 3, 1)
+            e = b[24:24 + 176]                                  # BlobEntry (s3d_api.hip): 124 bytes of common fields,
+            assert struct.unpack_from("<I", e, 0)[0] == 0x45443353 and struct.unpack_from("<i", e, 124)[0] == 0   # layout 0
+            nbytes, _ = struct.unpack_from("<QQ", e, 160)       # layout + fz (36 bytes, padded to 160), then size and hash
+            assert 24 + 176 + nbytes == len(b)
+            blobs2.append(struct.pack("<IIIIQ", magic, 2, entries, n_raw, ph) + e[:124] + b"\0" * 4 + e[160:176] + b[24 + 176:])
+        gpu_ctx.cache_control(clear=True)
+        assert gpu_ctx.cache_control()["entries"] == 0
+        for c, b in zip(cl, blobs2):
+            assert gpu_ctx.cache_import(c, b) == 0, gpu_ctx.last_error()
+        st0 = gpu_ctx.cache_control()
+        assert st0["entries"] == 2
+        got = gpu_ctx.align_batch([cl[0]], [cl[1]], None, p, _opts(s3d, True))
+        st1 = gpu_ctx.cache_control()
+        assert np.array_equal(got, want) and st1["misses"] == st0["misses"] and st1["hits"] == st0["hits"] + 2
+        # and what is exported from the imported entries is version 3 again, byte for byte
+        assert [gpu_ctx.cache_export(c) for c in cl] == blobs3
+        assert gpu_ctx.cache_import(cl[0], blobs2[0][:150]) == 7         # truncated inside a version-2 entry header
+        # an unknown version is refused
+        assert gpu_ctx.cache_import(cl[0], blobs3[0][:4] + struct.pack("<I", 9) + blobs3[0][8:]) == 7
+    finally:
+        for c in cl:
+            c.release()
+        gpu_ctx.cache_control(clear=True)
+
+
 def test_cpp_mirror_device_cache_across_a_checkpoint(fixture_clouds, tmp_path):
     """cpp/example_checkpoint.cpp: PointCloudSensor::saveDeviceCache / loadDeviceCache around a save + reload of two
     measurements (new objects carrying the stored uuids, GraphSerialization.cpp:40-47 / :68-135): the edge after the

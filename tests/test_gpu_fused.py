@@ -133,6 +133,13 @@ def test_fused_prepass_falls_back_to_two_sorts(gpu_ctx, fixture_clouds):
         assert gpu_ctx.fused_reruns() == before + 1
         assert np.array_equal(r1, r0) and i1 == i0
         assert i1[0]["n_source_filtered"] == len(small[0])             # (passthrough: nothing was filtered)
+        # the failure is remembered per (cloud, voxel size): the same batch again starts on the two-sort path (no second
+        # rerun), another voxel size is served by the fused path as before
+        r2, i2 = gpu_ctx.align_batch(dev[:2], dev[1:3], None, p, want_infos=True)
+        assert gpu_ctx.fused_reruns() == before + 1 and np.array_equal(r2, r0) and i2 == i0
+        pd = s3d.default_params(maximum_iterations=8)
+        rd = gpu_ctx.align_batch(dev[:2], dev[1:3], None, pd)
+        assert gpu_ctx.fused_reruns() == before + 1 and (rd[:, 15] >= 0).all()
     finally:
         for h in dev:
             h.release()

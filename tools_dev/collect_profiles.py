@@ -9,6 +9,12 @@ from bench import kernel_source_hash
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = list(csv.DictReader(open(f"{R}/{c}/p_counter_collection.csv")))
+    if not rows or not {"Counter_Name", "Counter_Value", "Kernel_Name", "Grid_Size"} <= set(rows[0]):
+        sys.exit(f"{c}: p_counter_collection.csv is empty or lacks a column this walk reads: {sorted(rows[0]) if rows else []}")
+    order_key = next((k for k in ("Dispatch_Id", "Start_Timestamp") if k in rows[0]), None)
+    if order_key is None:
+        sys.exit(f"{c}: neither Dispatch_Id nor Start_Timestamp in the csv: dispatch order unknown")
+    rows.sort(key=lambda r: int(r[order_key]))      # (the per-step walk below needs dispatch order)
     # (round 5: the counter passes run the driver's whole command; the launches of the BATCH workload are those with the
     # largest grid of their kernel - the single-pair / real-scan legs launch the same kernels on smaller grids)
     biggest = collections.defaultdict(int)
@@ -30,7 +36,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     FAM = ("nn_search_kernel<0>", "nn_first_kernel", "nn_scan27_kernel", "nn_worklist_kernel", "nn_record_test_kernel",
            "nn_record_touch_kernel", "nn_record_search_kernel")
     seq = [(r["Kernel_Name"], float(r["Counter_Value"]), int(r["Grid_Size"] or 0)) for r in rows if r["Counter_Name"] == c]
-    G = max(g for k, _, g in seq if "nn_first_kernel" in k)
+    firsts = [g for k, _, g in seq if "nn_first_kernel" in k]
+    if not firsts:
+        sys.exit(f"{c}: no s3d_nn_first_kernel launch in the counter rows (kernel renamed?)")
+    G = max(firsts)
     steps, cur, npass = [], None, 0
     STARTS = ("nn_first_kernel", "nn_scan27_kernel", "nn_record_test_kernel", "nn_record_touch_kernel<false>", "nn_search_kernel<0>")
     for k, v, g in seq:
@@ -46,7 +55,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             npass += 1 if any(t in k for t in STARTS) else 0
     # the first 25 batch steps of the run are the driver command's 5 warm-up + 20 timed steps; later legs of the line launch the
     # batch again (profile runs; two_in_flight, whose two contexts interleave their launches): not walked
-    steps = steps[:25]
+    bj = json.load(open(f"{R}/bench_under_rocprof.json")) if os.path.exists(f"{R}/bench_under_rocprof.json") else {}
+    n_driver = int(bj.get("steps", 20)) + int(bj.get("warmup", 5))      # the driver command's warm-up + timed steps
+    if len(steps) < n_driver:
+        sys.exit(f"{c}: {len(steps)} batch steps found (first kernel at the largest grid ... fitness pass), {n_driver} expected")
+    steps = steps[:n_driver]
     out[c] = sum(steps) / len(steps)
     print(c, "batch steps", len(steps), "passes per step", npass, "KB per pass", round(out[c], 1))
 hbm = int(2 * out["FETCH_SIZE"] * 1024 + out["WRITE_SIZE"] * 1024)

@@ -14,6 +14,8 @@ tr.sort(key=lambda r: int(r['Start_Timestamp']))
 mark = os.environ['MARK']
 starts = [i for i, r in enumerate(tr) if mark in r['Kernel_Name']]
 # the last complete call: from the second-to-last marker to the last marker
+if len(starts) < 2:
+    raise SystemExit('marker kernel %r occurs %d time(s) in the trace: need two calls (the last complete one lies between them)' % (mark, len(starts)))
 a, b = starts[-2], starts[-1]
 prev_end = None
 tot = 0
