@@ -156,13 +156,23 @@ S3D_HD VoxelParams voxel_params_from_bbox(const float mn[3], const float mx[3], 
   VoxelParams vp;
   vp.inv_leaf = 1.0f / leaf;
   int64_t d[3];
+  // PCL's conversions (static_cast<std::int64_t> / static_cast<int> of float products) are undefined beyond the
+  // integer's range - a leaf tens of orders of magnitude below the cloud's extent.  Each d is >= 1, so ONE axis beyond
+  // INT_MAX already means dx*dy*dz > INT_MAX: such a cloud is PCL's "leaf size is too small" case (passthrough)
+  // without the out-of-range conversion ever being made; wherever PCL's arithmetic is defined this is PCL's result.
+  bool over = false;
   for (int a = 0; a < 3; ++a) {
-    d[a] = (int64_t)((mx[a] - mn[a]) * vp.inv_leaf) + 1;
-    vp.min_b[a] = (int)floorf(mn[a] * vp.inv_leaf);
-    int max_b = (int)floorf(mx[a] * vp.inv_leaf);
+    const float e = (mx[a] - mn[a]) * vp.inv_leaf, lo = floorf(mn[a] * vp.inv_leaf), hi = floorf(mx[a] * vp.inv_leaf);
+    const bool in_range = e < 2147483648.0f && fabsf(lo) < 2147483648.0f && fabsf(hi) < 2147483648.0f;   // (false for NaN)
+    over = over || !in_range;
+    d[a] = in_range ? (int64_t)e + 1 : 1;
+    vp.min_b[a] = in_range ? (int)lo : 0;
+    const int max_b = in_range ? (int)hi : 0;
     vp.div_b[a] = max_b - vp.min_b[a] + 1;
   }
-  vp.passthrough = (d[0] * d[1] * d[2] > (int64_t)2147483647) ? 1 : 0;
+  const int64_t d01 = d[0] * d[1];                                   // (<= 2^62)
+  over = over || d01 > (int64_t)2147483647 || d01 * d[2] > (int64_t)2147483647;
+  vp.passthrough = over ? 1 : 0;
   return vp;
 }
 
@@ -188,14 +198,24 @@ struct GridParams {
 S3D_HD GridParams grid_params_from_bbox(const float mn[3], const float mx[3], float h0, int cap) {
   GridParams g;
   float h = h0;
-  for (int it = 0; it < 400; ++it) {
+  // (the count is compared axis by axis: every dim is >= 1, so a partial product beyond the budget decides - and an
+  // edge so small that an axis alone has more cells than an int holds never reaches the int conversion.  400 steps of
+  // 2^(1/6) cover 20 orders of magnitude; a wanted edge farther than that below the cloud's extent goes on by doubling)
+  bool fits = false;
+  for (int it = 0; it < 700 && !fits; ++it) {
+    if (it > 0) h *= it <= 400 ? 1.1224620f : 2.0f;   // 2^(1/6): the cell count lands within sqrt(2) of the budget
     int64_t nc = 1;
+    fits = h > 0.f;
     for (int a = 0; a < 3; ++a) {
-      g.dim[a] = (int)floorf((mx[a] - mn[a]) / h) + 1;
-      nc *= g.dim[a];
+      const float q = floorf((mx[a] - mn[a]) / h);
+      if (!(q < 2.0e9f)) { fits = false; g.dim[a] = 1; continue; }      // (also NaN)
+      g.dim[a] = (int)q + 1;
+      if (fits) { nc *= g.dim[a]; fits = nc <= (int64_t)cap; }
     }
-    if (nc <= (int64_t)cap) break;
-    h *= 1.1224620f;   // 2^(1/6): the cell count lands within sqrt(2) of the budget
+  }
+  if (!fits) {   // no finite edge serves (an extent beyond float's range): one cell
+    h = 3.0e38f;
+    g.dim[0] = g.dim[1] = g.dim[2] = 1;
   }
   g.h = h;
   g.inv_h = 1.0f / h;

@@ -136,6 +136,12 @@ print("RESULT " + json.dumps(out))
 
 
 def _run_child(code, timeout=600):
+    """Runs `code` in a child python; every `out[...] = ` statement first announces itself on stdout (flushed), so that
+    the case that killed the child can be named."""
+    import re
+    # (S3D_HOSTILE_SKIP="name,name": a dev run that steps over known crashers to find the next one - tools_dev/hostile_all.sh)
+    code = "import os\n_SKIP = set(filter(None, os.environ.get('S3D_HOSTILE_SKIP', '').split(',')))\n" + re.sub(
+        r"(?m)^(\s*)out\[(.+?)\] = ", r'\1print("CASE", \2, flush=True)\n\1if (\2) in _SKIP: pass\n\1else: out[\2] = ', code)
     env = dict(os.environ)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     return r
@@ -143,8 +149,9 @@ def _run_child(code, timeout=600):
 
 def test_hostile_arguments_return_a_status_and_never_abort():
     r = _run_child(_HOSTILE % {"root": ROOT})
-    assert r.returncode == 0, "the child died (exit code %d): an entry point aborted\n%s\n%s" % (
-        r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    cases = [x for x in r.stdout.splitlines() if x.startswith("CASE ")]
+    assert r.returncode == 0, "the child died (exit code %d) in %s: an entry point aborted\n%s" % (
+        r.returncode, cases[-1] if cases else "its set-up", r.stderr[-3000:])
     line = [x for x in r.stdout.splitlines() if x.startswith("RESULT ")]
     assert line, r.stdout[-2000:]
     out = json.loads(line[-1][7:])
