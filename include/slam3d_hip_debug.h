@@ -30,6 +30,8 @@
                                                   search, whatever the batch size (default: small batches take the
                                                   wave-cooperative kernel)                                               */
 #define S3D_DBG_KNN_FORCE_FAR_COOP 0x40000000u /* ... through the wave-cooperative kernel, whatever the batch size          */
+#define S3D_DBG_KNN_NO_RINGS       0x80000000u /* k-NN pre-pass of a large batch: the sparse-region declines of the fast path
+                                                  through the per-lane exact search instead of the ring-by-ring med3 search */
 
 /* ---- test hooks: exported by the library, used by tests/ only ---------------------------------------------------- */
 #ifdef __cplusplus

@@ -609,7 +609,11 @@ struct Batch {
                 {&ctx->rec_counts, sizeof(int) * 2 * (kNNRecSublists + kNNSearchSublists)},
                 {&ctx->search_list, sizeof(uint4) * (icp_buffers && settled_wanted() ? (size_t)kNNSearchSublists * (size_t)search_sub_cap() : 1)},
                 {&ctx->t_hist, sizeof(Mat4f) * (icp_buffers ? (size_t)std::max(1, P()) * (size_t)hist_stride() : 1)},
-                {&ctx->knn_fallback, sizeof(int) * npi}, {&ctx->knn_redo, sizeof(int2) * npi}});
+                {&ctx->knn_fallback, sizeof(int) * npi},
+                // four lists, a quarter each: near declines from the front; from the back of the second, third and fourth
+                // quarter the ring search's leftovers, the far list and the far entries that need more rings (what a launch
+                // of the ring search hands on is appended to other lists while it reads its own)
+                {&ctx->knn_redo, sizeof(int2) * 4 * npi}});
     ctx->pairs.p = (char*)ctx->slots.p + slots_bytes();
     ctx->pairs.cap = sizeof(PairDev) * (size_t)P();
     ctx->knn_list.p = (char*)ctx->slots.p + slots_bytes() + pairs_bytes() + 16;
@@ -854,7 +858,7 @@ struct Batch {
     int* fb_count = (int*)ctx->n_active.p + 4;
     int* fb_list = (int*)ctx->knn_fallback.p;
     if (!k4_counters_zeroed)
-      HIPCHK(hipMemsetAsync(fb_count, 0, 3 * sizeof(int), st));   // eigen fallback, near redo, far / cooperative list
+      HIPCHK(hipMemsetAsync(fb_count, 0, 5 * sizeof(int), st));   // eigen fallback, near redo, far list, ring-search leftovers, deep entries
     k4_counters_zeroed = false;
     // k = 20 (the reference default): 32-bit keys + med3 insertion; what it does not answer goes through the exact
     // 64-bit search (redo list, counted in n_active[5]).  S3D_DBG_KNN_EXACT64: the 64-bit search for every point.
@@ -870,21 +874,40 @@ struct Batch {
       const bool small_batch = (long long)NL * max_n <= 2000000ll;
       const bool coop = (opts.debug_flags & S3D_DBG_KNN_NO_FAR_COOP) ? false
                         : (opts.debug_flags & S3D_DBG_KNN_FORCE_FAR_COOP) ? true : small_batch;
-      int* far_count = coop ? fb_count + 2 : nullptr;
-      const int redo_cap = (int)std::min<size_t>(std::max<size_t>(total_pts, 4), 0x7FFFFFF0);
+      // round 6: a LARGE batch puts every query whose 27 cells hold fewer than 20 points, or whose 20th neighbour lies beyond
+      // the 5x5x5 proof, on the far list and serves it ring by ring (s3d_knn3_rings_kernel: the fast path's table + flat scan
+      // carried on over rings 2 ... 6; on the reference's scans 93 % of all declines are of that kind, and the per-lane exact
+      // search took 2.8 of the pre-pass's 4.4 ms for them).  S3D_DBG_KNN_NO_RINGS: the exact search for all of them.
+      const bool rings = !coop && !(opts.debug_flags & S3D_DBG_KNN_NO_RINGS) && total_pts <= (size_t)0x1FFFFFF0;
+      int* far_count = (coop || rings) ? fb_count + 2 : nullptr;
+      const size_t redo_half = std::min<size_t>(std::max<size_t>(total_pts, 4), 0x1FFFFFF0);
+      const int redo_cap = (int)(3 * redo_half);      // (far entries count down from the end of the buffer)
+      const int iso_cap = (int)(2 * redo_half);       // (isolated points - the ring search's - from the end of the middle third)
+      int* iso_count = fb_count + 3;
+      int* deep_count = fb_count + 4;                 // (n_active[8]: the ICP stage zeroes and reuses it afterwards)
+      const int deep_cap = (int)(4 * redo_half);
       // (a small batch hands EVERY decline to the cooperative kernel - also the near ones, ties and table overflows, whose
-      // per-lane search keeps a wave busy with one lane: far_all)
-      const int far_all = coop && small_batch ? 1 : 0;
+      // per-lane search keeps a wave busy with one lane: far_all = 2; the ring search takes every "27 cells are not enough": 1)
+      const int far_all = coop && small_batch ? 2 : (rings ? 1 : 0);
       s3d_knn3_moments_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), sorted(), cells(), mom, mom_plane, nb_head, d_list, NL, normals(), fb_count, fb_list, redo_count, redo_list, far_count, redo_cap, far_all);
-      if (far_count) {
+      if (rings) {
+        const int rblocks = (int)std::min<long long>(std::max<long long>((long long)NL * max_n / (16 * kBlock), 64), 1280);
+        s3d_knn3_rings_kernel<20, kKnn3RingMax><<<rblocks, kBlock, 0, st>>>(d_slots(), sorted(), cells(), mom, mom_plane, normals(), fb_count, fb_list, redo_list, far_count, redo_cap, iso_count, iso_cap);
+        // the isolated points among them (the 20th neighbour more than kKnn3RingMax rings away), a wave per query
+        const int fblocks = (int)std::min<long long>(std::max<long long>((long long)NL * max_n / 512, 256), 8192);
+        if (fused)
+          s3d_knn_moments_far_kernel<20, true><<<fblocks, kWave, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, iso_count, redo_list, iso_cap, 3.0f);
+        else
+          s3d_knn_moments_far_kernel<20, false><<<fblocks, kWave, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, iso_count, redo_list, iso_cap, 3.0f);
+      } else if (far_count) {
         const int fblocks = (int)std::min<long long>(std::max<long long>((long long)NL * max_n / 64, 256), 16384);
         if (fused)
-          s3d_knn_moments_far_kernel<20, true><<<fblocks, kWave, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, far_count, redo_list, redo_cap);
+          s3d_knn_moments_far_kernel<20, true><<<fblocks, kWave, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, far_count, redo_list, redo_cap, 3.0f);
         else
-          s3d_knn_moments_far_kernel<20, false><<<fblocks, kWave, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, far_count, redo_list, redo_cap);
+          s3d_knn_moments_far_kernel<20, false><<<fblocks, kWave, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, far_count, redo_list, redo_cap, 3.0f);
       }
       const bool thin = small_batch;   // a few clouds: the redo list's latency counts (see the kernel)
-      if (far_all) {
+      if (far_all == 2) {
         // nothing on the near list
       } else if (thin && !fused)
         s3d_knn_moments_redo_kernel<20, true, true><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list);
@@ -917,11 +940,11 @@ struct Batch {
       s3d_knn_moments_kernel<32><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
     s3d_normals_fallback_kernel<<<256, kBlock, 0, st>>>(fb_count, fb_list, mom, mom_plane, normals(), k);
     if (opts.debug_flags & S3D_DBG_PRINT_KNN) {   // dev aid: how many points took the eigen fallback / the exact-search redo
-      int cnt[3];
+      int cnt[5];
       HIPCHK(hipMemcpyAsync(cnt, fb_count, sizeof cnt, hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
-      std::fprintf(stderr, "[s3d] k-NN pre-pass: %zu points, eigen fallback %d, exact-search redo %d, cooperative (far) list %d\n",
-                   total_pts, cnt[0], cnt[1], cnt[2]);
+      std::fprintf(stderr, "[s3d] k-NN pre-pass: %zu points, eigen fallback %d, exact-search redo %d, far list (ring search / cooperative) %d, of those beyond %d rings %d, ring-search leftovers (cooperative) %d\n",
+                   total_pts, cnt[0], cnt[1], cnt[2], kKnn3RingFirst, cnt[4], cnt[3]);
     }
   }
 

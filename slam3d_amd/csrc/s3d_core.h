@@ -1256,9 +1256,11 @@ S3D_HD void knn3_insert(uint32_t (&keys)[KL], uint32_t c) {
 
 // a row range [s, e) of the cell-sorted cloud -> one table entry, tab[j * tstride] = (start << 7) | (len - 1).
 // false: the table is full or the range is longer than an entry can say (the caller gives the query up).
+template <int SEGBITS = 4>
 S3D_HD bool knn3_push(uint32_t* tab, int tstride, int& nseg, uint32_t s, uint32_t e) {
   if (s >= e) return true;
   constexpr uint32_t kMax = kKnn3OffMask + 1u;
+  constexpr int kKnn3Segs = 1 << SEGBITS;      // (4: the 16-entry table of the fast path, == s3d::kKnn3Segs)
   if (e - s > kMax) {          // a long range (coarse grids): two entries, beyond that the exact search
     if (nseg >= kKnn3Segs || e - s > 2u * kMax) return false;
     tab[nseg * tstride] = (s << kKnn3OffBits) | kKnn3OffMask;
@@ -1274,10 +1276,11 @@ S3D_HD bool knn3_push(uint32_t* tab, int tstride, int& nseg, uint32_t s, uint32_
 // scan the table entries [e0, nseg) of this lane into the list: ONE flat loop over all their points (a wave runs
 // max-over-lanes of the TOTAL, not of every row), two points per trip with the loads of the next two in flight.
 // A lane that has run out carries the invalid id: its key is the sentinel and the insertion leaves its list alone.
-template <int KL, typename F4T>
+template <int KL, int SEGBITS = 4, typename F4T>
 S3D_HD void knn3_scan(uint32_t (&keys)[KL], const uint32_t* tab, int tstride, int e0, int nseg,
                       const F4T* __restrict__ pts, float qx, float qy, float qz) {
   constexpr uint32_t kNone = 0xFFFFFFFFu;
+  constexpr uint32_t kKnn3IdMask = (1u << (kKnn3OffBits + SEGBITS)) - 1u;   // (SEGBITS = 4: s3d::kKnn3IdMask)
   int e = e0;
   uint32_t pos = 0, end = 0, idelta = 0;
   // [pos, end): what is left of the current entry; id of a point = pos + idelta.  The load itself is unconditional
@@ -1335,7 +1338,8 @@ S3D_HD void knn3_scan(uint32_t (&keys)[KL], const uint32_t* tab, int tstride, in
 }
 
 // the largest d2 a key can stand for
-S3D_HD float knn3_key_d2_upper(uint32_t key) { return __builtin_bit_cast(float, key | kKnn3IdMask); }
+template <int SEGBITS = 4>
+S3D_HD float knn3_key_d2_upper(uint32_t key) { return __builtin_bit_cast(float, key | ((1u << (kKnn3OffBits + SEGBITS)) - 1u)); }
 
 // ---- the stages of the search (grid_knn_med3 below runs them back to back for one query; the block kernel
 // s3d_knn3_moments_kernel re-deals the queries of a block between them)
@@ -1352,6 +1356,7 @@ S3D_HD float knn3_face(const GridParams& g, float qx, float qy, float qz) {
 
 // stage 1: the row segments of the 3x3x3 cells around the point -> table entries [0, nseg); total = their points.
 // false: a range the table cannot hold.
+template <int SEGBITS = 4>
 S3D_HD bool knn3_build27(const GridParams& g, const uint32_t* __restrict__ cell_start, float qx, float qy, float qz,
                          uint32_t* tab, int tstride, int& nseg, uint32_t& total) {
   const int ix = grid_coord(g, 0, qx), iy = grid_coord(g, 1, qy), iz = grid_coord(g, 2, qz);
@@ -1370,7 +1375,7 @@ S3D_HD bool knn3_build27(const GridParams& g, const uint32_t* __restrict__ cell_
   nseg = 0; total = 0;
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
-    ok = knn3_push(tab, tstride, nseg, rs[r], re[r]) && ok;
+    ok = knn3_push<SEGBITS>(tab, tstride, nseg, rs[r], re[r]) && ok;
     total += re[r] - rs[r];
   }
   return ok;
@@ -1437,9 +1442,9 @@ S3D_HD bool knn3_build_shell(const GridParams& g, const uint32_t* __restrict__ c
 }
 
 // the K-th and the (K+1)-th key in one distance band: the truncated order may not be the exact one
-template <int KL>
+template <int KL, int SEGBITS = 4>
 S3D_HD bool knn3_unambiguous(const uint32_t (&keys)[KL]) {
-  return (keys[KL - 1] >> kKnn3IdBits) != (keys[KL - 2] >> kKnn3IdBits);
+  return (keys[KL - 1] >> (kKnn3OffBits + SEGBITS)) != (keys[KL - 2] >> (kKnn3OffBits + SEGBITS));
 }
 
 // Exact K-NN of a point of the cloud among the cloud (K = KL - 1).  true: keys[0..K-1] hold the K nearest in
@@ -1449,9 +1454,11 @@ template <int KL, typename F4T>
 // far (may be null): set when the query is declined because its K-th neighbour lies beyond the 5x5x5 cells (or the cells
 // hold fewer than K points) - a point in a sparse part of the cloud, whose exact search is a long walk (the caller
 // serves those wave-cooperatively, s3d_knn_moments_far_kernel); left alone otherwise.
+// (round 6: *far = 2 for such a query, 1 for one declined at this point - the 27 cells searched, the K-th neighbour
+// beyond the 5x5x5 proof - that is not "far": a large batch hands both kinds to the ring search, grid_knn_med3_rings below)
 S3D_HD bool grid_knn_med3(const GridParams& g, const uint32_t* __restrict__ cell_start, const F4T* __restrict__ pts,
                           float qx, float qy, float qz, uint32_t* tab, int tstride, uint32_t (&keys)[KL],
-                          bool* far = nullptr) {
+                          int* far = nullptr) {
 #pragma unroll
   for (int j = 0; j < KL; ++j) keys[j] = kKnn3Sentinel;
   int nseg;
@@ -1466,7 +1473,7 @@ S3D_HD bool grid_knn_med3(const GridParams& g, const uint32_t* __restrict__ cell
     // cells, it is a long one
     if (far) {
       const float reach = (float)kKnn3FarRings * g.h;
-      *far = keys[KL - 2] == kKnn3Sentinel || knn3_key_d2_upper(keys[KL - 2]) > reach * reach;
+      *far = (keys[KL - 2] == kKnn3Sentinel || knn3_key_d2_upper(keys[KL - 2]) > reach * reach) ? 2 : 1;
     }
     return false;
   }
@@ -1479,8 +1486,173 @@ S3D_HD bool grid_knn_med3(const GridParams& g, const uint32_t* __restrict__ cell
 }
 
 // position (in the cell-sorted cloud) of the neighbour a key stands for
+template <int SEGBITS = 4>
 S3D_HD uint32_t knn3_position(uint32_t key, const uint32_t* tab, int tstride) {
-  return (tab[((key >> kKnn3OffBits) & 15u) * tstride] >> kKnn3OffBits) + (key & kKnn3OffMask);
+  return (tab[((key >> kKnn3OffBits) & ((1u << SEGBITS) - 1u)) * tstride] >> kKnn3OffBits) + (key & kKnn3OffMask);
+}
+
+// ------------------------------------------------------------------ K4, round 6: the SPARSE parts of a cloud, ring by ring
+//
+// What the fast path above declines on a real lidar scan is not what it declines on a dense cloud.  Measured on the
+// reference's scans (tools_dev/knn3_declines.cpp; 0.2 m voxels, 1.0-1.2 m cells of which 98 % are empty): 5-7 % of the
+// points have FEWER THAN K points in their 27 cells - the far field, ring lines metres apart - against 0.2 % whose
+// K-th neighbour lies beyond the 5x5x5 proof, 0.2 % ties and 0.05 % table overflows; their true K-th neighbour lies in
+// ring 2 (44 %), 3 (37 %), 4 (11 %), 5 (8 %).  The exact per-lane search (grid_knn_sorted) serves them ring after ring
+// through nested per-row loops: on a batch of such scans it took 2.8 of the pre-pass's 4.4 ms for 13 % of the points.
+// Here the same machinery that makes the fast path fast - row segments into a per-lane LDS table by batches of
+// look-ups, ONE flat candidate loop per stage, 32-bit keys, v_med3 insertion - goes on beyond the 5x5x5 cells:
+//   stage A  while the list holds fewer than K keys: whole rings, several at a time (rings 2 ... 3, then 4 ... 6: the
+//            rows outside the examined square as one x-range each, the cells left and right of it for the rows
+//            inside) - nearly all of it empty cells, so few segments;
+//   stage B  the list is full, its K-th key bounds the true K-th distance: proven if that ball lies inside the cube of
+//            rings examined so far, otherwise ONE pruned box finishes - the rows of the ball's box, slab-tested and cut to
+//            the chord, the examined cube left out (what grid_knn_sorted does at its end).
+// A table with 2^SEGBITS entries per lane; a key keeps 32 - 7 - SEGBITS distance bits (SEGBITS = 5: 11 mantissa bits,
+// a tie band of 2^-11 at the K-th place: ~1 % of these queries are ambiguous and, like everything else this path cannot
+// answer - table full, K-th neighbour beyond `rmax` rings - go on to the exact 64-bit search).  Same K-NN set, same tie
+// rule as every other route (the neighbours' moments are sums of floats in double: exact, so their order is free).
+#ifndef S3D_KNN_RING_BATCH
+#define S3D_KNN_RING_BATCH 4
+#endif
+constexpr int kKnn3RingBatch = S3D_KNN_RING_BATCH;   // rows whose (up to four) table look-ups are in flight together
+constexpr int kKnn3RingSegBits = 5;    // the ring search's table: 32 entries per lane (s3d_knn3_rings_kernel) - on the reference's
+                                       // scans 64 entries answer FEWER queries (a key keeps one distance bit less: more ties)
+#ifndef S3D_KNN_RING_MAX
+#define S3D_KNN_RING_MAX 6
+#endif
+#ifndef S3D_KNN_RING_STEP
+#define S3D_KNN_RING_STEP 3
+#endif
+constexpr int kKnn3RingMax = S3D_KNN_RING_MAX;     // ... how many rings it looks at before it hands the query on
+constexpr int kKnn3RingStep = S3D_KNN_RING_STEP;   // ... in two steps while the list is short: rings 2 ... Step, then Step + 1 ... Max
+
+// t / d for 0 <= t < 4096, 1 <= d <= 64, without an integer division (a multiply by ceil(2^18 / d) is exact there:
+// the error t (ceil(2^18 / d) - 2^18 / d) < 4096 stays below 2^18 / d)
+S3D_HD int small_div(int t, int magic) { return (int)(((unsigned)t * (unsigned)magic) >> 18); }
+S3D_HD int small_div_magic(int d) { return ((1 << 18) + d - 1) / d; }
+
+template <int SEGBITS>
+S3D_HD bool knn3_build_ring(const GridParams& g, const uint32_t* __restrict__ cell_start, int ix, int iy, int iz, int rex,
+                            int r, uint32_t* tab, int tstride, int& nseg) {
+  // the cube of rings <= r less the cube of rings <= rex (examined): rows (cy, cz) of the square +-r in batches of
+  // kKnn3RingBatch, their (up to four) table look-ups in flight together.  A row outside the examined square: ONE range
+  // [ix - r, ix + r]; inside it: the cells left and right of the examined ones.  (Several rings in one step - rex + 1 < r
+  // - cost far fewer look-ups than ring by ring: an x-range is one look-up however long, so the rows of rings 4, 5, 6
+  // together are 218 look-ups instead of 130 + 202 + 290.)
+  const int side = 2 * r + 1, nrows = side * side, magic = small_div_magic(side);
+  bool ok = true;
+  for (int t0 = 0; t0 < nrows; t0 += kKnn3RingBatch) {
+    uint32_t a[kKnn3RingBatch][2], b[kKnn3RingBatch][2];
+#pragma unroll
+    for (int u = 0; u < kKnn3RingBatch; ++u) {
+      const int t = t0 + u;
+      const int tz = small_div(t, magic);
+      const int dy = t - tz * side - r, dz = tz - r;
+      const int cy = iy + dy, cz = iz + dz;
+      const bool in = t < nrows && cy >= 0 && cy < g.dim[1] && cz >= 0 && cz < g.dim[2];
+      const bool outer = dy < -rex || dy > rex || dz < -rex || dz > rex;
+      const int rowbase = in ? g.dim[0] * (cy + g.dim[1] * cz) : 0;
+      const int xl = imax(ix - r, 0), xh = imin(ix + r, g.dim[0] - 1);
+      const int s0b = outer ? xh : imin(ix - rex - 1, g.dim[0] - 1);   // first range: [xl, s0b]
+      const int s1a = imax(ix + rex + 1, 0);                          // second range (inner rows): [s1a, xh]
+      const bool v0 = in && xl <= s0b;
+      const bool v1 = in && !outer && s1a <= xh;
+      a[u][0] = cell_start[rowbase + (v0 ? xl : 0)];  b[u][0] = cell_start[rowbase + (v0 ? s0b + 1 : 0)];
+      a[u][1] = cell_start[rowbase + (v1 ? s1a : 0)]; b[u][1] = cell_start[rowbase + (v1 ? xh + 1 : 0)];
+      if (!v0) b[u][0] = a[u][0];
+      if (!v1) b[u][1] = a[u][1];
+    }
+#pragma unroll
+    for (int u = 0; u < kKnn3RingBatch; ++u) {
+      ok = knn3_push<SEGBITS>(tab, tstride, nseg, a[u][0], b[u][0]) && ok;
+      ok = knn3_push<SEGBITS>(tab, tstride, nseg, a[u][1], b[u][1]) && ok;
+    }
+  }
+  return ok;
+}
+
+// stage B: the rows of the box of the ball (q, sqrt(lim2)) outside the cube of rings <= rex, slab-tested and cut to
+// the chord, appended to the table.  false: the table is full.
+template <int SEGBITS>
+S3D_HD bool knn3_build_box(const GridParams& g, const uint32_t* __restrict__ cell_start, float qx, float qy, float qz,
+                           int ix, int iy, int iz, float lim2, int rex, uint32_t* tab, int tstride, int& nseg) {
+  const float eps = 2.0e-3f * g.h;
+  const float R = sqrt_bound(lim2) * 1.0001f + eps;
+  const int z0 = imax(grid_coord(g, 2, qz - R), 0), z1 = imin(grid_coord(g, 2, qz + R), g.dim[2] - 1);
+  const int y0 = imax(grid_coord(g, 1, qy - R), 0), y1 = imin(grid_coord(g, 1, qy + R), g.dim[1] - 1);
+  const int ny = y1 - y0 + 1, nrows = (y0 <= y1 && z0 <= z1) ? ny * (z1 - z0 + 1) : 0;
+  if (ny > 64 || nrows > 4096) return false;      // (the caller bounds the ball to a few rings: never on that path)
+  const int magic = small_div_magic(imax(ny, 1));
+  bool ok = true;
+  for (int t0 = 0; t0 < nrows; t0 += kKnn3RingBatch) {
+    uint32_t a[kKnn3RingBatch][2], b[kKnn3RingBatch][2];
+#pragma unroll
+    for (int u = 0; u < kKnn3RingBatch; ++u) {
+      const int t = t0 + u;
+      const int tz = small_div(t, magic);
+      const int cy = y0 + (t - tz * ny), cz = z0 + tz;
+      const float zlo = g.origin[2] + (float)cz * g.h, ylo = g.origin[1] + (float)cy * g.h;
+      const float fz2 = fmaxf(fmaxf(zlo - qz, qz - (zlo + g.h)) - eps, 0.f);
+      const float fy2 = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.h)) - eps, 0.f);
+      const float rowd2 = fy2 * fy2 + fz2 * fz2;
+      const bool in = t < nrows && rowd2 <= lim2;
+      const float rx = sqrt_bound(fmaxf(lim2 - rowd2, 0.f)) * 1.0001f + eps;
+      const int xa = imax(grid_coord(g, 0, qx - rx), 0), xb = imin(grid_coord(g, 0, qx + rx), g.dim[0] - 1);
+      const bool inner = cy >= iy - rex && cy <= iy + rex && cz >= iz - rex && cz <= iz + rex;
+      // outside the examined cube: [xa, xb]; inside its (y, z) shadow: what lies left and right of it
+      const int s0b = inner ? imin(xb, ix - rex - 1) : xb;
+      const int s1a = imax(xa, ix + rex + 1);
+      const bool v0 = in && xa <= s0b, v1 = in && inner && s1a <= xb;
+      const int rowbase = in ? g.dim[0] * (cy + g.dim[1] * cz) : 0;
+      a[u][0] = cell_start[rowbase + (v0 ? xa : 0)];  b[u][0] = cell_start[rowbase + (v0 ? s0b + 1 : 0)];
+      a[u][1] = cell_start[rowbase + (v1 ? s1a : 0)]; b[u][1] = cell_start[rowbase + (v1 ? xb + 1 : 0)];
+      if (!v0) b[u][0] = a[u][0];
+      if (!v1) b[u][1] = a[u][1];
+    }
+#pragma unroll
+    for (int u = 0; u < kKnn3RingBatch; ++u) {
+      ok = knn3_push<SEGBITS>(tab, tstride, nseg, a[u][0], b[u][0]) && ok;
+      ok = knn3_push<SEGBITS>(tab, tstride, nseg, a[u][1], b[u][1]) && ok;
+    }
+  }
+  return ok;
+}
+
+// 0: keys[0..K-1] hold the K nearest (K = KL - 1), places through knn3_position<SEGBITS>; not answered: 1 = a tie band
+// at the K-th place or a full table (an ordinary point: the exact per-lane search is quick), 2 = the K-th neighbour lies
+// beyond `rmax` rings (an ISOLATED point, whose exact search is a walk over thousands of rows: wave-cooperatively).
+// tab: 2^SEGBITS entries of this lane, stride tstride.
+template <int KL, int SEGBITS, typename F4T>
+S3D_HD int grid_knn_med3_rings(const GridParams& g, const uint32_t* __restrict__ cell_start, const F4T* __restrict__ pts,
+                               float qx, float qy, float qz, uint32_t* tab, int tstride, uint32_t (&keys)[KL], int rmax) {
+  constexpr int K = KL - 1;
+#pragma unroll
+  for (int j = 0; j < KL; ++j) keys[j] = kKnn3Sentinel;
+  int nseg;
+  uint32_t total;
+  if (!knn3_build27<SEGBITS>(g, cell_start, qx, qy, qz, tab, tstride, nseg, total)) return 1;
+  knn3_scan<KL, SEGBITS>(keys, tab, tstride, 0, nseg, pts, qx, qy, qz);
+  const float face = knn3_face(g, qx, qy, qz);
+  const int ix = grid_coord(g, 0, qx), iy = grid_coord(g, 1, qy), iz = grid_coord(g, 2, qz);
+  int rex = 1;                                   // the cube of rings <= rex has been examined
+  while (keys[K - 1] == kKnn3Sentinel) {         // stage A: rings rex + 1 ... rnext together, rnext = kKnn3RingStep, then rmax
+    if (rex >= rmax) return 2;
+    const int rnext = rex < kKnn3RingStep && kKnn3RingStep < rmax ? kKnn3RingStep : rmax;
+    const int first = nseg;
+    if (!knn3_build_ring<SEGBITS>(g, cell_start, ix, iy, iz, rex, rnext, tab, tstride, nseg)) return 1;
+    knn3_scan<KL, SEGBITS>(keys, tab, tstride, first, nseg, pts, qx, qy, qz);
+    rex = rnext;
+  }
+  const float lim2 = knn3_key_d2_upper<SEGBITS>(keys[K - 1]);
+  const float proven = ((float)rex + face) * g.h;
+  if (lim2 > proven * proven) {                  // stage B
+    const float reach = ((float)rmax + face) * g.h;
+    if (lim2 > reach * reach) return 2;
+    const int first = nseg;
+    if (!knn3_build_box<SEGBITS>(g, cell_start, qx, qy, qz, ix, iy, iz, lim2, rex, tab, tstride, nseg)) return 1;
+    knn3_scan<KL, SEGBITS>(keys, tab, tstride, first, nseg, pts, qx, qy, qz);
+  }
+  return knn3_unambiguous<KL, SEGBITS>(keys) ? 0 : 1;
 }
 
 // ------------------------------------------------------------------ K5, round 3: 1-NN by a flat scan of the 27 cells

@@ -209,7 +209,7 @@ __device__ __forceinline__ void block_bbox_merge(unsigned int (&mn)[3], unsigned
 
 // which = 0: raw points (n_raw); 1: filtered points (n)
 // zero_digit_tot / zero_counters (may be null): what the stages after this first kernel of the pre-pass want cleared - the
-// digit totals of the one-sweep sort (kSortPlaces << kSortMaxBits words per slot) and the three K4 list counters - so
+// digit totals of the one-sweep sort (kSortPlaces << kSortMaxBits words per slot) and the five K4 list counters - so
 // that a lone registration does not pay two more 4-us fill launches
 template <int WHICH>
 __global__ void __launch_bounds__(kBlock) k_bbox(SlotDev* slots, const float4* __restrict__ filt,
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(kBlock) k_bbox(SlotDev* slots, const float4* _
   if (blockIdx.x == 0) {
     if (zero_digit_tot)
       for (int d = threadIdx.x; d < (4 << 10); d += kBlock) zero_digit_tot[(size_t)blockIdx.y * (4 << 10) + d] = 0u;
-    if (zero_counters && blockIdx.y == 0 && threadIdx.x < 3) zero_counters[threadIdx.x] = 0;
+    if (zero_counters && blockIdx.y == 0 && threadIdx.x < 5) zero_counters[threadIdx.x] = 0;
   }
   SlotDev& s = slots[blockIdx.y];
   const int n = WHICH == 0 ? s.n_raw : s.n;
@@ -1197,11 +1197,14 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN3_WAVES) s3d_knn3_moments_kerne
   const float4 q = pts[i];
   uint32_t keys[KL];
   uint32_t* ctab = tab + threadIdx.x;
-  bool far = false;
+  int far = 0;
   if (!grid_knn_med3<KL>(s.g, cell_start + s.cell_off, pts, q.x, q.y, q.z, ctab, kBlock, keys, far_count ? &far : nullptr)) {
-    // two lists in one buffer: the near declines (ties, table overflow) grow from the front, the FAR ones - the K-th
-    // neighbour beyond the 5x5x5 cells - from the back (s3d_knn_moments_far_kernel)
-    if (far || far_all) redo_list[redo_cap - 1 - atomicAdd(far_count, 1)] = make_int2(slot, i);
+    // two lists in one buffer: the near declines (ties, table overflow) grow from the front, the FAR ones from the back.
+    // far = 2: fewer than K points in the 27 cells, or the K-th neighbour more than kKnn3FarRings cells away; 1: the K-th
+    // beyond the 5x5x5 proof but not that far; 0: a tie, a full table.  far_all = 0: the far list takes far = 2 (the
+    // wave-cooperative kernel forced on a large batch); 1: far >= 1 (a large batch: s3d_knn3_rings_kernel serves them ring
+    // by ring); 2: every decline (a small batch: all of them wave-cooperatively, s3d_knn_moments_far_kernel)
+    if (far + far_all >= 2) redo_list[redo_cap - 1 - atomicAdd(far_count, 1)] = make_int2(slot, i);
     else redo_list[atomicAdd(redo_count, 1)] = make_int2(slot, i);
     return;
   }
@@ -1222,6 +1225,79 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN3_WAVES) s3d_knn3_moments_kerne
   o[3 * plane] = mo.c00; o[4 * plane] = mo.c10; o[5 * plane] = mo.c11;
   o[6 * plane] = mo.c20; o[7 * plane] = mo.c21; o[8 * plane] = mo.c22;
   fallback_list[atomicAdd(fallback_count, 1)] = s.off + i;
+}
+
+// ---- K4, round 6: the sparse parts of a cloud, ring by ring (grid_knn_med3_rings, s3d_core.h "K4, round 6").
+// The far list of s3d_knn3_moments_kernel (far_all = 2: fewer than K points in the 27 cells, or the K-th beyond the 5x5x5
+// proof - 5-13 % of the points of a real lidar scan) through the fast path's own machinery carried on beyond the 5x5x5
+// cells: 32 table entries per lane in LDS, whole rings while the list is short, then one pruned box.  What it cannot
+// answer (~5 % of its entries: the K-th neighbour beyond kKnn3RingMax rings, a tie band at the K-th place, a full table)
+// goes on to a list of its own for s3d_knn_moments_far_kernel, a wave per query.
+// A fixed grid strides over the list; its length is read on the device.
+#ifndef S3D_KNN_RINGS_WAVES
+#define S3D_KNN_RINGS_WAVES 4
+#endif
+#ifndef S3D_KNN_RINGS_FIRST
+#define S3D_KNN_RINGS_FIRST 3
+#endif
+// Two launches.  A wave runs as long as its deepest lane, and the depths are skewed - ring 2 / 3 / 4 / 5+ for 44 / 37 / 11 /
+// 8 % of the entries, ring r costing (2 r + 1)^2 row look-ups - so a wave of mixed entries paid rings 2 ... 6 (445 rows) for
+// nearly everyone.  The first launch stops at kKnn3RingFirst rings (74 rows) and lists the entries it does not answer
+// (the fourth quarter of the buffer, from its back); the second launch serves those up to kKnn3RingMax, from the start
+// again (the table is per lane), in waves of their own, and lists ITS leftovers (the second quarter) for the
+// wave-cooperative kernel.  (Tried first: both phases in one kernel, the deep entries of a block packed into its first
+// lanes through LDS: no better, see EXPERIMENTS.md.)
+constexpr int kKnn3RingFirst = S3D_KNN_RINGS_FIRST;
+template <int K, int RMAX>
+__global__ void __launch_bounds__(kBlock, S3D_KNN_RINGS_WAVES) s3d_knn3_rings_kernel(const SlotDev* __restrict__ slots,
+                                                                  const float4* __restrict__ sorted,
+                                                                  const uint32_t* __restrict__ cell_start,
+                                                                  double* __restrict__ moments, size_t plane,
+                                                                  NormalRec* __restrict__ normals,
+                                                                  int* __restrict__ fallback_count,
+                                                                  int* __restrict__ fallback_list,
+                                                                  int2* __restrict__ redo_list,
+                                                                  const int* __restrict__ in_count, int in_cap,
+                                                                  int* __restrict__ out_count, int out_cap) {
+  constexpr int KL = K + 1, SB = kKnn3RingSegBits;
+  __shared__ uint32_t tab[(1 << SB) * kBlock];   // entry j of thread t at tab[j * kBlock + t]
+  const int count = *in_count;
+  uint32_t* ctab = tab + threadIdx.x;
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < count; j += gridDim.x * kBlock) {
+    const int2 e = redo_list[in_cap - 1 - j];
+    const SlotDev& s = slots[e.x];
+    const float4* __restrict__ pts = sorted + s.off;
+    const float4 q = pts[e.y];
+    uint32_t keys[KL];
+    const int why = grid_knn_med3_rings<KL, SB>(s.g, cell_start + s.cell_off, pts, q.x, q.y, q.z, ctab, kBlock, keys, RMAX);
+    if (why != 0) {
+      // not answered (the 20th neighbour beyond this launch's rings, a tie band at the K-th place, a full table): on to
+      // the list of the next stage - the launch with more rings, then the wave-cooperative kernel.  (The first launch hands
+      // its ties on with the rest: telling them apart here - two destinations - makes hipcc spill 470 registers instead of
+      // 40.)  NOT to the per-lane exact search: these are points of the sparse parts, where that search walks ring after
+      // ring of empty rows - one such lane keeps its wave for hundreds of microseconds, and the launch lasts as long as
+      // the slowest of them (measured on a batch of real scans: 3.0 ms for 0.4 % of the points, 1.2 ms for the ties alone)
+      redo_list[out_cap - 1 - atomicAdd(out_count, 1)] = e;
+      continue;
+    }
+    Moments mo;
+    moments_init(mo);
+#pragma unroll
+    for (int n = 0; n < K; ++n) {
+      const float4 p = pts[knn3_position<SB>(keys[n], ctab, kBlock)];
+      moments_add(mo, p.x, p.y, p.z);
+    }
+    double nrm[3];
+    if (moments_normal_direct(mo, K, nrm)) {
+      normals[s.off + e.y] = normal_encode(nrm);
+      continue;
+    }
+    double* o = moments + (size_t)(s.off + e.y);
+    o[0] = mo.mean[0]; o[plane] = mo.mean[1]; o[2 * plane] = mo.mean[2];
+    o[3 * plane] = mo.c00; o[4 * plane] = mo.c10; o[5 * plane] = mo.c11;
+    o[6 * plane] = mo.c20; o[7 * plane] = mo.c21; o[8 * plane] = mo.c22;
+    fallback_list[atomicAdd(fallback_count, 1)] = s.off + e.y;
+  }
 }
 
 // (Round 4, measured and dropped: the SHELL stage compacted over the block.  Half of the benchmark's queries need the
@@ -1334,7 +1410,8 @@ __global__ void __launch_bounds__(kWave) s3d_knn_moments_far_kernel(const SlotDe
                                                                      int* __restrict__ fallback_count,
                                                                      int* __restrict__ fallback_list,
                                                                      const int* __restrict__ far_count,
-                                                                     const int2* __restrict__ redo_list, int redo_cap) {
+                                                                     const int2* __restrict__ redo_list, int redo_cap,
+                                                                     float first_box_cells) {
   __shared__ unsigned long long buf[kKnnFarCap + kWave];
   __shared__ unsigned long long sel[K];
   const int count = *far_count;
@@ -1348,7 +1425,7 @@ __global__ void __launch_bounds__(kWave) s3d_knn_moments_far_kernel(const SlotDe
     const float4* __restrict__ pts = sorted + s.off;
     const float4 q = pts[i];
     int nbest = 0;
-    float d = 3.0f * g.h;
+    float d = first_box_cells * g.h;   // (3 cells for the fast path's declines; the ring search's leftovers start beyond its rings)
     for (int attempt = 0; attempt < 48; ++attempt) {
       const float m = d * 1.0001f + 2.0e-3f * g.h;
       const int x0 = imax(grid_coord(g, 0, q.x - m), 0), x1 = imin(grid_coord(g, 0, q.x + m), g.dim[0] - 1);

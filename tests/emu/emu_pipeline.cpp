@@ -384,6 +384,47 @@ void emu_fused_knn_check(const float* xyz, int n, int stride, double leaf, int c
   }
 }
 
+// the ring-by-ring med3 search (round 6: grid_knn_med3_rings, what serves the sparse parts of a scan) on a fused grid, for
+// EVERY point or only those the fast path declines (only_declined), against the exact search by position.
+// out[0] = points tried, [1] = not answered, [2] = answered with a different K-NN set, [3] = declined by the fast path
+}  // extern "C"
+template <int SB>
+static void fused_knn_rings_check(const float* xyz, int n, int stride, double leaf, int cpp, int rmax, int only_declined,
+                                  long long* out) {
+  Fused F = build_fused(xyz, n, stride, leaf, cpp);
+  const GridParams& g = F.G.g;
+  const int np_ = (int)F.G.sorted.size();
+  out[0] = out[1] = out[2] = out[3] = 0;
+  for (int i = 0; i < np_; ++i) {
+    const F4& q = F.G.sorted[i];
+    uint32_t tab[1 << SB], keys[21];
+    {
+      uint32_t t16[kKnn3Segs], k16[21];
+      const bool fast = grid_knn_med3<21>(g, F.G.cell_start.data(), F.G.sorted.data(), q.x, q.y, q.z, t16, 1, k16);
+      if (!fast) ++out[3];
+      if (fast && only_declined) continue;
+    }
+    ++out[0];
+    if (grid_knn_med3_rings<21, SB>(g, F.G.cell_start.data(), F.G.sorted.data(), q.x, q.y, q.z, tab, 1, keys, rmax) != 0) { ++out[1]; continue; }
+    unsigned long long ref[20];
+    const int cnt = grid_knn_sorted<20, true, true>(g, F.G.cell_start.data(), F.G.sorted.data(), q.x, q.y, q.z, 20, ref);
+    std::vector<uint32_t> a, b;
+    for (int j = 0; j < cnt; ++j) b.push_back((uint32_t)(ref[j] & 0xFFFFFFFFull));
+    for (int j = 0; j < 20; ++j) a.push_back(knn3_position<SB>(keys[j], tab, 1));
+    std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+    if (a != b) ++out[2];
+  }
+}
+extern "C" {
+// rmax + 100 * segbits (segbits 0: the device's table size)
+void emu_fused_knn_rings_check(const float* xyz, int n, int stride, double leaf, int cpp, int rmax, int only_declined,
+                               long long* out) {
+  const int sb = rmax / 100;
+  rmax %= 100;
+  if (sb == 6) fused_knn_rings_check<6>(xyz, n, stride, leaf, cpp, rmax, only_declined, out);
+  else fused_knn_rings_check<kKnn3RingSegBits>(xyz, n, stride, leaf, cpp, rmax, only_declined, out);
+}
+
 // B1/B2 (patch accumulation, radius outlier removal) as the kernels run them ---------------------
 void emu_transform(const float* xyz, int n, const double* tf_colmajor, float* out) {
   double T[12];

@@ -459,3 +459,21 @@ def test_fused_prepass_knn_is_exact(emu, fixture_clouds, leaf, cpp):
     emu.emu_fused_knn_check(src.ctypes.data_as(fp), len(src), 3, C.c_double(leaf), cpp, out.ctypes.data_as(C.POINTER(C.c_longlong)))
     assert out[0] > 1000 and out[2] == 0 and out[3] == 0, out
     assert out[1] < 0.7 * out[0], out
+
+
+@pytest.mark.parametrize("leaf,cpp,rmax,only", [(0.2, 2, 6, 1), (0.2, 2, 6, 0), (0.3, 2, 4, 1), (0.5, 16, 6, 1), (0.2, 1, 3, 1),
+                                                (0.2, 2, 606, 1)])     # (+ 600: a 64-entry table instead of the device's 32)
+def test_ring_by_ring_knn_is_exact(emu, fixture_clouds, leaf, cpp, rmax, only):
+    """Round 6: the sparse parts of a scan ring by ring (grid_knn_med3_rings: whole rings while the list is short, then
+    one pruned box) - every point it answers has the exact 20-NN set of the search by position, on the points the fast
+    path declines (what the device hands to it) and on every point; and it answers most of those declines (the
+    reference's scans: 93 % of them have fewer than 20 points in their 27 cells, tools_dev/knn3_declines.cpp)."""
+    for cloud in (fixture_clouds[0], fixture_clouds[3]):
+        src = np.ascontiguousarray(cloud[:, :3])
+        out = np.zeros(4, np.int64)
+        emu.emu_fused_knn_rings_check(src.ctypes.data_as(fp), len(src), 3, C.c_double(leaf), cpp, rmax, only,
+                                      out.ctypes.data_as(C.POINTER(C.c_longlong)))
+        assert out[0] > 200 and out[2] == 0, out
+        if only and rmax % 100 >= 6:
+            assert out[1] < 0.25 * out[0], out          # most of the fast path's declines are answered here
+        print("leaf %g cpp %d rmax %d: tried %d, not answered %d, fast-path declines %d" % (leaf, cpp, rmax, out[0], out[1], out[3]))
