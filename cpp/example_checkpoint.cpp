@@ -35,6 +35,7 @@ int main(int argc, char** argv) {
   logger.setLogLevel(ERROR);
   try {
     PointCloudSensor sensor("velodyne", &logger);
+    sensor.setPrepassCache(true);   // (off by default, like the reference: nothing is kept between calls unless asked for)
     Uuid id[2];
     {
       PointCloudMeasurement::Ptr m[2];
