@@ -998,7 +998,7 @@ struct Batch {
         s3d_nn_scan27_kernel<true, true><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), wc + (it & 7), wl_pair, wl_index, pc);
       else
         s3d_nn_scan27_kernel<true, false><<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), wc + (it & 7), wl_pair, wl_index, pc);
-      s3d_nn_worklist_kernel<<<4096, kWave, 0, st>>>(d_pairs(), d_slots(), A, max_d, dbg_nn, wc + (it & 7), wl_pair, wl_index,
+      s3d_nn_worklist_kernel<<<S3D_WL_BLOCKS, kWave, 0, st>>>(d_pairs(), d_slots(), A, max_d, dbg_nn, wc + (it & 7), wl_pair, wl_index,
                                                       wc + ((it + 1) & 7));
       return;
     }

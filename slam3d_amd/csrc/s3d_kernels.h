@@ -851,6 +851,45 @@ __global__ void __launch_bounds__(kBlock) k_heads_scan(SlotDev* slots, uint32_t*
   if (threadIdx.x == kBlock - 1) s.n = (int)v;
 }
 
+// (round 6) the run sums of a 256-element chunk of the sorted raw points, for both centroid kernels.  Until round 6 a head
+// walked its run through global memory - key, index, gather: two dependent round trips per point, on a quarter of the
+// lanes - which a lidar scan punishes: 0.2 m voxels next to the sensor hold tens of returns each, and a wave lasted as long
+// as its longest run (the reference's scans: 37 ps per raw point against 20 on the synthetic cloud, whose voxels hold one
+// point).  Here EVERY lane gathers its own point at once (one round trip for the block), the points and keys go through
+// LDS, and a head adds its run up from there in the same order - ((0 + p0) + p1) + ... as pcl::VoxelGrid does: the same
+// floats bit for bit.  A run that leaves the chunk goes on through global memory as before; a lane whose run started in an
+// earlier chunk (its key equals the key before the chunk) gathers nothing.
+struct RunSum { float sx, sy, sz; int end; float4 first; uint32_t key; };   // end: global index one past the run
+__device__ __forceinline__ bool block_run_sums(const SlotDev& s, const uint32_t* __restrict__ k, const uint32_t* __restrict__ v,
+                                               int base, RunSum& out) {
+  __shared__ float lx[kBlock], ly[kBlock], lz[kBlock];
+  __shared__ uint32_t lk[kBlock];
+  const int t = (int)threadIdx.x, i = base + t;
+  const bool in = i < s.n_raw;
+  const uint32_t key = in ? k[i] : kInvalidKey;
+  const uint32_t kb = base > 0 ? k[base - 1] : kInvalidKey;      // (uniform: the key before the chunk)
+  const uint32_t idx = in ? v[i] : 0u;
+  const bool mine = in && key != kInvalidKey && !(base > 0 && key == kb);
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (mine) p = s.raw[idx];
+  lk[t] = key; lx[t] = p.x; ly[t] = p.y; lz[t] = p.z;
+  __syncthreads();
+  const bool head = mine && (t == 0 || lk[t - 1] != key);
+  if (head) {
+    float sx = 0.f + p.x, sy = 0.f + p.y, sz = 0.f + p.z;   // (0 + x: the sums start as they always did)
+    int j = t + 1;
+    for (; j < kBlock && lk[j] == key; ++j) { sx += lx[j]; sy += ly[j]; sz += lz[j]; }
+    int jg = base + j;
+    if (j == kBlock)
+      for (; jg < s.n_raw && k[jg] == key; ++jg) {
+        const float4 q = s.raw[v[jg]];
+        sx += q.x; sy += q.y; sz += q.z;
+      }
+    out.sx = sx; out.sy = sy; out.sz = sz; out.end = jg; out.first = p; out.key = key;
+  }
+  return head;
+}
+
 // one thread per sorted element; heads walk their run and emit the centroid
 // (pcl::VoxelGrid fourth pass: float sum in order, divided by float count)
 __global__ void __launch_bounds__(kBlock) k_centroids(const SlotDev* __restrict__ slots, const uint32_t* __restrict__ keys,
@@ -869,12 +908,8 @@ __global__ void __launch_bounds__(kBlock) k_centroids(const SlotDev* __restrict_
   const int i = base + threadIdx.x;
   const uint32_t* __restrict__ k = keys + s.off;
   const uint32_t* __restrict__ v = vals + s.off;
-  const bool head = i < s.n_raw && voxel_head(k, i);
-  // the first point of a head's run is fetched before the block scan (its index, then the gather: two dependent
-  // round trips that otherwise follow the scan's barriers).  Heads only: at map resolution most positions are not
-  // heads, and a wasted gather per position cost the 96-scan map 8 %
-  float4 p_first = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (head) p_first = s.raw[v[i]];
+  RunSum rs;
+  const bool head = block_run_sums(s, k, v, base, rs);
   int total;
   const int pos = block_excl_flag(head, &total, lds4) + (int)blockcnt[(size_t)slot_i * nb_max + chunk_i];
   // the bounding box of the centroids (what the search grid is laid over) is gathered here, where they are written (a
@@ -883,15 +918,8 @@ __global__ void __launch_bounds__(kBlock) k_centroids(const SlotDev* __restrict_
   // 1.8 ms; k_grid_params reduces the block words
   unsigned int mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
   if (head) {
-    const uint32_t key = k[i];
-    float sx = 0.f + p_first.x, sy = 0.f + p_first.y, sz = 0.f + p_first.z;   // (0 + x: the sums start as they always did)
-    int j = i + 1;
-    for (; j < s.n_raw && k[j] == key; ++j) {
-      const float4 p = s.raw[v[j]];
-      sx += p.x; sy += p.y; sz += p.z;
-    }
-    const float c = (float)(j - i);
-    const float4 q = make_float4(sx / c, sy / c, sz / c, 1.f);
+    const float c = (float)(rs.end - i);
+    const float4 q = make_float4(rs.sx / c, rs.sy / c, rs.sz / c, 1.f);
     filt[s.off + pos] = q;
     if (finite3(q.x, q.y, q.z)) {
       const unsigned int a = f2ord(q.x), b = f2ord(q.y), cc = f2ord(q.z);
@@ -943,23 +971,18 @@ __global__ void __launch_bounds__(kBlock) k_centroids_fused(SlotDev* __restrict_
   const uint32_t* __restrict__ k = keys + s.off;
   const uint32_t* __restrict__ v = vals + s.off;
   uint32_t* __restrict__ cs = cell_start + s.cell_off;
-  const bool head = i < s.n_raw && voxel_head(k, i);
-  float4 p_first = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (head) p_first = s.raw[v[i]];
+  RunSum rs;
+  const bool head = block_run_sums(s, k, v, base, rs);   // (pcl::VoxelGrid: float sums in index order)
   int total;
   const int pos = block_excl_flag(head, &total, lds4) + (int)blockcnt[(size_t)slot_i * nb_max + chunk_i];
   int lo = 0, hi = -1, lo2 = 0, hi2 = -1;
   uint32_t val = 0, val2 = 0;
   if (head) {
-    const uint32_t key = k[i];
-    float sx = 0.f + p_first.x, sy = 0.f + p_first.y, sz = 0.f + p_first.z;   // (pcl::VoxelGrid: float sums in index order)
-    int j = i + 1;
-    for (; j < s.n_raw && k[j] == key; ++j) {
-      const float4 p = s.raw[v[j]];
-      sx += p.x; sy += p.y; sz += p.z;
-    }
+    const uint32_t key = rs.key;
+    const float4 p_first = rs.first;
+    const int j = rs.end;
     const float c = (float)(j - i);
-    const float qx = sx / c, qy = sy / c, qz = sz / c;
+    const float qx = rs.sx / c, qy = rs.sy / c, qz = rs.sz / c;
     // (no division: the cell by a multiply-high, the id from the run's first raw point with pcl::VoxelGrid's own float
     // operations - every point of the run has that voxel -, the cell check from the centroid's position; the decode with
     // its six divisions only for a centroid that is not plainly inside its cell: 0.98 -> 0.8x ms at 256 pairs)
@@ -2257,6 +2280,13 @@ __device__ __forceinline__ void nn_search_one_coop(const PairDev& P, const SlotD
 // A LONG list - a registration that has not settled yet: every record has searching queries - is a matter of
 // throughput, not latency: 64 queries per wave and trip, each lane its own search (nn_query PHASE 2, as the lists of
 // the scan27 passes are served).
+// (round 6) throughput mode: what the flat scan of a wave's 64 entries declines - queries without a near neighbour, a
+// walk through a wide box each - is served wave-cooperatively, one after the other, while at most this many lanes of the
+// wave are left (the per-lane walks of a few lanes kept the whole wave for the slowest of them: passes 4-6 of a 96-pair
+// batch of the reference's scans 0.36 + 0.26 + 0.23 -> 0.32 + 0.23 + 0.19 ms; 8 or 16: the same)
+#ifndef S3D_RS_COOP_LANES
+#define S3D_RS_COOP_LANES 16
+#endif
 __global__ void __launch_bounds__(kWave) s3d_nn_record_search_kernel(const PairDev* __restrict__ pairs,
                                                                       const SlotDev* __restrict__ slots, NNArrays A,
                                                                       float max_d, int dbg,
@@ -2307,6 +2337,22 @@ __global__ void __launch_bounds__(kWave) s3d_nn_record_search_kernel(const PairD
           done = true;
         }
       }
+#if S3D_RS_COOP_LANES > 0
+      {
+        unsigned long long left = __ballot(need && !done);
+        if (left != 0ull && __popcll(left) <= S3D_RS_COOP_LANES && !(dbg & 2048)) {
+          while (left) {
+            const int src = __ffsll((long long)left) - 1;
+            left &= left - 1ull;
+            const int pair = __shfl((int)e.x, src, kWave), qi = __shfl((int)e.y, src, kWave);
+            const int ci = __shfl((int)e.z, src, kWave), ss = __shfl((int)e.w, src, kWave);
+            nn_search_one_coop(pairs[__builtin_amdgcn_readfirstlane(pair)], slots[__builtin_amdgcn_readfirstlane(ss)], A, max_d, dbg,
+                               __builtin_amdgcn_readfirstlane(qi), __builtin_amdgcn_readfirstlane(ci));
+          }
+          continue;
+        }
+      }
+#endif
       nn_query<0, 2>(P, slots[P.slot_t], Ss, (int)e.x, (int)e.z - P.corr_off, need && !done, A, max_d, dbg | 2048, nullptr,
                      nullptr, P.T_nn);
     }
@@ -2471,6 +2517,22 @@ __global__ void __launch_bounds__(kBlock, S3D_NN27_WAVES) s3d_nn_scan27_kernel(c
 // already").  One wave per block; a short list is dealt 8 entries per wave (their searches diverge, and a wave
 // serialises its lanes' paths: the list's latency is what counts), a long one 64.  The lanes of a wave serve
 // different pairs here: no wave-cooperative search, whose grid arguments are wave-uniform.
+// (round 6) how long a list is still served one query per wave: 16 entries per block instead of 2.  What a scan27 pass
+// declines on the reference's scans is ~500 queries per pair WITHOUT a neighbour in range, each a walk through the 5 x 5 rows
+// of a 2.9 m ball in cells that hold up to 60 points: 64 of them per wave, lane by lane, made the two worklist launches of
+// a 96-pair batch 250 + 190 us; wave-cooperatively 105 + 76 us (records bit-identical).  The synthetic benchmark's list
+// (cheap declines: a neighbour just beyond the 27 cells' reach) now falls under the rule too and pays 20 us in pass 2.
+// Tried: 8 / 64 entries per block, 8 192 / 16 384 blocks (the same within 0.03 ms), per-lane with ceil(count / blocks)
+// lanes per wave (0.60 + 0.45 ms against 0.50 + 0.39).
+#ifndef S3D_WL_BLOCKS
+#define S3D_WL_BLOCKS 4096
+#endif
+#ifndef S3D_WL_COOP_FACTOR
+#define S3D_WL_COOP_FACTOR 16
+#endif
+#ifndef S3D_WL_PER_MODE
+#define S3D_WL_PER_MODE 0
+#endif
 __global__ void __launch_bounds__(kWave) s3d_nn_worklist_kernel(const PairDev* __restrict__ pairs,
                                                                  const SlotDev* __restrict__ slots, NNArrays A,
                                                                  float max_d, int dbg, const int* __restrict__ work_count,
@@ -2478,7 +2540,7 @@ __global__ void __launch_bounds__(kWave) s3d_nn_worklist_kernel(const PairDev* _
                                                                  const uint32_t* __restrict__ work_index,
                                                                  int* __restrict__ work_count_next) {
   const int count = *work_count;
-  if (count <= 2 * (int)gridDim.x && !(dbg & 2048)) {
+  if (count <= S3D_WL_COOP_FACTOR * (int)gridDim.x && !(dbg & 2048)) {
     // (round 5) a SHORT list - a lone registration, a small batch: one query per wave and trip, wave-cooperative.  What a
     // scan27 pass declines is mostly queries without a near neighbour (a part of one scan the other does not cover), each
     // a walk through a wide box: eight of them per wave, each lane on its own, made the launch as long as the slowest
@@ -2492,7 +2554,11 @@ __global__ void __launch_bounds__(kWave) s3d_nn_worklist_kernel(const PairDev* _
     if (blockIdx.x == 0 && threadIdx.x == 0) *work_count_next = 0;
     return;
   }
+#if S3D_WL_PER_MODE
+  const int per = imin(imax((count + (int)gridDim.x - 1) / (int)gridDim.x, 1), kWave);
+#else
   const int per = count <= 8 * (int)gridDim.x ? 8 : kWave;
+#endif
   for (int j0 = blockIdx.x * per; j0 < count; j0 += gridDim.x * per) {   // (whole waves stay: nn_query votes)
     const int j = j0 + (int)threadIdx.x;
     const bool need = (int)threadIdx.x < per && j < count;
