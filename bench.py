@@ -83,6 +83,11 @@ def _usable_cpus():
     return n, quota
 
 
+def _host_threads(usable_cpus, world):
+    """host threads one rank may use (input generation, bulk hand-over): its share of the CPUs the JOB may use, 1 ... 16"""
+    return max(1, min(16, int(usable_cpus) // max(int(world), 1)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,11 +165,16 @@ def main():
     # threads, not processes: forking after a profiler / the HIP runtime is loaded hangs on this pool
     from multiprocessing.pool import ThreadPool
     jobs = [(args.points, rank * args.pairs + i) for i in range(args.pairs)]
-    with ThreadPool(min(16, os.cpu_count() or 1)) as pool:
+    # host threads of this rank (input generation, the bulk hand-over): its share of the CPUs the job may use - affinity
+    # mask and cgroup quota, e.g. 16 for 8 ranks -, so that N ranks do not oversubscribe the host into the timed region
+    usable_cpus, cpu_quota = _usable_cpus()
+    host_threads = _host_threads(usable_cpus, world)
+    with ThreadPool(host_threads) as pool:
         pairs = pool.map(_gen_pair, jobs, chunksize=2)
     gen_s = time.time() - t0
 
     ctx = s3d.Context(local_rank)
+    ctx.set_upload_threads(min(host_threads, 8))
     alg = s3d.ALG_GICP if args.algorithm == "gicp" else s3d.ALG_ICP
     params = s3d.default_params(registration_algorithm=alg, point_cloud_density=args.density,
                                 maximum_iterations=args.iters, max_correspondence_distance=2.5,
@@ -220,10 +230,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    step_ms_per_rank = [step_ms]
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # every rank's own step times (until round 6 only the maximum survived): a straggling rank shows
+        mine = torch.tensor(step_ms, dtype=torch.float64, device=coll_dev)
+        allr = torch.empty((world * len(step_ms),), dtype=torch.float64, device=coll_dev)
+        dist.all_gather_into_tensor(allr, mine)
+        step_ms_per_rank = [[round(float(x), 3) for x in allr[r * len(step_ms):(r + 1) * len(step_ms)].tolist()] for r in range(world)]
 
     total_pairs = args.pairs * world * args.steps
     value = total_pairs / elapsed
@@ -306,6 +322,28 @@ def main():
         except Exception as e:
             roofline["frac_search_passes_error"] = str(e)[:120]
         roofline["hbm_frac"] = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None
+        # The bound that actually binds: VALU issue slots and active lanes of the search passes, K4 and
+        # K6 from the committed counter summary (profiles/nn_valu.json <- tools_dev/pmc_valu.sh + pmc_valu.py: separate
+        # rocprofv3 --pmc passes of this workload), attached only while the library's source hash is the one measured.
+        # issue_frac_live prices the counted instructions against THIS run's launch time (HIP events) at the clock the
+        # counters saw: SQ_INSTS_VALU x 4 cycles / (1 024 SIMDs x clock x time).
+        valu = None
+        vfile = os.path.join(ROOT, "profiles", "nn_valu.json")
+        if os.path.exists(vfile) and args.pairs == 256 and args.points == 100000 and args.iters == 20:
+            vj = json.load(open(vfile))
+            if vj.get("kernel_src_sha256") == kernel_source_hash():
+                live_ms = {"nn_pass1": prof["nn_launch_ms"][0] if n_launch > 0 else None,
+                           "nn_pass2": None, "nn_pass3": None, "nn_pass4": None,     # (these passes are two or three launches: counter time only)
+                           "k4": None, "k6": None}
+                valu = {"source": "profiles/nn_valu.json (round %s)" % vj.get("round"), "definition": vj.get("definition"), "kernels": {}}
+                for tag, kv in vj.get("kernels", {}).items():
+                    e = {k: kv[k] for k in ("kernel", "insts_valu_per_wave", "clock_ghz", "duration_ms_under_pmc", "valu_issue_frac",
+                                            "active_lane_frac") if k in kv}
+                    t = live_ms.get(tag)
+                    if t:
+                        e["issue_frac_live"] = round(kv["insts_valu"] * 4.0 / (1024.0 * kv["clock_ghz"] * 1e9 * t * 1e-3), 4)
+                    valu["kernels"][tag] = e
+        roofline["valu"] = valu
         lms = [x for x in prof["nn_launch_ms"] if x > 0]
         if len(lms) >= 12:
             steady = float(np.mean(lms[8:]))
@@ -645,6 +683,10 @@ def main():
             "two_in_flight": inflight,
             "sweep_abi": sweep_abi,
             "step_ms": step_ms,
+            "step_ms_per_rank": step_ms_per_rank,
+            "host_threads_per_rank": host_threads,
+            "usable_cpus": usable_cpus,
+            "cpu_quota": cpu_quota,
             "stage_ms": {k: round(v, 3) for k, v in prof.items() if k.endswith("_ms") and k != "nn_launch_ms"},
             "nn_launch_ms": prof["nn_launch_ms"],
             "distinct_pairs_gathered": distinct,

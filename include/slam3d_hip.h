@@ -151,6 +151,10 @@ int  s3d_cloud_upload(s3d_context* ctx, const float* xyz, int n, int stride, s3d
  * (GraphSerialization.cpp:68-135 rebuilds every measurement) or the scans of a loop-closure sweep are handed over at
  * the link's rate instead of one allocation + staged copy + wait per scan.  out[i] are ordinary clouds. */
 int  s3d_cloud_upload_many(s3d_context* ctx, int n_clouds, const float* const* xyz, const int* n, int stride, s3d_cloud** out);
+/* host threads s3d_cloud_upload_many may use (default 0 = up to 8): a process that runs one rank per GPU on a host whose
+ * CPU quota is shared by the ranks (ScanSensor.cpp:179-201 as an 8-rank sweep: 16 CPUs / 8 ranks) gives each context its
+ * share, so that the hand-over threads of the ranks do not oversubscribe it.  n < 0: INVALID_ARGUMENT. */
+int  s3d_context_set_upload_threads(s3d_context* ctx, int n);
 /* wrap n float4 (x,y,z,*) already in HBM (e.g. a torch tensor); not copied, not freed */
 int  s3d_cloud_wrap_device(s3d_context* ctx, const void* device_float4, int n, s3d_cloud** out);
 int  s3d_cloud_size(const s3d_cloud* c);

@@ -184,6 +184,7 @@ def load_library():
         "s3d_default_params": (None, [pp]),
         "s3d_cloud_upload": (C.c_int, [vp, fp, C.c_int, C.c_int, C.POINTER(vp)]),
         "s3d_cloud_upload_many": (C.c_int, [vp, C.c_int, C.POINTER(fp), C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]),
+        "s3d_context_set_upload_threads": (C.c_int, [vp, C.c_int]),
         "s3d_cloud_wrap_device": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp)]),
         "s3d_cloud_size": (C.c_int, [vp]),
         "s3d_cloud_release": (None, [vp, vp]),
@@ -472,6 +473,12 @@ class Context:
         if st:
             raise ValueError(STATUS_NAMES[st])
         return [Cloud(self, C.c_void_p(out[i]), arrs[i][1]) for i in range(m)]
+
+    def set_upload_threads(self, n):
+        """host threads upload_many may use (0 = the default, up to 8): s3d_context_set_upload_threads"""
+        st = self._check(self._L.s3d_context_set_upload_threads(self._h, int(n)))
+        if st:
+            raise ValueError(STATUS_NAMES[st])
 
     def wrap_device(self, device_ptr, n):
         h = C.c_void_p()

@@ -235,6 +235,7 @@ struct s3d_context {
     hipEvent_t ev[2] = {nullptr, nullptr};
   };
   std::vector<UploadLane> upload_lanes;
+  int upload_threads_cap = 0;       // s3d_context_set_upload_threads (0: up to 8)
   void release_upload_lanes() {
     for (UploadLane& L : upload_lanes) {
       if (L.st) { (void)hipStreamSynchronize(L.st); (void)hipStreamDestroy(L.st); }
@@ -1127,7 +1128,10 @@ struct Batch {
   // idle for ~28 us, twice in a registration of two of the reference's scans), at most kIcpAhead empty iterations after
   // the last pair has stopped.  check_interval = N > 0: the host copies the active-pair counter every N iterations and
   // waits for it (the form of rounds 1-4).  Forced iterations: everything is launched at once.
-  static constexpr int kIcpAhead = 2;
+#ifndef S3D_ICP_AHEAD
+#define S3D_ICP_AHEAD 2
+#endif
+  static constexpr int kIcpAhead = S3D_ICP_AHEAD;
   void stage_icp() {
     hipStream_t st = ctx->stream;
     if (P() == 0) return;
@@ -1416,7 +1420,7 @@ void upload_many(s3d_context* ctx, int n_clouds, const float* const* xyz, const 
   const int hs = stride > 6 ? 3 : stride;                            // floats per point in the pinned slot
   const size_t slot_bytes = std::max<size_t>(sizeof(float) * most * (size_t)hs, 256);
   // up to eight worker threads, fewer for huge clouds: the pinned slots (two per thread) stay below 512 MiB
-  const int lanes = (int)std::max<size_t>(1, std::min<size_t>({(size_t)n_clouds, (size_t)8,
+  const int lanes = (int)std::max<size_t>(1, std::min<size_t>({(size_t)n_clouds, (size_t)(ctx->upload_threads_cap > 0 ? std::min(ctx->upload_threads_cap, 8) : 8),
                                                                  (size_t)std::max(1u, std::thread::hardware_concurrency()),
                                                                  ((size_t)512 << 20) / (2 * (slot_bytes + slot_bytes / 4))}));
   if ((int)ctx->upload_lanes.size() < lanes) ctx->upload_lanes.resize((size_t)lanes);
@@ -2280,6 +2284,12 @@ int s3d_cloud_upload_many(s3d_context* ctx, int n_clouds, const float* const* xy
     return fail_current(ctx);
   }
   for (int i = 0; i < n_clouds; ++i) out[i] = made[(size_t)i];
+  return S3D_STATUS_OK;
+} catch (...) { return fail_current(ctx); }
+
+int s3d_context_set_upload_threads(s3d_context* ctx, int n) try {
+  if (!ctx || n < 0) return S3D_STATUS_INVALID_ARGUMENT;
+  ctx->upload_threads_cap = n;
   return S3D_STATUS_OK;
 } catch (...) { return fail_current(ctx); }
 

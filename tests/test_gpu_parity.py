@@ -713,6 +713,7 @@ def test_bench_contract_line(tmp_path):
     r = line["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["avg_launch_ms"] > 0
+    assert "valu" in r and r["valu"] is None        # (the counter summary belongs to the default workload only)
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     assert line["accuracy"]["status_ok"] == 4
@@ -759,10 +760,12 @@ def test_ndt_batch_mixed_inputs(gpu_ctx, fixture_clouds):
     assert st == 0 and np.array_equal(s3d.api.record_transform(rec[4]), T)
 
 
-@pytest.mark.parametrize("ranks,port", [(2, 29521), (8, 29537)])
+# (round 6: the GPU boxes admit six processes on a card at once - this test's ranks plus the test runner itself -, so
+# the driver's 8-rank line is rehearsed with 4 ranks here; its host-side arithmetic for 8 ranks is tests/test_bench_host.py)
+@pytest.mark.parametrize("ranks,port", [(2, 29521), (4, 29537)])
 def test_bench_ranks_share_one_gpu_over_gloo(ranks, port):
     """The multi-rank path of bench.py (pair sharding, all-gather of the edge records, max-over-ranks timing) with two
-    and with EIGHT ranks - the driver's 8-GPU launch line - on this one GPU: S3D_BENCH_BACKEND=gloo maps ranks to devices
+    and with four ranks - the driver's multi-GPU launch line - on this one GPU: S3D_BENCH_BACKEND=gloo maps ranks to devices
     modulo the device count.  Every rank registers its own pairs (distinct generator seeds: rank * pairs + i), rank 0
     gathers all of them, and the C-ABI sweep over the same rank count returns the single-context records."""
     import subprocess
@@ -780,6 +783,11 @@ def test_bench_ranks_share_one_gpu_over_gloo(ranks, port):
     assert line["distinct_pairs_gathered"] == 4 * ranks        # no rank registered another rank's pairs
     sw = line["sweep_abi"]
     assert sw["ranks"] == ranks and sw["equals_single_context"] is True and sw["pairs"] == 4 * ranks
+    # (round 6) the ranks share the host: every rank's generator / hand-over threads are its share of the CPUs the job may
+    # use, and every rank reports its own step times (not only the maximum)
+    assert line["host_threads_per_rank"] >= 1
+    assert line["host_threads_per_rank"] * ranks <= max(line["usable_cpus"], ranks), line
+    assert len(line["step_ms_per_rank"]) == ranks and all(len(r) == 2 and min(r) > 0 for r in line["step_ms_per_rank"])
 
 
 def test_bench_nccl_branch_with_one_rank():
