@@ -885,15 +885,17 @@ struct Batch {
       const int redo_cap = (int)(3 * redo_half);      // (far entries count down from the end of the buffer)
       const int iso_cap = (int)(2 * redo_half);       // (isolated points - the ring search's - from the end of the middle third)
       int* iso_count = fb_count + 3;
-      int* deep_count = fb_count + 4;                 // (n_active[8]: the ICP stage zeroes and reuses it afterwards)
-      const int deep_cap = (int)(4 * redo_half);
+      // the far / near policy of a large batch on the DEVICE: a far list shorter than 1 % of the points is handed on to the
+      // exact search as it is (its length in n_active[8], which the ICP stage zeroes and reuses afterwards)
+      int* handed_on = rings ? fb_count + 4 : nullptr;
+      const int rings_min = (int)std::min<size_t>(total_pts / 100, 0x7FFFFFFF);
       // (a small batch hands EVERY decline to the cooperative kernel - also the near ones, ties and table overflows, whose
       // per-lane search keeps a wave busy with one lane: far_all = 2; the ring search takes every "27 cells are not enough": 1)
       const int far_all = coop && small_batch ? 2 : (rings ? 1 : 0);
       s3d_knn3_moments_kernel<20><<<grid, kBlock, 0, st>>>(d_slots(), sorted(), cells(), mom, mom_plane, nb_head, d_list, NL, normals(), fb_count, fb_list, redo_count, redo_list, far_count, redo_cap, far_all);
       if (rings) {
         const int rblocks = (int)std::min<long long>(std::max<long long>((long long)NL * max_n / (16 * kBlock), 64), 1280);
-        s3d_knn3_rings_kernel<20, kKnn3RingMax><<<rblocks, kBlock, 0, st>>>(d_slots(), sorted(), cells(), mom, mom_plane, normals(), fb_count, fb_list, redo_list, far_count, redo_cap, iso_count, iso_cap);
+        s3d_knn3_rings_kernel<20, kKnn3RingMax><<<rblocks, kBlock, 0, st>>>(d_slots(), sorted(), cells(), mom, mom_plane, normals(), fb_count, fb_list, redo_list, far_count, redo_cap, iso_count, iso_cap, handed_on, rings_min);
         // the isolated points among them (the 20th neighbour more than kKnn3RingMax rings away), a wave per query
         const int fblocks = (int)std::min<long long>(std::max<long long>((long long)NL * max_n / 512, 256), 8192);
         if (fused)
@@ -911,13 +913,13 @@ struct Batch {
       if (far_all == 2) {
         // nothing on the near list
       } else if (thin && !fused)
-        s3d_knn_moments_redo_kernel<20, true, true><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list);
+        s3d_knn_moments_redo_kernel<20, true, true><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list, handed_on, redo_cap);
       else if (!fused)
-        s3d_knn_moments_redo_kernel<20, true, false><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list);
+        s3d_knn_moments_redo_kernel<20, true, false><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list, handed_on, redo_cap);
       else if (thin)
-        s3d_knn_moments_redo_kernel<20, true, true, true><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list);
+        s3d_knn_moments_redo_kernel<20, true, true, true><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list, handed_on, redo_cap);
       else
-        s3d_knn_moments_redo_kernel<20, true, false, true><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list);
+        s3d_knn_moments_redo_kernel<20, true, false, true><<<1024, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, normals(), fb_count, fb_list, redo_count, redo_list, handed_on, redo_cap);
     } else if (fused) {    // (the positions in `sorted` name the neighbours: BYPOS)
       if (k <= 8)
         s3d_knn_moments_kernel<8, false, true><<<grid, kBlock, 0, st>>>(d_slots(), filt(), sorted(), cells(), mom, mom_plane, k, nb_head, d_list, NL, normals(), fb_count, fb_list);
@@ -944,8 +946,8 @@ struct Batch {
       int cnt[5];
       HIPCHK(hipMemcpyAsync(cnt, fb_count, sizeof cnt, hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
-      std::fprintf(stderr, "[s3d] k-NN pre-pass: %zu points, eigen fallback %d, exact-search redo %d, far list (ring search / cooperative) %d, of those beyond %d rings %d, ring-search leftovers (cooperative) %d\n",
-                   total_pts, cnt[0], cnt[1], cnt[2], kKnn3RingFirst, cnt[4], cnt[3]);
+      std::fprintf(stderr, "[s3d] k-NN pre-pass: %zu points, eigen fallback %d, exact-search redo %d, far list (ring search / cooperative) %d, of those handed on to the exact search (a short list) %d, ring-search leftovers (cooperative) %d\n",
+                   total_pts, cnt[0], cnt[1], cnt[2], cnt[4], cnt[3]);
     }
   }
 

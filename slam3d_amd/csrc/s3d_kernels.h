@@ -1260,17 +1260,10 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN3_WAVES) s3d_knn3_moments_kerne
 #ifndef S3D_KNN_RINGS_WAVES
 #define S3D_KNN_RINGS_WAVES 4
 #endif
-#ifndef S3D_KNN_RINGS_FIRST
-#define S3D_KNN_RINGS_FIRST 3
-#endif
-// Two launches.  A wave runs as long as its deepest lane, and the depths are skewed - ring 2 / 3 / 4 / 5+ for 44 / 37 / 11 /
-// 8 % of the entries, ring r costing (2 r + 1)^2 row look-ups - so a wave of mixed entries paid rings 2 ... 6 (445 rows) for
-// nearly everyone.  The first launch stops at kKnn3RingFirst rings (74 rows) and lists the entries it does not answer
-// (the fourth quarter of the buffer, from its back); the second launch serves those up to kKnn3RingMax, from the start
-// again (the table is per lane), in waves of their own, and lists ITS leftovers (the second quarter) for the
-// wave-cooperative kernel.  (Tried first: both phases in one kernel, the deep entries of a block packed into its first
-// lanes through LDS: no better, see EXPERIMENTS.md.)
-constexpr int kKnn3RingFirst = S3D_KNN_RINGS_FIRST;
+// (Tried: the list in TWO launches - rings up to 3 first, the entries beyond them in waves of their own, since a wave runs
+// as long as its deepest lane and the depths are skewed: ring 2 / 3 / 4 / 5+ for 44 / 37 / 11 / 8 % of the entries; and both
+// phases in one kernel with the deep entries of a block packed into its first lanes through LDS.  Neither was better than
+// the one launch: the interrupted work of this round's first session, EXPERIMENTS.md.)
 template <int K, int RMAX>
 __global__ void __launch_bounds__(kBlock, S3D_KNN_RINGS_WAVES) s3d_knn3_rings_kernel(const SlotDev* __restrict__ slots,
                                                                   const float4* __restrict__ sorted,
@@ -1281,11 +1274,22 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_RINGS_WAVES) s3d_knn3_rings_ke
                                                                   int* __restrict__ fallback_list,
                                                                   int2* __restrict__ redo_list,
                                                                   const int* __restrict__ in_count, int in_cap,
-                                                                  int* __restrict__ out_count, int out_cap) {
+                                                                  int* __restrict__ out_count, int out_cap,
+                                                                  int* __restrict__ handed_on, int min_count) {
   constexpr int KL = K + 1, SB = kKnn3RingSegBits;
   __shared__ uint32_t tab[(1 << SB) * kBlock];   // entry j of thread t at tab[j * kBlock + t]
   const int count = *in_count;
   uint32_t* ctab = tab + threadIdx.x;
+  // The policy decided ON THE DEVICE, from the list's length (the host cannot know it): a list of fewer than `min_count`
+  // entries - a cloud of even density, whose few declines have their K-th neighbour just beyond the 27 cells: 0.16 % of the
+  // synthetic benchmark's points against 13 % of a lidar scan's - is left to the exact search, which reads it where it
+  // is (`handed_on` = its length: s3d_knn_moments_redo_kernel).  That kernel absorbs 80 000 such entries in 0.1 ms; this
+  // one, a fifth of its lanes busy at half the occupancy, took 0.24.
+  if (handed_on) {
+    const bool hand_on = count < min_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *handed_on = hand_on ? count : 0;
+    if (hand_on) return;
+  }
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < count; j += gridDim.x * kBlock) {
     const int2 e = redo_list[in_cap - 1 - j];
     const SlotDev& s = slots[e.x];
@@ -1349,8 +1353,13 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_REDO_WAVES) s3d_knn_moments_re
                                                                        int* __restrict__ fallback_count,
                                                                        int* __restrict__ fallback_list,
                                                                        const int* __restrict__ redo_count,
-                                                                       const int2* __restrict__ redo_list) {
-  const int count = *redo_count;
+                                                                       const int2* __restrict__ redo_list,
+                                                                       const int* __restrict__ handed_on = nullptr,
+                                                                       int far_cap = 0) {
+  // (round 6) + the far list the ring search handed on (a short one: see s3d_knn3_rings_kernel), read where it lies -
+  // entry j of it at redo_list[far_cap - 1 - j]
+  const int near = *redo_count;
+  const int count = near + (handed_on ? *handed_on : 0);
   int first = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
   if (THIN) {
     const int waves = (int)gridDim.x * (kBlock / kWave);
@@ -1360,7 +1369,7 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN_REDO_WAVES) s3d_knn_moments_re
     stride = waves * per;
   }
   for (int j = first; j < count; j += stride) {
-    const int2 e = redo_list[j];
+    const int2 e = redo_list[j < near ? j : far_cap - 1 - (j - near)];
     knn_moments_point<KMAX, FULL, BYPOS>(slots[e.x], e.y, filt, sorted, cell_start, moments, plane, k, normals, fallback_count,
                                          fallback_list);
   }
