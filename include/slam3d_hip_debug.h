@@ -10,6 +10,8 @@
 
 #define S3D_DBG_NN_NO_REVALIDATE   0x00000040u /* every pass searches every query (no triangle-inequality shortcut)      */
 #define S3D_DBG_NN_NO_FAR_SEED     0x00000080u /* far previous neighbours are never trusted seeds                        */
+#define S3D_DBG_KNN_FORCE_RINGS    0x00000200u /* k-NN pre-pass of a large batch: the ring search whatever the length of the far list (the
+                                               * device hands a list shorter than 1 % of the points on to the exact search)              */
 #define S3D_DBG_NN_NO_COOP         0x00000800u /* no wave-cooperative wide search                                        */
 #define S3D_DBG_NN_NO_COMPACT      0x00010000u /* pass 4 (small batches: passes 3-5) without the block compaction         */
 #define S3D_DBG_NN_NO_FIRST_KERNEL 0x00040000u /* pass 1 through the general kernel (implies the next one)               */

@@ -888,7 +888,7 @@ struct Batch {
       // the far / near policy of a large batch on the DEVICE: a far list shorter than 1 % of the points is handed on to the
       // exact search as it is (its length in n_active[8], which the ICP stage zeroes and reuses afterwards)
       int* handed_on = rings ? fb_count + 4 : nullptr;
-      const int rings_min = (int)std::min<size_t>(total_pts / 100, 0x7FFFFFFF);
+      const int rings_min = (opts.debug_flags & S3D_DBG_KNN_FORCE_RINGS) ? 0 : (int)std::min<size_t>(total_pts / 100, 0x7FFFFFFF);
       // (a small batch hands EVERY decline to the cooperative kernel - also the near ones, ties and table overflows, whose
       // per-lane search keeps a wave busy with one lane: far_all = 2; the ring search takes every "27 cells are not enough": 1)
       const int far_all = coop && small_batch ? 2 : (rings ? 1 : 0);

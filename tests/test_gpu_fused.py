@@ -195,8 +195,10 @@ def test_far_knn_paths_agree_on_isolated_points_and_ties(gpu_ctx, density):
     p = s3d.default_params(point_cloud_density=density, maximum_iterations=5)
     recs = []
     # (round 6: NO_FAR_COOP alone = the ring-by-ring med3 search of large batches; with NO_RINGS the per-lane exact search)
-    for flags in (0, A.DBG_KNN_NO_FAR_COOP, A.DBG_KNN_NO_FAR_COOP | A.DBG_KNN_NO_RINGS, A.DBG_KNN_FORCE_FAR_COOP,
-                  A.DBG_KNN_EXACT64):
+    # (FORCE_RINGS: the ring search whatever the far list's length - without it the device hands a list shorter than 1 % of
+    # the points on to the exact search)
+    for flags in (0, A.DBG_KNN_NO_FAR_COOP, A.DBG_KNN_NO_FAR_COOP | A.DBG_KNN_FORCE_RINGS,
+                  A.DBG_KNN_NO_FAR_COOP | A.DBG_KNN_NO_RINGS, A.DBG_KNN_FORCE_FAR_COOP, A.DBG_KNN_EXACT64):
         st, T, info = gpu_ctx.align(ca, cb, np.eye(4), p, s3d.ExecOptions(force_iterations=1, debug_flags=flags))
         assert st == 0, (hex(flags), st)
         recs.append((T, info))

@@ -669,8 +669,8 @@ def test_fast_paths_are_bitwise_neutral(gpu_ctx, fixture_clouds):
             assert st0 == 0
             for flags in (A.DBG_NN_NO_FIRST_KERNEL, A.DBG_NN_NO_SCAN27, A.DBG_NN_NO_FIRST_KERNEL | A.DBG_NN_NO_SCAN27,
                           A.DBG_NN_FORCE_SETTLED, A.DBG_SCAN27_NO_COMPACT, A.DBG_KNN_EXACT64, A.DBG_KNN_NO_FAR_COOP,
-                          A.DBG_KNN_NO_FAR_COOP | A.DBG_KNN_NO_RINGS, A.DBG_KNN_FORCE_FAR_COOP,
-                          A.DBG_SORT_CLASSIC, A.DBG_SORT_ONESWEEP, A.DBG_SORT_FULL_KEYS,
+                          A.DBG_KNN_NO_FAR_COOP | A.DBG_KNN_NO_RINGS, A.DBG_KNN_NO_FAR_COOP | A.DBG_KNN_FORCE_RINGS,
+                          A.DBG_KNN_FORCE_FAR_COOP, A.DBG_SORT_CLASSIC, A.DBG_SORT_ONESWEEP, A.DBG_SORT_FULL_KEYS,
                           A.DBG_SORT_FULL_KEYS | A.DBG_SORT_CLASSIC):
                 st1, T1, i1 = gpu_ctx.align(src, tgt, np.eye(4), p,
                                             s3d.ExecOptions(force_iterations=force, debug_flags=base | flags))

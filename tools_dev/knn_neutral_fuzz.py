@@ -28,14 +28,14 @@ for case in range(ncase):
     p = s3d.default_params(registration_algorithm=alg, point_cloud_density=dens, maximum_iterations=6, correspondence_randomness=k)
     da, db = ctx.upload(a), ctx.upload(b)
     res = []
-    for fl in (0, A.DBG_KNN_FORCE_FAR_COOP, A.DBG_KNN_NO_FAR_COOP, A.DBG_KNN_EXACT64, A.DBG_NO_FUSED_PREPASS,
+    for fl in (0, A.DBG_KNN_FORCE_FAR_COOP, A.DBG_KNN_NO_FAR_COOP, A.DBG_KNN_NO_FAR_COOP | A.DBG_KNN_FORCE_RINGS, A.DBG_KNN_EXACT64, A.DBG_NO_FUSED_PREPASS,
                A.DBG_NO_FUSED_PREPASS | A.DBG_KNN_EXACT64):
         res.append((fl, ctx.align_batch([da], [db], None, p, s3d.ExecOptions(debug_flags=fl))))
     da.release(); db.release()
-    same_fused = all(np.array_equal(res[0][1], r[1]) for r in res[1:4])
-    same_two = np.array_equal(res[4][1], res[5][1])
+    same_fused = all(np.array_equal(res[0][1], r[1]) for r in res[1:5])
+    same_two = np.array_equal(res[5][1], res[6][1])
     # the two layouts order points differently inside a cell: equal statuses, transforms to 2e-6
-    close = res[0][1][0, 15] == res[4][1][0, 15] and np.abs(res[0][1][0, :12] - res[4][1][0, :12]).max() < 2e-6
+    close = res[0][1][0, 15] == res[5][1][0, 15] and np.abs(res[0][1][0, :12] - res[5][1][0, :12]).max() < 2e-6
     if not (same_fused and same_two and close):
         bad += 1; print('DIFF case %d kind %d n %d density %g k %d alg %d: fused paths equal %s, two-sort paths equal %s, layouts close %s' %
                         (case, kind, n, dens, k, alg, same_fused, same_two, close), flush=True)
