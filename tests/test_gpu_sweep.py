@@ -110,7 +110,10 @@ def test_every_ordered_pair_of_partly_overlapping_clouds(gpu_ctx):
         tgt = [dev[j] for _, j in idx]
         p = s3d.default_params(point_cloud_density=0.0, maximum_iterations=6, max_correspondence_distance=2.5)
         base = gpu_ctx.align_batch(src, tgt, None, p, s3d.ExecOptions(force_iterations=1))
-        for flags in (A.DBG_NN_NO_SCAN27, A.DBG_NN_NO_FIRST_KERNEL, A.DBG_NN_FORCE_SETTLED):
+        # (round 6: NO_COOP = the worklists and the flat-scan declines of the record search lane by lane instead of
+        # wave-cooperatively)
+        for flags in (A.DBG_NN_NO_SCAN27, A.DBG_NN_NO_FIRST_KERNEL, A.DBG_NN_FORCE_SETTLED, A.DBG_NN_NO_COOP,
+                      A.DBG_NN_FORCE_SETTLED | A.DBG_NN_NO_COOP):
             other = gpu_ctx.align_batch(src, tgt, None, p, s3d.ExecOptions(force_iterations=1, debug_flags=flags))
             assert np.array_equal(base, other), hex(flags)
         # neighbouring windows register (status OK), the result is deterministic
