@@ -2539,9 +2539,6 @@ __global__ void __launch_bounds__(kBlock, S3D_NN27_WAVES) s3d_nn_scan27_kernel(c
 #ifndef S3D_WL_COOP_FACTOR
 #define S3D_WL_COOP_FACTOR 16
 #endif
-#ifndef S3D_WL_PER_MODE
-#define S3D_WL_PER_MODE 0
-#endif
 __global__ void __launch_bounds__(kWave) s3d_nn_worklist_kernel(const PairDev* __restrict__ pairs,
                                                                  const SlotDev* __restrict__ slots, NNArrays A,
                                                                  float max_d, int dbg, const int* __restrict__ work_count,
@@ -2563,11 +2560,7 @@ __global__ void __launch_bounds__(kWave) s3d_nn_worklist_kernel(const PairDev* _
     if (blockIdx.x == 0 && threadIdx.x == 0) *work_count_next = 0;
     return;
   }
-#if S3D_WL_PER_MODE
-  const int per = imin(imax((count + (int)gridDim.x - 1) / (int)gridDim.x, 1), kWave);
-#else
   const int per = count <= 8 * (int)gridDim.x ? 8 : kWave;
-#endif
   for (int j0 = blockIdx.x * per; j0 < count; j0 += gridDim.x * per) {   // (whole waves stay: nn_query votes)
     const int j = j0 + (int)threadIdx.x;
     const bool need = (int)threadIdx.x < per && j < count;
