@@ -2291,6 +2291,7 @@ int s3d_cloud_upload_many(s3d_context* ctx, int n_clouds, const float* const* xy
 
 int s3d_context_set_upload_threads(s3d_context* ctx, int n) try {
   if (!ctx || n < 0) return S3D_STATUS_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(ctx->mtx);
   ctx->upload_threads_cap = n;
   return S3D_STATUS_OK;
 } catch (...) { return fail_current(ctx); }

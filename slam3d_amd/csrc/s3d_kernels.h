@@ -1263,7 +1263,8 @@ __global__ void __launch_bounds__(kBlock, S3D_KNN3_WAVES) s3d_knn3_moments_kerne
 // (Tried: the list in TWO launches - rings up to 3 first, the entries beyond them in waves of their own, since a wave runs
 // as long as its deepest lane and the depths are skewed: ring 2 / 3 / 4 / 5+ for 44 / 37 / 11 / 8 % of the entries; and both
 // phases in one kernel with the deep entries of a block packed into its first lanes through LDS.  Neither was better than
-// the one launch: the interrupted work of this round's first session, EXPERIMENTS.md.)
+// the one launch - two launches: normals of a batch of real scans 2.95 -> 3.3 ms, the second launch starts every entry
+// from its 27 cells again at a fifth of a wave's lanes: EXPERIMENTS.md Round 6 (v).)
 template <int K, int RMAX>
 __global__ void __launch_bounds__(kBlock, S3D_KNN_RINGS_WAVES) s3d_knn3_rings_kernel(const SlotDev* __restrict__ slots,
                                                                   const float4* __restrict__ sorted,
