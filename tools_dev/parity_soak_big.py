@@ -1,4 +1,4 @@
-"""dev tool: tests/test_gpu_fuzz.py::test_registration_soak_72_random_pairs over many more seeds (SEEDS, default 100..119 = 480
+"""dev tool: tests/test_gpu_fuzz.py::test_registration_soak_240_random_pairs over many more seeds (SEEDS, default 100..119 = 480
 registrations): GPU against the oracle's smooth-objective variant; prints every case that differs in status / iteration
 count or by more than 1e-4 m / 1e-4 rad, and the worst deltas."""
 import os, sys, numpy as np
