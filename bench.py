@@ -293,9 +293,10 @@ def main():
                               "+ s3d_nn_record_{test,touch,search}_kernel (passes 4-%d)"
                               % n_launch,
                     "bound": "hbm", "achieved": round(achieved, 2),
-                    "limiter": "VALU issue of divergent per-lane candidate walks in the first passes (82 % of the issue "
-                               "slots, 25 of 64 lanes active); in the settled passes the latency of three dependent "
-                               "launches (record test, touch of the ~10 % failing records, search of ~15 queries per pair)",
+                    "limiter": "VALU issue of divergent per-lane candidate walks in the first passes (75 / 78 / 52 % of the "
+                               "issue slots with 44 / 64 / 57 % of the lanes active in passes 1 / 2 / 3: roofline.valu); in "
+                               "the settled passes the latency of three dependent launches (record test, touch of the "
+                               "~10 % failing records, search of ~15 queries per pair)",
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": n_launch,
                     "algorithmic_bytes_per_launch": int(alg_bytes),
