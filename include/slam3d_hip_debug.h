@@ -12,6 +12,8 @@
 #define S3D_DBG_NN_NO_FAR_SEED     0x00000080u /* far previous neighbours are never trusted seeds                        */
 #define S3D_DBG_KNN_FORCE_RINGS    0x00000200u /* k-NN pre-pass of a large batch: the ring search whatever the length of the far list (the
                                                * device hands a list shorter than 1 % of the points on to the exact search)              */
+#define S3D_DBG_NO_K4_OVERLAP      0x00000400u /* a small batch's k-NN pre-pass on the context's own stream (not beside the first
+                                               * correspondence pass on a second one)                                                  */
 #define S3D_DBG_NN_NO_COOP         0x00000800u /* no wave-cooperative wide search                                        */
 #define S3D_DBG_NN_NO_COMPACT      0x00010000u /* pass 4 (small batches: passes 3-5) without the block compaction         */
 #define S3D_DBG_NN_NO_FIRST_KERNEL 0x00040000u /* pass 1 through the general kernel (implies the next one)               */

@@ -44,6 +44,7 @@ DBG_KNN_EXACT64, DBG_SORT_CLASSIC, DBG_SORT_ONESWEEP, DBG_SCAN27_NO_COMPACT = 0x
 DBG_PRINT_KNN, DBG_SORT_FULL_KEYS, DBG_NN_FORCE_SETTLED = 0x2000000, 0x4000000, 0x8000000
 DBG_NO_FUSED_PREPASS, DBG_KNN_NO_FAR_COOP, DBG_KNN_FORCE_FAR_COOP = 0x10000000, 0x20000000, 0x40000000
 DBG_KNN_NO_RINGS = 0x80000000
+DBG_NO_K4_OVERLAP = 0x400       # a small batch's k-NN pre-pass on the context's own stream
 DBG_KNN_FORCE_RINGS = 0x200     # the ring search whatever the length of the far list (no device-side hand-over)
 
 

@@ -226,6 +226,25 @@ struct s3d_context {
     }
   }
   hipEvent_t ev[8] = {};
+  // (round 6) a second stream for the k-NN pre-pass of a SMALL batch, which does not fill the chip: K4 runs there while
+  // the first correspondence pass - which needs the grid, not the normals - runs on the context's stream (Batch::run_all).
+  // Only for a context that owns a plain stream (no caller stream, CU mask or priority to carry over).
+  bool plain_stream = false;
+  hipStream_t side_stream = nullptr;
+  hipEvent_t side_ev[2] = {nullptr, nullptr};
+  bool ensure_side_stream() {
+    if (!plain_stream) return false;
+    if (!side_stream) {
+      if (hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking) != hipSuccess) { side_stream = nullptr; return false; }
+      for (int i = 0; i < 2; ++i)
+        if (hipEventCreateWithFlags(&side_ev[i], hipEventDisableTiming) != hipSuccess) {
+          for (int j = 0; j < 2; ++j) if (side_ev[j]) { (void)hipEventDestroy(side_ev[j]); side_ev[j] = nullptr; }
+          (void)hipStreamDestroy(side_stream); side_stream = nullptr;
+          return false;
+        }
+    }
+    return true;
+  }
   std::vector<hipEvent_t> nn_ev;
   // s3d_cloud_upload_many: per worker thread a stream and two pinned slots (grown on demand, kept)
   struct UploadLane {
@@ -839,9 +858,15 @@ struct Batch {
                                                                           in_a ? vA() : vB(), sorted(), sorted3(), cells());
   }
 
-  // K4
+  // K4.  overlap_k4: on the context's side stream, next to the first correspondence pass (run_all)
+  bool overlap_k4 = false, k4_pending = false;
+  void join_k4() {           // everything after this on the context's stream sees the normals
+    if (!k4_pending) return;
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->side_ev[1], 0));
+    k4_pending = false;
+  }
   void stage_normals() {
-    hipStream_t st = ctx->stream;
+    hipStream_t st = overlap_k4 ? ctx->side_stream : ctx->stream;
     if (C() == 0) return;
     const int k = std::max(1, std::min(rp.k, 64));
     if (k > 32) {
@@ -978,9 +1003,20 @@ struct Batch {
     int* pc = (prof_slot >= 0 && prof_slot < 64) ? (int*)ctx->n_active.p + 16 + 4 * prof_slot : nullptr;
     const bool family = mode == 0 && it >= 0 && !(dbg_nn & (262144 | 64));
     if (family && it == 0) {
+      if (k4_pending) {
+        // K4 is still running on the side stream: the pass leaves the copies of the neighbours' normals out (it needs the
+        // grid only), and they are filled in once K4 is done - before the first accumulate launch reads them
+        NNArrays A0 = A;
+        A0.normals = nullptr;
+        s3d_nn_first_kernel<<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A0, max_d, chunks, P(), dbg_nn, pc);
+        join_k4();
+        k_fill_corr_normals<<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, chunks, P());
+        return;
+      }
       s3d_nn_first_kernel<<<grid, kBlock, 0, st>>>(d_pairs(), d_slots(), A, max_d, chunks, P(), dbg_nn, pc);
       return;
     }
+    join_k4();        // (any other first pass reads the normals itself)
     // passes 2 and 3: the flat 27-cell scan + a worklist for what it declines (S3D_DBG_NN_NO_SCAN27 = off; the bits
     // that switch the re-validation off imply it)
     // (measured per 128 pairs: pass 2 1.47 -> 0.99 ms, pass 3 0.90 -> 0.80 ms with the compacting form; passes 4 and 5,
@@ -1225,6 +1261,7 @@ struct Batch {
   // A9: final_transformation_, one more NN pass, masked mean
   void stage_fitness() {
     hipStream_t st = ctx->stream;
+    join_k4();         // (no correspondence pass has run - no pairs, no iterations: the normals are awaited here)
     if (P() == 0) return;
     k_pair_finalize<<<cdiv(P(), 64), 64, 0, st>>>(d_pairs(), P());
     launch_nn(1, (float)(std::sqrt(std::max(rp.fit_range, 0.0)) * 1.0001));
@@ -1236,6 +1273,7 @@ struct Batch {
 
   void download() {
     hipStream_t st = ctx->stream;
+    join_k4();
     const size_t bs = slots_bytes(), bp = pairs_bytes();
     char* stage = ctx->stage_host(records_bytes());   // (the uploads of this call have completed by now: stream order)
     // slots, pairs and the sort's error word in one copy (the one-sweep sort's look-back gives up after ~4 M polls instead
@@ -1259,13 +1297,40 @@ struct Batch {
       HIPCHK(hipEventRecord(ctx->ev[i], st));
     };
     ctx->prof = s3d_profile{};
+    struct SideGuard {      // a call that unwinds must not leave K4 running into the next call's pre-pass
+      Batch* b;
+      ~SideGuard() { if (b->k4_pending && b->ctx->side_stream) (void)hipStreamSynchronize(b->ctx->side_stream); b->k4_pending = false; }
+    } side_guard{this};
     for (int attempt = 0; attempt < 2; ++attempt) {
       mark(0);
       if (fused) stage_prepass_fused(); else stage_voxel();
       mark(1);
       if (!fused) stage_grid();
       mark(2);
+      // (round 6) a SMALL registration batch - the reference's own call is ONE pair - does not fill the chip: its k-NN
+      // pre-pass runs on a second stream next to the first correspondence pass (which needs the grid, not the normals;
+      // launch_nn fills the copies of the neighbours' normals in afterwards): one registration of two of the reference's
+      // scans waits ~60 us less.  Not with the K4 debug switches (their lists share counters with the ICP stage), not
+      // under the profile (its stage split is one stream's), not beyond ~two clouds (400 k raw points: the mapper's one
+      // scan against eight already keeps the chip busy - 1.50 -> 1.52 ms with the pre-pass beside the pass).
+      overlap_k4 = false;
+      {
+        const unsigned k4_dbg = S3D_DBG_KNN_NO_FAR_COOP | S3D_DBG_KNN_FORCE_FAR_COOP | S3D_DBG_KNN_NO_RINGS |
+                                S3D_DBG_KNN_FORCE_RINGS | S3D_DBG_KNN_EXACT64 | S3D_DBG_PRINT_KNN | S3D_DBG_NO_K4_OVERLAP;
+        const bool first_kernel = !(dbg_nn & (262144 | 64));
+        if (registration_batch && !prof && P() > 0 && rp.max_iterations >= 1 && first_kernel && !(opts.debug_flags & k4_dbg) &&
+            !knn_slots.empty() && (long long)knn_slots.size() * max_n <= 400000ll && ctx->ensure_side_stream()) {
+          HIPCHK(hipEventRecord(ctx->side_ev[0], st));
+          HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
+          overlap_k4 = true;
+        }
+      }
       stage_normals();
+      if (overlap_k4) {
+        HIPCHK(hipEventRecord(ctx->side_ev[1], ctx->side_stream));
+        k4_pending = true;
+        overlap_k4 = false;
+      }
       mark(3);
       stage_icp();
       mark(4);
@@ -1982,6 +2047,7 @@ static int context_create(int device, void* hip_stream, int priority_class, s3d_
         HIPCHK(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest));
       } else {
         HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->plain_stream = true;
       }
       ctx->own_stream = true;
     }
@@ -2010,6 +2076,8 @@ void s3d_context_destroy(s3d_context* ctx) try {
   for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->nn_ev) (void)hipEventDestroy(e);
   ctx->release_upload_lanes();
+  if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+  for (hipEvent_t e : ctx->side_ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 } catch (...) {}   // (a destructor-like entry point has no status to return)

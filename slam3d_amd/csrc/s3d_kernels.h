@@ -1888,7 +1888,9 @@ __device__ __forceinline__ void nn_query(const PairDev& P, const SlotDev& St, co
     // a copy of the matched point and of its normal is kept with the correspondence: the re-validation
     // above and the accumulate kernel then stream them instead of gathering by index
     A.corr_q[ci] = corr_vec(A.sorted[Ss.off + r.pos]);
-    A.corr_n[ci] = A.normals[Ss.off + r.pos];
+    // (PHASE 5 without normals: the k-NN pre-pass of a small batch is still running on a second stream;
+    // k_fill_corr_normals fills this copy in before anything reads it)
+    if (PHASE != 5 || A.normals) A.corr_n[ci] = A.normals[Ss.off + r.pos];
   } else if (MODE == 0) {
     // no neighbour within max_d: a neighbour at infinity, so that the distance the accumulate kernels compute from
     // this copy fails their threshold like the stored 3e38 did
@@ -2401,6 +2403,22 @@ __global__ void __launch_bounds__(kBlock, S3D_NN_FIRST_WAVES) s3d_nn_first_kerne
   const int i = chunk * kBlock + threadIdx.x;
   if (chunk * kBlock >= St.n) return;
   nn_query<0, 5>(P, St, slots[P.slot_s], pair, i, i < St.n, A, max_d, dbg, prof_counts, nullptr, P.T_nn);
+}
+
+// the copies of the neighbours' normals a first pass without normals left out (see nn_query PHASE 5): the launch
+// geometry of the pass itself
+__global__ void __launch_bounds__(kBlock) k_fill_corr_normals(const PairDev* __restrict__ pairs, const SlotDev* __restrict__ slots,
+                                                               NNArrays A, int chunks_per_pair, int npairs) {
+  int pair, chunk;
+  nn_block_map(chunks_per_pair, npairs, &pair, &chunk);
+  if (pair >= npairs) return;
+  const PairDev& P = pairs[pair];
+  if (!P.active) return;
+  const int i = chunk * kBlock + (int)threadIdx.x;
+  if (i >= slots[P.slot_t].n) return;
+  const int ci = P.corr_off + i;
+  const int pos = A.corr_idx[ci];
+  if (pos >= 0) A.corr_n[ci] = A.normals[slots[P.slot_s].off + pos];
 }
 
 // ---- passes 2 and 3 of the ICP loop: the flat 27-cell scan (grid_nn1_scan27, s3d_core.h "K5, round 3").

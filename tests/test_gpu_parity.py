@@ -670,11 +670,34 @@ def test_fast_paths_are_bitwise_neutral(gpu_ctx, fixture_clouds):
             for flags in (A.DBG_NN_NO_FIRST_KERNEL, A.DBG_NN_NO_SCAN27, A.DBG_NN_NO_FIRST_KERNEL | A.DBG_NN_NO_SCAN27,
                           A.DBG_NN_FORCE_SETTLED, A.DBG_SCAN27_NO_COMPACT, A.DBG_KNN_EXACT64, A.DBG_KNN_NO_FAR_COOP,
                           A.DBG_KNN_NO_FAR_COOP | A.DBG_KNN_NO_RINGS, A.DBG_KNN_NO_FAR_COOP | A.DBG_KNN_FORCE_RINGS,
-                          A.DBG_KNN_FORCE_FAR_COOP, A.DBG_SORT_CLASSIC, A.DBG_SORT_ONESWEEP, A.DBG_SORT_FULL_KEYS,
+                          A.DBG_KNN_FORCE_FAR_COOP, A.DBG_NO_K4_OVERLAP, A.DBG_SORT_CLASSIC, A.DBG_SORT_ONESWEEP, A.DBG_SORT_FULL_KEYS,
                           A.DBG_SORT_FULL_KEYS | A.DBG_SORT_CLASSIC):
                 st1, T1, i1 = gpu_ctx.align(src, tgt, np.eye(4), p,
                                             s3d.ExecOptions(force_iterations=force, debug_flags=base | flags))
                 assert st1 == 0 and np.array_equal(T0, T1) and i0 == i1, (hex(base), hex(flags))
+
+
+def test_knn_prepass_beside_the_first_pass_is_neutral_and_deterministic(gpu_ctx, fixture_clouds):
+    """Round 6: a small batch runs its k-NN pre-pass on a second stream next to the first correspondence pass (which
+    leaves the copies of the neighbours' normals out; they are filled in before the first accumulate launch).  Same
+    records as with everything on one stream (S3D_DBG_NO_K4_OVERLAP), for one pair, for the mapper's 1-against-8 pattern
+    and with a single iteration (the fitness pass is then the first reader of the normals) - and the same again and again
+    (a missed dependency would show as a record that changes between runs)."""
+    import slam3d_amd as s3d
+    A = s3d.api
+    dev = [gpu_ctx.upload(np.ascontiguousarray(c[:, :3])) for c in fixture_clouds]
+    try:
+        for its, src, tgt in ((50, [dev[0]], [dev[1]]), (1, [dev[1]], [dev[2]]), (6, [dev[0]] * 3, dev[1:4]),
+                              (0, [dev[0]], [dev[1]])):
+            for alg in (s3d.ALG_GICP, s3d.ALG_ICP):
+                p = s3d.default_params(registration_algorithm=alg, maximum_iterations=its)
+                ref = gpu_ctx.align_batch(src, tgt, None, p, s3d.ExecOptions(debug_flags=A.DBG_NO_K4_OVERLAP))
+                for _ in range(12):
+                    rec = gpu_ctx.align_batch(src, tgt, None, p, s3d.ExecOptions())
+                    assert np.array_equal(rec, ref), (its, alg)
+    finally:
+        for c in dev:
+            c.release()
 
 
 def test_million_point_pair(gpu_ctx, oracle_mod):
