@@ -230,6 +230,10 @@ struct s3d_context {
   // the first correspondence pass - which needs the grid, not the normals - runs on the context's stream (Batch::run_all).
   // Only for a context that owns a plain stream (no caller stream, CU mask or priority to carry over).
   bool plain_stream = false;
+  // a private second context on the same device (workspace and stream of its own), created on first use:
+  // create_constraint_impl runs the FINE registration's pre-pass there while the coarse one registers
+  s3d_context* twin = nullptr;
+  hipEvent_t twin_ev = nullptr;
   hipStream_t side_stream = nullptr;
   hipEvent_t side_ev[2] = {nullptr, nullptr};
   bool ensure_side_stream() {
@@ -858,6 +862,14 @@ struct Batch {
                                                                           in_a ? vA() : vB(), sorted(), sorted3(), cells());
   }
 
+  // run_all in two halves (create_constraint_impl): phase 1 = pre-pass + k-NN only, nothing waited for; phase 2 = the
+  // same batch goes on from there (ICP loop, fitness, download; the two-sort rerun of a fused failure as ever)
+  int phase = 0;
+  void set_guess(int p, const double g[16]) {     // a guess that is known only after phase 1 (it is not read before the ICP loop)
+    for (int i = 0; i < 16; ++i) h_pairs[(size_t)p].guess.m[i] = (float)g[i];
+    if ((size_t)p < h_pairs0.size()) h_pairs0[(size_t)p].guess = h_pairs[(size_t)p].guess;
+    HIPCHK(hipMemcpyAsync(&d_pairs()[p].guess, &h_pairs[(size_t)p].guess, sizeof(Mat4f), hipMemcpyHostToDevice, ctx->stream));
+  }
   // K4.  overlap_k4: on the context's side stream, next to the first correspondence pass (run_all)
   bool overlap_k4 = false, k4_pending = false;
   void join_k4() {           // everything after this on the context's stream sees the normals
@@ -1302,6 +1314,8 @@ struct Batch {
       ~SideGuard() { if (b->k4_pending && b->ctx->side_stream) (void)hipStreamSynchronize(b->ctx->side_stream); b->k4_pending = false; }
     } side_guard{this};
     for (int attempt = 0; attempt < 2; ++attempt) {
+      const bool resume = phase == 2 && attempt == 0;     // (pre-pass and k-NN of this attempt ran in the phase-1 call)
+      if (!resume) {
       mark(0);
       if (fused) stage_prepass_fused(); else stage_voxel();
       mark(1);
@@ -1318,7 +1332,7 @@ struct Batch {
         const unsigned k4_dbg = S3D_DBG_KNN_NO_FAR_COOP | S3D_DBG_KNN_FORCE_FAR_COOP | S3D_DBG_KNN_NO_RINGS |
                                 S3D_DBG_KNN_FORCE_RINGS | S3D_DBG_KNN_EXACT64 | S3D_DBG_PRINT_KNN | S3D_DBG_NO_K4_OVERLAP;
         const bool first_kernel = !(dbg_nn & (262144 | 64));
-        if (registration_batch && !prof && P() > 0 && rp.max_iterations >= 1 && first_kernel && !(opts.debug_flags & k4_dbg) &&
+        if (phase == 0 && registration_batch && !prof && P() > 0 && rp.max_iterations >= 1 && first_kernel && !(opts.debug_flags & k4_dbg) &&
             !knn_slots.empty() && (long long)knn_slots.size() * max_n <= 400000ll && ctx->ensure_side_stream()) {
           HIPCHK(hipEventRecord(ctx->side_ev[0], st));
           HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
@@ -1332,6 +1346,8 @@ struct Batch {
         overlap_k4 = false;
       }
       mark(3);
+      }
+      if (phase == 1) return;
       stage_icp();
       mark(4);
       stage_fitness();
@@ -2076,6 +2092,8 @@ void s3d_context_destroy(s3d_context* ctx) try {
   for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->nn_ev) (void)hipEventDestroy(e);
   ctx->release_upload_lanes();
+  if (ctx->twin) { s3d_context_destroy(ctx->twin); ctx->twin = nullptr; }
+  if (ctx->twin_ev) (void)hipEventDestroy(ctx->twin_ev);
   if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
   for (hipEvent_t e : ctx->side_ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -2775,12 +2793,54 @@ static int create_constraint_impl(s3d_context* ctx, s3d_cloud* source, const dou
     ScopedDevice sd(ctx);
     int st;
     double result[16];
+    // (round 6) coarse + fine: the FINE registration's pre-pass (voxel filter at its own density, grid, k-NN normals - a
+    // third of a registration of two scans) depends on the clouds only, not on the coarse result: it runs on a private
+    // second context (workspace and stream of its own) while the coarse registration runs here, and the fine ICP loop
+    // goes on there once its guess is known.  Same records as one after the other (S3D_DBG_NO_K4_OVERLAP).  Not with the
+    // pre-pass cache (its entries belong to this context), the profile, NDT, or a context on a caller's / masked stream.
+    const bool caching = persistent && opts && opts->cache_prepass != 0;
+    const bool two = loop && ctx->plain_stream && !caching && !(opts && (opts->profile != 0 || (opts->debug_flags & S3D_DBG_NO_K4_OVERLAP))) &&
+                     check_algorithm(fine, opts) == S3D_STATUS_OK && !is_ndt(fine) &&
+                     (long long)source->n + (long long)target->n <= 400000ll;
+    if (two && !ctx->twin) {
+      s3d_context* tw = nullptr;
+      if (context_create(ctx->device, nullptr, 0, &tw) == S3D_STATUS_OK) ctx->twin = tw;
+      if (ctx->twin && hipEventCreateWithFlags(&ctx->twin_ev, hipEventDisableTiming) != hipSuccess) ctx->twin_ev = nullptr;
+    }
+    if (two && ctx->twin && ctx->twin_ev) {
+      s3d_context* tw = ctx->twin;
+      struct Drain {          // nothing of this call may still run on the twin when it returns or unwinds
+        s3d_context* t;
+        ~Drain() { (void)hipStreamSynchronize(t->stream); if (t->side_stream) (void)hipStreamSynchronize(t->side_stream); }
+      } drain{tw};
+      // (the clouds may have been uploaded on this context's stream a moment ago)
+      HIPCHK(hipEventRecord(ctx->twin_ev, ctx->stream));
+      HIPCHK(hipStreamWaitEvent(tw->stream, ctx->twin_ev, 0));
+      Batch f;
+      f.ctx = tw;
+      f.use_cache = false;
+      f.set_params(fine, opts);
+      f.add_pairs(1, &source, &target, guess);      // (the guess is replaced below: nothing reads it before the ICP loop)
+      f.registration_batch = true;
+      f.allocate();
+      f.phase = 1;
+      f.run_all();
+      st = align_dev(ctx, source, target, guess, coarse, opts, result, info, persistent);
+      if (st != S3D_STATUS_OK) return st;
+      std::memcpy(guess, result, sizeof guess);
+      f.set_guess(0, guess);
+      f.phase = 2;
+      f.run_all();
+      st = f.finish_pair(0, fine, guess, result, info);
+      HIPCHK(hipStreamSynchronize(tw->stream));
+    } else {
     if (loop) {                                // :286-289
       st = align_dev(ctx, source, target, guess, coarse, opts, result, info, persistent);
       if (st != S3D_STATUS_OK) return st;
       std::memcpy(guess, result, sizeof guess);
     }
     st = align_dev(ctx, source, target, guess, fine, opts, result, info, persistent);   // :292
+    }
     if (st != S3D_STATUS_OK) return st;
     mat4d_mul(source_sensor_pose, result, tmp);   // :295
     mat4d_mul(tmp, tinv, relative_pose);

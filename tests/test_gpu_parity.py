@@ -695,6 +695,24 @@ def test_knn_prepass_beside_the_first_pass_is_neutral_and_deterministic(gpu_ctx,
                 for _ in range(12):
                     rec = gpu_ctx.align_batch(src, tgt, None, p, s3d.ExecOptions())
                     assert np.array_equal(rec, ref), (its, alg)
+        # createConstraint with loop = true: the fine registration's pre-pass on a private second context while the coarse
+        # one registers - the same edge as one after the other, also when the coarse stage fails (nothing of the fine one
+        # may outlive the call), again and again
+        ident = np.eye(4)
+        odo = np.eye(4); odo[0, 3] = 2.0
+        coarse = s3d.default_params(point_cloud_density=0.5)
+        tight = s3d.default_params(point_cloud_density=0.5, max_fitness_score=1e-9)
+        seen = []
+        for args in ((dev[0], ident, dev[3], ident, odo, True, s3d.default_params(), coarse),
+                     (dev[0], ident, dev[1], ident, ident, True, s3d.default_params(), coarse),
+                     (dev[0], ident, dev[3], ident, ident, True, s3d.default_params(), tight)):
+            ref = gpu_ctx.create_constraint_clouds(*args, 1.0, s3d.ExecOptions(debug_flags=A.DBG_NO_K4_OVERLAP))
+            seen.append(ref[0])
+            for _ in range(8):
+                got = gpu_ctx.create_constraint_clouds(*args, 1.0, s3d.ExecOptions())
+                assert got[0] == ref[0] and got[3] == ref[3], (got[0], ref[0])
+                assert got[0] != 0 or np.array_equal(got[1], ref[1])      # (a failed call leaves the pose unwritten)
+        assert seen[0] == 0 and seen[1] == 0 and seen[2] != 0, seen        # (two edges and a failing coarse stage)
     finally:
         for c in dev:
             c.release()
