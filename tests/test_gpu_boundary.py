@@ -195,13 +195,14 @@ def _mem_free():
 
 def test_resource_soak_leaves_device_memory_where_it_was(fixture_clouds):
     """5 000 mixed calls (s3d_align, s3d_align_batch, s3d_cloud_upload_many, cache export / import, map building, k-NN,
-    failing calls in between) on two contexts from two threads: hipMemGetInfo ends within 64 MiB of where it started
+    createConstraint with and without the coarse stage, failing calls in between) on two contexts from two threads: hipMemGetInfo ends within 64 MiB of where it started
     (the workspaces are grown on demand and kept: the first 50 calls of each kind are the warm-up), and the contexts'
     caches end empty."""
     import slam3d_amd as s3d
     clouds = [np.ascontiguousarray(c[::3, :3]) for c in fixture_clouds]            # ~10 k points: ~0.5 ms per call
     p = s3d.default_params(maximum_iterations=6)
     pn = s3d.default_params(registration_algorithm=s3d.ALG_NDT, maximum_iterations=3)
+    pc = s3d.default_params(point_cloud_density=0.5, maximum_iterations=6)
     errors = []
 
     def worker(ctx, seed, rounds):
@@ -245,8 +246,13 @@ def test_resource_soak_leaves_device_memory_where_it_was(fixture_clouds):
                 else:
                     h = ctx.upload(clouds[i])
                     ident = np.eye(4)
-                    r = ctx.create_constraint_clouds(h, ident, h, ident, ident, False, p, None, 1.0,
-                                                     s3d.ExecOptions(cache_prepass=1))
+                    if (it // 10) % 2 == 0:
+                        r = ctx.create_constraint_clouds(h, ident, h, ident, ident, False, p, None, 1.0,
+                                                         s3d.ExecOptions(cache_prepass=1))
+                    else:     # (round 6) coarse + fine: the fine pre-pass on the context's private second context
+                        g = ctx.upload(clouds[j])
+                        r = ctx.create_constraint_clouds(h, ident, g, ident, ident, True, p, pc, 1.0, s3d.ExecOptions())
+                        g.release()
                     assert r[0] in (0, 1, 2, 3, 4)
                     h.release()
         except Exception as e:       # noqa: BLE001 - reported by the main thread
