@@ -2817,22 +2817,34 @@ static int create_constraint_impl(s3d_context* ctx, s3d_cloud* source, const dou
       HIPCHK(hipEventRecord(ctx->twin_ev, ctx->stream));
       HIPCHK(hipStreamWaitEvent(tw->stream, ctx->twin_ev, 0));
       Batch f;
-      f.ctx = tw;
-      f.use_cache = false;
-      f.set_params(fine, opts);
-      f.add_pairs(1, &source, &target, guess);      // (the guess is replaced below: nothing reads it before the ICP loop)
-      f.registration_batch = true;
-      f.allocate();
-      f.phase = 1;
-      f.run_all();
+      bool ahead = false;
+      try {
+        f.ctx = tw;
+        f.use_cache = false;
+        f.set_params(fine, opts);
+        f.add_pairs(1, &source, &target, guess);      // (the guess is replaced below: nothing reads it before the ICP loop)
+        f.registration_batch = true;
+        f.allocate();
+        f.phase = 1;
+        f.run_all();
+        ahead = true;
+      } catch (...) {
+        // whatever is wrong with the fine stage is reported when its turn comes - after the coarse stage, as in the
+        // reference's order (a failing coarse registration is what the caller then sees, :288)
+        (void)hipStreamSynchronize(tw->stream);
+      }
       st = align_dev(ctx, source, target, guess, coarse, opts, result, info, persistent);
       if (st != S3D_STATUS_OK) return st;
       std::memcpy(guess, result, sizeof guess);
-      f.set_guess(0, guess);
-      f.phase = 2;
-      f.run_all();
-      st = f.finish_pair(0, fine, guess, result, info);
-      HIPCHK(hipStreamSynchronize(tw->stream));
+      if (ahead) {
+        f.set_guess(0, guess);
+        f.phase = 2;
+        f.run_all();
+        st = f.finish_pair(0, fine, guess, result, info);
+        HIPCHK(hipStreamSynchronize(tw->stream));
+      } else {
+        st = align_dev(ctx, source, target, guess, fine, opts, result, info, persistent);
+      }
     } else {
     if (loop) {                                // :286-289
       st = align_dev(ctx, source, target, guess, coarse, opts, result, info, persistent);

@@ -705,14 +705,18 @@ def test_knn_prepass_beside_the_first_pass_is_neutral_and_deterministic(gpu_ctx,
         seen = []
         for args in ((dev[0], ident, dev[3], ident, odo, True, s3d.default_params(), coarse),
                      (dev[0], ident, dev[1], ident, ident, True, s3d.default_params(), coarse),
-                     (dev[0], ident, dev[3], ident, ident, True, s3d.default_params(), tight)):
+                     (dev[0], ident, dev[3], ident, ident, True, s3d.default_params(), tight),
+                     # an unusable fine stage is reported when its turn comes: after a coarse stage that fails ...
+                     (dev[0], ident, dev[3], ident, ident, True, s3d.default_params(correspondence_randomness=0), tight),
+                     # ... or succeeds
+                     (dev[0], ident, dev[1], ident, ident, True, s3d.default_params(correspondence_randomness=0), coarse)):
             ref = gpu_ctx.create_constraint_clouds(*args, 1.0, s3d.ExecOptions(debug_flags=A.DBG_NO_K4_OVERLAP))
             seen.append(ref[0])
             for _ in range(8):
                 got = gpu_ctx.create_constraint_clouds(*args, 1.0, s3d.ExecOptions())
                 assert got[0] == ref[0] and got[3] == ref[3], (got[0], ref[0])
                 assert got[0] != 0 or np.array_equal(got[1], ref[1])      # (a failed call leaves the pose unwritten)
-        assert seen[0] == 0 and seen[1] == 0 and seen[2] != 0, seen        # (two edges and a failing coarse stage)
+        assert seen[0] == 0 and seen[1] == 0 and seen[2] != 0 and seen[3] == seen[2] and seen[4] == 7, seen
     finally:
         for c in dev:
             c.release()
